@@ -1,0 +1,129 @@
+/*
+ * lz4hip.h -- C ABI of liblz4hip.so, the MI355X (gfx950) LZ4 block engine that sits behind
+ * lz4-java's LZ4Factory as the fourth ("HIP") implementation family.
+ *
+ * Every entry point replaces one native call of the reference's JNI shim, but processes a BATCH
+ * of independent blocks per HIP launch (the reference makes one liblz4 call per block):
+ *
+ *   lz4hip_compress_fast*     <- Java_net_jpountz_lz4_LZ4JNI_LZ4_1compress_1limitedOutput
+ *                                -> LZ4_compress_default   (src/jni/net_jpountz_lz4_LZ4JNI.c:46-86, call :75)
+ *   lz4hip_decompress_safe*   <- ..._LZ4_1decompress_1safe -> LZ4_decompress_safe (LZ4JNI.c:187-227, call :216)
+ *   lz4hip_decompress_fast*   <- ..._LZ4_1decompress_1fast -> LZ4_decompress_fast (LZ4JNI.c:140-180, call :169)
+ *   lz4hip_compress_hc*       <- ..._LZ4_1compressHC       -> LZ4_compress_HC     (LZ4JNI.c:93-133,  call :122)
+ *   lz4hip_compress_bound     <- ..._LZ4_1compressBound    -> LZ4_compressBound   (LZ4JNI.c:234-239)
+ *   lz4hip_xxh32* / xxh64*    <- Java_net_jpountz_xxhash_XXHashJNI_XXH32 / XXH64
+ *                                (src/jni/net_jpountz_xxhash_XXHashJNI.c:42-59 / :152-169, calls :54 / :164)
+ *
+ * Return conventions deliberately equal liblz4's so the Java error mapping of the JNI family
+ * (LZ4JNICompressor.java:39-41, LZ4JNISafeDecompressor.java:39-41, LZ4JNIFastDecompressor.java:40-42)
+ * carries over unchanged:
+ *   compress   : out_len[i] > 0 compressed size, 0 = dst_cap[i] too small
+ *   decompress_safe : out_len[i] >= 0 decoded size, < 0 = -(input position) - 1
+ *   decompress_fast : out_len[i] > 0 bytes consumed from src, < 0 = -(input position) - 1
+ * Results are bit-exact against liblz4 1.9.3 (what LZ4Factory.nativeInstance() loads on linux/amd64).
+ *
+ * All functions return LZ4HIP_OK (0) or a negative lz4hip_status describing a LIBRARY failure
+ * (no device, HIP error, bad argument); per-block codec results go to the out arrays.  There is
+ * NO CPU fallback: without a usable gfx950 device every compute entry point fails with
+ * LZ4HIP_E_NO_DEVICE.  All entry points are re-entrant and thread-safe; the library never keeps a
+ * caller pointer past the call.
+ */
+#ifndef LZ4HIP_H
+#define LZ4HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LZ4HIP_VERSION 100 /* 0.1.0 */
+
+typedef enum lz4hip_status {
+  LZ4HIP_OK = 0,
+  LZ4HIP_E_NO_DEVICE = -1,  /* no HIP device / not initialised and auto-init failed */
+  LZ4HIP_E_HIP = -2,        /* a HIP runtime call failed (see lz4hip_last_error) */
+  LZ4HIP_E_ARG = -3,        /* null pointer, negative length, bad device index, ... */
+  LZ4HIP_E_NOMEM = -4,      /* device or pinned-host allocation failed */
+  LZ4HIP_E_UNSUPPORTED = -5 /* e.g. HC level outside what this build implements */
+} lz4hip_status;
+
+/* ---- lifecycle ----------------------------------------------------------------------------- */
+/* device_ids == NULL or n_devices <= 0: use every visible device.  Idempotent, thread-safe.      */
+int lz4hip_init(const int* device_ids, int n_devices);
+void lz4hip_shutdown(void);
+int lz4hip_device_count(void);            /* devices the engine is initialised on (0 if none)   */
+const char* lz4hip_last_error(void);      /* thread-local description of the last failure       */
+int lz4hip_version(void);
+
+/* == LZ4_compressBound (LZ4JNI.c:237): n + n/255 + 16, 0 if n < 0 or n > 0x7E000000            */
+int lz4hip_compress_bound(int n);
+
+/* ---- host-pointer batch API ----------------------------------------------------------------
+ * Block i occupies src[src_off[i] .. +src_len[i]) and owns the slot dst[dst_off[i] .. +dst_cap[i]).
+ * The library stages H2D/D2H itself and shards contiguous block ranges over the initialised
+ * devices; slots must not overlap.                                        */
+int lz4hip_compress_fast_batch(const uint8_t* src, const uint64_t* src_off, const int32_t* src_len,
+                               uint8_t* dst, const uint64_t* dst_off, const int32_t* dst_cap,
+                               int32_t* out_len, uint32_t n_blocks);
+int lz4hip_compress_hc_batch(const uint8_t* src, const uint64_t* src_off, const int32_t* src_len,
+                             uint8_t* dst, const uint64_t* dst_off, const int32_t* dst_cap,
+                             int32_t* out_len, uint32_t n_blocks, int level);
+int lz4hip_decompress_safe_batch(const uint8_t* src, const uint64_t* src_off, const int32_t* src_len,
+                                 uint8_t* dst, const uint64_t* dst_off, const int32_t* dst_cap,
+                                 int32_t* out_len, uint32_t n_blocks);
+/* src_cap[i] bounds how far block i may be read (the Java array/buffer length past srcOff):
+ * unlike liblz4's LZ4_decompress_fast this implementation never reads beyond it.                */
+int lz4hip_decompress_fast_batch(const uint8_t* src, const uint64_t* src_off, const int32_t* src_cap,
+                                 uint8_t* dst, const uint64_t* dst_off, const int32_t* dst_len,
+                                 int32_t* out_consumed, uint32_t n_blocks);
+int lz4hip_xxh32_batch(const uint8_t* buf, const uint64_t* off, const int32_t* len, uint32_t seed,
+                       uint32_t* out, uint32_t n);
+int lz4hip_xxh64_batch(const uint8_t* buf, const uint64_t* off, const int32_t* len, uint64_t seed,
+                       uint64_t* out, uint32_t n);
+
+/* ---- device-pointer batch API ----------------------------------------------------------------
+ * Same contracts, every pointer is a DEVICE pointer on `device` (an index into the initialised
+ * device list), work is enqueued on `stream` (a hipStream_t, NULL = the null stream) and the call
+ * returns without synchronising: no PCIe traffic, this is what bench.py times.                  */
+int lz4hip_compress_fast_batch_dev(const uint8_t* src, const uint64_t* src_off, const int32_t* src_len,
+                                   uint8_t* dst, const uint64_t* dst_off, const int32_t* dst_cap,
+                                   int32_t* out_len, uint32_t n_blocks, int device, void* stream);
+int lz4hip_compress_hc_batch_dev(const uint8_t* src, const uint64_t* src_off, const int32_t* src_len,
+                                 uint8_t* dst, const uint64_t* dst_off, const int32_t* dst_cap,
+                                 int32_t* out_len, uint32_t n_blocks, int level, int device, void* stream);
+int lz4hip_decompress_safe_batch_dev(const uint8_t* src, const uint64_t* src_off, const int32_t* src_len,
+                                     uint8_t* dst, const uint64_t* dst_off, const int32_t* dst_cap,
+                                     int32_t* out_len, uint32_t n_blocks, int device, void* stream);
+int lz4hip_decompress_fast_batch_dev(const uint8_t* src, const uint64_t* src_off, const int32_t* src_cap,
+                                     uint8_t* dst, const uint64_t* dst_off, const int32_t* dst_len,
+                                     int32_t* out_consumed, uint32_t n_blocks, int device, void* stream);
+int lz4hip_xxh32_batch_dev(const uint8_t* buf, const uint64_t* off, const int32_t* len, uint32_t seed,
+                           uint32_t* out, uint32_t n, int device, void* stream);
+int lz4hip_xxh64_batch_dev(const uint8_t* buf, const uint64_t* off, const int32_t* len, uint64_t seed,
+                           uint64_t* out, uint32_t n, int device, void* stream);
+
+/* ---- single-block convenience (== batch of 1; what the Java single-call path and the
+ * LZ4Factory constructor self-test, LZ4Factory.java:204-220, go through).  Return value is the
+ * liblz4 return value of the corresponding function, or a lz4hip_status < -0x7F000000+... never:
+ * library failures are reported as INT32_MIN + (-status) so they cannot collide with a codec
+ * result; use LZ4HIP_IS_LIB_ERROR(). -------------------------------------------------------- */
+#define LZ4HIP_LIB_ERROR(status) ((int)(INT32_MIN + (-(status))))
+#define LZ4HIP_IS_LIB_ERROR(ret) ((ret) < (int)(INT32_MIN + 64))
+int lz4hip_compress_fast(const uint8_t* src, int src_len, uint8_t* dst, int dst_cap);
+int lz4hip_compress_hc(const uint8_t* src, int src_len, uint8_t* dst, int dst_cap, int level);
+int lz4hip_decompress_safe(const uint8_t* src, int src_len, uint8_t* dst, int dst_cap);
+int lz4hip_decompress_fast(const uint8_t* src, int src_cap, uint8_t* dst, int dst_len);
+int lz4hip_xxh32(const uint8_t* buf, int len, uint32_t seed, uint32_t* out);
+int lz4hip_xxh64(const uint8_t* buf, int len, uint64_t seed, uint64_t* out);
+
+/* ---- workload helper (not part of the reference API) ------------------------------------------
+ * Fills n_blocks slots of `block_len` bytes at dst + i*stride with the SURVEY.md App. F synthetic
+ * blocks idx = first_idx + i (deterministic, seed-addressed).  Device pointer, async on stream.
+ * bench.py uses it so BASELINE.json's 4 GiB batch never crosses PCIe.                           */
+int lz4hip_gen_blocks_dev(uint8_t* dst, uint64_t stride, int32_t block_len, uint64_t seed, uint64_t first_idx,
+                          uint32_t litmax, uint32_t win, uint32_t n_blocks, int device, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LZ4HIP_H */

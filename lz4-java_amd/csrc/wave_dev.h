@@ -1,0 +1,114 @@
+// wave_dev.h -- gfx950 backend of the "wave" interface used by lz4_fast_core.h.
+// One instance per 64-lane wavefront; per-lane types are plain scalars (SIMT), ballots and
+// broadcasts are the CDNA wave intrinsics, the match table lives in LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lz4hip {
+
+struct WaveDev {
+  using VU = uint32_t;
+  using VU64 = uint64_t;
+  using VB = bool;
+  template <bool U16> struct Entry;
+
+  void* lds;  // 32 KB table of this wavefront
+
+  __device__ __forceinline__ explicit WaveDev(void* l) : lds(l) {}
+
+  // orders this wave's LDS traffic (hardware executes a wave's DS ops in order; this stops the compiler moving them)
+  __device__ __forceinline__ static void sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  __device__ __forceinline__ static VU lane() { return __lane_id(); }
+  __device__ __forceinline__ static VU64 lanemask_lt() { return (1ull << __lane_id()) - 1ull; }
+  __device__ __forceinline__ static uint64_t ballot(bool b) { return __ballot(b); }
+  template <class T> __device__ __forceinline__ static T select(bool c, T a, T b) { return c ? a : b; }
+  __device__ __forceinline__ static VU64 u64(VU v) { return (uint64_t)v; }
+  __device__ __forceinline__ static VU lo32(VU64 v) { return (uint32_t)v; }
+  __device__ __forceinline__ static VU clz64(VU64 v) { return (uint32_t)__clzll((long long)v); }
+
+  __device__ __forceinline__ static uint32_t bcast(VU v, int l) { return __builtin_amdgcn_readlane(v, l); }
+  __device__ __forceinline__ static uint64_t bcast64(VU64 v, int l) {
+    uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, l);
+    uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), l);
+    return ((uint64_t)hi << 32) | lo;
+  }
+  template <bool U16> __device__ __forceinline__ static auto bcast_e(typename Entry<U16>::V v, int l) {
+    if constexpr (U16) return bcast(v, l);
+    else return bcast64(v, l);
+  }
+  template <bool U16> __device__ __forceinline__ static auto shfl_e(typename Entry<U16>::V v, VU srcl) {
+    if constexpr (U16) return (uint32_t)__shfl((int)v, (int)srcl, 64);
+    else {
+      uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, (int)srcl, 64);
+      uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), (int)srcl, 64);
+      return ((uint64_t)hi << 32) | lo;
+    }
+  }
+
+  // ---- global memory (unaligned accesses are single instructions on gfx950/amdhsa) ----
+  __device__ __forceinline__ static VU ld8(const uint8_t* b, VU i, bool m) { return m ? (uint32_t)b[i] : 0u; }
+  __device__ __forceinline__ static VU ld32(const uint8_t* b, VU i, bool m) {
+    uint32_t v = 0;
+    if (m) __builtin_memcpy(&v, b + i, 4);
+    return v;
+  }
+  __device__ __forceinline__ static VU64 ld64(const uint8_t* b, VU i, bool m) {
+    uint64_t v = 0;
+    if (m) __builtin_memcpy(&v, b + i, 8);
+    return v;
+  }
+  __device__ __forceinline__ static uint32_t sld32(const uint8_t* b, uint32_t i) {
+    uint32_t v;
+    __builtin_memcpy(&v, b + i, 4);
+    return v;
+  }
+  __device__ __forceinline__ static void st8(uint8_t* b, VU i, VU v, bool m) {
+    if (m) b[i] = (uint8_t)v;
+  }
+  // cooperative byte copy dst[dpos..+len) = src[spos..+len); regions never overlap
+  __device__ __forceinline__ static void copy(uint8_t* dst, uint32_t dpos, const uint8_t* src, uint32_t spos, uint32_t len) {
+    const uint32_t l = __lane_id();
+    uint8_t* d = dst + dpos;
+    const uint8_t* s = src + spos;
+    const uint32_t body = len & ~15u;
+    for (uint32_t i = l * 16u; i < body; i += 1024u) {
+      uint4 v;
+      __builtin_memcpy(&v, s + i, 16);
+      __builtin_memcpy(d + i, &v, 16);
+    }
+    const uint32_t i = body + l;
+    if (i < len) d[i] = s[i];
+  }
+
+  // ---- LDS table ----
+  template <bool U16> __device__ __forceinline__ void lds_fill(uint32_t count, typename Entry<U16>::S val) {
+    using S = typename Entry<U16>::S;
+    S* t = (S*)lds;
+    for (uint32_t i = __lane_id(); i < count; i += 64u) t[i] = val;
+  }
+  template <bool U16> __device__ __forceinline__ auto lds_rd(VU h, bool m) {
+    using S = typename Entry<U16>::S;
+    return m ? ((S*)lds)[h] : (S)0;
+  }
+  template <bool U16> __device__ __forceinline__ auto lds_max(VU h, typename Entry<U16>::V v, bool m) {
+    using S = typename Entry<U16>::S;
+    S old = 0;
+    if (m) {
+      if constexpr (U16) old = atomicMax(&((uint32_t*)lds)[h], v);
+      else old = atomicMax(&((unsigned long long*)lds)[h], (unsigned long long)v);
+    }
+    return old;
+  }
+  template <bool U16> __device__ __forceinline__ void lds_wr(VU h, typename Entry<U16>::V v, bool m) {
+    using S = typename Entry<U16>::S;
+    if (m) ((S*)lds)[h] = v;
+  }
+};
+template <> struct WaveDev::Entry<true> { using S = uint32_t; using V = uint32_t; };
+template <> struct WaveDev::Entry<false> { using S = uint64_t; using V = uint64_t; };
+
+}  // namespace lz4hip

@@ -1,0 +1,133 @@
+// tests/hostsim/wave_host.h -- TEST INFRASTRUCTURE ONLY (never part of liblz4hip.so).
+//
+// A lock-step 64-lane simulator of the "wave" backend, so the CPU test-suite can execute the very
+// source of lz4-java_amd/csrc/lz4_fast_core.h (the algorithm the gfx950 kernel runs) and compare it
+// with the oracle before any GPU time is spent.  Per-lane values are 64-element vectors; LDS
+// atomics are applied in a PSEUDO-RANDOM lane order on purpose: the algorithm must not depend on
+// the order in which the hardware serialises colliding lanes of one DS instruction.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+#include <vector>
+
+namespace hostsim {
+
+template <class T>
+struct V {
+  T v[64];
+  V() { for (int i = 0; i < 64; i++) v[i] = T(); }
+  V(T s) { for (int i = 0; i < 64; i++) v[i] = s; }  // broadcast (implicit on purpose)
+#define HS_BIN(OP)                                                                  \
+  friend V operator OP(const V& a, const V& b) {                                    \
+    V r;                                                                            \
+    for (int i = 0; i < 64; i++) r.v[i] = (T)(a.v[i] OP b.v[i]);                    \
+    return r;                                                                       \
+  }
+  HS_BIN(+) HS_BIN(-) HS_BIN(*) HS_BIN(&) HS_BIN(|) HS_BIN(^)
+#undef HS_BIN
+#define HS_CMP(OP)                                                                  \
+  friend V<bool> operator OP(const V& a, const V& b) {                              \
+    V<bool> r;                                                                      \
+    for (int i = 0; i < 64; i++) r.v[i] = a.v[i] OP b.v[i];                         \
+    return r;                                                                       \
+  }
+  HS_CMP(==) HS_CMP(!=) HS_CMP(<) HS_CMP(<=) HS_CMP(>) HS_CMP(>=)
+#undef HS_CMP
+  friend V operator<<(const V& a, int s) { V r; for (int i = 0; i < 64; i++) r.v[i] = (T)(a.v[i] << s); return r; }
+  friend V operator>>(const V& a, int s) { V r; for (int i = 0; i < 64; i++) r.v[i] = (T)(a.v[i] >> s); return r; }
+  V<bool> operator!() const { V<bool> r; for (int i = 0; i < 64; i++) r.v[i] = !v[i]; return r; }
+};
+
+struct WaveHost {
+  using VU = V<uint32_t>;
+  using VU64 = V<uint64_t>;
+  using VB = V<bool>;
+  template <bool U16> struct Entry;
+
+  std::vector<uint64_t> lds;  // 4096 x u64 == 8192 x u32 == 32 KB
+  uint64_t rng = 0x9E3779B97F4A7C15ull;
+  const uint8_t* src_lo = nullptr; const uint8_t* src_hi = nullptr;  // bounds for checking loads
+  uint8_t* dst_lo = nullptr; uint8_t* dst_hi = nullptr;              // bounds for checking stores
+  bool oob = false;
+
+  WaveHost() : lds(4096, 0) {}
+  void bounds(const uint8_t* s, size_t n, uint8_t* d, size_t cap) { src_lo = s; src_hi = s + n; dst_lo = d; dst_hi = d + cap; }
+
+  static void sync() {}
+  static VU lane() { VU r; for (int i = 0; i < 64; i++) r.v[i] = (uint32_t)i; return r; }
+  static VU64 lanemask_lt() { VU64 r; for (int i = 0; i < 64; i++) r.v[i] = (1ull << i) - 1ull; return r; }
+  static uint64_t ballot(const VB& b) { uint64_t m = 0; for (int i = 0; i < 64; i++) if (b.v[i]) m |= 1ull << i; return m; }
+  template <class T> static V<T> select(const VB& c, const V<T>& a, const V<T>& b) {
+    V<T> r; for (int i = 0; i < 64; i++) r.v[i] = c.v[i] ? a.v[i] : b.v[i]; return r;
+  }
+  static VU64 u64(const VU& v) { VU64 r; for (int i = 0; i < 64; i++) r.v[i] = v.v[i]; return r; }
+  static VU lo32(const VU64& v) { VU r; for (int i = 0; i < 64; i++) r.v[i] = (uint32_t)v.v[i]; return r; }
+  static VU clz64(const VU64& v) { VU r; for (int i = 0; i < 64; i++) r.v[i] = v.v[i] ? (uint32_t)__builtin_clzll(v.v[i]) : 64u; return r; }
+  static uint32_t bcast(const VU& v, int l) { return v.v[l]; }
+  static uint64_t bcast64(const VU64& v, int l) { return v.v[l]; }
+  template <bool U16> static auto bcast_e(const typename Entry<U16>::V& v, int l) { return v.v[l]; }
+  template <bool U16> static auto shfl_e(const typename Entry<U16>::V& v, const VU& srcl) {
+    typename Entry<U16>::V r;
+    for (int i = 0; i < 64; i++) r.v[i] = v.v[srcl.v[i] & 63u];
+    return r;
+  }
+
+  bool in_ok(const uint8_t* p, size_t k) { if (p < src_lo || p + k > src_hi) { oob = true; return false; } return true; }
+  bool out_ok(const uint8_t* p, size_t k) { if (p < dst_lo || p + k > dst_hi) { oob = true; return false; } return true; }
+
+  VU ld8(const uint8_t* b, const VU& i, const VB& m) {
+    VU r; for (int l = 0; l < 64; l++) if (m.v[l] && in_ok(b + i.v[l], 1)) r.v[l] = b[i.v[l]]; return r;
+  }
+  VU ld32(const uint8_t* b, const VU& i, const VB& m) {
+    VU r; for (int l = 0; l < 64; l++) if (m.v[l] && in_ok(b + i.v[l], 4)) memcpy(&r.v[l], b + i.v[l], 4); return r;
+  }
+  VU64 ld64(const uint8_t* b, const VU& i, const VB& m) {
+    VU64 r; for (int l = 0; l < 64; l++) if (m.v[l] && in_ok(b + i.v[l], 8)) memcpy(&r.v[l], b + i.v[l], 8); return r;
+  }
+  uint32_t sld32(const uint8_t* b, uint32_t i) { uint32_t v = 0; if (in_ok(b + i, 4)) memcpy(&v, b + i, 4); return v; }
+  void st8(uint8_t* b, const VU& i, const VU& v, const VB& m) {
+    for (int l = 0; l < 64; l++) if (m.v[l] && out_ok(b + i.v[l], 1)) b[i.v[l]] = (uint8_t)v.v[l];
+  }
+  void copy(uint8_t* dst, uint32_t dpos, const uint8_t* src, uint32_t spos, uint32_t len) {
+    if (len && in_ok(src + spos, len) && out_ok(dst + dpos, len)) memcpy(dst + dpos, src + spos, len);
+  }
+
+  template <bool U16> void lds_fill(uint32_t count, typename Entry<U16>::S val) {
+    using S = typename Entry<U16>::S;
+    S* t = (S*)lds.data();
+    for (uint32_t i = 0; i < count; i++) t[i] = val;
+  }
+  template <bool U16> auto lds_rd(const VU& h, const VB& m) {
+    using S = typename Entry<U16>::S;
+    typename Entry<U16>::V r;
+    for (int l = 0; l < 64; l++) if (m.v[l]) r.v[l] = ((S*)lds.data())[h.v[l]];
+    return r;
+  }
+  template <bool U16> auto lds_max(const VU& h, const typename Entry<U16>::V& v, const VB& m) {
+    using S = typename Entry<U16>::S;
+    typename Entry<U16>::V old;
+    int order[64];
+    for (int i = 0; i < 64; i++) order[i] = i;
+    for (int i = 63; i > 0; i--) {  // Fisher-Yates with a splitmix-style step
+      rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+      int j = (int)((rng >> 33) % (uint64_t)(i + 1));
+      int t = order[i]; order[i] = order[j]; order[j] = t;
+    }
+    for (int q = 0; q < 64; q++) {
+      int l = order[q];
+      if (!m.v[l]) continue;
+      S* p = &((S*)lds.data())[h.v[l]];
+      old.v[l] = *p;
+      if (v.v[l] > *p) *p = v.v[l];
+    }
+    return old;
+  }
+  template <bool U16> void lds_wr(const VU& h, const typename Entry<U16>::V& v, const VB& m) {
+    using S = typename Entry<U16>::S;
+    for (int l = 0; l < 64; l++) if (m.v[l]) ((S*)lds.data())[h.v[l]] = v.v[l];
+  }
+};
+template <> struct WaveHost::Entry<true> { using S = uint32_t; using V = hostsim::V<uint32_t>; };
+template <> struct WaveHost::Entry<false> { using S = uint64_t; using V = hostsim::V<uint64_t>; };
+
+}  // namespace hostsim
