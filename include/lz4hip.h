@@ -35,6 +35,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default) /* the library itself is built with -fvisibility=hidden */
+#endif
 
 #define LZ4HIP_VERSION 100 /* 0.1.0 */
 
@@ -54,6 +57,9 @@ void lz4hip_shutdown(void);
 int lz4hip_device_count(void);            /* devices the engine is initialised on (0 if none)   */
 const char* lz4hip_last_error(void);      /* thread-local description of the last failure       */
 int lz4hip_version(void);
+/* tuning knobs (not part of the reference API): "decode_lanes" = lanes of a wavefront sharing one
+ * block in the decoder (0 = default, 4/8/16/32/64).                                              */
+int lz4hip_set_option(const char* name, int value);
 
 /* == LZ4_compressBound (LZ4JNI.c:237): n + n/255 + 16, 0 if n < 0 or n > 0x7E000000            */
 int lz4hip_compress_bound(int n);
@@ -103,10 +109,9 @@ int lz4hip_xxh64_batch_dev(const uint8_t* buf, const uint64_t* off, const int32_
                            uint64_t* out, uint32_t n, int device, void* stream);
 
 /* ---- single-block convenience (== batch of 1; what the Java single-call path and the
- * LZ4Factory constructor self-test, LZ4Factory.java:204-220, go through).  Return value is the
- * liblz4 return value of the corresponding function, or a lz4hip_status < -0x7F000000+... never:
- * library failures are reported as INT32_MIN + (-status) so they cannot collide with a codec
- * result; use LZ4HIP_IS_LIB_ERROR(). -------------------------------------------------------- */
+ * LZ4Factory constructor self-test, LZ4Factory.java:204-220, go through).  The return value is the
+ * liblz4 return value of the corresponding function.  A LIBRARY failure (no device, HIP error) is
+ * reported as INT32_MIN + (-status), which no codec result can equal: test LZ4HIP_IS_LIB_ERROR().  */
 #define LZ4HIP_LIB_ERROR(status) ((int)(INT32_MIN + (-(status))))
 #define LZ4HIP_IS_LIB_ERROR(ret) ((ret) < (int)(INT32_MIN + 64))
 int lz4hip_compress_fast(const uint8_t* src, int src_len, uint8_t* dst, int dst_cap);
@@ -123,6 +128,9 @@ int lz4hip_xxh64(const uint8_t* buf, int len, uint64_t seed, uint64_t* out);
 int lz4hip_gen_blocks_dev(uint8_t* dst, uint64_t stride, int32_t block_len, uint64_t seed, uint64_t first_idx,
                           uint32_t litmax, uint32_t win, uint32_t n_blocks, int device, void* stream);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

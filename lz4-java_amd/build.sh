@@ -1,0 +1,9 @@
+#!/bin/bash
+# Builds lz4-java_amd/liblz4hip.so for gfx950 (cross-compiles without a GPU).
+set -euo pipefail
+here="$(cd "$(dirname "$0")" && pwd)"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+"$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fvisibility=hidden \
+  -Wl,-rpath,/opt/rocm/lib -Wl,--exclude-libs,ALL \
+  "$here/csrc/kernels.hip" "$here/csrc/api.cpp" -o "$here/liblz4hip.so"
+echo "built $here/liblz4hip.so"

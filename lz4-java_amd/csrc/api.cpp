@@ -1,0 +1,389 @@
+// api.cpp -- the C ABI of liblz4hip.so (include/lz4hip.h): device context, staging for the
+// host-pointer batch API, contiguous-range sharding over the initialised devices, and the
+// device-pointer entry points bench.py times.  There is deliberately NO CPU code path here:
+// without a HIP device every compute entry point returns LZ4HIP_E_NO_DEVICE.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <limits.h>
+#include <mutex>
+#include <thread>
+#include <vector>
+#include <string>
+#include "../../include/lz4hip.h"
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+std::mutex g_mu;
+std::vector<int> g_devs;  // HIP device ordinals the engine is initialised on
+bool g_inited = false;
+
+int fail(int status, const char* what, hipError_t e = hipSuccess) {
+  char buf[512];
+  if (e != hipSuccess) snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+  else snprintf(buf, sizeof buf, "%s", what);
+  g_err = buf;
+  return status;
+}
+
+#define HIPCHK(call)                                                   \
+  do {                                                                 \
+    hipError_t e_ = (call);                                            \
+    if (e_ != hipSuccess) return fail(LZ4HIP_E_HIP, #call, e_);        \
+  } while (0)
+
+int ensure_init() {
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_inited) return g_devs.empty() ? LZ4HIP_E_NO_DEVICE : LZ4HIP_OK;
+  }
+  return lz4hip_init(nullptr, 0);
+}
+
+// the HIP ordinal of engine device index `device`
+int ordinal(int device, int* out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (device < 0 || device >= (int)g_devs.size()) return LZ4HIP_E_ARG;
+  *out = g_devs[device];
+  return LZ4HIP_OK;
+}
+
+struct DeviceGuard {  // callers (e.g. PyTorch) own the thread's current device: restore it
+  int prev = -1;
+  bool ok = false;
+  explicit DeviceGuard(int ord) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    ok = (prev == ord) || hipSetDevice(ord) == hipSuccess;
+  }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+enum Op { OP_COMPRESS_FAST, OP_DECODE_SAFE, OP_DECODE_FAST };
+int g_decode_lanes = 0;  // tuning knob (lz4hip_set_option "decode_lanes"); 0 = kernel default
+
+int launch_op(Op op, const lz4hip::BatchArgs& a, hipStream_t st) {
+  int e = 0;
+  switch (op) {
+    case OP_COMPRESS_FAST: e = lz4hip::launch_compress_fast(a, st); break;
+    case OP_DECODE_SAFE: e = lz4hip::launch_decompress(a, true, g_decode_lanes, st); break;
+    case OP_DECODE_FAST: e = lz4hip::launch_decompress(a, false, g_decode_lanes, st); break;
+  }
+  if (e != 0) return fail(LZ4HIP_E_HIP, "kernel launch", (hipError_t)e);
+  return LZ4HIP_OK;
+}
+
+int dev_batch(Op op, const uint8_t* src, const uint64_t* src_off, const int32_t* src_len, uint8_t* dst,
+              const uint64_t* dst_off, const int32_t* dst_cap, int32_t* out, uint32_t n, int device, void* stream) {
+  int rc = ensure_init();
+  if (rc) return fail(rc, "no HIP device: liblz4hip has no CPU fallback");
+  if (n == 0) return LZ4HIP_OK;
+  if (!src || !src_off || !src_len || !dst || !dst_off || !dst_cap || !out) return fail(LZ4HIP_E_ARG, "null pointer argument");
+  int ord;
+  if (ordinal(device, &ord)) return fail(LZ4HIP_E_ARG, "bad device index");
+  DeviceGuard g(ord);
+  if (!g.ok) return fail(LZ4HIP_E_HIP, "hipSetDevice failed");
+  lz4hip::BatchArgs a{src, src_off, src_len, dst, dst_off, dst_cap, out, n};
+  return launch_op(op, a, (hipStream_t)stream);
+}
+
+// ---- host-pointer path ---------------------------------------------------------------------------
+struct Span { uint64_t lo, hi; };
+Span span_of(const uint64_t* off, const int32_t* len, uint32_t b0, uint32_t b1) {
+  Span s{UINT64_MAX, 0};
+  for (uint32_t i = b0; i < b1; i++) {
+    const uint64_t l = len[i] > 0 ? (uint64_t)len[i] : 0;
+    if (off[i] < s.lo) s.lo = off[i];
+    if (off[i] + l > s.hi) s.hi = off[i] + l;
+  }
+  if (s.lo == UINT64_MAX) s.lo = s.hi = 0;
+  return s;
+}
+
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
+};
+
+// one device's share [b0, b1) of a host batch
+int host_shard(Op op, int ord, const uint8_t* src, const uint64_t* src_off, const int32_t* src_len, uint8_t* dst,
+               const uint64_t* dst_off, const int32_t* dst_cap, int32_t* out, uint32_t b0, uint32_t b1, std::string* err) {
+  auto bad = [&](const char* what, hipError_t e) {
+    char buf[512];
+    snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    *err = buf;
+    return (int)LZ4HIP_E_HIP;
+  };
+  const uint32_t n = b1 - b0;
+  if (n == 0) return LZ4HIP_OK;
+  hipError_t e;
+  if ((e = hipSetDevice(ord)) != hipSuccess) return bad("hipSetDevice", e);
+  const Span ss = span_of(src_off, src_len, b0, b1);
+  const Span ds = span_of(dst_off, dst_cap, b0, b1);
+  std::vector<uint64_t> so(n), dof(n);
+  for (uint32_t i = 0; i < n; i++) { so[i] = src_off[b0 + i] - ss.lo; dof[i] = dst_off[b0 + i] - ds.lo; }
+  DevBuf dsrc, ddst, dso, ddo, dsl, ddc, dout;
+  const size_t slen = (size_t)(ss.hi - ss.lo), dlen = (size_t)(ds.hi - ds.lo);
+  if ((e = dsrc.alloc(slen + 16)) != hipSuccess || (e = ddst.alloc(dlen + 16)) != hipSuccess || (e = dso.alloc(n * 8)) != hipSuccess ||
+      (e = ddo.alloc(n * 8)) != hipSuccess || (e = dsl.alloc(n * 4)) != hipSuccess || (e = ddc.alloc(n * 4)) != hipSuccess ||
+      (e = dout.alloc(n * 4)) != hipSuccess) {
+    *err = std::string("hipMalloc: ") + hipGetErrorString(e);
+    return LZ4HIP_E_NOMEM;
+  }
+  hipStream_t st;
+  if ((e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) return bad("hipStreamCreate", e);
+  int rc = LZ4HIP_OK;
+  do {
+    if (slen && (e = hipMemcpyAsync(dsrc.p, src + ss.lo, slen, hipMemcpyHostToDevice, st)) != hipSuccess) { rc = bad("H2D src", e); break; }
+    if ((e = hipMemcpyAsync(dso.p, so.data(), n * 8, hipMemcpyHostToDevice, st)) != hipSuccess) { rc = bad("H2D", e); break; }
+    if ((e = hipMemcpyAsync(ddo.p, dof.data(), n * 8, hipMemcpyHostToDevice, st)) != hipSuccess) { rc = bad("H2D", e); break; }
+    if ((e = hipMemcpyAsync(dsl.p, src_len + b0, n * 4, hipMemcpyHostToDevice, st)) != hipSuccess) { rc = bad("H2D", e); break; }
+    if ((e = hipMemcpyAsync(ddc.p, dst_cap + b0, n * 4, hipMemcpyHostToDevice, st)) != hipSuccess) { rc = bad("H2D", e); break; }
+    lz4hip::BatchArgs a{(const uint8_t*)dsrc.p, (const uint64_t*)dso.p, (const int32_t*)dsl.p, (uint8_t*)ddst.p,
+                        (const uint64_t*)ddo.p, (const int32_t*)ddc.p, (int32_t*)dout.p, n};
+    int le = 0;
+    switch (op) {
+      case OP_COMPRESS_FAST: le = lz4hip::launch_compress_fast(a, st); break;
+      case OP_DECODE_SAFE: le = lz4hip::launch_decompress(a, true, g_decode_lanes, st); break;
+      case OP_DECODE_FAST: le = lz4hip::launch_decompress(a, false, g_decode_lanes, st); break;
+    }
+    if (le) { rc = bad("kernel launch", (hipError_t)le); break; }
+    if ((e = hipMemcpyAsync(out + b0, dout.p, n * 4, hipMemcpyDeviceToHost, st)) != hipSuccess) { rc = bad("D2H out", e); break; }
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) { rc = bad("hipStreamSynchronize", e); break; }
+    // bring the destination span back once, then hand each block exactly the bytes it produced
+    // (slots may be far larger than their content, and bytes past a result stay untouched)
+    {
+      std::vector<uint8_t> host(dlen ? dlen : 1);
+      if (dlen && (e = hipMemcpyAsync(host.data(), ddst.p, dlen, hipMemcpyDeviceToHost, st)) != hipSuccess) { rc = bad("D2H dst", e); break; }
+      if ((e = hipStreamSynchronize(st)) != hipSuccess) { rc = bad("hipStreamSynchronize", e); break; }
+      for (uint32_t i = 0; i < n; i++) {
+        int64_t produced;
+        if (op == OP_DECODE_FAST) produced = out[b0 + i] > 0 ? dst_cap[b0 + i] : 0;
+        else produced = out[b0 + i] > 0 ? out[b0 + i] : 0;
+        if (produced > 0) memcpy(dst + dst_off[b0 + i], host.data() + dof[i], (size_t)produced);
+      }
+    }
+    if (rc) break;
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) { rc = bad("hipStreamSynchronize", e); break; }
+  } while (0);
+  (void)hipStreamDestroy(st);
+  return rc;
+}
+
+int host_batch(Op op, const uint8_t* src, const uint64_t* src_off, const int32_t* src_len, uint8_t* dst,
+               const uint64_t* dst_off, const int32_t* dst_cap, int32_t* out, uint32_t n) {
+  int rc = ensure_init();
+  if (rc) return fail(rc, "no HIP device: liblz4hip has no CPU fallback");
+  if (n == 0) return LZ4HIP_OK;
+  if (!src || !src_off || !src_len || !dst || !dst_off || !dst_cap || !out) return fail(LZ4HIP_E_ARG, "null pointer argument");
+  std::vector<int> devs;
+  { std::lock_guard<std::mutex> lk(g_mu); devs = g_devs; }
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  // contiguous block ranges per device; small batches stay on one device
+  const uint32_t D = (uint32_t)std::min<size_t>(devs.size(), std::max<uint32_t>(1u, n / 64u));
+  std::vector<int> rcs(D, 0);
+  std::vector<std::string> errs(D);
+  if (D == 1) {
+    rcs[0] = host_shard(op, devs[0], src, src_off, src_len, dst, dst_off, dst_cap, out, 0, n, &errs[0]);
+  } else {
+    std::vector<std::thread> th;
+    for (uint32_t d = 0; d < D; d++) {
+      const uint32_t b0 = (uint32_t)((uint64_t)n * d / D), b1 = (uint32_t)((uint64_t)n * (d + 1) / D);
+      th.emplace_back([&, d, b0, b1] { rcs[d] = host_shard(op, devs[d], src, src_off, src_len, dst, dst_off, dst_cap, out, b0, b1, &errs[d]); });
+    }
+    for (auto& t : th) t.join();
+  }
+  if (prev >= 0) (void)hipSetDevice(prev);
+  for (uint32_t d = 0; d < D; d++)
+    if (rcs[d]) return fail(rcs[d], errs[d].c_str());
+  return LZ4HIP_OK;
+}
+
+template <class T>
+int host_xxh(bool is64, const uint8_t* buf, const uint64_t* off, const int32_t* len, uint64_t seed, T* out, uint32_t n) {
+  int rc = ensure_init();
+  if (rc) return fail(rc, "no HIP device: liblz4hip has no CPU fallback");
+  if (n == 0) return LZ4HIP_OK;
+  if (!buf || !off || !len || !out) return fail(LZ4HIP_E_ARG, "null pointer argument");
+  int ord;
+  if (ordinal(0, &ord)) return fail(LZ4HIP_E_NO_DEVICE, "no device");
+  DeviceGuard g(ord);
+  const Span s = span_of(off, len, 0, n);
+  std::vector<uint64_t> o(n);
+  for (uint32_t i = 0; i < n; i++) o[i] = off[i] - s.lo;
+  DevBuf db, dof, dl, dout;
+  const size_t blen = (size_t)(s.hi - s.lo);
+  if (db.alloc(blen + 32) != hipSuccess || dof.alloc(n * 8) != hipSuccess || dl.alloc(n * 4) != hipSuccess || dout.alloc(n * sizeof(T)) != hipSuccess)
+    return fail(LZ4HIP_E_NOMEM, "hipMalloc failed");
+  if (blen) HIPCHK(hipMemcpy(db.p, buf + s.lo, blen, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dof.p, o.data(), n * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dl.p, len, n * 4, hipMemcpyHostToDevice));
+  int e = is64 ? lz4hip::launch_xxh64((const uint8_t*)db.p, (const uint64_t*)dof.p, (const int32_t*)dl.p, seed, (uint64_t*)dout.p, n, nullptr)
+               : lz4hip::launch_xxh32((const uint8_t*)db.p, (const uint64_t*)dof.p, (const int32_t*)dl.p, (uint32_t)seed, (uint32_t*)dout.p, n, nullptr);
+  if (e) return fail(LZ4HIP_E_HIP, "kernel launch", (hipError_t)e);
+  HIPCHK(hipMemcpy(out, dout.p, n * sizeof(T), hipMemcpyDeviceToHost));
+  return LZ4HIP_OK;
+}
+
+int single(Op op, const uint8_t* src, int src_len, uint8_t* dst, int dst_cap) {
+  const uint64_t zero = 0;
+  int32_t sl = src_len, dc = dst_cap, out = 0;
+  uint8_t dummy = 0;
+  int rc = host_batch(op, src ? src : &dummy, &zero, &sl, dst ? dst : &dummy, &zero, &dc, &out, 1);
+  if (rc) return LZ4HIP_LIB_ERROR(rc);
+  return out;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lz4hip_version(void) { return LZ4HIP_VERSION; }
+const char* lz4hip_last_error(void) { return g_err.c_str(); }
+
+int lz4hip_init(const int* device_ids, int n_devices) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (g_inited) return g_devs.empty() ? LZ4HIP_E_NO_DEVICE : LZ4HIP_OK;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    g_inited = true;  // remember: there is nothing to run on (and nothing else to fall back to)
+    g_devs.clear();
+    return fail(LZ4HIP_E_NO_DEVICE, "hipGetDeviceCount found no device", e);
+  }
+  std::vector<int> devs;
+  if (device_ids && n_devices > 0) {
+    for (int i = 0; i < n_devices; i++) {
+      if (device_ids[i] < 0 || device_ids[i] >= count) return fail(LZ4HIP_E_ARG, "device id out of range");
+      devs.push_back(device_ids[i]);
+    }
+  } else {
+    for (int i = 0; i < count; i++) devs.push_back(i);
+  }
+  g_devs = devs;
+  g_inited = true;
+  return LZ4HIP_OK;
+}
+
+void lz4hip_shutdown(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_devs.clear();
+  g_inited = false;
+}
+
+int lz4hip_device_count(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  return (int)g_devs.size();
+}
+
+int lz4hip_set_option(const char* name, int value) {
+  if (name && strcmp(name, "decode_lanes") == 0) {
+    if (value != 0 && value != 4 && value != 8 && value != 16 && value != 32 && value != 64) return fail(LZ4HIP_E_ARG, "decode_lanes must be 0,4,8,16,32,64");
+    g_decode_lanes = value;
+    return LZ4HIP_OK;
+  }
+  return fail(LZ4HIP_E_ARG, "unknown option");
+}
+
+int lz4hip_compress_bound(int n) {
+  if (n < 0 || (uint32_t)n > 0x7E000000u) return 0;
+  return n + n / 255 + 16;
+}
+
+// ---- host-pointer batch API ----
+int lz4hip_compress_fast_batch(const uint8_t* src, const uint64_t* src_off, const int32_t* src_len, uint8_t* dst,
+                               const uint64_t* dst_off, const int32_t* dst_cap, int32_t* out_len, uint32_t n) {
+  return host_batch(OP_COMPRESS_FAST, src, src_off, src_len, dst, dst_off, dst_cap, out_len, n);
+}
+int lz4hip_decompress_safe_batch(const uint8_t* src, const uint64_t* src_off, const int32_t* src_len, uint8_t* dst,
+                                 const uint64_t* dst_off, const int32_t* dst_cap, int32_t* out_len, uint32_t n) {
+  return host_batch(OP_DECODE_SAFE, src, src_off, src_len, dst, dst_off, dst_cap, out_len, n);
+}
+int lz4hip_decompress_fast_batch(const uint8_t* src, const uint64_t* src_off, const int32_t* src_cap, uint8_t* dst,
+                                 const uint64_t* dst_off, const int32_t* dst_len, int32_t* out_consumed, uint32_t n) {
+  return host_batch(OP_DECODE_FAST, src, src_off, src_cap, dst, dst_off, dst_len, out_consumed, n);
+}
+int lz4hip_compress_hc_batch(const uint8_t*, const uint64_t*, const int32_t*, uint8_t*, const uint64_t*, const int32_t*, int32_t*, uint32_t, int) {
+  return fail(LZ4HIP_E_UNSUPPORTED, "HC compressor: not built yet (SURVEY.md section 8 row a4)");
+}
+int lz4hip_xxh32_batch(const uint8_t* buf, const uint64_t* off, const int32_t* len, uint32_t seed, uint32_t* out, uint32_t n) {
+  return host_xxh<uint32_t>(false, buf, off, len, seed, out, n);
+}
+int lz4hip_xxh64_batch(const uint8_t* buf, const uint64_t* off, const int32_t* len, uint64_t seed, uint64_t* out, uint32_t n) {
+  return host_xxh<uint64_t>(true, buf, off, len, seed, out, n);
+}
+
+// ---- device-pointer batch API ----
+int lz4hip_compress_fast_batch_dev(const uint8_t* src, const uint64_t* src_off, const int32_t* src_len, uint8_t* dst,
+                                   const uint64_t* dst_off, const int32_t* dst_cap, int32_t* out_len, uint32_t n, int device, void* stream) {
+  return dev_batch(OP_COMPRESS_FAST, src, src_off, src_len, dst, dst_off, dst_cap, out_len, n, device, stream);
+}
+int lz4hip_decompress_safe_batch_dev(const uint8_t* src, const uint64_t* src_off, const int32_t* src_len, uint8_t* dst,
+                                     const uint64_t* dst_off, const int32_t* dst_cap, int32_t* out_len, uint32_t n, int device, void* stream) {
+  return dev_batch(OP_DECODE_SAFE, src, src_off, src_len, dst, dst_off, dst_cap, out_len, n, device, stream);
+}
+int lz4hip_decompress_fast_batch_dev(const uint8_t* src, const uint64_t* src_off, const int32_t* src_cap, uint8_t* dst,
+                                     const uint64_t* dst_off, const int32_t* dst_len, int32_t* out_consumed, uint32_t n, int device, void* stream) {
+  return dev_batch(OP_DECODE_FAST, src, src_off, src_cap, dst, dst_off, dst_len, out_consumed, n, device, stream);
+}
+int lz4hip_compress_hc_batch_dev(const uint8_t*, const uint64_t*, const int32_t*, uint8_t*, const uint64_t*, const int32_t*, int32_t*, uint32_t, int, int, void*) {
+  return fail(LZ4HIP_E_UNSUPPORTED, "HC compressor: not built yet (SURVEY.md section 8 row a4)");
+}
+int lz4hip_xxh32_batch_dev(const uint8_t* buf, const uint64_t* off, const int32_t* len, uint32_t seed, uint32_t* out, uint32_t n, int device, void* stream) {
+  int rc = ensure_init();
+  if (rc) return fail(rc, "no HIP device: liblz4hip has no CPU fallback");
+  if (n == 0) return LZ4HIP_OK;
+  if (!buf || !off || !len || !out) return fail(LZ4HIP_E_ARG, "null pointer argument");
+  int ord;
+  if (ordinal(device, &ord)) return fail(LZ4HIP_E_ARG, "bad device index");
+  DeviceGuard g(ord);
+  int e = lz4hip::launch_xxh32(buf, off, len, seed, out, n, stream);
+  return e ? fail(LZ4HIP_E_HIP, "kernel launch", (hipError_t)e) : LZ4HIP_OK;
+}
+int lz4hip_xxh64_batch_dev(const uint8_t* buf, const uint64_t* off, const int32_t* len, uint64_t seed, uint64_t* out, uint32_t n, int device, void* stream) {
+  int rc = ensure_init();
+  if (rc) return fail(rc, "no HIP device: liblz4hip has no CPU fallback");
+  if (n == 0) return LZ4HIP_OK;
+  if (!buf || !off || !len || !out) return fail(LZ4HIP_E_ARG, "null pointer argument");
+  int ord;
+  if (ordinal(device, &ord)) return fail(LZ4HIP_E_ARG, "bad device index");
+  DeviceGuard g(ord);
+  int e = lz4hip::launch_xxh64(buf, off, len, seed, out, n, stream);
+  return e ? fail(LZ4HIP_E_HIP, "kernel launch", (hipError_t)e) : LZ4HIP_OK;
+}
+
+// ---- single-block convenience ----
+int lz4hip_compress_fast(const uint8_t* src, int src_len, uint8_t* dst, int dst_cap) { return single(OP_COMPRESS_FAST, src, src_len, dst, dst_cap); }
+int lz4hip_compress_hc(const uint8_t*, int, uint8_t*, int, int) { return LZ4HIP_LIB_ERROR(fail(LZ4HIP_E_UNSUPPORTED, "HC compressor: not built yet")); }
+int lz4hip_decompress_safe(const uint8_t* src, int src_len, uint8_t* dst, int dst_cap) { return single(OP_DECODE_SAFE, src, src_len, dst, dst_cap); }
+int lz4hip_decompress_fast(const uint8_t* src, int src_cap, uint8_t* dst, int dst_len) { return single(OP_DECODE_FAST, src, src_cap, dst, dst_len); }
+int lz4hip_xxh32(const uint8_t* buf, int len, uint32_t seed, uint32_t* out) {
+  const uint64_t zero = 0;
+  int32_t l = len;
+  uint8_t dummy = 0;
+  return lz4hip_xxh32_batch(buf ? buf : &dummy, &zero, &l, seed, out, 1);
+}
+int lz4hip_xxh64(const uint8_t* buf, int len, uint64_t seed, uint64_t* out) {
+  const uint64_t zero = 0;
+  int32_t l = len;
+  uint8_t dummy = 0;
+  return lz4hip_xxh64_batch(buf ? buf : &dummy, &zero, &l, seed, out, 1);
+}
+
+int lz4hip_gen_blocks_dev(uint8_t* dst, uint64_t stride, int32_t block_len, uint64_t seed, uint64_t first_idx, uint32_t litmax,
+                          uint32_t win, uint32_t n_blocks, int device, void* stream) {
+  int rc = ensure_init();
+  if (rc) return fail(rc, "no HIP device: liblz4hip has no CPU fallback");
+  if (!dst || block_len < 0 || litmax == 0 || win == 0) return fail(LZ4HIP_E_ARG, "bad argument");
+  int ord;
+  if (ordinal(device, &ord)) return fail(LZ4HIP_E_ARG, "bad device index");
+  DeviceGuard g(ord);
+  int e = lz4hip::launch_gen_blocks(dst, stride, block_len, seed, first_idx, litmax, win, n_blocks, stream);
+  return e ? fail(LZ4HIP_E_HIP, "kernel launch", (hipError_t)e) : LZ4HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,59 @@
+// group_dev.h -- gfx950 backend of the lane-group interface used by lz4_decode_core.h.
+// GL lanes (a power of two, 4..64) of one wavefront decode one block; the wavefront's other
+// 64/GL groups decode other blocks in the same instruction stream.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lz4hip {
+
+template <int GL>
+struct GroupDev {
+  uint32_t l;  // lane index inside the group
+  __device__ __forceinline__ GroupDev() : l(threadIdx.x & (GL - 1)) {}
+
+  __device__ __forceinline__ static uint32_t ld8(const uint8_t* p) { return *p; }
+  __device__ __forceinline__ static uint32_t ld16(const uint8_t* p) { uint16_t v; __builtin_memcpy(&v, p, 2); return v; }
+  __device__ __forceinline__ static uint32_t ld32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+
+  // d[0..len) = s[0..len); wild: 4 bytes per lane, may read/write up to 3 bytes past len
+  __device__ __forceinline__ void copy_lits(uint8_t* d, const uint8_t* s, uint32_t len, bool wild) const {
+    if (wild) {
+      for (uint32_t i = l * 4u; i < len; i += 4u * GL) {
+        uint32_t v;
+        __builtin_memcpy(&v, s + i, 4);
+        __builtin_memcpy(d + i, &v, 4);
+      }
+    } else {
+      for (uint32_t i = l; i < len; i += GL) d[i] = s[i];
+    }
+  }
+
+  // dst[op+i] = dst[op-offset+i] for i in [0,len), byte-forward (overlap replicates the pattern)
+  __device__ __forceinline__ void copy_match(uint8_t* dst, uint32_t op, uint32_t offset, uint32_t len, bool wild) const {
+    uint8_t* d = dst + op;
+    const uint8_t* m = d - offset;
+    if (wild && offset >= 4u * GL) {
+      // one step stores [d+i0, d+i0+4*GL) and reads [m+i0, m+i0+4*GL) <= d+i0: only bytes stored by
+      // EARLIER instructions of this wave (or earlier sequences) are read
+      for (uint32_t i = l * 4u; i < len; i += 4u * GL) {
+        uint32_t v;
+        __builtin_memcpy(&v, m + i, 4);
+        __builtin_memcpy(d + i, &v, 4);
+      }
+    } else if (offset == 0) {
+      for (uint32_t i = l; i < len; i += GL) d[i] = 0;
+    } else {
+      // replicate: byte i comes from m[i mod offset], all of which precede the match
+      uint32_t r = l < offset ? l : l % offset;
+      const uint32_t stp = GL < offset ? (uint32_t)GL : (uint32_t)GL % offset;
+      for (uint32_t i = l; i < len; i += GL) {
+        d[i] = m[r];
+        r += stp;
+        if (r >= offset) r -= offset;
+      }
+    }
+  }
+};
+
+}  // namespace lz4hip

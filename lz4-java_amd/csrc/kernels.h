@@ -1,0 +1,22 @@
+// kernels.h -- host-callable launchers of the gfx950 kernels (kernels.hip).  All pointers are device
+// pointers; launches are asynchronous on `stream`.  Return value: hipError_t as int.
+#pragma once
+#include <stdint.h>
+
+namespace lz4hip {
+
+struct BatchArgs {
+  const uint8_t* src; const uint64_t* src_off; const int32_t* src_len;
+  uint8_t* dst; const uint64_t* dst_off; const int32_t* dst_cap;
+  int32_t* out; uint32_t n;
+};
+
+int launch_compress_fast(const BatchArgs& a, void* stream);
+// lanes_per_block: lanes of a wavefront that share one block in the decoder (4..64); 0 = default
+int launch_decompress(const BatchArgs& a, bool safe, int lanes_per_block, void* stream);
+int launch_xxh32(const uint8_t* buf, const uint64_t* off, const int32_t* len, uint32_t seed, uint32_t* out, uint32_t n, void* stream);
+int launch_xxh64(const uint8_t* buf, const uint64_t* off, const int32_t* len, uint64_t seed, uint64_t* out, uint32_t n, void* stream);
+int launch_gen_blocks(uint8_t* dst, uint64_t stride, int32_t block_len, uint64_t seed, uint64_t first_idx,
+                      uint32_t litmax, uint32_t win, uint32_t n_blocks, void* stream);
+
+}  // namespace lz4hip

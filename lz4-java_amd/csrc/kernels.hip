@@ -1,0 +1,154 @@
+// kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the LZ4 block engine.
+//
+//   compress_fast_kernel : one wavefront (= one 64-thread workgroup) per block, 32 KB LDS table of
+//                          {position, fingerprint} entries, algorithm in lz4_fast_core.h.
+//                          Bound: LDS/L2 latency of the serial parse chain (roofline: HBM, 1+1/ratio B/B).
+//   decode_kernel<GL>    : GL lanes per block, 64/GL blocks per wavefront, no LDS, algorithm in
+//                          lz4_decode_core.h.  Bound: HBM (reads C, writes N per block).
+//   xxh32/xxh64_kernel   : one thread per buffer, 16/32-byte loads (xxh_core.h). Bound: HBM (1 B/B).
+//   gen_blocks_kernel    : SURVEY.md App. F workload generator (setup only, never timed).
+// No MFMA anywhere: this is byte shuffling, not a contraction.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "kernels.h"
+#include "wave_dev.h"
+#include "group_dev.h"
+#include "lz4_fast_core.h"
+#include "lz4_decode_core.h"
+#include "xxh_core.h"
+
+namespace lz4hip {
+
+// ------------------------------------------------------------------------------------------------
+// fast compress
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void compress_fast_kernel(BatchArgs a) {
+  __shared__ __attribute__((aligned(16))) uint64_t table[4096];  // 32 KB: 8192 x u32 (byU16) or 4096 x u64 (byU32)
+  const uint32_t b = blockIdx.x;
+  const int32_t n = a.src_len[b];
+  const int32_t cap = a.dst_cap[b];
+  uint32_t r = 0;
+  if (n >= 0 && (uint32_t)n <= 0x7E000000u && cap >= 0) {
+    const uint8_t* s = a.src + a.src_off[b];
+    uint8_t* d = a.dst + a.dst_off[b];
+    WaveDev w(table);
+    if (n < 65547) {
+      FastCore<WaveDev, true> c(w, s, (uint32_t)n, d, (uint32_t)cap);
+      r = c.run();
+    } else {
+      FastCore<WaveDev, false> c(w, s, (uint32_t)n, d, (uint32_t)cap);
+      r = c.run();
+    }
+  }
+  if (threadIdx.x == 0) a.out[b] = (int32_t)r;
+}
+
+int launch_compress_fast(const BatchArgs& a, void* stream) {
+  if (a.n == 0) return 0;
+  hipLaunchKernelGGL(compress_fast_kernel, dim3(a.n), dim3(64), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// decode
+// ------------------------------------------------------------------------------------------------
+template <int GL, bool SAFE>
+__global__ __launch_bounds__(256) void decode_kernel(BatchArgs a) {
+  const uint32_t gid = (blockIdx.x * 256u + threadIdx.x) / GL;
+  if (gid >= a.n) return;  // a whole group leaves together
+  GroupDev<GL> g;
+  const int r = decode_block<GroupDev<GL>, SAFE>(g, a.src + a.src_off[gid], a.src_len[gid], a.dst + a.dst_off[gid], a.dst_cap[gid]);
+  if (g.l == 0) a.out[gid] = r;
+}
+
+template <int GL>
+static int launch_decode_gl(const BatchArgs& a, bool safe, hipStream_t st) {
+  const uint32_t per_wg = 256u / GL;
+  const uint32_t grid = (a.n + per_wg - 1u) / per_wg;
+  if (safe) hipLaunchKernelGGL((decode_kernel<GL, true>), dim3(grid), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((decode_kernel<GL, false>), dim3(grid), dim3(256), 0, st, a);
+  return (int)hipGetLastError();
+}
+
+int launch_decompress(const BatchArgs& a, bool safe, int lanes_per_block, void* stream) {
+  if (a.n == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  switch (lanes_per_block) {
+    case 4: return launch_decode_gl<4>(a, safe, st);
+    case 8: return launch_decode_gl<8>(a, safe, st);
+    case 32: return launch_decode_gl<32>(a, safe, st);
+    case 64: return launch_decode_gl<64>(a, safe, st);
+    case 0:
+    case 16:
+    default: return launch_decode_gl<16>(a, safe, st);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// xxhash
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void xxh32_kernel(const uint8_t* buf, const uint64_t* off, const int32_t* len, uint32_t seed, uint32_t* out, uint32_t n) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const int32_t l = len[i];
+  out[i] = xxh32_one(buf + off[i], l < 0 ? 0u : (uint32_t)l, seed);
+}
+__global__ __launch_bounds__(256) void xxh64_kernel(const uint8_t* buf, const uint64_t* off, const int32_t* len, uint64_t seed, uint64_t* out, uint32_t n) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const int32_t l = len[i];
+  out[i] = xxh64_one(buf + off[i], l < 0 ? 0u : (uint32_t)l, seed);
+}
+int launch_xxh32(const uint8_t* buf, const uint64_t* off, const int32_t* len, uint32_t seed, uint32_t* out, uint32_t n, void* stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(xxh32_kernel, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, buf, off, len, seed, out, n);
+  return (int)hipGetLastError();
+}
+int launch_xxh64(const uint8_t* buf, const uint64_t* off, const int32_t* len, uint64_t seed, uint64_t* out, uint32_t n, void* stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(xxh64_kernel, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, buf, off, len, seed, out, n);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// synthetic workload -- one thread per block, setup only
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix64(uint64_t& s) {
+  uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(64) void gen_blocks_kernel(uint8_t* dst, uint64_t stride, int32_t block_len, uint64_t seed, uint64_t first_idx,
+                                                        uint32_t litmax, uint32_t win, uint32_t n_blocks) {
+  const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+  if (i >= n_blocks) return;
+  uint8_t* out = dst + (uint64_t)i * stride;
+  const int64_t n = block_len;
+  uint64_t s = seed ^ ((first_idx + i) * 0x9E3779B97F4A7C15ull);
+  int64_t len = 0;
+  while (len < n) {
+    uint32_t ll = 1u + (uint32_t)(splitmix64(s) % litmax);
+    while (ll > 0) {
+      const uint64_t w = splitmix64(s);
+      const uint32_t k = ll < 8u ? ll : 8u;
+      for (uint32_t j = 0; j < k; j++) { if (len < n) out[len] = (uint8_t)(w >> (8u * j)); len++; }
+      ll -= k;
+    }
+    if (len >= 16 && len < n) {
+      const uint32_t ml = 4u + (uint32_t)(splitmix64(s) % 61u);
+      const uint64_t lim = (uint64_t)len < (uint64_t)win ? (uint64_t)len : (uint64_t)win;
+      const uint64_t off = 1u + splitmix64(s) % lim;
+      for (uint32_t j = 0; j < ml; j++) { if (len < n) out[len] = out[len - (int64_t)off]; len++; }
+    }
+  }
+}
+int launch_gen_blocks(uint8_t* dst, uint64_t stride, int32_t block_len, uint64_t seed, uint64_t first_idx,
+                      uint32_t litmax, uint32_t win, uint32_t n_blocks, void* stream) {
+  if (n_blocks == 0) return 0;
+  hipLaunchKernelGGL(gen_blocks_kernel, dim3((n_blocks + 63u) / 64u), dim3(64), 0, (hipStream_t)stream,
+                     dst, stride, block_len, seed, first_idx, litmax, win, n_blocks);
+  return (int)hipGetLastError();
+}
+
+}  // namespace lz4hip

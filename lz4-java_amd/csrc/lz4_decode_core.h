@@ -1,0 +1,208 @@
+// lz4_decode_core.h -- LZ4 block decoder for a small lane group (G lanes of a wavefront per block).
+//
+// Replaces, for the "HIP" family, LZ4_decompress_safe (/root/reference/src/jni/net_jpountz_lz4_LZ4JNI.c:216,
+// reached from LZ4JNISafeDecompressor.java:34-43) and LZ4_decompress_fast (LZ4JNI.c:169,
+// LZ4JNIFastDecompressor.java:35-44); SURVEY.md App. C.  Return values -- decoded size / bytes
+// consumed, or -(input position)-1 -- equal liblz4 1.9.3's on valid AND malformed input: liblz4
+// decodes in three tiers (a fast loop while >= 64 output bytes remain, a two-stage shortcut and a
+// fully checked path) and which malformed streams are accepted depends on the tier, so the tiers'
+// checks are kept.  What is different is the execution shape: every lane of the group runs the
+// (cheap, serial) token parse redundantly -- no cross-lane traffic, parse loads are broadcast
+// loads -- and the lanes split every literal / match copy between them.  A wavefront holds 64/G
+// independent blocks; thousands of groups per CU-set keep HBM busy while each parse chain waits.
+//
+// Match copies read the block's own output from global memory: a wavefront's vector memory
+// operations execute in order, so bytes stored by an earlier instruction of the same wave are
+// visible to its later loads (same CU L1, no fence needed).  Within ONE copy instruction lanes
+// never read bytes written by that instruction: overlapping matches (offset < bytes per step) use
+// the replicate path, which only reads bytes that precede the match.
+//
+// Backend `Grp` (group_dev.h on the GPU, tests/hostsim/group_host.h in the CPU test-suite):
+//   ld8/ld16/ld32(p)                        uniform loads (all lanes of the group, same address)
+//   copy_lits(d, s, len, wild)               d[0..len) = s[0..len); wild: may touch <= 3 bytes past len on both sides
+//   copy_match(dst, op, offset, len, wild)   dst[op+i] = dst[op-offset+i], byte-forward semantics;
+//                                            offset 0 zero-fills (liblz4 1.9.3 behaviour)
+#pragma once
+#include <stdint.h>
+
+#ifndef LZ4HIP_DEV
+#if defined(__HIPCC__)
+#define LZ4HIP_DEV __device__ __forceinline__
+#else
+#define LZ4HIP_DEV inline
+#endif
+#endif
+
+namespace lz4hip {
+
+// SAFE: LZ4_decompress_safe(src, dst, src_size, out_size) -> decoded size or negative.
+// !SAFE: LZ4_decompress_fast(src, dst, out_size) -> bytes consumed or negative; `src_size` is then
+//        the readable capacity of the source slot and is never exceeded (liblz4 itself trusts the
+//        stream blindly; results on valid streams are identical).
+template <class Grp, bool SAFE>
+LZ4HIP_DEV int decode_block(Grp& g, const uint8_t* src, int src_size, uint8_t* dst, int out_size) {
+  int ip = 0, op = 0;
+  const int iend = src_size, oend = out_size;  // iend: real end (SAFE) / read bound (!SAFE)
+  const int shortiend = iend - (SAFE ? 14 : 8) - 2;
+  const int shortoend = oend - (SAFE ? 14 : 8) - 18;
+  uint32_t token;
+  int length, offset, cpy;
+
+#define LZ4HIP_LEN_CAP 0x7F000000  /* a run this long can never fit; stops 32-bit wrap on absurd input */
+#define LZ4HIP_NEED_IN(k) do { if (!SAFE && ip + (int)(k) > iend) goto output_error; } while (0)
+  if (out_size < 0 || src_size < 0) return -1;
+  if (SAFE && out_size == 0) return (src_size == 1 && g.ld8(src) == 0) ? 0 : -1;
+  if (!SAFE && out_size == 0) { LZ4HIP_NEED_IN(1); return g.ld8(src) == 0 ? 1 : -1; }
+  if (SAFE && src_size == 0) return -1;
+
+  if (oend - op >= 64) {
+    for (;;) {  // ---- tier 1: fast loop ----
+      uint32_t w4;  // token + next 3 bytes when they are readable
+      if (ip + 4 <= iend) { w4 = g.ld32(src + ip); } else { LZ4HIP_NEED_IN(1); w4 = g.ld8(src + ip); }
+      token = w4 & 255u;
+      ip++;
+      length = (int)(token >> 4);
+      bool wild;
+      if (length == 15) {
+        // read_variable_length(limit iend-15, initial+loop checks when SAFE); a limit hit inside
+        // the loop is not an error in liblz4 1.9.3: the partial length is used
+        if (SAFE && ip >= iend - 15) goto output_error;
+        uint32_t s = (w4 >> 8) & 255u;  // readable: ip+4 <= iend held (SAFE: ip < iend-15; !SAFE: checked next)
+        if (!SAFE && ip + 3 > iend) { LZ4HIP_NEED_IN(1); s = g.ld8(src + ip); }
+        for (;;) {
+          ip++;
+          length += (int)s;
+          if (SAFE && ip >= iend - 15) break;
+          if (s != 255u) break;
+          LZ4HIP_NEED_IN(1);
+          s = g.ld8(src + ip);
+          if (length > LZ4HIP_LEN_CAP) goto output_error;
+        }
+        if ((uint32_t)length > (uint32_t)(oend - op)) goto output_error;  // cannot fit: every tier rejects it at this ip
+        cpy = op + length;
+        if (SAFE) { if (cpy > oend - 32 || ip + length > iend - 32) goto safe_literal_copy; }
+        else      { if (cpy > oend - 8) goto safe_literal_copy; }
+        wild = SAFE || (ip + length + 4 <= iend);
+      } else {
+        cpy = op + length;
+        if (SAFE && ip > iend - (16 + 1)) goto safe_literal_copy;
+        wild = SAFE || (ip + length + 4 <= iend);
+      }
+      LZ4HIP_NEED_IN(length);
+      g.copy_lits(dst + op, src + ip, (uint32_t)length, wild);
+      ip += length;
+      op = cpy;
+
+      LZ4HIP_NEED_IN(2);
+      if (ip + 4 <= iend) w4 = g.ld32(src + ip); else w4 = g.ld16(src + ip);
+      offset = (int)(w4 & 0xFFFFu);
+      ip += 2;
+      length = (int)(token & 15u);
+      if (length == 15) {
+        if (SAFE && offset > op) goto output_error;
+        uint32_t s = (w4 >> 16) & 255u;
+        if (ip + 2 > iend) { LZ4HIP_NEED_IN(1); s = g.ld8(src + ip); }  // (SAFE: error follows below anyway)
+        for (;;) {  // read_variable_length(limit iend-4, loop check when SAFE)
+          ip++;
+          length += (int)s;
+          if (SAFE && ip >= iend - 4) goto output_error;
+          if (s != 255u) break;
+          LZ4HIP_NEED_IN(1);
+          s = g.ld8(src + ip);
+          if (length > LZ4HIP_LEN_CAP) goto output_error;
+        }
+        if ((uint32_t)length > (uint32_t)(oend - op)) goto output_error;  // (offset <= op was checked / is checked first by liblz4 too)
+        length += 4;
+        if (op + length >= oend - 64) goto safe_match_copy;
+      } else {
+        length += 4;
+        if (op + length >= oend - 64) goto safe_match_copy;
+      }
+      if (offset > op) goto output_error;  // liblz4 checks this only when SAFE; the HIP engine never reads before dst
+      g.copy_match(dst, (uint32_t)op, (uint32_t)offset, (uint32_t)length, true);
+      op += length;
+    }
+  }
+
+  for (;;) {  // ---- tiers 2+3: shortcut and fully checked path ----
+    LZ4HIP_NEED_IN(1);
+    token = g.ld8(src + ip);
+    ip++;
+    length = (int)(token >> 4);
+    if ((SAFE ? length != 15 : length <= 8) && (SAFE ? ip < shortiend : true) && op <= shortoend) {
+      LZ4HIP_NEED_IN(length + 2);
+      g.copy_lits(dst + op, src + ip, (uint32_t)length, false);
+      op += length;
+      ip += length;
+      length = (int)(token & 15u);
+      offset = (int)g.ld16(src + ip);
+      ip += 2;
+      if (length != 15 && offset >= 8 && offset <= op) {
+        g.copy_match(dst, (uint32_t)op, (uint32_t)offset, (uint32_t)(length + 4), false);
+        op += length + 4;
+        continue;
+      }
+      if (!SAFE && length != 15 && offset >= 8 && offset > op) goto output_error;  // liblz4 would read before dst
+      goto copy_match_label;
+    }
+    if (length == 15) {
+      if (SAFE && ip >= iend - 15) goto output_error;
+      for (;;) {
+        LZ4HIP_NEED_IN(1);
+        const uint32_t s = g.ld8(src + ip);
+        ip++;
+        length += (int)s;
+        if (length > LZ4HIP_LEN_CAP) goto output_error;
+        if (SAFE && ip >= iend - 15) break;
+        if (s != 255u) break;
+      }
+      if ((uint32_t)length > (uint32_t)(oend - op)) goto output_error;
+    }
+    cpy = op + length;
+  safe_literal_copy:
+    if ((SAFE && (cpy > oend - 12 || ip + length > iend - (2 + 1 + 5))) || (!SAFE && cpy > oend - 8)) {
+      if (!SAFE && cpy != oend) goto output_error;
+      if (SAFE && (ip + length != iend || cpy > oend)) goto output_error;
+      LZ4HIP_NEED_IN(length);
+      g.copy_lits(dst + op, src + ip, (uint32_t)length, false);
+      ip += length;
+      op += length;
+      break;
+    }
+    LZ4HIP_NEED_IN(length);
+    g.copy_lits(dst + op, src + ip, (uint32_t)length, false);
+    ip += length;
+    op = cpy;
+    LZ4HIP_NEED_IN(2);
+    offset = (int)g.ld16(src + ip);
+    ip += 2;
+    length = (int)(token & 15u);
+  copy_match_label:
+    if (length == 15) {
+      for (;;) {
+        LZ4HIP_NEED_IN(1);
+        const uint32_t s = g.ld8(src + ip);
+        ip++;
+        length += (int)s;
+        if (SAFE && ip >= iend - 4) goto output_error;
+        if (length > LZ4HIP_LEN_CAP) goto output_error;
+        if (s != 255u) break;
+      }
+      if (offset <= op && (uint32_t)length > (uint32_t)(oend - op)) goto output_error;
+    }
+    length += 4;
+  safe_match_copy:
+    if (offset > op) goto output_error;
+    cpy = op + length;
+    if (cpy > oend - 5) goto output_error;  // the last 5 bytes are always literals
+    g.copy_match(dst, (uint32_t)op, (uint32_t)offset, (uint32_t)length, false);
+    op = cpy;
+  }
+  return SAFE ? op : ip;
+output_error:
+  return -ip - 1;
+#undef LZ4HIP_NEED_IN
+#undef LZ4HIP_LEN_CAP
+}
+
+}  // namespace lz4hip

@@ -1,0 +1,102 @@
+/*
+ * oracle/cpu_bench.c -- TEST/BENCH INFRASTRUCTURE ONLY: the CPU baseline that bench.py reports next
+ * to the GPU number ("cpu_baseline").  Times, on THIS box's host cores, exactly the functions the
+ * reference's JNI shim calls (LZ4_compress_default, LZ4_decompress_safe, LZ4_decompress_fast:
+ * /root/reference/src/jni/net_jpountz_lz4_LZ4JNI.c:75,216,169) on the same synthetic blocks the GPU
+ * processes.  kind "reference" = dlopen of the reference's own liblz4 1.9.3
+ * (oracle/_ref/liblz4-java.so); kind "port" = the C restatement in lz4_oracle.c.  No JVM exists in
+ * this image, so JNI call overhead (array pinning + one call, sub-microsecond vs >= 25 us of work per
+ * 64 KiB block) is not included.
+ *
+ *   cpu_bench <reference|port> <lib.so> <liblz4oracle.so> <n_blocks> <block_size> <threads> <reps> <first_idx> <litmax> <win>
+ * prints one JSON line.
+ */
+#define _GNU_SOURCE
+#include <dlfcn.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+typedef int (*compress_fn)(const char*, char*, int, int);
+typedef int (*dsafe_fn)(const char*, char*, int, int);
+typedef int (*dfast_fn)(const char*, char*, int);
+typedef int (*p_compress_fn)(const uint8_t*, int, uint8_t*, int);
+typedef int (*p_dsafe_fn)(const uint8_t*, int, uint8_t*, int);
+typedef int (*p_dfast_fn)(const uint8_t*, uint8_t*, int);
+typedef void (*gen_fn)(uint8_t*, int64_t, uint64_t, uint64_t, uint32_t, uint32_t);
+
+static int is_ref;
+static compress_fn r_c; static dsafe_fn r_ds; static dfast_fn r_df;
+static p_compress_fn p_c; static p_dsafe_fn p_ds; static p_dfast_fn p_df;
+static gen_fn gen;
+static int n_blocks, block_size, n_threads, bound;
+static uint64_t first_idx; static uint32_t litmax, win;
+static uint8_t *src, *comp, *back; static int* clen;
+static int phase;  /* 0 gen, 1 compress, 2 dsafe, 3 dfast */
+static volatile int bad = 0;
+
+static double now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+
+static void* worker(void* arg) {
+  long t = (long)arg;
+  int b0 = (int)((long long)n_blocks * t / n_threads), b1 = (int)((long long)n_blocks * (t + 1) / n_threads);
+  for (int i = b0; i < b1; i++) {
+    uint8_t* s = src + (size_t)i * block_size; uint8_t* c = comp + (size_t)i * bound; uint8_t* d = back + (size_t)i * block_size;
+    int r;
+    switch (phase) {
+      case 0: gen(s, block_size, 0x4C5A3447ull, first_idx + (uint64_t)i, litmax, win); break;
+      case 1: r = is_ref ? r_c((const char*)s, (char*)c, block_size, bound) : p_c(s, block_size, c, bound); clen[i] = r; if (r <= 0) bad = 1; break;
+      case 2: r = is_ref ? r_ds((const char*)c, (char*)d, clen[i], block_size) : p_ds(c, clen[i], d, block_size); if (r != block_size) bad = 1; break;
+      case 3: r = is_ref ? r_df((const char*)c, (char*)d, block_size) : p_df(c, d, block_size); if (r != clen[i]) bad = 1; break;
+    }
+  }
+  return NULL;
+}
+
+static double run_phase(int ph) {
+  pthread_t th[256];
+  phase = ph;
+  double t0 = now();
+  for (long t = 0; t < n_threads; t++) pthread_create(&th[t], NULL, worker, (void*)t);
+  for (int t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
+  return now() - t0;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 10) { fprintf(stderr, "usage: cpu_bench <reference|port> <lib.so> <port.so> n_blocks block_size threads reps first_idx litmax win\n"); return 2; }
+  is_ref = strcmp(argv[1], "reference") == 0;
+  void* lib = dlopen(argv[2], RTLD_NOW | RTLD_LOCAL);
+  void* plib = dlopen(argv[3], RTLD_NOW | RTLD_LOCAL);
+  if (!lib || !plib) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 3; }
+  n_blocks = atoi(argv[4]); block_size = atoi(argv[5]); n_threads = atoi(argv[6]);
+  int reps = atoi(argv[7]); first_idx = strtoull(argv[8], 0, 10); litmax = (uint32_t)atoi(argv[9]); win = (uint32_t)atoi(argv[10]);
+  if (n_threads > 256) n_threads = 256;
+  gen = (gen_fn)dlsym(plib, "lz4o_gen_block");
+  if (is_ref) {
+    r_c = (compress_fn)dlsym(lib, "LZ4_compress_default"); r_ds = (dsafe_fn)dlsym(lib, "LZ4_decompress_safe"); r_df = (dfast_fn)dlsym(lib, "LZ4_decompress_fast");
+    if (!r_c || !r_ds || !r_df) { fprintf(stderr, "missing LZ4_* symbols\n"); return 4; }
+  } else {
+    p_c = (p_compress_fn)dlsym(lib, "lz4o_compress_fast"); p_ds = (p_dsafe_fn)dlsym(lib, "lz4o_decompress_safe"); p_df = (p_dfast_fn)dlsym(lib, "lz4o_decompress_fast");
+    if (!p_c || !p_ds || !p_df) { fprintf(stderr, "missing lz4o_* symbols\n"); return 4; }
+  }
+  bound = block_size + block_size / 255 + 16;
+  src = malloc((size_t)n_blocks * block_size); comp = malloc((size_t)n_blocks * bound); back = malloc((size_t)n_blocks * block_size);
+  clen = malloc(sizeof(int) * n_blocks);
+  if (!src || !comp || !back || !clen) { fprintf(stderr, "malloc\n"); return 5; }
+  run_phase(0);
+  double best[4] = {0, 1e30, 1e30, 1e30};
+  run_phase(1); run_phase(2);  /* warm-up */
+  for (int r = 0; r < reps; r++)
+    for (int ph = 1; ph <= 3; ph++) { double t = run_phase(ph); if (t < best[ph]) best[ph] = t; }
+  if (memcmp(src, back, (size_t)n_blocks * block_size) != 0) bad = 1;
+  long long csum = 0; for (int i = 0; i < n_blocks; i++) csum += clen[i];
+  double bytes = (double)n_blocks * block_size;
+  printf("{\"kind\": \"%s\", \"threads\": %d, \"n_blocks\": %d, \"block_size\": %d, \"ratio\": %.4f, \"ok\": %s, "
+         "\"compress_GBps\": %.4f, \"decompress_safe_GBps\": %.4f, \"decompress_fast_GBps\": %.4f, \"roundtrip_GBps\": %.4f}\n",
+         argv[1], n_threads, n_blocks, block_size, bytes / (double)csum, bad ? "false" : "true",
+         bytes / best[1] / 1e9, bytes / best[2] / 1e9, bytes / best[3] / 1e9, bytes / (best[1] + best[2]) / 1e9);
+  return bad ? 1 : 0;
+}

@@ -229,7 +229,10 @@ static int decode_generic(const uint8_t* src, int src_size, uint8_t* dst, int ou
         length += MINMATCH;
         if (op + length >= oend - FASTLOOP_SAFE_DISTANCE) goto safe_match_copy;
         if (!safe || offset <= op) {
-          if (offset >= 8) { copy_match(dst, op, offset, length); op += length; continue; }
+          if (offset >= 8) {
+            if (!safe && in_cap >= 0 && offset > op) goto output_error; /* bounded variant never reads before dst */
+            copy_match(dst, op, offset, length); op += length; continue;
+          }
         }
       }
       if (safe && offset > op) goto output_error;

@@ -200,7 +200,8 @@ def gen_block(n, idx, seed=SEED, litmax=38, win=65535):
 
 def decompress_fast_bounded(src, src_cap, dst_len):
     port()
-    p, _k = _buf(bytes(src) + b"\0" * 8)
+    p, _k = _buf(bytes(src) + b"\0" * (8 + max(0, src_cap - len(src))))
     out = (C.c_uint8 * (dst_len + 8))()
+    C.memset(out, 0xA5, dst_len + 8)
     r = _PORT._l.lz4o_decompress_fast_bounded(p, src_cap, C.cast(out, _u8p), dst_len)
     return r, bytes(out[:dst_len])

@@ -1,0 +1,74 @@
+// tests/hostsim/group_host.h -- TEST INFRASTRUCTURE ONLY.
+// Lock-step simulator of a GL-lane group for lz4_decode_core.h: every "instruction" of a copy loop
+// performs all lanes' loads first and all lanes' stores afterwards (SIMT order), with the same
+// chunking, wild over-copy and replicate logic as lz4-java_amd/csrc/group_dev.h, and records any
+// access outside the source / destination slots.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+namespace hostsim {
+
+struct GroupHost {
+  int GL;
+  const uint8_t* src_lo; const uint8_t* src_hi;
+  uint8_t* dst_lo; uint8_t* dst_hi;
+  bool oob = false;
+  GroupHost(int gl, const uint8_t* s, long n, uint8_t* d, long cap) : GL(gl), src_lo(s), src_hi(s + n), dst_lo(d), dst_hi(d + cap) {}
+
+  bool rd_ok(const uint8_t* p, long k) {
+    bool in_src = p >= src_lo && p + k <= src_hi, in_dst = p >= dst_lo && p + k <= dst_hi;
+    if (!in_src && !in_dst) { oob = true; return false; }
+    return true;
+  }
+  bool wr_ok(uint8_t* p, long k) { if (p < dst_lo || p + k > dst_hi) { oob = true; return false; } return true; }
+
+  uint32_t ld8(const uint8_t* p) { return rd_ok(p, 1) ? *p : 0; }
+  uint32_t ld16(const uint8_t* p) { uint16_t v = 0; if (rd_ok(p, 2)) memcpy(&v, p, 2); return v; }
+  uint32_t ld32(const uint8_t* p) { uint32_t v = 0; if (rd_ok(p, 4)) memcpy(&v, p, 4); return v; }
+
+  void copy_lits(uint8_t* d, const uint8_t* s, uint32_t len, bool wild) {
+    if (wild) {
+      for (uint32_t base = 0; base < len; base += 4u * GL) {
+        uint32_t v[64]; bool act[64];
+        for (int l = 0; l < GL; l++) { uint32_t i = base + 4u * l; act[l] = i < len; v[l] = 0; if (act[l] && rd_ok(s + i, 4)) memcpy(&v[l], s + i, 4); }
+        for (int l = 0; l < GL; l++) { uint32_t i = base + 4u * l; if (act[l] && wr_ok(d + i, 4)) memcpy(d + i, &v[l], 4); }
+      }
+    } else {
+      for (uint32_t base = 0; base < len; base += GL) {
+        uint8_t v[64]; bool act[64];
+        for (int l = 0; l < GL; l++) { uint32_t i = base + l; act[l] = i < len; v[l] = 0; if (act[l] && rd_ok(s + i, 1)) v[l] = s[i]; }
+        for (int l = 0; l < GL; l++) { uint32_t i = base + l; if (act[l] && wr_ok(d + i, 1)) d[i] = v[l]; }
+      }
+    }
+  }
+
+  void copy_match(uint8_t* dst, uint32_t op, uint32_t offset, uint32_t len, bool wild) {
+    uint8_t* d = dst + op;
+    const uint8_t* m = d - offset;
+    if (wild && offset >= 4u * GL) {
+      for (uint32_t base = 0; base < len; base += 4u * GL) {
+        uint32_t v[64]; bool act[64];
+        for (int l = 0; l < GL; l++) { uint32_t i = base + 4u * l; act[l] = i < len; v[l] = 0; if (act[l] && rd_ok(m + i, 4)) memcpy(&v[l], m + i, 4); }
+        for (int l = 0; l < GL; l++) { uint32_t i = base + 4u * l; if (act[l] && wr_ok(d + i, 4)) memcpy(d + i, &v[l], 4); }
+      }
+    } else if (offset == 0) {
+      for (uint32_t i = 0; i < len; i++) if (wr_ok(d + i, 1)) d[i] = 0;
+    } else {
+      uint32_t r[64];
+      for (int l = 0; l < GL; l++) r[l] = (uint32_t)l < offset ? (uint32_t)l : (uint32_t)l % offset;
+      const uint32_t stp = (uint32_t)GL < offset ? (uint32_t)GL : (uint32_t)GL % offset;
+      for (uint32_t base = 0; base < len; base += GL) {
+        uint8_t v[64]; bool act[64];
+        for (int l = 0; l < GL; l++) { uint32_t i = base + l; act[l] = i < len; v[l] = 0; if (act[l] && rd_ok(m + r[l], 1)) v[l] = m[r[l]]; }
+        for (int l = 0; l < GL; l++) {
+          uint32_t i = base + l;
+          if (act[l] && wr_ok(d + i, 1)) d[i] = v[l];
+          r[l] += stp; if (r[l] >= offset) r[l] -= offset;
+        }
+      }
+    }
+  }
+};
+
+}  // namespace hostsim

@@ -6,6 +6,8 @@
 #include <stdlib.h>
 #include "../../lz4-java_amd/csrc/lz4_fast_core.h"
 #include "wave_host.h"
+#include "../../lz4-java_amd/csrc/lz4_decode_core.h"
+#include "group_host.h"
 
 extern "C" {
 
@@ -28,6 +30,16 @@ int sim_compress_fast(const uint8_t* src, int n, uint8_t* dst, int cap, uint64_t
   if (stats4) { stats4[0] = st.steps; stats4[1] = st.slow_steps; stats4[2] = st.false_pos; stats4[3] = st.sequences; }
   if (w.oob) return -1000;
   return (int)r;
+}
+
+// safe != 0: (src_size = compressed length) -> decoded size; safe == 0: (src_size = readable
+// capacity) -> bytes consumed.  `gl` = lanes per group (4..64).  -1000000 = out-of-slot access.
+int sim_decompress(const uint8_t* src, int src_size, uint8_t* dst, int out_size, int safe, int gl) {
+  hostsim::GroupHost g(gl, src, src_size, dst, out_size);
+  int r = safe ? lz4hip::decode_block<hostsim::GroupHost, true>(g, src, src_size, dst, out_size)
+               : lz4hip::decode_block<hostsim::GroupHost, false>(g, src, src_size, dst, out_size);
+  if (g.oob) return -1000000;
+  return r;
 }
 
 }  // extern "C"

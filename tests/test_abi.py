@@ -1,0 +1,83 @@
+"""No-GPU checks of the drop-in boundary: the C-ABI library builds/loads, exports every symbol that
+include/lz4hip.h declares, and FAILS LOUDLY (no CPU fallback) when there is no device."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+
+def header_symbols():
+    h = open(os.path.join(ROOT, "include", "lz4hip.h")).read()
+    h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
+    return sorted(set(re.findall(r"\b(lz4hip_[a-z0-9_]+)\s*\(", h)))
+
+
+def test_library_exports_every_declared_symbol(amd):
+    so = os.path.join(ROOT, "lz4-java_amd", "liblz4hip.so")
+    assert os.path.exists(so), "run lz4-java_amd/build.sh (or __graft_entry__.build())"
+    exported = set(re.findall(r" T (lz4hip_\w+)", subprocess.check_output(["nm", "-D", so]).decode()))
+    declared = header_symbols()
+    assert len(declared) >= 26
+    assert set(declared) <= exported, sorted(set(declared) - exported)
+    assert set(declared) == set(amd.C_ABI), "python binding table out of sync with the header"
+    l = amd.lib()
+    for s in declared:
+        assert hasattr(l, s)
+    assert l.lz4hip_version() == 100
+
+
+def test_no_oracle_in_product():
+    """the product must not reference the oracle (test infrastructure) anywhere"""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "lz4-java_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp", ".sh", ".java", ".c")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "liblz4oracle" not in txt and "lz4o_" not in txt, f
+    so = os.path.join(ROOT, "lz4-java_amd", "liblz4hip.so")
+    deps = subprocess.check_output(["readelf", "-d", so]).decode()
+    assert "lz4oracle" not in deps and "liblz4.so" not in deps and "lz4-java" not in deps
+
+
+def test_compress_bound(amd, golden):
+    l = amd.lib()
+    for n, b in golden["compress_bound"].items():
+        assert l.lz4hip_compress_bound(int(n)) == b           # LZ4Test.java:80-87 testMaxCompressedLength
+    assert l.lz4hip_compress_bound(-1) == 0
+    assert amd.maxCompressedLength(65536) == 65809
+    with pytest.raises(ValueError):
+        amd.maxCompressedLength(-1)
+    with pytest.raises(ValueError):
+        amd.maxCompressedLength(0x7E000000)                    # LZ4Utils.java:37-39
+
+
+def test_range_checks_before_native(amd):
+    """argument checking order of LZ4JNICompressor.java:47-49 / SafeUtils.java:24-42 (no GPU needed:
+    the checks fire before the native call)"""
+    c = amd.LZ4HIPCompressor()
+    with pytest.raises(IndexError):
+        c.compress(b"abcdef", 2, 10, bytearray(100), 0, 100)
+    with pytest.raises(ValueError):
+        c.compress(b"abcdef", 0, -1, bytearray(100), 0, 100)
+    with pytest.raises(IndexError):
+        c.compress(b"abcdef", 0, 6, bytearray(10), 5, 10)
+    with pytest.raises(amd.ReadOnlyBufferException):
+        c.compress(b"abcdef", 0, 6, b"\0" * 100, 0, 100)      # LZ4Test.java:421-454
+    d = amd.LZ4SafeDecompressor()
+    with pytest.raises(IndexError):
+        d.decompress(b"abc", 1, 5, bytearray(10), 0, 10)
+    with pytest.raises(IndexError):
+        amd.XXHash32().hash(b"abc", 2, 5, 0)
+
+
+def test_fails_loudly_without_gpu(amd):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(amd.LZ4HIPError):
+        amd.LZ4HIPCompressor().compress(b"hello hello hello hello")
+    with pytest.raises(amd.LZ4HIPError):
+        amd.LZ4Factory.hipInstance()
+    assert amd.lib().lz4hip_device_count() == 0

@@ -1,0 +1,269 @@
+"""Parity of the HIP engine against the oracle, through the C ABI (-m gpu).
+
+Structure follows the reference's LZ4Test.java: golden/known-answer vectors, the compressor x
+decompressor cross-product (here: HIP x reference-liblz4), dest-too-small and malformed-input
+behaviour, fixtures (Calgary slices, all-equal, max-distance, random), plus batch / device entry
+points the reference does not have.  Bit-exact everywhere: compressed bytes, decoded bytes, return
+codes."""
+import random
+
+import pytest
+
+from conftest import rnd_inputs, sha
+
+pytestmark = pytest.mark.gpu
+
+
+def pack(blocks, caps):
+    src = b"".join(blocks)
+    so, sl, do, p, q = [], [], [], 0, 0
+    for b, c in zip(blocks, caps):
+        so.append(p); sl.append(len(b)); do.append(q)
+        p += len(b); q += c
+    return src, so, sl, bytearray(max(q, 1)), do
+
+
+def gpu_compress_many(amd, blocks, caps):
+    src, so, sl, dst, do = pack(blocks, caps)
+    out = amd.LZ4HIPBatch.compress(src, so, sl, dst, do, list(caps))
+    return [(r, bytes(dst[o:o + max(r, 0)])) for r, o in zip(out, do)]
+
+
+def gpu_decode_safe_many(amd, streams, caps):
+    src, so, sl, dst, do = pack(streams, caps)
+    for i in range(len(dst)):
+        pass
+    dst[:] = b"\xA5" * len(dst)
+    out = amd.LZ4HIPBatch.decompressSafe(src, so, sl, dst, do, list(caps))
+    return [(r, bytes(dst[o:o + c])) for r, o, c in zip(out, do, caps)]
+
+
+def test_factory_selftest_and_known_answers(amd):
+    f = amd.LZ4Factory.hipInstance()                       # runs LZ4Factory.java:204-220's round trip
+    c = f.fastCompressor().compress(b"abcd      abcdefghij")
+    assert c.hex() == "5161626364200100a06162636465666768696a"
+    assert f.fastCompressor().compress(b"12345345234572").hex() == "e03132333435333435323334353732"
+    assert f.safeDecompressor().decompress(c, 20) == b"abcd      abcdefghij"
+    assert f.fastDecompressor().decompress(c, 20) == b"abcd      abcdefghij"
+    assert f.fastCompressor().compress(b"") == b"\x00"     # LZ4Test.java:111-114 testEmpty
+    assert f.safeDecompressor().decompress(b"\x00", 0) == b""
+    assert f.fastDecompressor().decompress(b"\x00", 0) == b""
+
+
+def test_golden_table_gpu(amd, golden, corpus, ref):
+    names = list(corpus)
+    blocks = [corpus[n] for n in names]
+    res = gpu_compress_many(amd, blocks, [ref.compress_bound(len(b)) for b in blocks])
+    for n, b, (r, c) in zip(names, blocks, res):
+        g = golden["inputs"][n]
+        assert (r, sha(c)) == (g["fast_size"], g["fast_sha256"]), n
+    # 4x4 cross product (LZ4Test.java:312-324): HIP->reference, reference->HIP, HIP->HIP
+    streams = [c for _, c in res]
+    for b, c in zip(blocks, streams):
+        assert ref.decompress_safe(c, len(b)) == b
+    dec = gpu_decode_safe_many(amd, [ref.compress_fast(b) for b in blocks], [len(b) for b in blocks])
+    for b, (r, d) in zip(blocks, dec):
+        assert r == len(b) and d == b
+    src, so, sl, dst, do = pack(streams, [len(b) for b in blocks])
+    out = amd.LZ4HIPBatch.decompressFast(src, so, sl, dst, do, [len(b) for b in blocks])
+    for b, c, r, o in zip(blocks, streams, out, do):
+        assert r == len(c) and bytes(dst[o:o + len(b)]) == b
+
+
+def test_compress_fuzz_bit_exact(amd, ref, O, corpus):
+    rng = random.Random(101)
+    blocks, caps = [], []
+    for v in rnd_inputs(O, corpus, 41, 1500):
+        full = ref.compress_bound(len(v))
+        er, _ = ref.compress_fast_raw(v, full)
+        for cap in (full, max(0, er + rng.choice([-1, 0, 1, 2, -5, 5, -20, 20])), rng.randrange(0, full + 1)):
+            blocks.append(v); caps.append(cap)
+    res = gpu_compress_many(amd, blocks, caps)
+    for v, cap, (r, c) in zip(blocks, caps, res):
+        er, eb = ref.compress_fast_raw(v, cap)
+        assert r == er and (er <= 0 or c == eb), (len(v), cap, r, er)
+
+
+def test_fixtures_like_lz4test(amd, ref):
+    """LZ4Test.java:456-485: testAllEqual, testMaxDistance, testRandomData shapes"""
+    rng = random.Random(5)
+    blocks = [bytes([rng.randrange(256)]) * n for n in (0, 1, 4, 13, 100, 4096, 65535, 65536, 100000)]
+    for ln in (1 << 17, (1 << 17) + 12345):                   # repeat at distance 65535
+        buf = bytearray(rng.randbytes(ln))
+        for i in range(65535, ln):
+            if rng.random() < 0.5:
+                buf[i] = buf[i - 65535]
+        blocks.append(bytes(buf))
+    for n in (100, 5000, 70000, 300000):                       # alphabet 1..15
+        k = rng.randrange(1, 16)
+        blocks.append(bytes(rng.randrange(k) for _ in range(n)))
+    res = gpu_compress_many(amd, blocks, [ref.compress_bound(len(b)) for b in blocks])
+    for b, (r, c) in zip(blocks, res):
+        assert c == ref.compress_fast(b), len(b)
+    dec = gpu_decode_safe_many(amd, [c for _, c in res], [len(b) for b in blocks])
+    for b, (r, d) in zip(blocks, dec):
+        assert r == len(b) and d == b
+
+
+def test_decode_fuzz_bit_exact(amd, ref, O, corpus):
+    """return codes and bytes of LZ4_decompress_safe on valid / truncated / extended / corrupted / random
+    streams and wrong capacities (LZ4Test.java:188-255, :350-419)"""
+    rng = random.Random(77)
+    streams, caps = [], []
+    for v in rnd_inputs(O, corpus, 43, 4000, max_n=30000):
+        c = bytearray(ref.compress_fast(v))
+        mode, cap = rng.randrange(6), len(v)
+        if mode == 1:
+            cap = max(0, len(v) + rng.choice([-1, 1, -5, 5, -12, 12, -33, 33, 64, 100]))
+        elif mode == 2 and c:
+            for _ in range(rng.randrange(1, 4)):
+                c[rng.randrange(len(c))] = rng.randrange(256)
+        elif mode == 3 and len(c) > 1:
+            c = c[:rng.randrange(1, len(c))]
+        elif mode == 4:
+            c = c + rng.randbytes(rng.randrange(1, 20))
+        elif mode == 5:
+            c, cap = bytearray(rng.randbytes(rng.randrange(1, 40))), rng.randrange(0, 200)
+        streams.append(bytes(c)); caps.append(cap)
+    for lanes in (0, 4, 64):
+        amd.set_option("decode_lanes", lanes)
+        res = gpu_decode_safe_many(amd, streams, caps)
+        for c, cap, (r, d) in zip(streams, caps, res):
+            er, ed = ref.decompress_safe_raw(c, cap)
+            assert r == er, (lanes, len(c), cap, r, er, c[:24].hex())
+            if er >= 0:
+                assert d[:er] == ed[:er]
+    amd.set_option("decode_lanes", 0)
+    # fast decoder: bounded-input semantics defined by the oracle port; equal to liblz4 on valid streams
+    src, so, sl, dst, do = pack(streams, caps)
+    out = amd.LZ4HIPBatch.decompressFast(src, so, sl, dst, do, caps)
+    for c, cap, r, o in zip(streams, caps, out, do):
+        er, ed = O.decompress_fast_bounded(c, len(c), cap)
+        assert r == er, (len(c), cap, r, er)
+        if er >= 0:
+            assert bytes(dst[o:o + cap]) == ed[:cap]
+
+
+def test_malformed_vectors_gpu(amd, golden):
+    """LZ4Test.java:350-419 -- exact oracle return codes, not just 'throws'"""
+    vecs = golden["malformed"]
+    res = gpu_decode_safe_many(amd, [bytes.fromhex(v["hex"]) for v in vecs], [v["safe_cap"] for v in vecs])
+    for v, (r, d) in zip(vecs, res):
+        assert r == v["safe_ret"]
+        if r >= 0:
+            assert d[:r].hex() == v["safe_out_hex"]
+    dec = amd.LZ4SafeDecompressor()
+    with pytest.raises(amd.LZ4Exception):
+        dec.decompress(bytes([96, 42, 43, 44, 45, 46, 47, 5, 0]), 0, 9, bytearray(20), 0, 20)
+    assert dec.decompress(bytes([16, 42, 0, 0, 128] + [42] * 8), 0, 13, bytearray(20), 0, 20) == 13  # must not throw or hang
+
+
+def test_dest_too_small(amd, ref, corpus):
+    """LZ4Test.java:188-226"""
+    data = corpus["book1[:65536]"]
+    f = amd.LZ4Factory.hipInstance()
+    c = f.fastCompressor().compress(data)
+    with pytest.raises(amd.LZ4Exception):
+        f.fastCompressor().compress(data, 0, len(data), bytearray(len(c) - 1), 0, len(c) - 1)
+    for bad in (len(data) - 1, len(data) + 1):
+        with pytest.raises(amd.LZ4Exception):
+            f.fastDecompressor().decompress(c, 0, bytearray(bad), 0, bad)
+    with pytest.raises(amd.LZ4Exception):
+        f.safeDecompressor().decompress(c, 0, len(c), bytearray(len(data) - 1), 0, len(data) - 1)
+    out = bytearray(len(data) + 100)
+    assert f.safeDecompressor().decompress(c, 0, len(c), out, 0, len(out)) == len(data)
+    try:
+        f.safeDecompressor().decompress(c + b"\0", 0, len(c) + 1, bytearray(len(data)), 0, len(data))
+        assert False
+    except amd.LZ4Exception as e:
+        assert str(e) == "Error decoding offset %d of input buffer" % (-ref.decompress_safe_raw(c + b"\0", len(data))[0])
+
+
+def test_offsets_inside_bigger_buffers(amd, ref, corpus):
+    """srcOff/destOff handling (AbstractLZ4Test.java:66-116 slices)"""
+    data = corpus["book1[:65536]"][:5000]
+    f = amd.LZ4Factory.hipInstance()
+    src = b"x" * 17 + data + b"y" * 9
+    dest = bytearray(b"\x11" * (33 + amd.maxCompressedLength(len(data)) + 5))
+    n = f.fastCompressor().compress(src, 17, len(data), dest, 33, len(dest) - 33 - 5)
+    assert bytes(dest[33:33 + n]) == ref.compress_fast(data) and dest[:33] == b"\x11" * 33 and dest[33 + n:] == b"\x11" * (len(dest) - 33 - n)
+    out = bytearray(b"\x22" * (len(data) + 20))
+    assert f.safeDecompressor().decompress(dest, 33, n, out, 7, len(data)) == len(data)
+    assert bytes(out[7:7 + len(data)]) == data and out[:7] == b"\x22" * 7 and out[7 + len(data):] == b"\x22" * 13
+
+
+def test_device_batch_and_generator(amd, O, ref):
+    """device-pointer entry points (what bench.py times) + the on-device workload generator"""
+    import torch
+    n, blk = 256, 65536
+    cap = amd.maxCompressedLength(blk)
+    dev = torch.device("cuda:0")
+    src = torch.empty(n * blk, dtype=torch.uint8, device=dev)
+    amd.DeviceBatch.gen_blocks(src, blk, blk, n, first_idx=5)
+    host = src.cpu().numpy().tobytes()
+    for i in (0, 1, 100, 255):
+        assert host[i * blk:(i + 1) * blk] == O.gen_block(blk, 5 + i)
+    i64, i32 = torch.int64, torch.int32
+    so = torch.arange(n, dtype=i64, device=dev) * blk
+    sl = torch.full((n,), blk, dtype=i32, device=dev)
+    comp = torch.zeros(n * cap, dtype=torch.uint8, device=dev)
+    co = torch.arange(n, dtype=i64, device=dev) * cap
+    cc = torch.full((n,), cap, dtype=i32, device=dev)
+    clen = torch.zeros(n, dtype=i32, device=dev)
+    amd.DeviceBatch.compress_fast(src, so, sl, comp, co, cc, clen)
+    back = torch.zeros(n * blk, dtype=torch.uint8, device=dev)
+    dlen = torch.zeros(n, dtype=i32, device=dev)
+    amd.DeviceBatch.decompress_safe(comp, co, clen, back, so, sl, dlen)
+    back2 = torch.zeros(n * blk, dtype=torch.uint8, device=dev)
+    used = torch.zeros(n, dtype=i32, device=dev)
+    amd.DeviceBatch.decompress_fast(comp, co, cc, back2, so, sl, used)
+    torch.cuda.synchronize()
+    assert torch.equal(back, src) and torch.equal(back2, src)
+    assert torch.equal(dlen, sl) and torch.equal(used, clen)
+    ch = comp.cpu().numpy().tobytes()
+    cl = clen.cpu().tolist()
+    for i in (0, 7, 255):
+        assert ch[i * cap:i * cap + cl[i]] == ref.compress_fast(host[i * blk:(i + 1) * blk])
+
+
+def test_large_blocks_byu32(amd, O, ref):
+    """blocks >= 65547 B use the 5-byte-hash / 4096 x u32 table; 4 MiB = LZ4Frame default"""
+    blocks = [O.gen_block(4 << 20, 0, win=4096), O.gen_block(1 << 20, 1, win=65535), O.gen_block(300000, 2, litmax=4, win=8)]
+    res = gpu_compress_many(amd, blocks, [ref.compress_bound(len(b)) for b in blocks])
+    for b, (r, c) in zip(blocks, res):
+        assert c == ref.compress_fast(b)
+    dec = gpu_decode_safe_many(amd, [c for _, c in res], [len(b) for b in blocks])
+    for b, (r, d) in zip(blocks, dec):
+        assert r == len(b) and d == b
+
+
+def test_full_size_roundtrip_properties(amd):
+    """BASELINE.json configs[1] shape (64 KiB blocks, ratio ~2) at 16384 blocks = 1 GiB: size-independent
+    properties -- decode(encode(x)) == x for BOTH decoders, every size in (0, bound], hash-of-hashes stable"""
+    import torch
+    n, blk = 16384, 65536
+    cap = amd.maxCompressedLength(blk)
+    dev = torch.device("cuda:0")
+    src = torch.empty(n * blk, dtype=torch.uint8, device=dev)
+    amd.DeviceBatch.gen_blocks(src, blk, blk, n)
+    so = torch.arange(n, dtype=torch.int64, device=dev) * blk
+    sl = torch.full((n,), blk, dtype=torch.int32, device=dev)
+    comp = torch.empty(n * cap, dtype=torch.uint8, device=dev)
+    co = torch.arange(n, dtype=torch.int64, device=dev) * cap
+    cc = torch.full((n,), cap, dtype=torch.int32, device=dev)
+    clen = torch.zeros(n, dtype=torch.int32, device=dev)
+    amd.DeviceBatch.compress_fast(src, so, sl, comp, co, cc, clen)
+    back = torch.zeros(n * blk, dtype=torch.uint8, device=dev)
+    dlen = torch.zeros(n, dtype=torch.int32, device=dev)
+    amd.DeviceBatch.decompress_safe(comp, co, clen, back, so, sl, dlen)
+    torch.cuda.synchronize()
+    assert int(clen.min()) > 0 and int(clen.max()) <= cap
+    ratio = n * blk / float(clen.sum())
+    assert 1.9 < ratio < 2.1, ratio                              # 2.0035
+    assert torch.equal(dlen, sl) and torch.equal(back, src)
+    h1 = torch.zeros(n, dtype=torch.int32, device=dev)
+    h2 = torch.zeros(n, dtype=torch.int32, device=dev)
+    amd.DeviceBatch.xxh32(src, so, sl, 0, h1)
+    amd.DeviceBatch.xxh32(back, so, sl, 0, h2)
+    torch.cuda.synchronize()
+    assert torch.equal(h1, h2)

@@ -1,0 +1,107 @@
+"""The ALGORITHMS of the gfx950 kernels, executed on the CPU: tests/hostsim compiles the product's
+cores (lz4-java_amd/csrc/lz4_fast_core.h, lz4_decode_core.h) against lock-step lane simulators and
+this file checks them bit-for-bit against the oracle.  (The kernels proper are checked on the GPU by
+test_gpu_*.py; this catches algorithmic regressions before any GPU time is spent.)"""
+import ctypes as C
+import os
+import random
+import subprocess
+
+import pytest
+
+from conftest import ROOT, rnd_inputs
+
+_u8p = C.POINTER(C.c_uint8)
+
+
+@pytest.fixture(scope="module")
+def sim():
+    d = os.path.join(ROOT, "tests", "hostsim")
+    so = os.path.join(d, "libhostsim.so")
+    srcs = [os.path.join(d, f) for f in ("hostsim.cpp", "wave_host.h", "group_host.h")] + \
+           [os.path.join(ROOT, "lz4-java_amd", "csrc", f) for f in ("lz4_fast_core.h", "lz4_decode_core.h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, os.path.join(d, "hostsim.cpp")])
+    l = C.CDLL(so)
+    l.sim_compress_fast.restype = C.c_int
+    l.sim_compress_fast.argtypes = [C.c_char_p, C.c_int, _u8p, C.c_int, C.POINTER(C.c_uint64), C.c_uint64]
+    l.sim_decompress.restype = C.c_int
+    l.sim_decompress.argtypes = [C.c_char_p, C.c_int, _u8p, C.c_int, C.c_int, C.c_int]
+    return l
+
+
+def sim_compress(sim, v, cap, seed=0):
+    out = (C.c_uint8 * max(cap, 1))()
+    st = (C.c_uint64 * 4)()
+    r = sim.sim_compress_fast(bytes(v), len(v), out, cap, st, seed)
+    return r, bytes(out[:max(r, 0)]), list(st)
+
+
+def sim_decode(sim, c, cap, safe, gl, src_size=None):
+    out = (C.c_uint8 * max(cap, 1))()
+    C.memset(out, 0xA5, max(cap, 1))
+    r = sim.sim_decompress(bytes(c), len(c) if src_size is None else src_size, out, cap, safe, gl)
+    return r, bytes(out[:cap])
+
+
+def test_compress_core_golden(sim, ref, corpus):
+    slow = 0
+    for name, v in corpus.items():
+        cap = ref.compress_bound(len(v))
+        r, b, st = sim_compress(sim, v, cap)
+        assert b == ref.compress_fast(v), name
+        slow += st[1]
+    assert slow > 0  # the collision-resolution path was exercised
+
+
+def test_compress_core_fuzz(sim, ref, O, corpus):
+    """random inputs x {full, tight, random} capacities x random LDS-atomic lane orders"""
+    rng = random.Random(3)
+    for v in rnd_inputs(O, corpus, 21, 500):
+        full = ref.compress_bound(len(v))
+        er, _ = ref.compress_fast_raw(v, full)
+        for cap in (full, max(0, er + rng.choice([-1, 0, 1, 2, -5, 5, -20, 20])), rng.randrange(0, full + 1)):
+            a = ref.compress_fast_raw(v, cap)
+            r, b, _ = sim_compress(sim, v, cap, seed=rng.getrandbits(63) | 1)
+            assert r == a[0] and (r <= 0 or b == a[1]), (len(v), cap, r, a[0])
+
+
+def test_decode_core_fuzz(sim, ref, O, corpus):
+    rng = random.Random(9)
+    for v in rnd_inputs(O, corpus, 31, 2500, max_n=20000):
+        c = bytearray(ref.compress_fast(v))
+        mode, cap = rng.randrange(6), len(v)
+        if mode == 1:
+            cap = max(0, len(v) + rng.choice([-1, 1, -5, 5, -12, 12, -33, 33, 64, 100]))
+        elif mode == 2 and c:
+            for _ in range(rng.randrange(1, 4)):
+                c[rng.randrange(len(c))] = rng.randrange(256)
+        elif mode == 3 and len(c) > 1:
+            c = c[:rng.randrange(1, len(c))]
+        elif mode == 4:
+            c = c + rng.randbytes(rng.randrange(1, 20))
+        elif mode == 5:
+            c, cap = bytearray(rng.randbytes(rng.randrange(1, 40))), rng.randrange(0, 200)
+        c = bytes(c)
+        gl = rng.choice([4, 8, 16, 32, 64])
+        r2, d2 = ref.decompress_safe_raw(c, cap)
+        r1, d1 = sim_decode(sim, c, cap, 1, gl)
+        assert r1 == r2 and (r2 < 0 or d1[:r2] == d2[:r2]), ("safe", mode, gl, len(v), cap, r1, r2)
+        # fast decoder: bounded-input semantics are defined by the oracle port
+        scap = max(len(c) + rng.choice([0, 0, 0, 3, 16, -1]), 0)
+        r3, d3 = O.decompress_fast_bounded(c, scap, cap)
+        padded = c + bytes(max(0, scap - len(c)))
+        r4, d4 = sim_decode(sim, padded, cap, 0, gl, src_size=scap)
+        assert r3 == r4 and (r3 < 0 or d3[:cap] == d4[:cap]), ("fast", mode, gl, len(v), cap, scap, r3, r4)
+        if mode == 0 and scap >= len(c):
+            assert ref.decompress_fast_raw(c, cap)[0] == r4
+
+
+def test_decode_core_malformed_vectors(sim, golden):
+    for v in golden["malformed"]:
+        vec = bytes.fromhex(v["hex"])
+        for gl in (4, 16, 64):
+            r, d = sim_decode(sim, vec, v["safe_cap"], 1, gl)
+            assert r == v["safe_ret"]
+            if r >= 0:
+                assert d[:r].hex() == v["safe_out_hex"]
