@@ -56,9 +56,13 @@ LZ4HIP_DEV int decode_block(Grp& g, const uint8_t* src, int src_size, uint8_t* d
   if (SAFE && src_size == 0) return -1;
 
   if (oend - op >= 64) {
-    for (;;) {  // ---- tier 1: fast loop ----
-      uint32_t w4;  // token + next 3 bytes when they are readable
-      if (ip + 4 <= iend) { w4 = g.ld32(src + ip); } else { LZ4HIP_NEED_IN(1); w4 = g.ld8(src + ip); }
+    // ---- tier 1: fast loop.  Software-pipelined: the word holding {offset, first match-length byte}
+    // is requested BEFORE the literal copy, and the next sequence's token word BEFORE the match copy,
+    // so a sequence costs two dependent memory round trips (literals+offset, then match source)
+    // instead of four; the token fetch rides under the match-source latency. ----
+    uint32_t w4;  // token + next 3 bytes when they are readable
+    if (ip + 4 <= iend) { w4 = g.ld32(src + ip); } else { LZ4HIP_NEED_IN(1); w4 = g.ld8(src + ip); }
+    for (;;) {
       token = w4 & 255u;
       ip++;
       length = (int)(token >> 4);
@@ -89,12 +93,15 @@ LZ4HIP_DEV int decode_block(Grp& g, const uint8_t* src, int src_size, uint8_t* d
         wild = SAFE || (ip + length + 4 <= iend);
       }
       LZ4HIP_NEED_IN(length);
-      g.copy_lits(dst + op, src + ip, (uint32_t)length, wild);
-      ip += length;
-      op = cpy;
-
-      LZ4HIP_NEED_IN(2);
-      if (ip + 4 <= iend) w4 = g.ld32(src + ip); else w4 = g.ld16(src + ip);
+      {
+        const int ipo = ip + length;  // where {offset lo, offset hi, first ML byte, ...} sit
+        const bool have_off = SAFE || ipo + 2 <= iend;
+        if (ipo + 4 <= iend) w4 = g.ld32(src + ipo); else if (have_off) w4 = g.ld16(src + ipo);
+        g.copy_lits(dst + op, src + ip, (uint32_t)length, wild);
+        ip = ipo;
+        op = cpy;
+        if (!have_off) goto output_error;  // the bounded fast decoder ran out of input at the offset
+      }
       offset = (int)(w4 & 0xFFFFu);
       ip += 2;
       length = (int)(token & 15u);
@@ -119,6 +126,8 @@ LZ4HIP_DEV int decode_block(Grp& g, const uint8_t* src, int src_size, uint8_t* d
         if (op + length >= oend - 64) goto safe_match_copy;
       }
       if (offset > op) goto output_error;  // liblz4 checks this only when SAFE; the HIP engine never reads before dst
+      // next token word (SAFE: ip < iend holds after a non-final sequence)
+      if (ip + 4 <= iend) { w4 = g.ld32(src + ip); } else { LZ4HIP_NEED_IN(1); w4 = g.ld8(src + ip); }
       g.copy_match(dst, (uint32_t)op, (uint32_t)offset, (uint32_t)length, true);
       op += length;
     }

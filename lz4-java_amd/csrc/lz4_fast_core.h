@@ -119,21 +119,80 @@ struct FastCore {
     return op + 1u + nlx + last;
   }
 
-  // one sequence: literals [anchor, anchor+lit), match code mc (= length-4), offset.
-  LZ4HIP_DEV bool emit_sequence(uint32_t lit, uint32_t mc, uint32_t offset, bool check_lits) {
+  // ---- match extension ------------------------------------------------------------------------
+  // tail of a forward count: lane granularity ran into `limit`; at most 7 bytes are left to compare
+  LZ4HIP_DEV uint32_t count_tail(uint32_t pa_t, uint32_t pb_t, uint32_t limit) {
+    const uint32_t tail = pa_t < limit ? limit - pa_t : 0u;
+    if (tail == 0) return 0;
+    const VB act = w.lane() < tail;
+    const VU ca = w.ld8(src, w.lane() + pa_t, act);
+    const VU cb = w.ld8(src, w.lane() + pb_t, act);
+    const uint64_t bad = w.ballot(act & (ca != cb));
+    return bad ? (uint32_t)ctz64(bad) : tail;
+  }
+
+  // number of equal bytes src[a+i]==src[b+i], a+i < limit (b < a); 8 bytes per lane, 512 per round
+  LZ4HIP_DEV uint32_t count_fwd(uint32_t a, uint32_t b, uint32_t limit) {
+    uint32_t cnt = 0;
+    for (;;) {
+      const VU off = w.lane() * 8u + cnt;
+      const VU pa = off + a;
+      const VB full = pa + 8u <= limit;
+      const VU64 x = w.ldu64(src, W::vmin(pa, n - 8u)) ^ w.ldu64(src, W::vmin(off + b, n - 8u));
+      const VB diff = full & (x != VU64(0));
+      const uint64_t dm = w.ballot(diff);
+      const uint64_t stop = dm | w.ballot(!full);
+      if (stop == 0) { cnt += 512u; continue; }
+      const int f = ctz64(stop);
+      cnt += 8u * (uint32_t)f;
+      if ((dm >> f) & 1u) return cnt + (uint32_t)(ctz64(w.bcast64(x, f)) >> 3);
+      return cnt + count_tail(a + cnt, b + cnt, limit);
+    }
+  }
+
+  // catch-up beyond the first 64 bytes (rare): equal bytes before (ip, m), bounded by maxback
+  LZ4HIP_DEV uint32_t count_back(uint32_t ip, uint32_t m, uint32_t maxback) {
+    uint32_t back = 0;
+    while (back < maxback) {
+      const VU jj = w.lane() + back;
+      const VB act = jj < maxback;
+      const VU ca = w.ld8(src, (ip - 1u) - jj, act);
+      const VU cb = w.ld8(src, (m - 1u) - jj, act);
+      const uint64_t am = w.ballot(act);
+      const uint64_t bad = w.ballot(act & (ca != cb));
+      if (bad) return back + (uint32_t)ctz64(bad);
+      back += (uint32_t)popc64(am);
+    }
+    return back;
+  }
+
+  // ---- deferred emission ---------------------------------------------------------------------
+  // A sequence found in step t is written out in step t+1, AFTER step t+1 has issued its own
+  // candidate loads: the token/literal/offset stores then overlap the HBM/L2 latency of those loads.
+  struct Pending {
+    bool have = false, check_lits = false, regs = false;
+    uint32_t lit = 0, mc = 0, offset = 0, anchor = 0;
+  };
+  Pending pend;
+  VU pend_bytes;  // regs: lane i holds the literal byte that output byte i of the sequence needs
+
+  LZ4HIP_DEV bool emit_pending() {
+    if (!pend.have) return true;
+    pend.have = false;
+    const uint32_t lit = pend.lit, mc = pend.mc, offset = pend.offset;
     const uint32_t nlx = ext_count(lit), nmx = ext_count(mc);
     if (limited) {
-      if (check_lits && (uint64_t)op + 1u + lit + (2u + 1u + 5u) + lit / 255u > cap) return false;
+      if (pend.check_lits && (uint64_t)op + 1u + lit + (2u + 1u + 5u) + lit / 255u > cap) return false;
       if ((uint64_t)op + 1u + nlx + lit + 2u + (1u + 5u) + (mc + 240u) / 255u > cap) return false;
     }
     const uint32_t token = ((lit < 15u ? lit : 15u) << 4) | (mc < 15u ? mc : 15u);
     const uint32_t total = 1u + nlx + lit + 2u + nmx;
-    if (total <= 64u) {  // common case: one byte per lane, one load + one store instruction
-      VU i = w.lane();
+    if (total <= 64u) {  // common case: one output byte per lane, a single store instruction
+      const VU i = w.lane();
       const uint32_t lit0 = 1u + nlx, off0 = lit0 + lit;
-      VB is_lit = (i >= lit0) & (i < off0);
-      VU lb = w.ld8(src, i + (anchor - lit0), is_lit);
-      VU b = lb;
+      VU b;
+      if (pend.regs) b = pend_bytes;
+      else b = w.ld8(src, i + (pend.anchor - lit0), (i >= lit0) & (i < off0));
       b = W::select(i == 0u, VU(token), b);
       if (nlx) {
         const uint32_t rem = (lit - 15u) - 255u * (nlx - 1u);
@@ -149,59 +208,13 @@ struct FastCore {
     } else {
       w.st8(dst, VU(op), VU(token), w.lane() == 0u);
       if (nlx) put_ext(op + 1u, lit, nlx);
-      w.copy(dst, op + 1u + nlx, src, anchor, lit);
+      w.copy(dst, op + 1u + nlx, src, pend.anchor, lit);
       const uint32_t o2 = op + 1u + nlx + lit;
       w.st8(dst, w.lane() + o2, W::select(w.lane() == 0u, VU(offset & 255u), VU(offset >> 8)), w.lane() < 2u);
       if (nmx) put_ext(o2 + 2u, mc, nmx);
     }
     op += total;
     return true;
-  }
-
-  // number of equal bytes src[a+i]==src[b+i], a+i < limit   (b < a)
-  LZ4HIP_DEV uint32_t count_fwd(uint32_t a, uint32_t b, uint32_t limit) {
-    uint32_t cnt = 0;
-    for (;;) {
-      VU off = w.lane() * 8u + cnt;
-      VU pa = off + a;
-      VB full = pa + 8u <= limit;
-      VU64 xa = w.ld64(src, pa, full);
-      VU64 xb = w.ld64(src, off + b, full);
-      VU64 x = xa ^ xb;
-      VB diff = full & (x != VU64(0));
-      const uint64_t stop = w.ballot(diff | !full);
-      if (stop == 0) { cnt += 512u; continue; }
-      const int f = ctz64(stop);
-      cnt += 8u * (uint32_t)f;
-      const uint64_t xf = w.bcast64(x, f);
-      const bool is_diff = (w.ballot(diff) >> f) & 1u;
-      if (is_diff) return cnt + (uint32_t)(ctz64(xf) >> 3);
-      // lane f straddles (or lies beyond) the limit: finish bytewise, at most 7 bytes
-      const uint32_t pa_t = a + cnt;
-      const uint32_t tail = pa_t < limit ? limit - pa_t : 0u;
-      if (tail == 0) return cnt;
-      VB act = w.lane() < tail;
-      VU ca = w.ld8(src, w.lane() + pa_t, act);
-      VU cb = w.ld8(src, w.lane() + (b + cnt), act);
-      const uint64_t bad = w.ballot(act & (ca != cb));
-      return cnt + (bad ? (uint32_t)ctz64(bad) : tail);
-    }
-  }
-
-  // catch-up: how many bytes before (ip, m) are equal, bounded by maxback
-  LZ4HIP_DEV uint32_t count_back(uint32_t ip, uint32_t m, uint32_t maxback) {
-    uint32_t back = 0;
-    while (back < maxback) {
-      VU jj = w.lane() + back;
-      VB act = jj < maxback;
-      VU ca = w.ld8(src, (ip - 1u) - jj, act);
-      VU cb = w.ld8(src, (m - 1u) - jj, act);
-      const uint64_t am = w.ballot(act);
-      const uint64_t bad = w.ballot(act & (ca != cb));
-      if (bad) return back + (uint32_t)ctz64(bad);
-      back += (uint32_t)popc64(am);
-    }
-    return back;
   }
 
   // ---- the compressor ------------------------------------------------------------------------
@@ -227,31 +240,36 @@ struct FastCore {
     bool post = false;       // step kind: false = run probes only; true = {insert ip-2, probe ip, run from ip+1}
     uint32_t S = 1, r = 0;   // run start, index of the first run probe of this step
     uint32_t ip = 0;         // post-match position (== anchor) when post
+    const VU j = w.lane();
+    const VU o8 = j * 8u;
 
     for (;;) {
       if (st) st->steps++;
+      // ---- [1] positions of this step's 64 slots ----
       const uint32_t nspecial = post ? 2u : 0u;
-      const VU j = w.lane();
       const VB isrun = j >= nspecial;
       const VU k = j - nspecial + r;
-      const VU prun = g(k) + S;
-      const VU pnext = g(k + 1u) + S;
+      VU prun, pnext;
+      if (r + 64u - nspecial <= 65u) { prun = k + S; pnext = prun + 1u; }  // probes 0..65 of a run are consecutive
+      else { prun = g(k) + S; pnext = g(k + 1u) + S; }
       const VU pos = W::select(isrun, prun, W::select(j == 0u, VU(ip - 2u), VU(ip)));
       const VB valid = (!isrun) | (pnext <= mfl1);
 
+      // ---- [2] input window, hash, fingerprint (invalid lanes read a clamped, harmless address) ----
       VU x32, h, fp;
       if constexpr (U16) {
-        x32 = w.ld32(src, pos, valid);
-        VU prod = x32 * 2654435761u;
+        x32 = w.ldu32(src, W::vmin(pos, n - 8u));
+        const VU prod = x32 * 2654435761u;
         h = prod >> (32 - HLOG);
         fp = (prod >> 3) & 0xFFFFu;
       } else {
-        VU64 x64 = w.ld64(src, pos, valid);
+        const VU64 x64 = w.ldu64(src, W::vmin(pos, n - 8u));
         x32 = W::lo32(x64);
         h = W::lo32(((x64 << 24) * 889523592379ull) >> (64 - HLOG));
         fp = (x32 * 2654435761u) >> 16;
       }
-      const VE e = w.template lds_rd<U16>(h, valid);
+      // ---- [3] table lookup, tentative hits, commit ----
+      const VE e = w.template lds_rdu<U16>(h);
       const VE newe = mk_entry(pos, fp);
       const VB probe = valid & (isrun | (j == 1u));  // lane 0 of a post step only inserts
       VB tent = probe & (e_fp(e) == fp);
@@ -263,19 +281,40 @@ struct FastCore {
       const uint32_t kinv = imask ? (uint32_t)ctz64(imask) : 64u;
       uint32_t ncommit = (k0 + 1u < kinv) ? k0 + 1u : kinv;
       bool have_hit = k0 < kinv;
-      VE se = e;  // candidate each lane sees under sequential semantics
-
       VB inrange = j < ncommit;
       const VE old = w.template lds_max<U16>(h, newe, inrange);
+
+      // ---- [4] speculative candidate fetch: verify + forward + backward extension in ONE round trip ----
+      uint32_t hpos = 0, mpos = 0, maxback = 0;
+      bool hit_post = false;
+      VU64 fx;       // (bytes at hpos+8*lane) xor (bytes at mpos+8*lane)
+      VU ba, bb;     // bytes before hpos / mpos
+      if (have_hit) {
+        hpos = w.bcast(pos, (int)k0);
+        mpos = se_pos(w.template bcast_e<U16>(e, (int)k0));
+        hit_post = post && k0 == 1u;
+        maxback = hit_post ? 0u : ((hpos - anchor) < mpos ? (hpos - anchor) : mpos);
+        fx = w.ldu64(src, W::vmin(o8 + hpos, n - 8u)) ^ w.ldu64(src, W::vmin(o8 + mpos, n - 8u));
+        if (maxback) {
+          const VB bact = j < maxback;
+          ba = w.ldu8(src, W::select(bact, (hpos - 1u) - j, VU(0u)));
+          bb = w.ldu8(src, W::select(bact, (mpos - 1u) - j, VU(0u)));
+        }
+      }
+
+      // ---- [5] write out the previous sequence while those loads are in flight ----
+      if (!emit_pending()) return 0;
+
+      // ---- [6] intra-step bucket collisions (rare): undo, resolve exactly, commit again ----
       const uint64_t det = w.ballot(inrange & (old != e));
       if (det) {
-        // two or more committed lanes share a bucket: undo, resolve exactly, commit again
         if (st) st->slow_steps++;
         w.template lds_wr<U16>(h, e, inrange);
         w.sync();
-        uint64_t pend = det;
-        while (pend) {
-          const int d = ctz64(pend);
+        VE se = e;  // candidate each lane sees under sequential semantics
+        uint64_t pendm = det;
+        while (pendm) {
+          const int d = ctz64(pendm);
           const uint32_t hd = w.bcast(h, d);
           const VB grp = inrange & (h == hd);
           const uint64_t gm = w.ballot(grp);
@@ -284,71 +323,99 @@ struct FastCore {
           const VU srcl = VU(63u) - W::clz64(lower);
           const VE pe = w.template shfl_e<U16>(newe, srcl);
           se = W::select(has, pe, se);
-          pend &= ~gm;
+          pendm &= ~gm;
         }
         VB tent2 = inrange & probe & (e_fp(se) == fp);
         if constexpr (!U16) tent2 = tent2 & (e_pos(se) + MAXD >= pos);
         const uint64_t t2 = w.ballot(tent2);
+        const bool had = have_hit;
+        const uint32_t hpos_old = hpos, mpos_old = mpos;
         if (t2) {
           k0 = (uint32_t)ctz64(t2);
           ncommit = k0 + 1u;
           have_hit = true;
         } else {
-          // the tentative lane (if any) no longer matches under the sequential candidates
-          if (have_hit) { have_hit = false; }
+          have_hit = false;  // the tentative lane (if any) no longer matches under the sequential candidates
         }
         inrange = j < ncommit;
         (void)w.template lds_max<U16>(h, newe, inrange);
+        if (have_hit) {
+          hpos = w.bcast(pos, (int)k0);
+          mpos = se_pos(w.template bcast_e<U16>(se, (int)k0));
+          if (!had || hpos != hpos_old || mpos != mpos_old) {  // the speculation fetched the wrong candidate
+            hit_post = post && k0 == 1u;
+            maxback = hit_post ? 0u : ((hpos - anchor) < mpos ? (hpos - anchor) : mpos);
+            fx = w.ldu64(src, W::vmin(o8 + hpos, n - 8u)) ^ w.ldu64(src, W::vmin(o8 + mpos, n - 8u));
+            if (maxback) {
+              const VB bact = j < maxback;
+              ba = w.ldu8(src, W::select(bact, (hpos - 1u) - j, VU(0u)));
+              bb = w.ldu8(src, W::select(bact, (mpos - 1u) - j, VU(0u)));
+            }
+          }
+        }
       }
       w.sync();  // table updates of this step are ordered before the next step's reads
 
-      // position of lane `l` of this step (wave-uniform helper)
-      const uint32_t last_lane = ncommit - 1u;  // ncommit >= 1 unless kinv == 0
-      bool hit = false, hit_post = false;
-      uint32_t hpos = 0, mpos = 0;
+      // ---- [7] verify the tentative hit (4 bytes) ----
+      bool hit = false;
       if (have_hit) {
-        hpos = w.bcast(pos, (int)k0);
-        mpos = se_pos(w.template bcast_e<U16>(se, (int)k0));
-        const uint32_t xa = w.sld32(src, mpos);
-        const uint32_t xb = w.bcast(x32, (int)k0);
-        hit = (xa == xb);
-        hit_post = post && k0 == 1u;
+        hit = (uint32_t)w.bcast64(fx, 0) == 0u;
         if (!hit && st) st->false_pos++;
       }
-
       if (!hit) {
-        if (!have_hit && kinv < 64u && kinv == ncommit) {
-          // first lane whose NEXT position passes mflimit: liblz4's `goto _last_literals`
-          const uint32_t total = emit_last();
-          return total;
-        }
+        if (!have_hit && kinv < 64u && kinv == ncommit) return emit_last();  // liblz4's `goto _last_literals`
         // continue the run after the last committed lane
-        if (post) {
-          if (ncommit >= 2u) { S = ip + 1u; r = ncommit - 2u; }   // run probes 0..ncommit-3 done
-          else { S = ip + 1u; r = 0; }                             // (cannot happen: post lanes are always valid)
-          post = false;
-        } else {
-          r += ncommit;
-        }
-        (void)last_lane;
+        if (post) { S = ip + 1u; r = ncommit >= 2u ? ncommit - 2u : 0u; post = false; }
+        else r += ncommit;
         continue;
       }
 
-      // ---- a match: ip = hpos, candidate = mpos ----
+      // ---- [8] a match at hpos against mpos: catch-up, length ----
       if (st) st->sequences++;
-      uint32_t mip = hpos, mm = mpos, back = 0;
-      if (!hit_post) {
-        const uint32_t mb = (mip - anchor) < mm ? (mip - anchor) : mm;
-        if (mb) back = count_back(mip, mm, mb);
-        mip -= back;
-        mm -= back;
+      uint32_t back = 0;
+      if (maxback) {
+        const uint64_t bad = w.ballot((j < maxback) & (ba != bb));
+        if (bad) back = (uint32_t)ctz64(bad);
+        else if (maxback <= 64u) back = maxback;
+        else back = 64u + count_back(hpos - 64u, mpos - 64u, maxback - 64u);
       }
-      const uint32_t fwd = count_fwd(hpos + 4u, mpos + 4u, matchlimit);
-      const uint32_t mc = back + fwd;
-      if (!emit_sequence(mip - anchor, mc, mip - mm, !hit_post)) return 0;
+      uint32_t cnt;  // equal bytes from hpos on (>= 4)
+      {
+        const VB full = o8 + (hpos + 8u) <= matchlimit;
+        const VU64 xz = W::select(j == 0u, fx & VU64(0xFFFFFFFF00000000ull), fx);
+        const uint64_t dm = w.ballot(full & (xz != VU64(0)));
+        const uint64_t stop = dm | w.ballot(!full);
+        if (stop == 0) {
+          cnt = 512u + count_fwd(hpos + 512u, mpos + 512u, matchlimit);
+        } else {
+          const int f = ctz64(stop);
+          cnt = 8u * (uint32_t)f;
+          if ((dm >> f) & 1u) cnt += (uint32_t)(ctz64(w.bcast64(xz, f)) >> 3);
+          else if (cnt >= 4u) cnt += count_tail(hpos + cnt, mpos + cnt, matchlimit);
+          else cnt = 4u + count_tail(hpos + 4u, mpos + 4u, matchlimit);  // lane 0 itself straddles the limit
+        }
+      }
+      const uint32_t mc = back + (cnt - 4u);
+      const uint32_t mip = hpos - back;
+      pend.have = true;
+      pend.lit = mip - anchor;
+      pend.mc = mc;
+      pend.offset = hpos - mpos;
+      pend.anchor = anchor;
+      pend.check_lits = !hit_post;
+      // literals straight from this step's window registers: lane l (>= 1) of a post step that
+      // started its run here sits on position anchor + l - 1
+      pend.regs = post && r == 0u && (1u + ext_count(pend.lit) + pend.lit + 2u + ext_count(mc) <= 64u);
+      if (pend.regs) {
+        const VU b0 = x32 & 0xFFu;
+        pend_bytes = pend.lit >= 15u ? w.shfl_up1(b0) : b0;
+      }
       ip = mip + 4u + mc;
       anchor = ip;
-      if (ip >= mfl1) return emit_last();
+      if (ip >= mfl1) {
+        if (!emit_pending()) return 0;
+        return emit_last();
+      }
       post = true;
       S = ip + 1u;
       r = 0;

@@ -61,6 +61,12 @@ struct WaveDev {
     if (m) __builtin_memcpy(&v, b + i, 8);
     return v;
   }
+  // unconditional loads: the caller passes an in-bounds (clamped) index, so no exec-mask branch is needed
+  __device__ __forceinline__ static VU ldu8(const uint8_t* b, VU i) { return (uint32_t)b[i]; }
+  __device__ __forceinline__ static VU ldu32(const uint8_t* b, VU i) { uint32_t v; __builtin_memcpy(&v, b + i, 4); return v; }
+  __device__ __forceinline__ static VU64 ldu64(const uint8_t* b, VU i) { uint64_t v; __builtin_memcpy(&v, b + i, 8); return v; }
+  __device__ __forceinline__ static VU vmin(VU a, VU b) { return a < b ? a : b; }
+  __device__ __forceinline__ static VU shfl_up1(VU v) { return (uint32_t)__shfl_up((int)v, 1, 64); }  // lane l <- lane l-1
   __device__ __forceinline__ static uint32_t sld32(const uint8_t* b, uint32_t i) {
     uint32_t v;
     __builtin_memcpy(&v, b + i, 4);
@@ -93,6 +99,10 @@ struct WaveDev {
   template <bool U16> __device__ __forceinline__ auto lds_rd(VU h, bool m) {
     using S = typename Entry<U16>::S;
     return m ? ((S*)lds)[h] : (S)0;
+  }
+  template <bool U16> __device__ __forceinline__ auto lds_rdu(VU h) {
+    using S = typename Entry<U16>::S;
+    return ((S*)lds)[h];
   }
   template <bool U16> __device__ __forceinline__ auto lds_max(VU h, typename Entry<U16>::V v, bool m) {
     using S = typename Entry<U16>::S;

@@ -84,6 +84,11 @@ struct WaveHost {
   VU64 ld64(const uint8_t* b, const VU& i, const VB& m) {
     VU64 r; for (int l = 0; l < 64; l++) if (m.v[l] && in_ok(b + i.v[l], 8)) memcpy(&r.v[l], b + i.v[l], 8); return r;
   }
+  VU ldu8(const uint8_t* b, const VU& i) { return ld8(b, i, VB(true)); }
+  VU ldu32(const uint8_t* b, const VU& i) { return ld32(b, i, VB(true)); }
+  VU64 ldu64(const uint8_t* b, const VU& i) { return ld64(b, i, VB(true)); }
+  static VU vmin(const VU& a, const VU& b) { VU r; for (int l = 0; l < 64; l++) r.v[l] = a.v[l] < b.v[l] ? a.v[l] : b.v[l]; return r; }
+  static VU shfl_up1(const VU& v) { VU r; r.v[0] = v.v[0]; for (int l = 1; l < 64; l++) r.v[l] = v.v[l - 1]; return r; }
   uint32_t sld32(const uint8_t* b, uint32_t i) { uint32_t v = 0; if (in_ok(b + i, 4)) memcpy(&v, b + i, 4); return v; }
   void st8(uint8_t* b, const VU& i, const VU& v, const VB& m) {
     for (int l = 0; l < 64; l++) if (m.v[l] && out_ok(b + i.v[l], 1)) b[i.v[l]] = (uint8_t)v.v[l];
@@ -103,6 +108,7 @@ struct WaveHost {
     for (int l = 0; l < 64; l++) if (m.v[l]) r.v[l] = ((S*)lds.data())[h.v[l]];
     return r;
   }
+  template <bool U16> auto lds_rdu(const VU& h) { return lds_rd<U16>(h, VB(true)); }
   template <bool U16> auto lds_max(const VU& h, const typename Entry<U16>::V& v, const VB& m) {
     using S = typename Entry<U16>::S;
     typename Entry<U16>::V old;
