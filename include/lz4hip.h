@@ -128,6 +128,14 @@ int lz4hip_xxh64(const uint8_t* buf, int len, uint64_t seed, uint64_t* out);
 int lz4hip_gen_blocks_dev(uint8_t* dst, uint64_t stride, int32_t block_len, uint64_t seed, uint64_t first_idx,
                           uint32_t litmax, uint32_t win, uint32_t n_blocks, int device, void* stream);
 
+/* ---- developer diagnostics (not part of the reference API) --------------------------------------
+ * lz4hip_compress_fast_batch_dev with per-phase shader-clock accounting: prof[b*12 .. b*12+11] =
+ * {steps, collision steps, fingerprint false positives, sequences, cycles of phases 0..7} of block b
+ * (phases are documented in csrc/lz4_fast_core.h).  Output bytes are identical to the product kernel. */
+int lz4hip_dbg_compress_fast_profile_dev(const uint8_t* src, const uint64_t* src_off, const int32_t* src_len,
+                                         uint8_t* dst, const uint64_t* dst_off, const int32_t* dst_cap,
+                                         int32_t* out_len, uint32_t n_blocks, uint64_t* prof, int device, void* stream);
+
 #if defined(__GNUC__)
 #pragma GCC visibility pop
 #endif

@@ -61,6 +61,7 @@ C_ABI = {
     "lz4hip_decompress_fast": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "lz4hip_xxh32": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, _u32p]),
     "lz4hip_xxh64": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, _u64p]),
+    "lz4hip_dbg_compress_fast_profile_dev": (C.c_int, [C.c_void_p] * 7 + [C.c_uint32, C.c_void_p, C.c_int, C.c_void_p]),
     "lz4hip_gen_blocks_dev": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
                                         C.c_uint32, C.c_int, C.c_void_p]),
 }
@@ -437,6 +438,14 @@ class DeviceBatch:
     @classmethod
     def compress_fast(cls, src, src_off, src_len, dst, dst_off, dst_cap, out):
         cls._call("lz4hip_compress_fast_batch_dev", src, src_off, src_len, dst, dst_off, dst_cap, out)
+
+    @classmethod
+    def compress_fast_profile(cls, src, src_off, src_len, dst, dst_off, dst_cap, out, prof):
+        """developer diagnostics: prof = int64 tensor [n, 12]"""
+        dev, st = cls._stream_dev(src)
+        _chk(lib().lz4hip_dbg_compress_fast_profile_dev(src.data_ptr(), src_off.data_ptr(), src_len.data_ptr(), dst.data_ptr(),
+                                                        dst_off.data_ptr(), dst_cap.data_ptr(), out.data_ptr(), src_off.numel(),
+                                                        prof.data_ptr(), dev, st))
 
     @classmethod
     def decompress_safe(cls, src, src_off, src_len, dst, dst_off, dst_cap, out):

@@ -356,6 +356,22 @@ int lz4hip_xxh64_batch_dev(const uint8_t* buf, const uint64_t* off, const int32_
   return e ? fail(LZ4HIP_E_HIP, "kernel launch", (hipError_t)e) : LZ4HIP_OK;
 }
 
+// developer diagnostics (see include/lz4hip.h)
+int lz4hip_dbg_compress_fast_profile_dev(const uint8_t* src, const uint64_t* src_off, const int32_t* src_len, uint8_t* dst,
+                                         const uint64_t* dst_off, const int32_t* dst_cap, int32_t* out_len, uint32_t n, uint64_t* prof,
+                                         int device, void* stream) {
+  int rc = ensure_init();
+  if (rc) return fail(rc, "no HIP device: liblz4hip has no CPU fallback");
+  if (n == 0) return LZ4HIP_OK;
+  if (!src || !src_off || !src_len || !dst || !dst_off || !dst_cap || !out_len || !prof) return fail(LZ4HIP_E_ARG, "null pointer argument");
+  int ord;
+  if (ordinal(device, &ord)) return fail(LZ4HIP_E_ARG, "bad device index");
+  DeviceGuard g(ord);
+  lz4hip::BatchArgs a{src, src_off, src_len, dst, dst_off, dst_cap, out_len, n};
+  int e = lz4hip::launch_compress_fast_prof(a, prof, stream);
+  return e ? fail(LZ4HIP_E_HIP, "kernel launch", (hipError_t)e) : LZ4HIP_OK;
+}
+
 // ---- single-block convenience ----
 int lz4hip_compress_fast(const uint8_t* src, int src_len, uint8_t* dst, int dst_cap) { return single(OP_COMPRESS_FAST, src, src_len, dst, dst_cap); }
 int lz4hip_compress_hc(const uint8_t*, int, uint8_t*, int, int) { return LZ4HIP_LIB_ERROR(fail(LZ4HIP_E_UNSUPPORTED, "HC compressor: not built yet")); }

@@ -43,6 +43,35 @@ __global__ __launch_bounds__(64) void compress_fast_kernel(BatchArgs a) {
   if (threadIdx.x == 0) a.out[b] = (int32_t)r;
 }
 
+// developer diagnostics: same algorithm with per-phase shader-clock accumulation; prof[b*12 + i] =
+// {steps, slow_steps, false_pos, sequences, t[0..7]} of block b
+__global__ __launch_bounds__(64) void compress_fast_prof_kernel(BatchArgs a, uint64_t* prof) {
+  __shared__ __attribute__((aligned(16))) uint64_t table[4096];
+  const uint32_t b = blockIdx.x;
+  const int32_t n = a.src_len[b];
+  const int32_t cap = a.dst_cap[b];
+  uint32_t r = 0;
+  FastStats st = {};
+  if (n >= 0 && (uint32_t)n <= 0x7E000000u && cap >= 0) {
+    const uint8_t* s = a.src + a.src_off[b];
+    uint8_t* d = a.dst + a.dst_off[b];
+    WaveDev w(table);
+    if (n < 65547) { FastCore<WaveDev, true> c(w, s, (uint32_t)n, d, (uint32_t)cap, &st); r = c.run(); }
+    else { FastCore<WaveDev, false> c(w, s, (uint32_t)n, d, (uint32_t)cap, &st); r = c.run(); }
+  }
+  if (threadIdx.x == 0) {
+    a.out[b] = (int32_t)r;
+    uint64_t* p = prof + (uint64_t)b * 12u;
+    p[0] = st.steps; p[1] = st.slow_steps; p[2] = st.false_pos; p[3] = st.sequences;
+    for (int i = 0; i < 8; i++) p[4 + i] = st.t[i];
+  }
+}
+int launch_compress_fast_prof(const BatchArgs& a, uint64_t* prof, void* stream) {
+  if (a.n == 0) return 0;
+  hipLaunchKernelGGL(compress_fast_prof_kernel, dim3(a.n), dim3(64), 0, (hipStream_t)stream, a, prof);
+  return (int)hipGetLastError();
+}
+
 int launch_compress_fast(const BatchArgs& a, void* stream) {
   if (a.n == 0) return 0;
   hipLaunchKernelGGL(compress_fast_kernel, dim3(a.n), dim3(64), 0, (hipStream_t)stream, a);

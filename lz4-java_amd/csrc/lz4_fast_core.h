@@ -42,8 +42,9 @@ namespace lz4hip {
 LZ4HIP_DEV int ctz64(uint64_t x) { return __builtin_ctzll(x); }
 LZ4HIP_DEV int popc64(uint64_t x) { return __builtin_popcountll(x); }
 
-struct FastStats {  // optional counters (host simulator / debugging); device passes nullptr
+struct FastStats {  // optional counters (host simulator / profiling kernel); the product kernel passes nullptr
   uint64_t steps, slow_steps, false_pos, sequences;
+  uint64_t t[8];  // shader-clock cycles per phase of a step (profiling kernel only), see run()
 };
 
 template <class W, bool U16>
@@ -245,6 +246,8 @@ struct FastCore {
 
     for (;;) {
       if (st) st->steps++;
+      uint64_t tk = st ? w.tick(0u) : 0;
+#define LZ4HIP_PHASE(i, dep) do { if (st) { const uint64_t t_ = w.tick(dep); st->t[i] += t_ - tk; tk = t_; } } while (0)
       // ---- [1] positions of this step's 64 slots ----
       const uint32_t nspecial = post ? 2u : 0u;
       const VB isrun = j >= nspecial;
@@ -268,6 +271,7 @@ struct FastCore {
         h = W::lo32(((x64 << 24) * 889523592379ull) >> (64 - HLOG));
         fp = (x32 * 2654435761u) >> 16;
       }
+      LZ4HIP_PHASE(0, w.bcast(h, 0));   // t[0]: positions + input window arrived + hash
       // ---- [3] table lookup, tentative hits, commit ----
       const VE e = w.template lds_rdu<U16>(h);
       const VE newe = mk_entry(pos, fp);
@@ -282,19 +286,21 @@ struct FastCore {
       uint32_t ncommit = (k0 + 1u < kinv) ? k0 + 1u : kinv;
       bool have_hit = k0 < kinv;
       VB inrange = j < ncommit;
+      LZ4HIP_PHASE(1, ncommit);          // t[1]: table read + ballots
       const VE old = w.template lds_max<U16>(h, newe, inrange);
 
       // ---- [4] speculative candidate fetch: verify + forward + backward extension in ONE round trip ----
       uint32_t hpos = 0, mpos = 0, maxback = 0;
       bool hit_post = false;
-      VU64 fx;       // (bytes at hpos+8*lane) xor (bytes at mpos+8*lane)
+      VU64 fa, fb;   // bytes at hpos+8*lane / mpos+8*lane (kept apart: xor-ing here would wait for the loads)
       VU ba, bb;     // bytes before hpos / mpos
       if (have_hit) {
         hpos = w.bcast(pos, (int)k0);
         mpos = se_pos(w.template bcast_e<U16>(e, (int)k0));
         hit_post = post && k0 == 1u;
         maxback = hit_post ? 0u : ((hpos - anchor) < mpos ? (hpos - anchor) : mpos);
-        fx = w.ldu64(src, W::vmin(o8 + hpos, n - 8u)) ^ w.ldu64(src, W::vmin(o8 + mpos, n - 8u));
+        fa = w.ldu64(src, W::vmin(o8 + hpos, n - 8u));
+        fb = w.ldu64(src, W::vmin(o8 + mpos, n - 8u));
         if (maxback) {
           const VB bact = j < maxback;
           ba = w.ldu8(src, W::select(bact, (hpos - 1u) - j, VU(0u)));
@@ -302,8 +308,10 @@ struct FastCore {
         }
       }
 
+      LZ4HIP_PHASE(2, hpos);             // t[2]: commit issue + candidate-fetch issue
       // ---- [5] write out the previous sequence while those loads are in flight ----
       if (!emit_pending()) return 0;
+      LZ4HIP_PHASE(3, op);               // t[3]: emission of the previous sequence
 
       // ---- [6] intra-step bucket collisions (rare): undo, resolve exactly, commit again ----
       const uint64_t det = w.ballot(inrange & (old != e));
@@ -345,7 +353,8 @@ struct FastCore {
           if (!had || hpos != hpos_old || mpos != mpos_old) {  // the speculation fetched the wrong candidate
             hit_post = post && k0 == 1u;
             maxback = hit_post ? 0u : ((hpos - anchor) < mpos ? (hpos - anchor) : mpos);
-            fx = w.ldu64(src, W::vmin(o8 + hpos, n - 8u)) ^ w.ldu64(src, W::vmin(o8 + mpos, n - 8u));
+            fa = w.ldu64(src, W::vmin(o8 + hpos, n - 8u));
+            fb = w.ldu64(src, W::vmin(o8 + mpos, n - 8u));
             if (maxback) {
               const VB bact = j < maxback;
               ba = w.ldu8(src, W::select(bact, (hpos - 1u) - j, VU(0u)));
@@ -355,13 +364,16 @@ struct FastCore {
         }
       }
       w.sync();  // table updates of this step are ordered before the next step's reads
+      LZ4HIP_PHASE(4, (uint32_t)det);    // t[4]: atomic result + collision handling
 
       // ---- [7] verify the tentative hit (4 bytes) ----
       bool hit = false;
+      const VU64 fx = fa ^ fb;
       if (have_hit) {
         hit = (uint32_t)w.bcast64(fx, 0) == 0u;
         if (!hit && st) st->false_pos++;
       }
+      LZ4HIP_PHASE(5, (uint32_t)hit);    // t[5]: wait for the candidate bytes
       if (!hit) {
         if (!have_hit && kinv < 64u && kinv == ncommit) return emit_last();  // liblz4's `goto _last_literals`
         // continue the run after the last committed lane
@@ -419,7 +431,9 @@ struct FastCore {
       post = true;
       S = ip + 1u;
       r = 0;
+      LZ4HIP_PHASE(6, ip);               // t[6]: catch-up + match length + bookkeeping
     }
+#undef LZ4HIP_PHASE
   }
 };
 

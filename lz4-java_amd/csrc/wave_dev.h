@@ -22,6 +22,12 @@ struct WaveDev {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
+  // shader clock, issued after `dep` is available (profiling kernel only)
+  __device__ __forceinline__ static uint64_t tick(uint32_t dep) {
+    uint64_t t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "s"(__builtin_amdgcn_readfirstlane(dep)) : "memory");
+    return t;
+  }
   __device__ __forceinline__ static VU lane() { return __lane_id(); }
   __device__ __forceinline__ static VU64 lanemask_lt() { return (1ull << __lane_id()) - 1ull; }
   __device__ __forceinline__ static uint64_t ballot(bool b) { return __ballot(b); }

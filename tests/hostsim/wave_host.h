@@ -54,6 +54,7 @@ struct WaveHost {
   void bounds(const uint8_t* s, size_t n, uint8_t* d, size_t cap) { src_lo = s; src_hi = s + n; dst_lo = d; dst_hi = d + cap; }
 
   static void sync() {}
+  static uint64_t tick(uint32_t) { return 0; }
   static VU lane() { VU r; for (int i = 0; i < 64; i++) r.v[i] = (uint32_t)i; return r; }
   static VU64 lanemask_lt() { VU64 r; for (int i = 0; i < 64; i++) r.v[i] = (1ull << i) - 1ull; return r; }
   static uint64_t ballot(const VB& b) { uint64_t m = 0; for (int i = 0; i < 64; i++) if (b.v[i]) m |= 1ull << i; return m; }

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Per-phase shader-clock breakdown of the fast-compress step (developer diagnostics kernel).
+usage: gpu_phase_profile.py <n_blocks> [data ...]"""
+import importlib, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch, numpy as np
+amd = importlib.import_module("lz4-java_amd")
+n = int(sys.argv[1]); kinds = sys.argv[2:] or ["synth", "book1"]
+dev = torch.device("cuda:0"); blk = 65536; cap = amd.maxCompressedLength(blk)
+names = ["window+hash", "table+ballot", "issue commit/fetch", "emit prev", "atomic/collision", "wait candidate", "extend+bookkeep", "-"]
+for data in kinds:
+    if data == "synth":
+        src = torch.empty(n * blk, dtype=torch.uint8, device=dev); amd.DeviceBatch.gen_blocks(src, blk, blk, n)
+    else:
+        b = {"book1": open(os.path.join(ROOT, "tests/golden/book1_200000.bin"), "rb").read()[:blk], "zeros": bytes(blk), "random": os.urandom(blk)}[data]
+        src = torch.from_numpy(np.frombuffer(b, dtype=np.uint8).copy()).to(dev).repeat(n)
+    so = torch.arange(n, dtype=torch.int64, device=dev) * blk; sl = torch.full((n,), blk, dtype=torch.int32, device=dev)
+    comp = torch.empty(n * cap, dtype=torch.uint8, device=dev); co = torch.arange(n, dtype=torch.int64, device=dev) * cap
+    cc = torch.full((n,), cap, dtype=torch.int32, device=dev); clen = torch.zeros(n, dtype=torch.int32, device=dev)
+    prof = torch.zeros((n, 12), dtype=torch.int64, device=dev)
+    for _ in range(2):
+        a, b2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); amd.DeviceBatch.compress_fast_profile(src, so, sl, comp, co, cc, clen, prof); b2.record(); torch.cuda.synchronize()
+    p = prof.double().mean(0).cpu().tolist()
+    steps = p[0]
+    print("== %s: %d blocks, kernel %.2f ms; per block: steps %.0f collision-steps %.0f false-pos %.1f sequences %.0f" % (data, n, a.elapsed_time(b2), p[0], p[1], p[2], p[3]))
+    tot = sum(p[4:11])
+    for i in range(7):
+        print("   %-20s %8.0f cycles/step  %5.1f%%" % (names[i], p[4 + i] / steps, 100 * p[4 + i] / tot))
+    print("   %-20s %8.0f cycles/step" % ("total", tot / steps))
