@@ -68,6 +68,7 @@ def main():
     import torch.distributed as dist
 
     amd = importlib.import_module("lz4-java_amd")
+    shard = importlib.import_module("lz4-java_amd.shard")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -93,7 +94,7 @@ def main():
     cc = torch.full((n,), cap, dtype=i32, device=dev)
     clen = torch.zeros(n, dtype=i32, device=dev)
     dlen = torch.zeros(n, dtype=i32, device=dev)
-    all_clen = torch.zeros(n * world, dtype=i32, device=dev) if world > 1 else None
+    assert shard.block_range(n * world, world, rank) == (rank * n, (rank + 1) * n)
     # rank r owns block indices [r*n, (r+1)*n): contiguous ranges, no data exchange
     amd.DeviceBatch.gen_blocks(src, blk, blk, n, first_idx=rank * n, litmax=args.litmax, win=args.win)
     torch.cuda.synchronize()
@@ -107,7 +108,7 @@ def main():
         if events:
             events[1].record()
         if world > 1:
-            dist.all_gather_into_tensor(all_clen, clen)                      # the ONLY collective: sizes, 4 B/block
+            shard.gather_sizes(clen, n * world)                              # the ONLY collective: sizes, 4 B/block
         if events:
             events[2].record()
         amd.DeviceBatch.decompress_safe(comp, co, clen, back, so, sl, dlen)

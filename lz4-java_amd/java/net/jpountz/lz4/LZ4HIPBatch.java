@@ -1,0 +1,59 @@
+package net.jpountz.lz4;
+
+import java.nio.ByteBuffer;
+
+/**
+ * Many independent blocks per HIP launch -- the entry point the one-block-per-call API of lz4-java
+ * lacks (LZ4Compressor.java:59, SURVEY.md fact 9).  All buffers must be DIRECT: block i is
+ * {@code src[srcOff[i], srcOff[i]+srcLen[i])} and owns the slot {@code dest[destOff[i], destOff[i]+destCap[i])}.
+ * Results follow liblz4's conventions per block (see include/lz4hip.h).
+ */
+public final class LZ4HIPBatch {
+  private LZ4HIPBatch() {}
+
+  private static void check(ByteBuffer src, ByteBuffer dest, long[] srcOff, int[] srcLen, long[] destOff, int[] destCap, int[] outLen) {
+    if (!src.isDirect() || !dest.isDirect()) {
+      throw new IllegalArgumentException("LZ4HIPBatch needs direct ByteBuffers");
+    }
+    if (dest.isReadOnly()) {
+      throw new java.nio.ReadOnlyBufferException();
+    }
+    final int n = srcOff.length;
+    if (srcLen.length != n || destOff.length != n || destCap.length != n || outLen.length < n) {
+      throw new IllegalArgumentException("per-block arrays must have the same length");
+    }
+    for (int i = 0; i < n; i++) {
+      if (srcLen[i] < 0 || destCap[i] < 0 || srcOff[i] < 0 || destOff[i] < 0
+          || srcOff[i] + srcLen[i] > src.capacity() || destOff[i] + destCap[i] > dest.capacity()) {
+        throw new ArrayIndexOutOfBoundsException(i);
+      }
+    }
+  }
+
+  private static void run(int op, int level, ByteBuffer src, long[] srcOff, int[] srcLen, ByteBuffer dest, long[] destOff, int[] destCap, int[] outLen) {
+    check(src, dest, srcOff, srcLen, destOff, destCap, outLen);
+    final int rc = LZ4HIPJNI.LZ4HIP_batch(op, level, src, srcOff, srcLen, dest, destOff, destCap, outLen, srcOff.length);
+    if (rc != 0) {
+      throw new LZ4Exception("liblz4hip status " + rc + ": " + LZ4HIPJNI.lastError());
+    }
+  }
+
+  /** outLen[i] &gt; 0: compressed size; 0: destCap[i] too small. */
+  public static void compress(ByteBuffer src, long[] srcOff, int[] srcLen, ByteBuffer dest, long[] destOff, int[] destCap, int[] outLen) {
+    run(0, 0, src, srcOff, srcLen, dest, destOff, destCap, outLen);
+  }
+
+  /** outLen[i] &gt;= 0: decompressed size; &lt; 0: -(input position)-1. */
+  public static void decompressSafe(ByteBuffer src, long[] srcOff, int[] srcLen, ByteBuffer dest, long[] destOff, int[] destCap, int[] outLen) {
+    run(1, 0, src, srcOff, srcLen, dest, destOff, destCap, outLen);
+  }
+
+  /** destLen[i] is the exact decompressed size; outConsumed[i] &gt; 0: bytes read from src. */
+  public static void decompressFast(ByteBuffer src, long[] srcOff, int[] srcCap, ByteBuffer dest, long[] destOff, int[] destLen, int[] outConsumed) {
+    run(2, 0, src, srcOff, srcCap, dest, destOff, destLen, outConsumed);
+  }
+
+  public static void compressHC(int level, ByteBuffer src, long[] srcOff, int[] srcLen, ByteBuffer dest, long[] destOff, int[] destCap, int[] outLen) {
+    run(3, level, src, srcOff, srcLen, dest, destOff, destCap, outLen);
+  }
+}

@@ -81,3 +81,17 @@ def test_fails_loudly_without_gpu(amd):
     with pytest.raises(amd.LZ4HIPError):
         amd.LZ4Factory.hipInstance()
     assert amd.lib().lz4hip_device_count() == 0
+
+
+def test_cpp_host_mirror_builds_and_jni_shim_typechecks():
+    """the compiled-language mirror of the reference's host API links against the C ABI; the JNI shim
+    type-checks against a stub jni.h (no JDK in this image)"""
+    exe = os.path.join(ROOT, "tests", "cpp", "host_mirror_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", os.path.join(ROOT, "tests", "cpp", "host_mirror_test.cpp"),
+                           "-L" + os.path.join(ROOT, "lz4-java_amd"), "-llz4hip", "-Wl,-rpath," + os.path.join(ROOT, "lz4-java_amd"),
+                           "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    subprocess.check_call(["gcc", "-fsyntax-only", "-Wall", "-std=c11", "-I" + os.path.join(ROOT, "tests", "jni_stub"),
+                           "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "lz4-java_amd", "jni", "net_jpountz_lz4_LZ4HIPJNI.c")])
+    import torch
+    if not torch.cuda.is_available():
+        assert subprocess.call([exe], stderr=subprocess.DEVNULL) == 3   # loud failure, no CPU path

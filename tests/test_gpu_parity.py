@@ -267,3 +267,13 @@ def test_full_size_roundtrip_properties(amd):
     amd.DeviceBatch.xxh32(back, so, sl, 0, h2)
     torch.cuda.synchronize()
     assert torch.equal(h1, h2)
+
+
+def test_cpp_host_mirror_runs():
+    import os, subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "tests", "cpp", "host_mirror_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tests", "cpp", "host_mirror_test.cpp"),
+                           "-L" + os.path.join(ROOT, "lz4-java_amd"), "-llz4hip", "-Wl,-rpath," + os.path.join(ROOT, "lz4-java_amd"),
+                           "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    assert subprocess.call([exe]) == 0

@@ -1,0 +1,68 @@
+"""world_size-2 (and 3, uneven) gloo test of the multi-GPU path: contiguous block ranges per rank and the
+int32 size all-gather (lz4-java_amd/shard.py).  The per-rank codec is played by the oracle here (test
+infrastructure standing in for the device launch); on GPUs bench.py drives the same functions over RCCL."""
+import importlib
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, n_blocks, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    shard = importlib.import_module("lz4-java_amd.shard")
+    from oracle import oracle as O
+    chk = O.port()
+
+    def codec(b0, b1):  # stand-in for DeviceBatch.compress_fast on this rank's slice
+        return torch.tensor([len(chk.compress_fast(O.gen_block(4096, i))) for i in range(b0, b1)], dtype=torch.int32)
+
+    (b0, b1), sizes = shard.compress_sharded(codec, n_blocks)
+    q.put((rank, b0, b1, sizes.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_blocks", [(2, 64), (3, 50), (2, 1)])
+def test_contiguous_shards_and_size_gather(world, n_blocks):
+    from oracle import oracle as O
+    chk = O.port()
+    expect = [len(chk.compress_fast(O.gen_block(4096, i))) for i in range(n_blocks)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_blocks, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    covered = []
+    for rank, b0, b1, sizes in sorted(res):
+        assert sizes == expect            # every rank ends up with every block's size, in block order
+        covered += list(range(b0, b1))
+    assert covered == list(range(n_blocks))  # ranges are contiguous, disjoint and complete
+
+
+def test_block_range_balance():
+    shard = importlib.import_module("lz4-java_amd.shard")
+    for n in (0, 1, 7, 65536, 65537):
+        for w in (1, 2, 3, 8):
+            r = [shard.block_range(n, w, k) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(r[k][1] == r[k + 1][0] for k in range(w - 1))
+            sizes = [b - a for a, b in r]
+            assert max(sizes) - min(sizes) <= 1
