@@ -210,6 +210,12 @@ class LZ4HCHIPCompressor(LZ4Compressor):
     def _native(self, sp, src_len, dp, max_dest_len):
         return _single(lib().lz4hip_compress_hc(sp, src_len, dp, max_dest_len, self.compressionLevel))
 
+    def compress(self, src, srcOff=None, srcLen=None, dest=None, destOff=None, maxDestLen=None):
+        try:
+            return super().compress(src, srcOff, srcLen, dest, destOff, maxDestLen)
+        except LZ4Exception:
+            raise LZ4Exception()  # LZ4HCJNICompressor.java:47-49 throws without a message
+
 
 # ----------------------------------------------------------------------------------------------
 # decompressors
@@ -283,11 +289,12 @@ class LZ4Factory:
         self._safe_dec = LZ4SafeDecompressor()
         # LZ4Factory.java:204-220: the constructor round-trips a 20-byte vector through all members
         original = b"abcd      abcdefghij"
-        compressed = self._fast.compress(original)
-        if self._fast_dec.decompress(compressed, len(original)) != original:
-            raise AssertionError("fast decompressor self-test failed")
-        if self._safe_dec.decompress(compressed, len(original)) != original:
-            raise AssertionError("safe decompressor self-test failed")
+        for compressor in (self._fast, self.highCompressor()):
+            compressed = compressor.compress(original)
+            if self._fast_dec.decompress(compressed, len(original)) != original:
+                raise AssertionError("fast decompressor self-test failed")
+            if self._safe_dec.decompress(compressed, len(original)) != original:
+                raise AssertionError("safe decompressor self-test failed")
 
     @classmethod
     def hipInstance(cls):
@@ -392,6 +399,19 @@ class LZ4HIPBatch:
         return cls._call("lz4hip_compress_fast_batch", src, srcOff, srcLen, dst, dstOff, dstCap)
 
     @classmethod
+    def compressHC(cls, src, srcOff, srcLen, dst, dstOff, dstCap, level=9):
+        n = len(srcOff)
+        for i in range(n):
+            _check_range(src, srcOff[i], srcLen[i])
+            _check_range(dst, dstOff[i], dstCap[i])
+        sp, sk = _ro_ptr(src)
+        dp, dk = _rw_ptr(dst)
+        out = (C.c_int32 * max(n, 1))()
+        _chk(lib().lz4hip_compress_hc_batch(sp, _arr(C.c_uint64, srcOff), _arr(C.c_int32, srcLen), dp, _arr(C.c_uint64, dstOff),
+                                            _arr(C.c_int32, dstCap), out, n, level))
+        return list(out[:n])
+
+    @classmethod
     def decompressSafe(cls, src, srcOff, srcLen, dst, dstOff, dstCap):
         return cls._call("lz4hip_decompress_safe_batch", src, srcOff, srcLen, dst, dstOff, dstCap)
 
@@ -438,6 +458,12 @@ class DeviceBatch:
     @classmethod
     def compress_fast(cls, src, src_off, src_len, dst, dst_off, dst_cap, out):
         cls._call("lz4hip_compress_fast_batch_dev", src, src_off, src_len, dst, dst_off, dst_cap, out)
+
+    @classmethod
+    def compress_hc(cls, src, src_off, src_len, dst, dst_off, dst_cap, out, level=9):
+        dev, st = cls._stream_dev(src)
+        _chk(lib().lz4hip_compress_hc_batch_dev(src.data_ptr(), src_off.data_ptr(), src_len.data_ptr(), dst.data_ptr(),
+                                                dst_off.data_ptr(), dst_cap.data_ptr(), out.data_ptr(), src_off.numel(), level, dev, st))
 
     @classmethod
     def compress_fast_profile(cls, src, src_off, src_len, dst, dst_off, dst_cap, out, prof):

@@ -61,8 +61,37 @@ struct DeviceGuard {  // callers (e.g. PyTorch) own the thread's current device:
   ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
-enum Op { OP_COMPRESS_FAST, OP_DECODE_SAFE, OP_DECODE_FAST };
+enum Op { OP_COMPRESS_FAST, OP_DECODE_SAFE, OP_DECODE_FAST, OP_COMPRESS_HC };
 int g_decode_lanes = 0;  // tuning knob (lz4hip_set_option "decode_lanes"); 0 = kernel default
+
+// liblz4's level handling: < 1 -> 9, > 12 -> 12; 10..12 are the optimal parser,
+// which this build does not implement
+int hc_level(int level, int* out) {
+  if (level < 1) level = 9;
+  if (level > 12) level = 12;
+  if (level > 9) return fail(LZ4HIP_E_UNSUPPORTED, "HC levels 10..12 (optimal parser; lz4-java levels 10..17) are not implemented yet");
+  *out = level;
+  return LZ4HIP_OK;
+}
+
+// HC on device pointers: sizes the u16 workspace (one stream synchronisation), runs build + parse
+int dev_hc(const lz4hip::BatchArgs& a, int level, hipStream_t st) {
+  uint64_t* d_span = nullptr;
+  uint64_t span = 0;
+  HIPCHK(hipMallocAsync((void**)&d_span, 8, st));
+  HIPCHK(hipMemsetAsync(d_span, 0, 8, st));
+  int e = lz4hip::launch_hc_span(a.src_off, a.src_len, a.n, d_span, st);
+  if (e) return fail(LZ4HIP_E_HIP, "kernel launch", (hipError_t)e);
+  HIPCHK(hipMemcpyAsync(&span, d_span, 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(hipFreeAsync(d_span, st));
+  uint16_t* ws = nullptr;
+  if (hipMallocAsync((void**)&ws, (size_t)span * 2 + 64, st) != hipSuccess) return fail(LZ4HIP_E_NOMEM, "HC workspace allocation failed");
+  e = lz4hip::launch_compress_hc(a, level, ws, st);
+  (void)hipFreeAsync(ws, st);
+  if (e) return fail(LZ4HIP_E_HIP, "kernel launch", (hipError_t)e);
+  return LZ4HIP_OK;
+}
 
 int launch_op(Op op, const lz4hip::BatchArgs& a, hipStream_t st) {
   int e = 0;
@@ -70,13 +99,14 @@ int launch_op(Op op, const lz4hip::BatchArgs& a, hipStream_t st) {
     case OP_COMPRESS_FAST: e = lz4hip::launch_compress_fast(a, st); break;
     case OP_DECODE_SAFE: e = lz4hip::launch_decompress(a, true, g_decode_lanes, st); break;
     case OP_DECODE_FAST: e = lz4hip::launch_decompress(a, false, g_decode_lanes, st); break;
+    case OP_COMPRESS_HC: return fail(LZ4HIP_E_ARG, "internal: HC goes through dev_hc");
   }
   if (e != 0) return fail(LZ4HIP_E_HIP, "kernel launch", (hipError_t)e);
   return LZ4HIP_OK;
 }
 
 int dev_batch(Op op, const uint8_t* src, const uint64_t* src_off, const int32_t* src_len, uint8_t* dst,
-              const uint64_t* dst_off, const int32_t* dst_cap, int32_t* out, uint32_t n, int device, void* stream) {
+              const uint64_t* dst_off, const int32_t* dst_cap, int32_t* out, uint32_t n, int device, void* stream, int level = 0) {
   int rc = ensure_init();
   if (rc) return fail(rc, "no HIP device: liblz4hip has no CPU fallback");
   if (n == 0) return LZ4HIP_OK;
@@ -86,6 +116,7 @@ int dev_batch(Op op, const uint8_t* src, const uint64_t* src_off, const int32_t*
   DeviceGuard g(ord);
   if (!g.ok) return fail(LZ4HIP_E_HIP, "hipSetDevice failed");
   lz4hip::BatchArgs a{src, src_off, src_len, dst, dst_off, dst_cap, out, n};
+  if (op == OP_COMPRESS_HC) return dev_hc(a, level, (hipStream_t)stream);
   return launch_op(op, a, (hipStream_t)stream);
 }
 
@@ -109,7 +140,7 @@ struct DevBuf {
 };
 
 // one device's share [b0, b1) of a host batch
-int host_shard(Op op, int ord, const uint8_t* src, const uint64_t* src_off, const int32_t* src_len, uint8_t* dst,
+int host_shard(Op op, int level, int ord, const uint8_t* src, const uint64_t* src_off, const int32_t* src_len, uint8_t* dst,
                const uint64_t* dst_off, const int32_t* dst_cap, int32_t* out, uint32_t b0, uint32_t b1, std::string* err) {
   auto bad = [&](const char* what, hipError_t e) {
     char buf[512];
@@ -125,11 +156,11 @@ int host_shard(Op op, int ord, const uint8_t* src, const uint64_t* src_off, cons
   const Span ds = span_of(dst_off, dst_cap, b0, b1);
   std::vector<uint64_t> so(n), dof(n);
   for (uint32_t i = 0; i < n; i++) { so[i] = src_off[b0 + i] - ss.lo; dof[i] = dst_off[b0 + i] - ds.lo; }
-  DevBuf dsrc, ddst, dso, ddo, dsl, ddc, dout;
+  DevBuf dsrc, ddst, dso, ddo, dsl, ddc, dout, dws;
   const size_t slen = (size_t)(ss.hi - ss.lo), dlen = (size_t)(ds.hi - ds.lo);
   if ((e = dsrc.alloc(slen + 16)) != hipSuccess || (e = ddst.alloc(dlen + 16)) != hipSuccess || (e = dso.alloc(n * 8)) != hipSuccess ||
       (e = ddo.alloc(n * 8)) != hipSuccess || (e = dsl.alloc(n * 4)) != hipSuccess || (e = ddc.alloc(n * 4)) != hipSuccess ||
-      (e = dout.alloc(n * 4)) != hipSuccess) {
+      (e = dout.alloc(n * 4)) != hipSuccess || (op == OP_COMPRESS_HC && (e = dws.alloc(slen * 2 + 64)) != hipSuccess)) {
     *err = std::string("hipMalloc: ") + hipGetErrorString(e);
     return LZ4HIP_E_NOMEM;
   }
@@ -149,6 +180,7 @@ int host_shard(Op op, int ord, const uint8_t* src, const uint64_t* src_off, cons
       case OP_COMPRESS_FAST: le = lz4hip::launch_compress_fast(a, st); break;
       case OP_DECODE_SAFE: le = lz4hip::launch_decompress(a, true, g_decode_lanes, st); break;
       case OP_DECODE_FAST: le = lz4hip::launch_decompress(a, false, g_decode_lanes, st); break;
+      case OP_COMPRESS_HC: le = lz4hip::launch_compress_hc(a, level, (uint16_t*)dws.p, st); break;
     }
     if (le) { rc = bad("kernel launch", (hipError_t)le); break; }
     if ((e = hipMemcpyAsync(out + b0, dout.p, n * 4, hipMemcpyDeviceToHost, st)) != hipSuccess) { rc = bad("D2H out", e); break; }
@@ -174,7 +206,7 @@ int host_shard(Op op, int ord, const uint8_t* src, const uint64_t* src_off, cons
 }
 
 int host_batch(Op op, const uint8_t* src, const uint64_t* src_off, const int32_t* src_len, uint8_t* dst,
-               const uint64_t* dst_off, const int32_t* dst_cap, int32_t* out, uint32_t n) {
+               const uint64_t* dst_off, const int32_t* dst_cap, int32_t* out, uint32_t n, int level = 0) {
   int rc = ensure_init();
   if (rc) return fail(rc, "no HIP device: liblz4hip has no CPU fallback");
   if (n == 0) return LZ4HIP_OK;
@@ -188,12 +220,12 @@ int host_batch(Op op, const uint8_t* src, const uint64_t* src_off, const int32_t
   std::vector<int> rcs(D, 0);
   std::vector<std::string> errs(D);
   if (D == 1) {
-    rcs[0] = host_shard(op, devs[0], src, src_off, src_len, dst, dst_off, dst_cap, out, 0, n, &errs[0]);
+    rcs[0] = host_shard(op, level, devs[0], src, src_off, src_len, dst, dst_off, dst_cap, out, 0, n, &errs[0]);
   } else {
     std::vector<std::thread> th;
     for (uint32_t d = 0; d < D; d++) {
       const uint32_t b0 = (uint32_t)((uint64_t)n * d / D), b1 = (uint32_t)((uint64_t)n * (d + 1) / D);
-      th.emplace_back([&, d, b0, b1] { rcs[d] = host_shard(op, devs[d], src, src_off, src_len, dst, dst_off, dst_cap, out, b0, b1, &errs[d]); });
+      th.emplace_back([&, d, b0, b1] { rcs[d] = host_shard(op, level, devs[d], src, src_off, src_len, dst, dst_off, dst_cap, out, b0, b1, &errs[d]); });
     }
     for (auto& t : th) t.join();
   }
@@ -307,8 +339,11 @@ int lz4hip_decompress_fast_batch(const uint8_t* src, const uint64_t* src_off, co
                                  const uint64_t* dst_off, const int32_t* dst_len, int32_t* out_consumed, uint32_t n) {
   return host_batch(OP_DECODE_FAST, src, src_off, src_cap, dst, dst_off, dst_len, out_consumed, n);
 }
-int lz4hip_compress_hc_batch(const uint8_t*, const uint64_t*, const int32_t*, uint8_t*, const uint64_t*, const int32_t*, int32_t*, uint32_t, int) {
-  return fail(LZ4HIP_E_UNSUPPORTED, "HC compressor: not built yet (SURVEY.md section 8 row a4)");
+int lz4hip_compress_hc_batch(const uint8_t* src, const uint64_t* src_off, const int32_t* src_len, uint8_t* dst,
+                             const uint64_t* dst_off, const int32_t* dst_cap, int32_t* out_len, uint32_t n, int level) {
+  int lv;
+  if (hc_level(level, &lv)) return LZ4HIP_E_UNSUPPORTED;
+  return host_batch(OP_COMPRESS_HC, src, src_off, src_len, dst, dst_off, dst_cap, out_len, n, lv);
 }
 int lz4hip_xxh32_batch(const uint8_t* buf, const uint64_t* off, const int32_t* len, uint32_t seed, uint32_t* out, uint32_t n) {
   return host_xxh<uint32_t>(false, buf, off, len, seed, out, n);
@@ -330,8 +365,11 @@ int lz4hip_decompress_fast_batch_dev(const uint8_t* src, const uint64_t* src_off
                                      const uint64_t* dst_off, const int32_t* dst_len, int32_t* out_consumed, uint32_t n, int device, void* stream) {
   return dev_batch(OP_DECODE_FAST, src, src_off, src_cap, dst, dst_off, dst_len, out_consumed, n, device, stream);
 }
-int lz4hip_compress_hc_batch_dev(const uint8_t*, const uint64_t*, const int32_t*, uint8_t*, const uint64_t*, const int32_t*, int32_t*, uint32_t, int, int, void*) {
-  return fail(LZ4HIP_E_UNSUPPORTED, "HC compressor: not built yet (SURVEY.md section 8 row a4)");
+int lz4hip_compress_hc_batch_dev(const uint8_t* src, const uint64_t* src_off, const int32_t* src_len, uint8_t* dst,
+                                 const uint64_t* dst_off, const int32_t* dst_cap, int32_t* out_len, uint32_t n, int level, int device, void* stream) {
+  int lv;
+  if (hc_level(level, &lv)) return LZ4HIP_E_UNSUPPORTED;
+  return dev_batch(OP_COMPRESS_HC, src, src_off, src_len, dst, dst_off, dst_cap, out_len, n, device, stream, lv);
 }
 int lz4hip_xxh32_batch_dev(const uint8_t* buf, const uint64_t* off, const int32_t* len, uint32_t seed, uint32_t* out, uint32_t n, int device, void* stream) {
   int rc = ensure_init();
@@ -374,7 +412,16 @@ int lz4hip_dbg_compress_fast_profile_dev(const uint8_t* src, const uint64_t* src
 
 // ---- single-block convenience ----
 int lz4hip_compress_fast(const uint8_t* src, int src_len, uint8_t* dst, int dst_cap) { return single(OP_COMPRESS_FAST, src, src_len, dst, dst_cap); }
-int lz4hip_compress_hc(const uint8_t*, int, uint8_t*, int, int) { return LZ4HIP_LIB_ERROR(fail(LZ4HIP_E_UNSUPPORTED, "HC compressor: not built yet")); }
+int lz4hip_compress_hc(const uint8_t* src, int src_len, uint8_t* dst, int dst_cap, int level) {
+  int lv;
+  if (hc_level(level, &lv)) return LZ4HIP_LIB_ERROR(LZ4HIP_E_UNSUPPORTED);
+  const uint64_t zero = 0;
+  int32_t sl = src_len, dc = dst_cap, out = 0;
+  uint8_t dummy = 0;
+  int rc = host_batch(OP_COMPRESS_HC, src ? src : &dummy, &zero, &sl, dst ? dst : &dummy, &zero, &dc, &out, 1, lv);
+  if (rc) return LZ4HIP_LIB_ERROR(rc);
+  return out;
+}
 int lz4hip_decompress_safe(const uint8_t* src, int src_len, uint8_t* dst, int dst_cap) { return single(OP_DECODE_SAFE, src, src_len, dst, dst_cap); }
 int lz4hip_decompress_fast(const uint8_t* src, int src_cap, uint8_t* dst, int dst_len) { return single(OP_DECODE_FAST, src, src_cap, dst, dst_len); }
 int lz4hip_xxh32(const uint8_t* buf, int len, uint32_t seed, uint32_t* out) {

@@ -15,6 +15,7 @@
 #include "group_dev.h"
 #include "lz4_fast_core.h"
 #include "lz4_decode_core.h"
+#include "lz4_hc_core.h"
 #include "xxh_core.h"
 
 namespace lz4hip {
@@ -75,6 +76,49 @@ int launch_compress_fast_prof(const BatchArgs& a, uint64_t* prof, void* stream) 
 int launch_compress_fast(const BatchArgs& a, void* stream) {
   if (a.n == 0) return 0;
   hipLaunchKernelGGL(compress_fast_kernel, dim3(a.n), dim3(64), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// HC compress (levels 1..9): phase 1 builds delta[] (workspace `ws`, one u16 per input byte, indexed by
+// the block's source offset), phase 2 parses.  One wavefront per block in both.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void hc_build_kernel(BatchArgs a, uint16_t* ws) {
+  __shared__ __attribute__((aligned(16))) uint32_t head[32768];  // 128 KB: liblz4's HC hashTable
+  const uint32_t b = blockIdx.x;
+  const int32_t n = a.src_len[b];
+  if (n < 0 || (uint32_t)n > 0x7E000000u) return;
+  WaveDev w(head);
+  HcBuild<WaveDev>::run(w, a.src + a.src_off[b], (uint32_t)n, ws + a.src_off[b]);
+}
+__global__ __launch_bounds__(64) void hc_parse_kernel(BatchArgs a, const uint16_t* ws, int level) {
+  const uint32_t b = blockIdx.x;
+  const int32_t n = a.src_len[b];
+  const int32_t cap = a.dst_cap[b];
+  int r = 0;
+  if (n >= 0 && (uint32_t)n <= 0x7E000000u && cap >= 0) {
+    WaveDev w(nullptr);
+    HcParse<WaveDev> p(w, a.src + a.src_off[b], n, ws + a.src_off[b], a.dst + a.dst_off[b], cap, level);
+    r = p.run();
+  }
+  if (threadIdx.x == 0) a.out[b] = r;
+}
+// max over blocks of (src_off + src_len): how many u16 the HC workspace needs
+__global__ void hc_span_kernel(const uint64_t* src_off, const int32_t* src_len, uint32_t n, unsigned long long* out) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const int32_t l = src_len[i];
+  atomicMax(out, (unsigned long long)(src_off[i] + (l > 0 ? (uint64_t)l : 0ull)));
+}
+int launch_hc_span(const uint64_t* src_off, const int32_t* src_len, uint32_t n, uint64_t* out_dev, void* stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(hc_span_kernel, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, src_off, src_len, n, (unsigned long long*)out_dev);
+  return (int)hipGetLastError();
+}
+int launch_compress_hc(const BatchArgs& a, int level, uint16_t* ws, void* stream) {
+  if (a.n == 0) return 0;
+  hipLaunchKernelGGL(hc_build_kernel, dim3(a.n), dim3(64), 0, (hipStream_t)stream, a, ws);
+  hipLaunchKernelGGL(hc_parse_kernel, dim3(a.n), dim3(64), 0, (hipStream_t)stream, a, (const uint16_t*)ws, level);
   return (int)hipGetLastError();
 }
 

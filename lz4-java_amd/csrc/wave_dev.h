@@ -81,6 +81,11 @@ struct WaveDev {
   __device__ __forceinline__ static void st8(uint8_t* b, VU i, VU v, bool m) {
     if (m) b[i] = (uint8_t)v;
   }
+  __device__ __forceinline__ static void st16(uint16_t* b, VU i, VU v, bool m) {
+    if (m) b[i] = (uint16_t)v;
+  }
+  // per-lane evaluation of a scalar function (lanes diverge freely inside f)
+  template <class F> __device__ __forceinline__ static VU64 map_lanes64(F f) { return f((uint32_t)__lane_id()); }
   // cooperative byte copy dst[dpos..+len) = src[spos..+len); regions never overlap
   __device__ __forceinline__ static void copy(uint8_t* dst, uint32_t dpos, const uint8_t* src, uint32_t spos, uint32_t len) {
     const uint32_t l = __lane_id();

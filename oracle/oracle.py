@@ -89,17 +89,21 @@ class _Lib:
             raise ValueError("maxDestLen is too small")
         return b
 
-    def compress_hc(self, src, level=9, cap=None):
-        cap = self.compress_bound(len(src)) if cap is None else cap
+    def compress_hc_raw(self, src, level, cap):
         p, _k = _buf(src)
         out = (C.c_uint8 * max(cap, 1))()
         if self.kind == "reference":
             r = self._hc(p, C.cast(out, _u8p), len(src), cap, level)
         else:
             r = self._hc(p, len(src), C.cast(out, _u8p), cap, level)
+        return r, bytes(out[: max(r, 0)])
+
+    def compress_hc(self, src, level=9, cap=None):
+        cap = self.compress_bound(len(src)) if cap is None else cap
+        r, b = self.compress_hc_raw(src, level, cap)
         if r <= 0:
             raise ValueError("maxDestLen is too small")
-        return bytes(out[:r])
+        return b
 
     def decompress_safe_raw(self, src, cap, src_len=None, prefill=0xA5):
         """returns (ret, dst bytes of size cap)"""

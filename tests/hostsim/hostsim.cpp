@@ -8,6 +8,8 @@
 #include "wave_host.h"
 #include "../../lz4-java_amd/csrc/lz4_decode_core.h"
 #include "group_host.h"
+#include "../../lz4-java_amd/csrc/lz4_hc_core.h"
+#include <vector>
 
 extern "C" {
 
@@ -39,6 +41,24 @@ int sim_decompress(const uint8_t* src, int src_size, uint8_t* dst, int out_size,
   int r = safe ? lz4hip::decode_block<hostsim::GroupHost, true>(g, src, src_size, dst, out_size)
                : lz4hip::decode_block<hostsim::GroupHost, false>(g, src, src_size, dst, out_size);
   if (g.oob) return -1000000;
+  return r;
+}
+
+// LZ4 HC (levels 1..9): phase 1 (delta[] build) + phase 2 (lazy parse) in the lock-step simulator.
+// returns the compressed size, 0 (does not fit), -1 (level not implemented) or -1000 (out-of-slot access)
+int sim_compress_hc(const uint8_t* src, int n, uint8_t* dst, int cap, int level, uint64_t rng_seed) {
+  if (n < 0 || (uint32_t)n > 0x7E000000u || cap < 0) return 0;
+  if (level < 1) level = 9;
+  if (level > 12) level = 12;
+  if (level > 9) return -1;
+  hostsim::WaveHost w;
+  if (rng_seed) w.rng = rng_seed;
+  w.bounds(src, (size_t)n, dst, (size_t)cap);
+  std::vector<uint16_t> delta((size_t)n + 8, 0xFFFF);
+  lz4hip::HcBuild<hostsim::WaveHost>::run(w, src, (uint32_t)n, delta.data());
+  lz4hip::HcParse<hostsim::WaveHost> p(w, src, n, delta.data(), dst, cap, level);
+  const int r = p.run();
+  if (w.oob) return -1000;
   return r;
 }
 

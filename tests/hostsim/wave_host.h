@@ -44,13 +44,13 @@ struct WaveHost {
   using VB = V<bool>;
   template <bool U16> struct Entry;
 
-  std::vector<uint64_t> lds;  // 4096 x u64 == 8192 x u32 == 32 KB
+  std::vector<uint64_t> lds;  // fast compressor: 32 KB; HC head table: 32768 x u32 = 128 KB
   uint64_t rng = 0x9E3779B97F4A7C15ull;
   const uint8_t* src_lo = nullptr; const uint8_t* src_hi = nullptr;  // bounds for checking loads
   uint8_t* dst_lo = nullptr; uint8_t* dst_hi = nullptr;              // bounds for checking stores
   bool oob = false;
 
-  WaveHost() : lds(4096, 0) {}
+  WaveHost() : lds(16384, 0) {}
   void bounds(const uint8_t* s, size_t n, uint8_t* d, size_t cap) { src_lo = s; src_hi = s + n; dst_lo = d; dst_hi = d + cap; }
 
   static void sync() {}
@@ -94,6 +94,10 @@ struct WaveHost {
   void st8(uint8_t* b, const VU& i, const VU& v, const VB& m) {
     for (int l = 0; l < 64; l++) if (m.v[l] && out_ok(b + i.v[l], 1)) b[i.v[l]] = (uint8_t)v.v[l];
   }
+  void st16(uint16_t* b, const VU& i, const VU& v, const VB& m) {
+    for (int l = 0; l < 64; l++) if (m.v[l]) b[i.v[l]] = (uint16_t)v.v[l];
+  }
+  template <class F> static VU64 map_lanes64(F f) { VU64 r; for (int l = 0; l < 64; l++) r.v[l] = f((uint32_t)l); return r; }
   void copy(uint8_t* dst, uint32_t dpos, const uint8_t* src, uint32_t spos, uint32_t len) {
     if (len && in_ok(src + spos, len) && out_ok(dst + dpos, len)) memcpy(dst + dpos, src + spos, len);
   }

@@ -1,0 +1,87 @@
+"""LZ4 HC (levels 1..9) on the GPU vs the oracle: golden table, level sweep and clamps, dest-too-small,
+BASELINE.json configs[3] shape (1 MiB blocks, win 4096)."""
+import random
+
+import pytest
+
+from conftest import rnd_inputs, sha
+from test_gpu_parity import pack
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_hc_many(amd, blocks, caps, level=9):
+    src, so, sl, dst, do = pack(blocks, caps)
+    out = amd.LZ4HIPBatch.compressHC(src, so, sl, dst, do, list(caps), level)
+    return [(r, bytes(dst[o:o + max(r, 0)])) for r, o in zip(out, do)]
+
+
+def test_hc_golden_and_factory(amd, golden, corpus, ref):
+    names = list(corpus)
+    blocks = [corpus[n] for n in names]
+    res = gpu_hc_many(amd, blocks, [ref.compress_bound(len(b)) for b in blocks])
+    for n, b, (r, c) in zip(names, blocks, res):
+        assert (r, sha(c)) == (golden["inputs"][n]["hc9_size"], golden["inputs"][n]["hc9_sha256"]), n
+        assert ref.decompress_safe(c, len(b)) == b
+    f = amd.LZ4Factory.hipInstance()
+    hc = f.highCompressor()
+    assert hc.compress(b"abcd      abcdefghij").hex() == "5161626364200100a06162636465666768696a"
+    assert f.safeDecompressor().decompress(hc.compress(corpus["book1[:65536]"]), 65536) == corpus["book1[:65536]"]
+    with pytest.raises(amd.LZ4Exception):
+        hc.compress(corpus["book1[:65536]"], 0, 65536, bytearray(1000), 0, 1000)
+    # LZ4Factory.highCompressor clamps: > 17 -> 17 (== native 12, not implemented), < 1 -> 9
+    assert f.highCompressor(0).compressionLevel == 9 and f.highCompressor(99).compressionLevel == 17
+    with pytest.raises(amd.LZ4HIPError):
+        f.highCompressor(12).compress(b"hello hello hello hello")
+
+
+def test_hc_levels_fuzz(amd, ref, O, corpus):
+    rng = random.Random(29)
+    inputs = rnd_inputs(O, corpus, 71, 400)
+    for lvl in (1, 3, 4, 6, 9, 0):
+        blocks, caps = [], []
+        for v in inputs[lvl * 50 % 300: lvl * 50 % 300 + 100]:
+            full = ref.compress_bound(len(v))
+            er, _ = ref.compress_hc_raw(v, lvl, full)
+            for cap in (full, max(0, er + rng.choice([-1, 0, 1, -9, 9])), rng.randrange(0, full + 1)):
+                blocks.append(v); caps.append(cap)
+        res = gpu_hc_many(amd, blocks, caps, lvl)
+        for v, cap, (r, c) in zip(blocks, caps, res):
+            er, eb = ref.compress_hc_raw(v, lvl, cap)
+            assert r == er and (er <= 0 or c == eb), (lvl, len(v), cap, r, er)
+    pats = []
+    for period in (1, 2, 3, 4, 7):
+        p = rng.randbytes(period)
+        for n in (3000, 70000, 300000):
+            v = bytearray((p * (n // period + 1))[:n])
+            for _ in range(n // 2500):
+                v[rng.randrange(n)] ^= 0x33
+            pats.append(bytes(v))
+    res = gpu_hc_many(amd, pats, [ref.compress_bound(len(b)) for b in pats])
+    for b, (r, c) in zip(pats, res):
+        assert c == ref.compress_hc(b, 9), len(b)
+
+
+def test_hc_cfg4_shape_device(amd, O, ref):
+    """4096 x 1 MiB is the bench shape; here 32 x 1 MiB, device-resident, every block checked"""
+    import torch
+    n, blk = 32, 1 << 20
+    cap = amd.maxCompressedLength(blk)
+    dev = torch.device("cuda:0")
+    src = torch.empty(n * blk, dtype=torch.uint8, device=dev)
+    amd.DeviceBatch.gen_blocks(src, blk, blk, n, win=4096)
+    so = torch.arange(n, dtype=torch.int64, device=dev) * blk
+    sl = torch.full((n,), blk, dtype=torch.int32, device=dev)
+    comp = torch.zeros(n * cap, dtype=torch.uint8, device=dev)
+    co = torch.arange(n, dtype=torch.int64, device=dev) * cap
+    cc = torch.full((n,), cap, dtype=torch.int32, device=dev)
+    clen = torch.zeros(n, dtype=torch.int32, device=dev)
+    amd.DeviceBatch.compress_hc(src, so, sl, comp, co, cc, clen, 9)
+    back = torch.zeros(n * blk, dtype=torch.uint8, device=dev)
+    dlen = torch.zeros(n, dtype=torch.int32, device=dev)
+    amd.DeviceBatch.decompress_safe(comp, co, clen, back, so, sl, dlen)
+    torch.cuda.synchronize()
+    assert torch.equal(back, src)
+    host, ch, cl = src.cpu().numpy().tobytes(), comp.cpu().numpy().tobytes(), clen.cpu().tolist()
+    for i in (0, 13, 31):
+        assert ch[i * cap:i * cap + cl[i]] == ref.compress_hc(host[i * blk:(i + 1) * blk], 9)

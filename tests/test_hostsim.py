@@ -105,3 +105,41 @@ def test_decode_core_malformed_vectors(sim, golden):
             assert r == v["safe_ret"]
             if r >= 0:
                 assert d[:r].hex() == v["safe_out_hex"]
+
+
+def sim_hc(sim, v, level, cap, seed=0):
+    sim.sim_compress_hc.restype = C.c_int
+    sim.sim_compress_hc.argtypes = [C.c_char_p, C.c_int, _u8p, C.c_int, C.c_int, C.c_uint64]
+    out = (C.c_uint8 * max(cap, 1))()
+    r = sim.sim_compress_hc(bytes(v), len(v), out, cap, level, seed)
+    return r, bytes(out[:max(r, 0)])
+
+
+def test_hc_core_golden(sim, ref, golden, corpus):
+    from conftest import sha
+    for name, v in corpus.items():
+        r, b = sim_hc(sim, v, 9, ref.compress_bound(len(v)))
+        assert (r, sha(b)) == (golden["inputs"][name]["hc9_size"], golden["inputs"][name]["hc9_sha256"]), name
+
+
+def test_hc_core_fuzz(sim, ref, O, corpus):
+    """delta[] builder + lazy parse vs liblz4: levels 1..9, level clamps, limited output, pattern-heavy inputs,
+    random LDS-atomic orders"""
+    rng = random.Random(23)
+    for v in rnd_inputs(O, corpus, 61, 300):
+        lvl = rng.choice([1, 2, 3, 5, 8, 9, 9, 9, 0, -2])
+        full = ref.compress_bound(len(v))
+        er, _ = ref.compress_hc_raw(v, lvl, full)
+        for cap in (full, max(0, er + rng.choice([-1, 0, 1, -9, 9])), rng.randrange(0, full + 1)):
+            a = ref.compress_hc_raw(v, lvl, cap)
+            r, b = sim_hc(sim, v, lvl, cap, seed=rng.getrandbits(63) | 1)
+            assert r == a[0] and (r <= 0 or b == a[1]), (len(v), lvl, cap, r, a[0])
+    for period in (1, 2, 3, 4, 7):
+        p = rng.randbytes(period)
+        for n in (3000, 70000):
+            v = bytearray((p * (n // period + 1))[:n])
+            for _ in range(n // 2500):
+                v[rng.randrange(n)] ^= 0x33
+            v = bytes(v)
+            assert sim_hc(sim, v, 9, ref.compress_bound(n))[1] == ref.compress_hc(v, 9), (period, n)
+    assert sim_hc(sim, b"x" * 100, 10, 200)[0] == -1  # optimal-parser levels are not implemented
