@@ -36,6 +36,15 @@
 #define LZ4HIP_DEV inline
 #endif
 #endif
+#ifndef LZ4HIP_COLD
+#if defined(__HIPCC__)
+#define LZ4HIP_COLD __device__ __forceinline__   /* (out-of-line calls measured 1.6x SLOWER: stack traffic around the call sites) */
+#else
+#define LZ4HIP_COLD inline
+#endif
+#endif
+#define LZ4HIP_LIKELY(x) __builtin_expect(!!(x), 1)
+#define LZ4HIP_UNLIKELY(x) __builtin_expect(!!(x), 0)
 
 namespace lz4hip {
 
@@ -110,7 +119,7 @@ struct FastCore {
   }
 
   // last literals: token + run + raw bytes; returns total size or 0
-  LZ4HIP_DEV uint32_t emit_last() {
+  LZ4HIP_COLD uint32_t emit_last() {
     const uint32_t last = n - anchor;
     if (limited && (uint64_t)op + last + 1u + (last + 255u - 15u) / 255u > cap) return 0;
     const uint32_t nlx = ext_count(last);
@@ -122,7 +131,7 @@ struct FastCore {
 
   // ---- match extension ------------------------------------------------------------------------
   // tail of a forward count: lane granularity ran into `limit`; at most 7 bytes are left to compare
-  LZ4HIP_DEV uint32_t count_tail(uint32_t pa_t, uint32_t pb_t, uint32_t limit) {
+  LZ4HIP_COLD uint32_t count_tail(uint32_t pa_t, uint32_t pb_t, uint32_t limit) {
     const uint32_t tail = pa_t < limit ? limit - pa_t : 0u;
     if (tail == 0) return 0;
     const VB act = w.lane() < tail;
@@ -133,7 +142,7 @@ struct FastCore {
   }
 
   // number of equal bytes src[a+i]==src[b+i], a+i < limit (b < a); 8 bytes per lane, 512 per round
-  LZ4HIP_DEV uint32_t count_fwd(uint32_t a, uint32_t b, uint32_t limit) {
+  LZ4HIP_COLD uint32_t count_fwd(uint32_t a, uint32_t b, uint32_t limit) {
     uint32_t cnt = 0;
     for (;;) {
       const VU off = w.lane() * 8u + cnt;
@@ -152,7 +161,7 @@ struct FastCore {
   }
 
   // catch-up beyond the first 64 bytes (rare): equal bytes before (ip, m), bounded by maxback
-  LZ4HIP_DEV uint32_t count_back(uint32_t ip, uint32_t m, uint32_t maxback) {
+  LZ4HIP_COLD uint32_t count_back(uint32_t ip, uint32_t m, uint32_t maxback) {
     uint32_t back = 0;
     while (back < maxback) {
       const VU jj = w.lane() + back;
@@ -175,25 +184,47 @@ struct FastCore {
     uint32_t lit = 0, mc = 0, offset = 0, anchor = 0;
   };
   Pending pend;
-  VU pend_bytes;  // regs: lane i holds the literal byte that output byte i of the sequence needs
+  VU pend_b0;  // regs: lane l (>= 1) holds literal l-1 of the pending sequence (byte 0 of its window word)
 
   LZ4HIP_DEV bool emit_pending() {
     if (!pend.have) return true;
     pend.have = false;
     const uint32_t lit = pend.lit, mc = pend.mc, offset = pend.offset;
     const uint32_t nlx = ext_count(lit), nmx = ext_count(mc);
-    if (limited) {
+    if (LZ4HIP_UNLIKELY(limited)) {
       if (pend.check_lits && (uint64_t)op + 1u + lit + (2u + 1u + 5u) + lit / 255u > cap) return false;
       if ((uint64_t)op + 1u + nlx + lit + 2u + (1u + 5u) + (mc + 240u) / 255u > cap) return false;
     }
     const uint32_t token = ((lit < 15u ? lit : 15u) << 4) | (mc < 15u ? mc : 15u);
     const uint32_t total = 1u + nlx + lit + 2u + nmx;
-    if (total <= 64u) {  // common case: one output byte per lane, a single store instruction
-      const VU i = w.lane();
+    const VU i = w.lane();
+    if (LZ4HIP_LIKELY(pend.regs)) {
+      // The common case, branch-free, ONE store instruction, no cross-lane traffic (nlx, nmx <= 1, total <= 63):
+      // lane 0 writes the token; lane l >= 1 writes output byte l + nlx, so the literal it needs (literal l-1)
+      // is byte 0 of its own window word; when a literal-length byte exists (nlx == 1) the otherwise idle lane
+      // 63 writes it at index 1; bytes past the literals come from the 3-byte trailer word {offset, ml-15}.
+      const uint32_t off0 = 1u + nlx + lit;
+      const uint32_t trl = offset | ((mc - 15u) << 16);  // third byte only used when nmx == 1
+      const VB ext_lane = (i == 63u) & VB(nlx != 0u);
+      const VU oi = W::select(ext_lane, VU(1u), W::select(i == 0u, VU(0u), i + nlx));
+      const VU tb = W::shr(VU(trl), ((oi - off0) * 8u) & 31u) & 0xFFu;  // garbage for oi < off0 (never selected)
+      VU b = W::select(oi >= off0, tb, pend_b0);
+      b = W::select(i == 0u, VU(token), b);
+      b = W::select(ext_lane, VU(lit - 15u), b);
+      w.st8(dst, oi + op, b, (oi < total));
+    } else {
+      emit_generic(lit, mc, offset, nlx, nmx, token, total);
+    }
+    op += total;
+    return true;
+  }
+
+  // sequences whose literals are not in the window registers, or that need more than 63 bytes / long length runs
+  LZ4HIP_COLD void emit_generic(uint32_t lit, uint32_t mc, uint32_t offset, uint32_t nlx, uint32_t nmx, uint32_t token, uint32_t total) {
+    const VU i = w.lane();
+    if (total <= 64u) {
       const uint32_t lit0 = 1u + nlx, off0 = lit0 + lit;
-      VU b;
-      if (pend.regs) b = pend_bytes;
-      else b = w.ld8(src, i + (pend.anchor - lit0), (i >= lit0) & (i < off0));
+      VU b = w.ld8(src, i + (pend.anchor - lit0), (i >= lit0) & (i < off0));
       b = W::select(i == 0u, VU(token), b);
       if (nlx) {
         const uint32_t rem = (lit - 15u) - 255u * (nlx - 1u);
@@ -207,15 +238,34 @@ struct FastCore {
       }
       w.st8(dst, i + op, b, i < total);
     } else {
-      w.st8(dst, VU(op), VU(token), w.lane() == 0u);
+      w.st8(dst, VU(op), VU(token), i == 0u);
       if (nlx) put_ext(op + 1u, lit, nlx);
       w.copy(dst, op + 1u + nlx, src, pend.anchor, lit);
       const uint32_t o2 = op + 1u + nlx + lit;
-      w.st8(dst, w.lane() + o2, W::select(w.lane() == 0u, VU(offset & 255u), VU(offset >> 8)), w.lane() < 2u);
+      w.st8(dst, i + o2, W::select(i == 0u, VU(offset & 255u), VU(offset >> 8)), i < 2u);
       if (nmx) put_ext(o2 + 2u, mc, nmx);
     }
-    op += total;
-    return true;
+  }
+
+  // ---- per-step inputs, prepared one step ahead so the window load overlaps bookkeeping ----------
+  VU sp_pos;      // position of each of the 64 slots
+  VB sp_valid, sp_isrun;
+  VU64 sp_x64;    // window word at the slot position (U32 mode: 8 bytes; U16 mode: low 4 bytes used)
+  VU sp_x32;
+
+  LZ4HIP_DEV void prepare_step(bool post, uint32_t S, uint32_t r, uint32_t ip) {
+    const VU j = w.lane();
+    const uint32_t nspecial = post ? 2u : 0u;
+    sp_isrun = j >= nspecial;
+    const VU k = j - nspecial + r;
+    VU prun, pnext;
+    if (LZ4HIP_LIKELY(r + 64u - nspecial <= 65u)) { prun = k + S; pnext = prun + 1u; }  // probes 0..65 of a run are consecutive
+    else { prun = g(k) + S; pnext = g(k + 1u) + S; }
+    sp_pos = W::select(sp_isrun, prun, W::select(j == 0u, VU(ip - 2u), VU(ip)));
+    sp_valid = (!sp_isrun) | (pnext <= mfl1);
+    // invalid lanes read a clamped, harmless address: no exec-mask branch around the load
+    if constexpr (U16) sp_x32 = w.ldu32(src, W::vmin(sp_pos, n - 8u));
+    else sp_x64 = w.ldu64(src, W::vmin(sp_pos, n - 8u));
   }
 
   // ---- the compressor ------------------------------------------------------------------------
@@ -243,36 +293,28 @@ struct FastCore {
     uint32_t ip = 0;         // post-match position (== anchor) when post
     const VU j = w.lane();
     const VU o8 = j * 8u;
+    prepare_step(post, S, r, ip);
 
     for (;;) {
       if (st) st->steps++;
       uint64_t tk = st ? w.tick(0u) : 0;
 #define LZ4HIP_PHASE(i, dep) do { if (st) { const uint64_t t_ = w.tick(dep); st->t[i] += t_ - tk; tk = t_; } } while (0)
-      // ---- [1] positions of this step's 64 slots ----
-      const uint32_t nspecial = post ? 2u : 0u;
-      const VB isrun = j >= nspecial;
-      const VU k = j - nspecial + r;
-      VU prun, pnext;
-      if (r + 64u - nspecial <= 65u) { prun = k + S; pnext = prun + 1u; }  // probes 0..65 of a run are consecutive
-      else { prun = g(k) + S; pnext = g(k + 1u) + S; }
-      const VU pos = W::select(isrun, prun, W::select(j == 0u, VU(ip - 2u), VU(ip)));
-      const VB valid = (!isrun) | (pnext <= mfl1);
-
-      // ---- [2] input window, hash, fingerprint (invalid lanes read a clamped, harmless address) ----
+      // ---- [1] this step's slots were prepared (and their window words requested) one step ahead ----
+      const VU pos = sp_pos;
+      const VB valid = sp_valid, isrun = sp_isrun;
       VU x32, h, fp;
       if constexpr (U16) {
-        x32 = w.ldu32(src, W::vmin(pos, n - 8u));
+        x32 = sp_x32;
         const VU prod = x32 * 2654435761u;
         h = prod >> (32 - HLOG);
         fp = (prod >> 3) & 0xFFFFu;
       } else {
-        const VU64 x64 = w.ldu64(src, W::vmin(pos, n - 8u));
-        x32 = W::lo32(x64);
-        h = W::lo32(((x64 << 24) * 889523592379ull) >> (64 - HLOG));
+        x32 = W::lo32(sp_x64);
+        h = W::lo32(((sp_x64 << 24) * 889523592379ull) >> (64 - HLOG));
         fp = (x32 * 2654435761u) >> 16;
       }
-      LZ4HIP_PHASE(0, w.bcast(h, 0));   // t[0]: positions + input window arrived + hash
-      // ---- [3] table lookup, tentative hits, commit ----
+      LZ4HIP_PHASE(0, w.bcast(h, 0));   // t[0]: input window arrived + hash
+      // ---- [2] table lookup, tentative hits, commit ----
       const VE e = w.template lds_rdu<U16>(h);
       const VE newe = mk_entry(pos, fp);
       const VB probe = valid & (isrun | (j == 1u));  // lane 0 of a post step only inserts
@@ -289,33 +331,30 @@ struct FastCore {
       LZ4HIP_PHASE(1, ncommit);          // t[1]: table read + ballots
       const VE old = w.template lds_max<U16>(h, newe, inrange);
 
-      // ---- [4] speculative candidate fetch: verify + forward + backward extension in ONE round trip ----
-      uint32_t hpos = 0, mpos = 0, maxback = 0;
-      bool hit_post = false;
-      VU64 fa, fb;   // bytes at hpos+8*lane / mpos+8*lane (kept apart: xor-ing here would wait for the loads)
-      VU ba, bb;     // bytes before hpos / mpos
-      if (have_hit) {
-        hpos = w.bcast(pos, (int)k0);
-        mpos = se_pos(w.template bcast_e<U16>(e, (int)k0));
-        hit_post = post && k0 == 1u;
-        maxback = hit_post ? 0u : ((hpos - anchor) < mpos ? (hpos - anchor) : mpos);
-        fa = w.ldu64(src, W::vmin(o8 + hpos, n - 8u));
-        fb = w.ldu64(src, W::vmin(o8 + mpos, n - 8u));
-        if (maxback) {
-          const VB bact = j < maxback;
-          ba = w.ldu8(src, W::select(bact, (hpos - 1u) - j, VU(0u)));
-          bb = w.ldu8(src, W::select(bact, (mpos - 1u) - j, VU(0u)));
-        }
+      // ---- [3] speculative candidate fetch: verify + forward + backward extension in ONE round trip.
+      // Branch-free: without a tentative hit the loads still go out (lane 0's slot vs position 0, L1 hits). ----
+      const uint32_t kk = have_hit ? k0 : 0u;
+      uint32_t hpos = w.bcast(pos, (int)kk);
+      uint32_t mpos = se_pos(w.template bcast_e<U16>(e, (int)kk));
+      bool hit_post = post && k0 == 1u;
+      uint32_t maxback = (!have_hit || hit_post) ? 0u : ((hpos - anchor) < mpos ? (hpos - anchor) : mpos);
+      VU64 fa = w.ldu64(src, W::vmin(o8 + hpos, n - 8u));   // kept apart from fb: xor-ing here would wait for the loads
+      VU64 fb = w.ldu64(src, W::vmin(o8 + mpos, n - 8u));
+      VU ba, bb;
+      {
+        const VB bact = j < maxback;
+        ba = w.ldu8(src, W::select(bact, (hpos - 1u) - j, VU(0u)));
+        bb = w.ldu8(src, W::select(bact, (mpos - 1u) - j, VU(0u)));
       }
-
       LZ4HIP_PHASE(2, hpos);             // t[2]: commit issue + candidate-fetch issue
-      // ---- [5] write out the previous sequence while those loads are in flight ----
+
+      // ---- [4] write out the previous sequence while those loads are in flight ----
       if (!emit_pending()) return 0;
       LZ4HIP_PHASE(3, op);               // t[3]: emission of the previous sequence
 
-      // ---- [6] intra-step bucket collisions (rare): undo, resolve exactly, commit again ----
+      // ---- [5] intra-step bucket collisions (rare): undo, resolve exactly, commit again ----
       const uint64_t det = w.ballot(inrange & (old != e));
-      if (det) {
+      if (LZ4HIP_UNLIKELY(det != 0)) {
         if (st) st->slow_steps++;
         w.template lds_wr<U16>(h, e, inrange);
         w.sync();
@@ -355,83 +394,83 @@ struct FastCore {
             maxback = hit_post ? 0u : ((hpos - anchor) < mpos ? (hpos - anchor) : mpos);
             fa = w.ldu64(src, W::vmin(o8 + hpos, n - 8u));
             fb = w.ldu64(src, W::vmin(o8 + mpos, n - 8u));
-            if (maxback) {
-              const VB bact = j < maxback;
-              ba = w.ldu8(src, W::select(bact, (hpos - 1u) - j, VU(0u)));
-              bb = w.ldu8(src, W::select(bact, (mpos - 1u) - j, VU(0u)));
-            }
+            const VB bact = j < maxback;
+            ba = w.ldu8(src, W::select(bact, (hpos - 1u) - j, VU(0u)));
+            bb = w.ldu8(src, W::select(bact, (mpos - 1u) - j, VU(0u)));
           }
         }
       }
       w.sync();  // table updates of this step are ordered before the next step's reads
       LZ4HIP_PHASE(4, (uint32_t)det);    // t[4]: atomic result + collision handling
 
-      // ---- [7] verify the tentative hit (4 bytes) ----
-      bool hit = false;
+      // ---- [6] verify the tentative hit (4 bytes) ----
       const VU64 fx = fa ^ fb;
-      if (have_hit) {
-        hit = (uint32_t)w.bcast64(fx, 0) == 0u;
-        if (!hit && st) st->false_pos++;
-      }
+      const bool hit = have_hit && (uint32_t)w.bcast64(fx, 0) == 0u;
+      if (st && have_hit && !hit) st->false_pos++;
       LZ4HIP_PHASE(5, (uint32_t)hit);    // t[5]: wait for the candidate bytes
-      if (!hit) {
+      if (LZ4HIP_UNLIKELY(!hit)) {
         if (!have_hit && kinv < 64u && kinv == ncommit) return emit_last();  // liblz4's `goto _last_literals`
         // continue the run after the last committed lane
         if (post) { S = ip + 1u; r = ncommit >= 2u ? ncommit - 2u : 0u; post = false; }
         else r += ncommit;
+        prepare_step(post, S, r, ip);
         continue;
       }
 
-      // ---- [8] a match at hpos against mpos: catch-up, length ----
+      // ---- [7] a match at hpos against mpos: forward length first -- it alone decides where the next step starts ----
       if (st) st->sequences++;
-      uint32_t back = 0;
-      if (maxback) {
-        const uint64_t bad = w.ballot((j < maxback) & (ba != bb));
-        if (bad) back = (uint32_t)ctz64(bad);
-        else if (maxback <= 64u) back = maxback;
-        else back = 64u + count_back(hpos - 64u, mpos - 64u, maxback - 64u);
-      }
       uint32_t cnt;  // equal bytes from hpos on (>= 4)
       {
         const VB full = o8 + (hpos + 8u) <= matchlimit;
         const VU64 xz = W::select(j == 0u, fx & VU64(0xFFFFFFFF00000000ull), fx);
         const uint64_t dm = w.ballot(full & (xz != VU64(0)));
         const uint64_t stop = dm | w.ballot(!full);
-        if (stop == 0) {
+        if (LZ4HIP_UNLIKELY(stop == 0)) {
           cnt = 512u + count_fwd(hpos + 512u, mpos + 512u, matchlimit);
         } else {
           const int f = ctz64(stop);
           cnt = 8u * (uint32_t)f;
-          if ((dm >> f) & 1u) cnt += (uint32_t)(ctz64(w.bcast64(xz, f)) >> 3);
+          if (LZ4HIP_LIKELY((dm >> f) & 1u)) cnt += (uint32_t)(ctz64(w.bcast64(xz, f)) >> 3);
           else if (cnt >= 4u) cnt += count_tail(hpos + cnt, mpos + cnt, matchlimit);
           else cnt = 4u + count_tail(hpos + 4u, mpos + 4u, matchlimit);  // lane 0 itself straddles the limit
         }
       }
+      const uint32_t ip_new = hpos + cnt;
+      const VU b0 = x32 & 0xFFu;         // literal bytes of this step (before the slots are re-prepared)
+      const bool was_post = post;
+      const bool done = ip_new >= mfl1;
+      if (!done) {                        // request the next step's window NOW; the rest of the bookkeeping overlaps it
+        post = true;
+        S = ip_new + 1u;
+        r = 0;
+        ip = ip_new;
+        prepare_step(true, S, 0u, ip_new);
+      }
+      // ---- [8] catch-up, pending-sequence record ----
+      uint32_t back = 0;
+      if (maxback) {
+        const uint64_t bad = w.ballot((j < maxback) & (ba != bb));
+        if (bad) back = (uint32_t)ctz64(bad);
+        else if (LZ4HIP_LIKELY(maxback <= 64u)) back = maxback;
+        else back = 64u + count_back(hpos - 64u, mpos - 64u, maxback - 64u);
+      }
       const uint32_t mc = back + (cnt - 4u);
-      const uint32_t mip = hpos - back;
       pend.have = true;
-      pend.lit = mip - anchor;
+      pend.lit = (hpos - back) - anchor;
       pend.mc = mc;
       pend.offset = hpos - mpos;
       pend.anchor = anchor;
       pend.check_lits = !hit_post;
-      // literals straight from this step's window registers: lane l (>= 1) of a post step that
-      // started its run here sits on position anchor + l - 1
-      pend.regs = post && r == 0u && (1u + ext_count(pend.lit) + pend.lit + 2u + ext_count(mc) <= 64u);
-      if (pend.regs) {
-        const VU b0 = x32 & 0xFFu;
-        pend_bytes = pend.lit >= 15u ? w.shfl_up1(b0) : b0;
-      }
-      ip = mip + 4u + mc;
-      anchor = ip;
-      if (ip >= mfl1) {
+      // literals straight from this step's window registers: lane l (>= 1) of a post step sits on position
+      // anchor + l - 1 (its run started in this step); needs at most one length byte each and lane 63 free
+      pend.regs = was_post && mc < 270u && (1u + (pend.lit >= 15u ? 1u : 0u) + pend.lit + 2u + (mc >= 15u ? 1u : 0u) <= 63u);
+      pend_b0 = b0;
+      anchor = ip_new;
+      LZ4HIP_PHASE(6, ip_new);           // t[6]: match length + catch-up + bookkeeping
+      if (done) {
         if (!emit_pending()) return 0;
         return emit_last();
       }
-      post = true;
-      S = ip + 1u;
-      r = 0;
-      LZ4HIP_PHASE(6, ip);               // t[6]: catch-up + match length + bookkeeping
     }
 #undef LZ4HIP_PHASE
   }
