@@ -63,6 +63,7 @@ struct DeviceGuard {  // callers (e.g. PyTorch) own the thread's current device:
 
 enum Op { OP_COMPRESS_FAST, OP_DECODE_SAFE, OP_DECODE_FAST, OP_COMPRESS_HC };
 int g_decode_lanes = 0;  // tuning knob (lz4hip_set_option "decode_lanes"); 0 = kernel default
+int g_compress_waves = 1; // 1 = single-wave kernel (default, fastest so far), 2 = match-finder wave + emitter wave per block
 
 // liblz4's level handling: < 1 -> 9, > 12 -> 12; 10..12 are the optimal parser,
 // which this build does not implement
@@ -93,10 +94,39 @@ int dev_hc(const lz4hip::BatchArgs& a, int level, hipStream_t st) {
   return LZ4HIP_OK;
 }
 
+// number of CUs of the current device (cached per ordinal)
+uint32_t cu_count() {
+  static std::mutex mu;
+  static std::vector<int> cache(64, 0);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!cache[dev]) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    cache[dev] = v;
+  }
+  return (uint32_t)cache[dev];
+}
+
+// fast compress: single-wave kernel, or (default) the two-wave kernel with its zeroed ring workspace
+int launch_fast(const lz4hip::BatchArgs& a, hipStream_t st) {
+  if (g_compress_waves != 2) return lz4hip::launch_compress_fast(a, st);
+  const uint32_t grid = lz4hip::compress_fast2_grid(a.n, cu_count());
+  const size_t bytes = lz4hip::compress_fast2_ws_bytes(grid);
+  uint8_t* ws = nullptr;
+  hipError_t e = hipMallocAsync((void**)&ws, bytes, st);
+  if (e != hipSuccess) return (int)e;
+  if ((e = hipMemsetAsync(ws, 0, bytes, st)) != hipSuccess) { (void)hipFreeAsync(ws, st); return (int)e; }
+  const int le = lz4hip::launch_compress_fast2(a, ws, grid, st);
+  (void)hipFreeAsync(ws, st);
+  return le;
+}
+
 int launch_op(Op op, const lz4hip::BatchArgs& a, hipStream_t st) {
   int e = 0;
   switch (op) {
-    case OP_COMPRESS_FAST: e = lz4hip::launch_compress_fast(a, st); break;
+    case OP_COMPRESS_FAST: e = launch_fast(a, st); break;
     case OP_DECODE_SAFE: e = lz4hip::launch_decompress(a, true, g_decode_lanes, st); break;
     case OP_DECODE_FAST: e = lz4hip::launch_decompress(a, false, g_decode_lanes, st); break;
     case OP_COMPRESS_HC: return fail(LZ4HIP_E_ARG, "internal: HC goes through dev_hc");
@@ -177,7 +207,7 @@ int host_shard(Op op, int level, int ord, const uint8_t* src, const uint64_t* sr
                         (const uint64_t*)ddo.p, (const int32_t*)ddc.p, (int32_t*)dout.p, n};
     int le = 0;
     switch (op) {
-      case OP_COMPRESS_FAST: le = lz4hip::launch_compress_fast(a, st); break;
+      case OP_COMPRESS_FAST: le = launch_fast(a, st); break;
       case OP_DECODE_SAFE: le = lz4hip::launch_decompress(a, true, g_decode_lanes, st); break;
       case OP_DECODE_FAST: le = lz4hip::launch_decompress(a, false, g_decode_lanes, st); break;
       case OP_COMPRESS_HC: le = lz4hip::launch_compress_hc(a, level, (uint16_t*)dws.p, st); break;
@@ -316,6 +346,12 @@ int lz4hip_set_option(const char* name, int value) {
   if (name && strcmp(name, "decode_lanes") == 0) {
     if (value != 0 && value != 4 && value != 8 && value != 16 && value != 32 && value != 64) return fail(LZ4HIP_E_ARG, "decode_lanes must be 0,4,8,16,32,64");
     g_decode_lanes = value;
+    return LZ4HIP_OK;
+  }
+  if (name && strcmp(name, "dbg_flags") == 0) { lz4hip::set_dbg_flags((uint32_t)value); return LZ4HIP_OK; }
+  if (name && strcmp(name, "compress_waves") == 0) {
+    if (value != 1 && value != 2) return fail(LZ4HIP_E_ARG, "compress_waves must be 1 or 2");
+    g_compress_waves = value;
     return LZ4HIP_OK;
   }
   return fail(LZ4HIP_E_ARG, "unknown option");

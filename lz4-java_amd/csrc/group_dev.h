@@ -15,6 +15,7 @@ struct GroupDev {
   __device__ __forceinline__ static uint32_t ld8(const uint8_t* p) { return *p; }
   __device__ __forceinline__ static uint32_t ld16(const uint8_t* p) { uint16_t v; __builtin_memcpy(&v, p, 2); return v; }
   __device__ __forceinline__ static uint32_t ld32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+  __device__ __forceinline__ static uint64_t ld64(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
 
   // d[0..len) = s[0..len); wild: 4 bytes per lane, may read/write up to 3 bytes past len
   __device__ __forceinline__ void copy_lits(uint8_t* d, const uint8_t* s, uint32_t len, bool wild) const {

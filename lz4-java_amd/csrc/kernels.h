@@ -2,6 +2,7 @@
 // pointers; launches are asynchronous on `stream`.  Return value: hipError_t as int.
 #pragma once
 #include <stdint.h>
+#include <stddef.h>
 
 namespace lz4hip {
 
@@ -12,6 +13,11 @@ struct BatchArgs {
 };
 
 int launch_compress_fast(const BatchArgs& a, void* stream);
+void set_dbg_flags(uint32_t f);  // developer diagnostics
+// two-wave variant: `ws` = zeroed device workspace of compress_fast2_ws_bytes(grid) bytes
+uint32_t compress_fast2_grid(uint32_t n_blocks, uint32_t n_cus);
+size_t compress_fast2_ws_bytes(uint32_t grid);
+int launch_compress_fast2(const BatchArgs& a, uint8_t* ws, uint32_t grid, void* stream);
 int launch_compress_fast_prof(const BatchArgs& a, uint64_t* prof, void* stream);  // developer diagnostics
 // HC levels 1..9: `ws` = device workspace of u16[max(src_off+src_len)] (see launch_hc_span)
 int launch_hc_span(const uint64_t* src_off, const int32_t* src_len, uint32_t n, uint64_t* out_dev, void* stream);

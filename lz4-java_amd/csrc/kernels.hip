@@ -20,10 +20,13 @@
 
 namespace lz4hip {
 
+uint32_t g_dbg_flags = 0;  // developer diagnostics (lz4hip_set_option "dbg_flags"): bit 0 = skip emission (timing only)
+void set_dbg_flags(uint32_t f) { g_dbg_flags = f; }
+
 // ------------------------------------------------------------------------------------------------
 // fast compress
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void compress_fast_kernel(BatchArgs a) {
+__global__ __launch_bounds__(64) void compress_fast_kernel(BatchArgs a, uint32_t dbg_flags) {
   __shared__ __attribute__((aligned(16))) uint64_t table[4096];  // 32 KB: 8192 x u32 (byU16) or 4096 x u64 (byU32)
   const uint32_t b = blockIdx.x;
   const int32_t n = a.src_len[b];
@@ -33,11 +36,17 @@ __global__ __launch_bounds__(64) void compress_fast_kernel(BatchArgs a) {
     const uint8_t* s = a.src + a.src_off[b];
     uint8_t* d = a.dst + a.dst_off[b];
     WaveDev w(table);
-    if (n < 65547) {
-      FastCore<WaveDev, true> c(w, s, (uint32_t)n, d, (uint32_t)cap);
+    DirectOut<WaveDev> out(w, s, (uint32_t)n, d, (uint32_t)cap);
+    if (dbg_flags & 1u) {  // developer diagnostics: match finder only (descriptors dropped; output is NOT written)
+      struct NullQ { __device__ void push(const SeqDesc&) {} } nq;
+      QueueOut<WaveDev, NullQ> qo(nq);
+      if (n < 65547) { FastCore<WaveDev, true, QueueOut<WaveDev, NullQ>> c(w, qo, s, (uint32_t)n); r = c.run(); }
+      else { FastCore<WaveDev, false, QueueOut<WaveDev, NullQ>> c(w, qo, s, (uint32_t)n); r = c.run(); }
+    } else if (n < 65547) {
+      FastCore<WaveDev, true> c(w, out, s, (uint32_t)n);
       r = c.run();
     } else {
-      FastCore<WaveDev, false> c(w, s, (uint32_t)n, d, (uint32_t)cap);
+      FastCore<WaveDev, false> c(w, out, s, (uint32_t)n);
       r = c.run();
     }
   }
@@ -57,8 +66,9 @@ __global__ __launch_bounds__(64) void compress_fast_prof_kernel(BatchArgs a, uin
     const uint8_t* s = a.src + a.src_off[b];
     uint8_t* d = a.dst + a.dst_off[b];
     WaveDev w(table);
-    if (n < 65547) { FastCore<WaveDev, true> c(w, s, (uint32_t)n, d, (uint32_t)cap, &st); r = c.run(); }
-    else { FastCore<WaveDev, false> c(w, s, (uint32_t)n, d, (uint32_t)cap, &st); r = c.run(); }
+    DirectOut<WaveDev> out(w, s, (uint32_t)n, d, (uint32_t)cap);
+    if (n < 65547) { FastCore<WaveDev, true> c(w, out, s, (uint32_t)n, &st); r = c.run(); }
+    else { FastCore<WaveDev, false> c(w, out, s, (uint32_t)n, &st); r = c.run(); }
   }
   if (threadIdx.x == 0) {
     a.out[b] = (int32_t)r;
@@ -73,9 +83,150 @@ int launch_compress_fast_prof(const BatchArgs& a, uint64_t* prof, void* stream) 
   return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// fast compress, two wavefronts per block: wave 0 finds matches (FastCore + QueueOut), wave 1 drains the
+// descriptor ring and writes the LZ4 stream (DirectOut).  Emission (about a third of the single-wave
+// instruction stream, plus its scalar state) leaves the match finder's serial path and runs on another
+// SIMD of the same CU.  Persistent workgroups pull block indices from a global counter.
+//
+// Ring: single producer / single consumer, both on the same CU (same vector L1, so plain stores/loads are
+// mutually visible without cache maintenance).  Each 16-byte descriptor is written by ONE dwordx4 store and
+// carries a 16-bit lap tag in its last word; the consumer polls that word -- no release/acquire fence, hence
+// no s_waitcnt vmcnt(0) on the match finder's critical path.  `tail` (consumer progress, for back-pressure)
+// is published every 64 pops.
+// ------------------------------------------------------------------------------------------------
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+constexpr uint32_t RING_ENTRIES = 256;
+constexpr uint32_t RING_WG_BYTES = RING_ENTRIES * 16u + 64u;
+
+struct RingProducer {
+  u32x4* ring;
+  volatile uint32_t* tail;
+  uint32_t head = 0, tail_seen = 0;
+  __device__ __forceinline__ void push(const SeqDesc& d) {
+    while (head - tail_seen >= RING_ENTRIES) {  // ring full (rare): wait for the drain side
+      tail_seen = *tail;
+      if (head - tail_seen >= RING_ENTRIES) __builtin_amdgcn_s_sleep(8);
+    }
+    const uint32_t lap = (head / RING_ENTRIES + 1u) & 0xFFFFu;
+    if (__lane_id() == 0) {
+      // two 8-byte relaxed stores, payload first, then the granule that carries the lap tag.  (A `volatile` store would make
+      // the compiler append s_waitcnt vmcnt(0) -- a full memory round trip on the match finder's critical path.)
+      uint64_t* slot = (uint64_t*)&ring[head % RING_ENTRIES];
+      __hip_atomic_store(slot, (uint64_t)d.anchor | ((uint64_t)d.lit << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_store(slot + 1, (uint64_t)d.mc | ((uint64_t)((d.offset & 0xFFFFu) | (lap << 16)) << 32), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    head++;
+  }
+};
+
+struct RingConsumer {
+  const u32x4* ring;
+  volatile uint32_t* tail;
+  uint32_t pos = 0;
+  // lane i looks at slot pos+i; returns how many consecutive descriptors (from lane 0) are ready and their words
+  __device__ __forceinline__ uint32_t peek(uint32_t& w0, uint32_t& w1, uint32_t& w2, uint32_t& w3) {
+    const uint32_t idx = pos + __lane_id();
+    const uint32_t lap = (idx / RING_ENTRIES + 1u) & 0xFFFFu;
+    uint64_t* p = (uint64_t*)&ring[idx % RING_ENTRIES];
+    const uint64_t g1 = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // {mc, offset | tag << 16}
+    w2 = (uint32_t)g1;
+    w3 = (uint32_t)(g1 >> 32);
+    const uint64_t ready = __ballot((w3 >> 16) == lap);
+    const uint32_t cnt = ready == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~ready);
+    // payload granule: stored BEFORE the tag granule by the producer (same wave, same cache line), loaded after it here
+    const uint64_t g0 = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    w0 = (uint32_t)g0;
+    w1 = (uint32_t)(g0 >> 32);
+    return cnt;
+  }
+  __device__ __forceinline__ void advance(uint32_t k) {
+    const uint32_t before = pos;
+    pos += k;
+    if (((before ^ pos) & ~63u) && __lane_id() == 0) *tail = pos;
+  }
+};
+
+__global__ __launch_bounds__(128) void compress_fast2_kernel(BatchArgs a, uint8_t* ws, uint32_t* next_block, uint32_t dbg_flags) {
+  __shared__ __attribute__((aligned(16))) uint64_t table[4096];
+  uint8_t* my = ws + (size_t)blockIdx.x * RING_WG_BYTES;
+  u32x4* ring = (u32x4*)my;
+  volatile uint32_t* tail = (volatile uint32_t*)(my + RING_ENTRIES * 16u);
+  if (threadIdx.x < 64) {
+    // ---- wave 0: match finder ----
+    RingProducer q{ring, tail};
+    QueueOut<WaveDev, RingProducer> qo(q);
+    WaveDev w(table);
+    for (;;) {
+      uint32_t b = 0;
+      if (__lane_id() == 0) b = atomicAdd(next_block, 1u);
+      b = __builtin_amdgcn_readfirstlane(b);
+      if (b >= a.n) { q.push(SeqDesc{0u, SEQ_KIND_STOP, 0u, 0u}); return; }
+      q.push(SeqDesc{b, SEQ_KIND_BEGIN, 0u, 0u});
+      const int32_t n = a.src_len[b];
+      if (n < 0 || (uint32_t)n > 0x7E000000u || a.dst_cap[b] < 0) { q.push(SeqDesc{0u, SEQ_KIND_LAST | SEQ_NOCHECK, 0u, 0u}); continue; }
+      const uint8_t* s = a.src + a.src_off[b];
+      if (n < 65547) { FastCore<WaveDev, true, QueueOut<WaveDev, RingProducer>> c(w, qo, s, (uint32_t)n); c.run(); }
+      else { FastCore<WaveDev, false, QueueOut<WaveDev, RingProducer>> c(w, qo, s, (uint32_t)n); c.run(); }
+    }
+  } else {
+    // ---- wave 1: drains descriptors in batches, writes the stream ----
+    RingConsumer q{ring, tail};
+    WaveDev w(nullptr);
+    uint32_t b = 0;
+    bool ok = false;
+    DirectOut<WaveDev> out(w, a.src, 0u, a.dst, 0u);
+    BatchEmitter<WaveDev> be(out);
+    for (;;) {
+      uint32_t w0, w1, w2, w3;
+      const uint32_t cnt = q.peek(w0, w1, w2, w3);
+      if (cnt == 0u) { __builtin_amdgcn_s_sleep(4); continue; }
+      const uint64_t ctrl = __ballot(__lane_id() < cnt && (w1 & SEQ_KIND_MASK) != SEQ_KIND_SEQ);
+      const uint32_t nseq = ctrl ? (uint32_t)__builtin_ctzll(ctrl) : cnt;
+      if (nseq) {
+        if (ok && !(dbg_flags & 1u)) ok = be.emit_batch(w0, w1, w2, w3 & 0xFFFFu, nseq);
+        q.advance(nseq);
+        continue;
+      }
+      const uint32_t kind = __builtin_amdgcn_readfirstlane(w1) & SEQ_KIND_MASK;
+      const uint32_t arg = __builtin_amdgcn_readfirstlane(w0);
+      q.advance(1u);
+      if (kind == SEQ_KIND_BEGIN) {
+        b = arg;
+        const int32_t n = a.src_len[b], cap = a.dst_cap[b];
+        ok = n >= 0 && (uint32_t)n <= 0x7E000000u && cap >= 0;
+        out.src = a.src + a.src_off[b];
+        out.dst = a.dst + a.dst_off[b];
+        out.n = ok ? (uint32_t)n : 0u;
+        out.cap = ok ? (uint32_t)cap : 0u;
+        out.limited = out.cap < out.n + out.n / 255u + 16u;
+        out.op = 0;
+      } else if (kind == SEQ_KIND_LAST) {
+        const uint32_t r = ok ? out.emit_last(arg) : 0u;
+        if (__lane_id() == 0) a.out[b] = (int32_t)r;
+      } else {
+        return;
+      }
+    }
+  }
+}
+
+int launch_compress_fast2(const BatchArgs& a, uint8_t* ws, uint32_t grid, void* stream) {
+  if (a.n == 0) return 0;
+  uint32_t* counter = (uint32_t*)(ws + (size_t)grid * RING_WG_BYTES);
+  hipLaunchKernelGGL(compress_fast2_kernel, dim3(grid), dim3(128), 0, (hipStream_t)stream, a, ws, counter, g_dbg_flags);
+  return (int)hipGetLastError();
+}
+uint32_t compress_fast2_grid(uint32_t n_blocks, uint32_t n_cus) {
+  const uint32_t resident = n_cus * 5u;  // 32 KB LDS per workgroup -> 5 per CU
+  return n_blocks < resident ? n_blocks : resident;
+}
+size_t compress_fast2_ws_bytes(uint32_t grid) { return (size_t)grid * RING_WG_BYTES + 64u; }
+
 int launch_compress_fast(const BatchArgs& a, void* stream) {
   if (a.n == 0) return 0;
-  hipLaunchKernelGGL(compress_fast_kernel, dim3(a.n), dim3(64), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(compress_fast_kernel, dim3(a.n), dim3(64), 0, (hipStream_t)stream, a, g_dbg_flags);
   return (int)hipGetLastError();
 }
 

@@ -18,7 +18,7 @@
 // the replicate path, which only reads bytes that precede the match.
 //
 // Backend `Grp` (group_dev.h on the GPU, tests/hostsim/group_host.h in the CPU test-suite):
-//   ld8/ld16/ld32(p)                        uniform loads (all lanes of the group, same address)
+//   ld8/ld16/ld32/ld64(p)                   uniform loads (all lanes of the group, same address)
 //   copy_lits(d, s, len, wild)               d[0..len) = s[0..len); wild: may touch <= 3 bytes past len on both sides
 //   copy_match(dst, op, offset, len, wild)   dst[op+i] = dst[op-offset+i], byte-forward semantics;
 //                                            offset 0 zero-fills (liblz4 1.9.3 behaviour)
@@ -56,6 +56,46 @@ LZ4HIP_DEV int decode_block(Grp& g, const uint8_t* src, int src_size, uint8_t* d
   if (SAFE && src_size == 0) return -1;
 
   if (oend - op >= 64) {
+    // ---- tier 1, interior fast loop.  While the block is far from both buffer ends (ip <= iend-306, op <= oend-606)
+    // and the sequence is "simple" -- literal and match lengths need at most ONE extension byte (<= 269 / <= 273),
+    // offset <= op -- every check of liblz4's fast loop provably passes (a sequence consumes <= 274 and produces
+    // <= 542 bytes), so only those few conditions are tested.  Anything else falls through, with ip/op still at the
+    // sequence start, to the exact tier-1 code below, which re-decodes that sequence with all checks. ----
+    // The 8 bytes fetched at the offset position also hold the NEXT sequence's token (and its first length byte), so the
+    // steady state costs two dependent loads per sequence: {offset word + literals} and {match source}.
+    if (ip <= iend - 306 && op <= oend - 606) {
+      uint32_t t4 = g.ld32(src + ip);  // {token, first literal-length byte, ...} of the sequence at ip
+      do {
+        int lit = (int)((t4 >> 4) & 15u);
+        int ml = (int)(t4 & 15u);
+        int hdr = 1;
+        if (lit == 15) {
+          const uint32_t e = (t4 >> 8) & 255u;
+          if (e == 255u) break;
+          lit += (int)e;
+          hdr = 2;
+        }
+        const uint64_t o8 = g.ld64(src + ip + hdr + lit);  // {offset lo, hi, [match-length byte], next token, ...}
+        g.copy_lits(dst + op, src + ip + hdr, (uint32_t)lit, true);
+        const int off = (int)((uint32_t)o8 & 0xFFFFu);
+        int adv = hdr + lit + 2;
+        uint32_t nxt = (uint32_t)(o8 >> 16);
+        if (ml == 15) {
+          const uint32_t e = nxt & 255u;
+          if (e == 255u) break;  // (the literals just written are simply written again by the exact path)
+          ml += (int)e;
+          adv++;
+          nxt = (uint32_t)(o8 >> 24);
+        }
+        ml += 4;
+        if (off > op + lit) break;  // invalid offset: let the exact path produce liblz4's error code
+        op += lit;
+        g.copy_match(dst, (uint32_t)op, (uint32_t)off, (uint32_t)ml, true);
+        op += ml;
+        ip += adv;
+        t4 = nxt;
+      } while (ip <= iend - 306 && op <= oend - 606);
+    }
     // ---- tier 1: fast loop.  Software-pipelined: the word holding {offset, first match-length byte}
     // is requested BEFORE the literal copy, and the next sequence's token word BEFORE the match copy,
     // so a sequence costs two dependent memory round trips (literals+offset, then match source)

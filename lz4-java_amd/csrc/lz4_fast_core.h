@@ -28,6 +28,7 @@
 // scalars (ballots, broadcasts).
 #pragma once
 #include <stdint.h>
+#include <stddef.h>
 
 #ifndef LZ4HIP_DEV
 #if defined(__HIPCC__)
@@ -56,16 +57,19 @@ struct FastStats {  // optional counters (host simulator / profiling kernel); th
   uint64_t t[8];  // shader-clock cycles per phase of a step (profiling kernel only), see run()
 };
 
-template <class W, bool U16>
-struct FastCore {
+// ---------------------------------------------------------------------------------------------------
+// Output policies.  The match finder (FastCore) hands every sequence to an `Out`:
+//   DirectOut  writes the LZ4 stream itself; a sequence found in step t is written in step t+1, after step
+//              t+1 has issued its candidate loads, so the stores overlap that latency (single-wave kernel);
+//   QueueOut   pushes 16-byte descriptors to a queue that a second wavefront drains with a DirectOut
+//              (two-wave kernel: emission leaves the match finder's serial instruction stream entirely).
+// ---------------------------------------------------------------------------------------------------
+template <class W>
+struct DirectOut {
   using VU = typename W::VU;
   using VU64 = typename W::VU64;
   using VB = typename W::VB;
-  using E = typename W::template Entry<U16>::S;   // scalar table entry (uint32_t / uint64_t)
-  using VE = typename W::template Entry<U16>::V;  // per-lane table entry
-  static constexpr int HLOG = U16 ? 13 : 12;
-  static constexpr int PSHIFT = U16 ? 16 : 32;
-  static constexpr uint32_t MAXD = 65535u;
+  static constexpr bool kUsesWindowRegs = true;
 
   W& w;
   const uint8_t* src;
@@ -73,37 +77,10 @@ struct FastCore {
   uint8_t* dst;
   uint32_t cap;
   bool limited;
-  uint32_t anchor = 0, op = 0;
-  uint32_t mfl1, matchlimit;  // mflimitPlusOne = n-11, matchlimit = n-5
-  FastStats* st;
+  uint32_t op = 0;
 
-  LZ4HIP_DEV FastCore(W& w_, const uint8_t* s, uint32_t n_, uint8_t* d, uint32_t cap_, FastStats* st_ = nullptr)
-      : w(w_), src(s), n(n_), dst(d), cap(cap_), st(st_) {
+  LZ4HIP_DEV DirectOut(W& w_, const uint8_t* s, uint32_t n_, uint8_t* d, uint32_t cap_) : w(w_), src(s), n(n_), dst(d), cap(cap_) {
     limited = cap < n + n / 255u + 16u;
-    mfl1 = n - 11u;
-    matchlimit = n - 5u;
-  }
-
-  // ---- table entry helpers ---------------------------------------------------------------
-  LZ4HIP_DEV static VE mk_entry(VU pos, VU fp) {
-    if constexpr (U16) return (pos << 16) | fp;
-    else return (W::u64(pos) << 32) | W::u64(fp);
-  }
-  LZ4HIP_DEV static VU e_pos(VE e) {
-    if constexpr (U16) return e >> 16;
-    else return W::lo32(e >> 32);
-  }
-  LZ4HIP_DEV static VU e_fp(VE e) {
-    if constexpr (U16) return e & 0xFFFFu;
-    else return W::lo32(e) & 0xFFFFu;
-  }
-  LZ4HIP_DEV static uint32_t se_pos(E e) { return (uint32_t)(e >> PSHIFT); }
-
-  // probe k of a miss-run starting at S sits at S + g(k): liblz4's `step = searchMatchNb++ >> 6`
-  LZ4HIP_DEV static VU g(VU k) {
-    VU T = k + 62u;
-    VU M = T >> 6;
-    return W::select(k >= 1u, VU(1u), VU(0u)) + 32u * M * (M - 1u) + M * (T - 64u * M + 1u);
   }
 
   // ---- small output helpers ---------------------------------------------------------------
@@ -118,8 +95,10 @@ struct FastCore {
     }
   }
 
+  LZ4HIP_DEV void put_ext_at(uint32_t o, uint32_t len, uint32_t cnt) { put_ext(o, len, cnt); }
+
   // last literals: token + run + raw bytes; returns total size or 0
-  LZ4HIP_COLD uint32_t emit_last() {
+  LZ4HIP_COLD uint32_t emit_last(uint32_t anchor) {
     const uint32_t last = n - anchor;
     if (limited && (uint64_t)op + last + 1u + (last + 255u - 15u) / 255u > cap) return 0;
     const uint32_t nlx = ext_count(last);
@@ -127,53 +106,6 @@ struct FastCore {
     if (nlx) put_ext(op + 1u, last, nlx);
     w.copy(dst, op + 1u + nlx, src, anchor, last);
     return op + 1u + nlx + last;
-  }
-
-  // ---- match extension ------------------------------------------------------------------------
-  // tail of a forward count: lane granularity ran into `limit`; at most 7 bytes are left to compare
-  LZ4HIP_COLD uint32_t count_tail(uint32_t pa_t, uint32_t pb_t, uint32_t limit) {
-    const uint32_t tail = pa_t < limit ? limit - pa_t : 0u;
-    if (tail == 0) return 0;
-    const VB act = w.lane() < tail;
-    const VU ca = w.ld8(src, w.lane() + pa_t, act);
-    const VU cb = w.ld8(src, w.lane() + pb_t, act);
-    const uint64_t bad = w.ballot(act & (ca != cb));
-    return bad ? (uint32_t)ctz64(bad) : tail;
-  }
-
-  // number of equal bytes src[a+i]==src[b+i], a+i < limit (b < a); 8 bytes per lane, 512 per round
-  LZ4HIP_COLD uint32_t count_fwd(uint32_t a, uint32_t b, uint32_t limit) {
-    uint32_t cnt = 0;
-    for (;;) {
-      const VU off = w.lane() * 8u + cnt;
-      const VU pa = off + a;
-      const VB full = pa + 8u <= limit;
-      const VU64 x = w.ldu64(src, W::vmin(pa, n - 8u)) ^ w.ldu64(src, W::vmin(off + b, n - 8u));
-      const VB diff = full & (x != VU64(0));
-      const uint64_t dm = w.ballot(diff);
-      const uint64_t stop = dm | w.ballot(!full);
-      if (stop == 0) { cnt += 512u; continue; }
-      const int f = ctz64(stop);
-      cnt += 8u * (uint32_t)f;
-      if ((dm >> f) & 1u) return cnt + (uint32_t)(ctz64(w.bcast64(x, f)) >> 3);
-      return cnt + count_tail(a + cnt, b + cnt, limit);
-    }
-  }
-
-  // catch-up beyond the first 64 bytes (rare): equal bytes before (ip, m), bounded by maxback
-  LZ4HIP_COLD uint32_t count_back(uint32_t ip, uint32_t m, uint32_t maxback) {
-    uint32_t back = 0;
-    while (back < maxback) {
-      const VU jj = w.lane() + back;
-      const VB act = jj < maxback;
-      const VU ca = w.ld8(src, (ip - 1u) - jj, act);
-      const VU cb = w.ld8(src, (m - 1u) - jj, act);
-      const uint64_t am = w.ballot(act);
-      const uint64_t bad = w.ballot(act & (ca != cb));
-      if (bad) return back + (uint32_t)ctz64(bad);
-      back += (uint32_t)popc64(am);
-    }
-    return back;
   }
 
   // ---- deferred emission ---------------------------------------------------------------------
@@ -247,6 +179,216 @@ struct FastCore {
     }
   }
 
+
+  // ---- the Out interface ----
+  LZ4HIP_DEV bool overlap_point() { return emit_pending(); }
+  LZ4HIP_DEV void seq(uint32_t lit, uint32_t mc, uint32_t offset, uint32_t anchor, bool check_lits, bool regs, VU b0) {
+    pend.have = true;
+    pend.lit = lit;
+    pend.mc = mc;
+    pend.offset = offset;
+    pend.anchor = anchor;
+    pend.check_lits = check_lits;
+    pend.regs = regs;
+    pend_b0 = b0;
+  }
+  // immediate emission of one sequence whose literals are in memory (used by the drain side of the two-wave kernel)
+  LZ4HIP_DEV bool seq_now(uint32_t lit, uint32_t mc, uint32_t offset, uint32_t anchor, bool check_lits) {
+    seq(lit, mc, offset, anchor, check_lits, false, VU(0u));
+    return emit_pending();
+  }
+  LZ4HIP_DEV uint32_t last(uint32_t anchor) {
+    if (!emit_pending()) return 0;
+    return emit_last(anchor);
+  }
+};
+
+// one queue entry (16 bytes): kind in the top bits of `lit`
+struct SeqDesc {
+  uint32_t anchor, lit, mc, offset;
+};
+constexpr uint32_t SEQ_KIND_SEQ = 0u, SEQ_KIND_LAST = 1u << 30, SEQ_KIND_BEGIN = 2u << 30, SEQ_KIND_STOP = 3u << 30;
+constexpr uint32_t SEQ_KIND_MASK = 3u << 30, SEQ_NOCHECK = 1u << 29, SEQ_LIT_MASK = (1u << 29) - 1u;
+
+// drains one block's descriptors (everything up to and including its LAST entry); returns the compressed size or 0
+template <class W>
+LZ4HIP_DEV uint32_t drain_block(DirectOut<W>& out, const SeqDesc* d, size_t count) {
+  bool ok = true;
+  for (size_t i = 0; i < count; i++) {
+    const uint32_t kind = d[i].lit & SEQ_KIND_MASK;
+    if (kind == SEQ_KIND_LAST) return ok ? out.emit_last(d[i].anchor) : 0u;
+    if (ok) ok = out.seq_now(d[i].lit & SEQ_LIT_MASK, d[i].mc, d[i].offset, d[i].anchor, !(d[i].lit & SEQ_NOCHECK));
+  }
+  return 0u;
+}
+
+// Batched drain (emitter wavefront of the two-wave kernel): up to 64 sequence descriptors at once, ONE LANE
+// PER SEQUENCE for everything that is per-sequence (sizes, output offsets by a wave prefix sum, capacity
+// checks, token / length / offset bytes: five scattered store instructions for the whole batch), then the
+// literal runs are copied sequence by sequence with all lanes.
+template <class W>
+struct BatchEmitter {
+  using VU = typename W::VU;
+  using VU64 = typename W::VU64;
+  using VB = typename W::VB;
+  DirectOut<W>& out;
+  LZ4HIP_DEV explicit BatchEmitter(DirectOut<W>& o) : out(o) {}
+
+  // lanes 0..m-1 hold one SEQ descriptor each (litw = lit | SEQ_NOCHECK flag); returns false on output overflow
+  LZ4HIP_DEV bool emit_batch(VU anchor, VU litw, VU mc, VU offset, uint32_t m) {
+    W& w = out.w;
+    const VU j = w.lane();
+    const VB act = j < m;
+    const VU lit = litw & SEQ_LIT_MASK;
+    const VU nlx = W::select(lit >= 15u, W::div255(lit - 15u) + 1u, VU(0u));
+    const VU nmx = W::select(mc >= 15u, W::div255(mc - 15u) + 1u, VU(0u));
+    const VU size = W::select(act, nlx + lit + nmx + 3u, VU(0u));
+    const VU o = w.excl_scan(size) + out.op;  // where each sequence starts
+    const uint32_t end = w.bcast(o + size, (int)(m - 1u));
+    if (out.limited) {
+      // liblz4's two per-sequence checks, with o = position of the token (op in liblz4 is o+1 at check 1)
+      const VB c1 = ((litw & SEQ_NOCHECK) == 0u) & (W::u64(o) + W::u64(lit) + W::u64(W::div255(lit)) + VU64(1u + 8u) > VU64((uint64_t)out.cap));
+      const VB c2 = W::u64(o) + W::u64(nlx) + W::u64(lit) + W::u64(W::div255(mc + 240u)) + VU64(1u + 2u + 6u) > VU64((uint64_t)out.cap);
+      if (w.ballot(act & (c1 | c2))) return false;
+    }
+    const VU tok = (W::vmin(lit, VU(15u)) << 4) | W::vmin(mc, VU(15u));
+    w.st8(out.dst, o, tok, act);
+    w.st8(out.dst, o + 1u, lit - 15u, act & (nlx == 1u));
+    const VU oo = o + nlx + lit + 1u;
+    w.st8(out.dst, oo, offset & 0xFFu, act);
+    w.st8(out.dst, oo + 1u, offset >> 8, act);
+    w.st8(out.dst, oo + 2u, mc - 15u, act & (nmx == 1u));
+    uint64_t longs = w.ballot(act & ((nlx > 1u) | (nmx > 1u)));  // length runs of more than one byte (rare)
+    while (longs) {
+      const int k = ctz64(longs);
+      longs &= longs - 1u;
+      const uint32_t l = w.bcast(lit, k), c = w.bcast(mc, k), ok_ = w.bcast(o, k), nl = w.bcast(nlx, k), nm = w.bcast(nmx, k);
+      if (nl > 1u) out.put_ext_at(ok_ + 1u, l, nl);
+      if (nm > 1u) out.put_ext_at(ok_ + 1u + nl + l + 2u, c, nm);
+    }
+    const VU ld = o + nlx + 1u;  // where each literal run goes
+    for (uint32_t k = 0; k < m; k++) {
+      const uint32_t l = w.bcast(lit, (int)k);
+      if (l == 0u) continue;
+      const uint32_t a = w.bcast(anchor, (int)k), d = w.bcast(ld, (int)k);
+      if (l <= 64u) w.st8(out.dst, j + d, w.ld8(out.src, j + a, j < l), j < l);
+      else w.copy(out.dst, d, out.src, a, l);
+    }
+    out.op = end;
+    return true;
+  }
+};
+
+template <class W, class Q>
+struct QueueOut {
+  using VU = typename W::VU;
+  static constexpr bool kUsesWindowRegs = false;
+  Q& q;
+  LZ4HIP_DEV explicit QueueOut(Q& q_) : q(q_) {}
+  LZ4HIP_DEV bool overlap_point() { return true; }
+  LZ4HIP_DEV void seq(uint32_t lit, uint32_t mc, uint32_t offset, uint32_t anchor, bool check_lits, bool, VU) {
+    q.push(SeqDesc{anchor, lit | (check_lits ? 0u : SEQ_NOCHECK), mc, offset});
+  }
+  LZ4HIP_DEV uint32_t last(uint32_t anchor) {
+    q.push(SeqDesc{anchor, SEQ_KIND_LAST, 0u, 0u});
+    return 1u;  // the drain side computes the real size
+  }
+};
+
+template <class W, bool U16, class Out = DirectOut<W>>
+struct FastCore {
+  using VU = typename W::VU;
+  using VU64 = typename W::VU64;
+  using VB = typename W::VB;
+  using E = typename W::template Entry<U16>::S;   // scalar table entry (uint32_t / uint64_t)
+  using VE = typename W::template Entry<U16>::V;  // per-lane table entry
+  static constexpr int HLOG = U16 ? 13 : 12;
+  static constexpr int PSHIFT = U16 ? 16 : 32;
+  static constexpr uint32_t MAXD = 65535u;
+
+  W& w;
+  Out& out;
+  const uint8_t* src;
+  uint32_t n;
+  uint32_t anchor = 0;
+  uint32_t mfl1, matchlimit;  // mflimitPlusOne = n-11, matchlimit = n-5
+  FastStats* st;
+
+  LZ4HIP_DEV FastCore(W& w_, Out& out_, const uint8_t* s, uint32_t n_, FastStats* st_ = nullptr)
+      : w(w_), out(out_), src(s), n(n_), st(st_) {
+    mfl1 = n - 11u;
+    matchlimit = n - 5u;
+  }
+
+  // ---- table entry helpers ---------------------------------------------------------------
+  LZ4HIP_DEV static VE mk_entry(VU pos, VU fp) {
+    if constexpr (U16) return (pos << 16) | fp;
+    else return (W::u64(pos) << 32) | W::u64(fp);
+  }
+  LZ4HIP_DEV static VU e_pos(VE e) {
+    if constexpr (U16) return e >> 16;
+    else return W::lo32(e >> 32);
+  }
+  LZ4HIP_DEV static VU e_fp(VE e) {
+    if constexpr (U16) return e & 0xFFFFu;
+    else return W::lo32(e) & 0xFFFFu;
+  }
+  LZ4HIP_DEV static uint32_t se_pos(E e) { return (uint32_t)(e >> PSHIFT); }
+
+  // probe k of a miss-run starting at S sits at S + g(k): liblz4's `step = searchMatchNb++ >> 6`
+  LZ4HIP_DEV static VU g(VU k) {
+    VU T = k + 62u;
+    VU M = T >> 6;
+    return W::select(k >= 1u, VU(1u), VU(0u)) + 32u * M * (M - 1u) + M * (T - 64u * M + 1u);
+  }
+
+  // ---- match extension ------------------------------------------------------------------------
+  // tail of a forward count: lane granularity ran into `limit`; at most 7 bytes are left to compare
+  LZ4HIP_COLD uint32_t count_tail(uint32_t pa_t, uint32_t pb_t, uint32_t limit) {
+    const uint32_t tail = pa_t < limit ? limit - pa_t : 0u;
+    if (tail == 0) return 0;
+    const VB act = w.lane() < tail;
+    const VU ca = w.ld8(src, w.lane() + pa_t, act);
+    const VU cb = w.ld8(src, w.lane() + pb_t, act);
+    const uint64_t bad = w.ballot(act & (ca != cb));
+    return bad ? (uint32_t)ctz64(bad) : tail;
+  }
+
+  // number of equal bytes src[a+i]==src[b+i], a+i < limit (b < a); 8 bytes per lane, 512 per round
+  LZ4HIP_COLD uint32_t count_fwd(uint32_t a, uint32_t b, uint32_t limit) {
+    uint32_t cnt = 0;
+    for (;;) {
+      const VU off = w.lane() * 8u + cnt;
+      const VU pa = off + a;
+      const VB full = pa + 8u <= limit;
+      const VU64 x = w.ldu64(src, W::vmin(pa, n - 8u)) ^ w.ldu64(src, W::vmin(off + b, n - 8u));
+      const VB diff = full & (x != VU64(0));
+      const uint64_t dm = w.ballot(diff);
+      const uint64_t stop = dm | w.ballot(!full);
+      if (stop == 0) { cnt += 512u; continue; }
+      const int f = ctz64(stop);
+      cnt += 8u * (uint32_t)f;
+      if ((dm >> f) & 1u) return cnt + (uint32_t)(ctz64(w.bcast64(x, f)) >> 3);
+      return cnt + count_tail(a + cnt, b + cnt, limit);
+    }
+  }
+
+  // catch-up beyond the first 64 bytes (rare): equal bytes before (ip, m), bounded by maxback
+  LZ4HIP_COLD uint32_t count_back(uint32_t ip, uint32_t m, uint32_t maxback) {
+    uint32_t back = 0;
+    while (back < maxback) {
+      const VU jj = w.lane() + back;
+      const VB act = jj < maxback;
+      const VU ca = w.ld8(src, (ip - 1u) - jj, act);
+      const VU cb = w.ld8(src, (m - 1u) - jj, act);
+      const uint64_t am = w.ballot(act);
+      const uint64_t bad = w.ballot(act & (ca != cb));
+      if (bad) return back + (uint32_t)ctz64(bad);
+      back += (uint32_t)popc64(am);
+    }
+    return back;
+  }
+
   // ---- per-step inputs, prepared one step ahead so the window load overlaps bookkeeping ----------
   VU sp_pos;      // position of each of the 64 slots
   VB sp_valid, sp_isrun;
@@ -270,12 +412,7 @@ struct FastCore {
 
   // ---- the compressor ------------------------------------------------------------------------
   LZ4HIP_DEV uint32_t run() {
-    if (n == 0) {
-      if (limited && cap == 0) return 0;
-      w.st8(dst, VU(0u), VU(0u), w.lane() == 0u);
-      return 1;
-    }
-    if (n < 13u) return emit_last();
+    if (n < 13u) return out.last(0u);  // all literals (n == 0: the single token 0x00)
 
     // every bucket starts as {pos 0, fp(bytes at 0)}: liblz4's zeroed table makes position 0 the
     // candidate of an empty bucket, and its explicit first insert (position 0) is then implied.
@@ -349,8 +486,8 @@ struct FastCore {
       LZ4HIP_PHASE(2, hpos);             // t[2]: commit issue + candidate-fetch issue
 
       // ---- [4] write out the previous sequence while those loads are in flight ----
-      if (!emit_pending()) return 0;
-      LZ4HIP_PHASE(3, op);               // t[3]: emission of the previous sequence
+      if (!out.overlap_point()) return 0;
+      LZ4HIP_PHASE(3, hpos);             // t[3]: emission of the previous sequence
 
       // ---- [5] intra-step bucket collisions (rare): undo, resolve exactly, commit again ----
       const uint64_t det = w.ballot(inrange & (old != e));
@@ -409,7 +546,7 @@ struct FastCore {
       if (st && have_hit && !hit) st->false_pos++;
       LZ4HIP_PHASE(5, (uint32_t)hit);    // t[5]: wait for the candidate bytes
       if (LZ4HIP_UNLIKELY(!hit)) {
-        if (!have_hit && kinv < 64u && kinv == ncommit) return emit_last();  // liblz4's `goto _last_literals`
+        if (!have_hit && kinv < 64u && kinv == ncommit) return out.last(anchor);  // liblz4's `goto _last_literals`
         // continue the run after the last committed lane
         if (post) { S = ip + 1u; r = ncommit >= 2u ? ncommit - 2u : 0u; post = false; }
         else r += ncommit;
@@ -455,22 +592,17 @@ struct FastCore {
         else back = 64u + count_back(hpos - 64u, mpos - 64u, maxback - 64u);
       }
       const uint32_t mc = back + (cnt - 4u);
-      pend.have = true;
-      pend.lit = (hpos - back) - anchor;
-      pend.mc = mc;
-      pend.offset = hpos - mpos;
-      pend.anchor = anchor;
-      pend.check_lits = !hit_post;
-      // literals straight from this step's window registers: lane l (>= 1) of a post step sits on position
-      // anchor + l - 1 (its run started in this step); needs at most one length byte each and lane 63 free
-      pend.regs = was_post && mc < 270u && (1u + (pend.lit >= 15u ? 1u : 0u) + pend.lit + 2u + (mc >= 15u ? 1u : 0u) <= 63u);
-      pend_b0 = b0;
+      {
+        const uint32_t lit = (hpos - back) - anchor;
+        // literals straight from this step's window registers: lane l (>= 1) of a post step sits on position
+        // anchor + l - 1 (its run started in this step); needs at most one length byte each and lane 63 free
+        const bool regs = Out::kUsesWindowRegs && was_post && mc < 270u &&
+                          (1u + (lit >= 15u ? 1u : 0u) + lit + 2u + (mc >= 15u ? 1u : 0u) <= 63u);
+        out.seq(lit, mc, hpos - mpos, anchor, !hit_post, regs, b0);
+      }
       anchor = ip_new;
       LZ4HIP_PHASE(6, ip_new);           // t[6]: match length + catch-up + bookkeeping
-      if (done) {
-        if (!emit_pending()) return 0;
-        return emit_last();
-      }
+      if (done) return out.last(anchor);
     }
 #undef LZ4HIP_PHASE
   }

@@ -72,6 +72,16 @@ struct WaveDev {
   __device__ __forceinline__ static VU ldu32(const uint8_t* b, VU i) { uint32_t v; __builtin_memcpy(&v, b + i, 4); return v; }
   __device__ __forceinline__ static VU64 ldu64(const uint8_t* b, VU i) { uint64_t v; __builtin_memcpy(&v, b + i, 8); return v; }
   __device__ __forceinline__ static VU vmin(VU a, VU b) { return a < b ? a : b; }
+  __device__ __forceinline__ static VU div255(VU a) { return a / 255u; }
+  // exclusive prefix sum across the wavefront (6 shuffle steps)
+  __device__ __forceinline__ static VU excl_scan(VU a) {
+    VU x = a;
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t y = (uint32_t)__shfl_up((int)x, d, 64);
+      if ((int)__lane_id() >= d) x += y;
+    }
+    return x - a;
+  }
   __device__ __forceinline__ static VU shr(VU a, VU k) { return a >> (k & 31u); }  // per-lane shift amount
   __device__ __forceinline__ static VU shfl_up1(VU v) { return (uint32_t)__shfl_up((int)v, 1, 64); }  // lane l <- lane l-1
   __device__ __forceinline__ static uint32_t sld32(const uint8_t* b, uint32_t i) {

@@ -26,6 +26,7 @@ struct GroupHost {
   uint32_t ld8(const uint8_t* p) { return rd_ok(p, 1) ? *p : 0; }
   uint32_t ld16(const uint8_t* p) { uint16_t v = 0; if (rd_ok(p, 2)) memcpy(&v, p, 2); return v; }
   uint32_t ld32(const uint8_t* p) { uint32_t v = 0; if (rd_ok(p, 4)) memcpy(&v, p, 4); return v; }
+  uint64_t ld64(const uint8_t* p) { uint64_t v = 0; if (rd_ok(p, 8)) memcpy(&v, p, 8); return v; }
 
   void copy_lits(uint8_t* d, const uint8_t* s, uint32_t len, bool wild) {
     if (wild) {

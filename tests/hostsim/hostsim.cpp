@@ -22,11 +22,12 @@ int sim_compress_fast(const uint8_t* src, int n, uint8_t* dst, int cap, uint64_t
   w.bounds(src, (size_t)n, dst, (size_t)cap);
   lz4hip::FastStats st = {0, 0, 0, 0};
   uint32_t r;
+  lz4hip::DirectOut<hostsim::WaveHost> out(w, src, (uint32_t)n, dst, (uint32_t)cap);
   if (n < 65547) {
-    lz4hip::FastCore<hostsim::WaveHost, true> c(w, src, (uint32_t)n, dst, (uint32_t)cap, &st);
+    lz4hip::FastCore<hostsim::WaveHost, true> c(w, out, src, (uint32_t)n, &st);
     r = c.run();
   } else {
-    lz4hip::FastCore<hostsim::WaveHost, false> c(w, src, (uint32_t)n, dst, (uint32_t)cap, &st);
+    lz4hip::FastCore<hostsim::WaveHost, false> c(w, out, src, (uint32_t)n, &st);
     r = c.run();
   }
   if (stats4) { stats4[0] = st.steps; stats4[1] = st.slow_steps; stats4[2] = st.false_pos; stats4[3] = st.sequences; }
@@ -41,6 +42,47 @@ int sim_decompress(const uint8_t* src, int src_size, uint8_t* dst, int out_size,
   int r = safe ? lz4hip::decode_block<hostsim::GroupHost, true>(g, src, src_size, dst, out_size)
                : lz4hip::decode_block<hostsim::GroupHost, false>(g, src, src_size, dst, out_size);
   if (g.oob) return -1000000;
+  return r;
+}
+
+// two-wave variant: the match finder pushes descriptors to a queue, a separate pass drains it through DirectOut
+// (on the GPU the two halves run concurrently in two wavefronts of one workgroup)
+struct VecQueue {
+  std::vector<lz4hip::SeqDesc> v;
+  void push(const lz4hip::SeqDesc& d) { v.push_back(d); }
+};
+int sim_compress_fast_queue(const uint8_t* src, int n, uint8_t* dst, int cap, uint64_t rng_seed) {
+  if (n < 0 || (uint32_t)n > 0x7E000000u || cap < 0) return 0;
+  hostsim::WaveHost w;
+  if (rng_seed) w.rng = rng_seed;
+  w.bounds(src, (size_t)n, dst, (size_t)cap);
+  VecQueue q;
+  lz4hip::QueueOut<hostsim::WaveHost, VecQueue> qo(q);
+  if (n < 65547) { lz4hip::FastCore<hostsim::WaveHost, true, lz4hip::QueueOut<hostsim::WaveHost, VecQueue>> c(w, qo, src, (uint32_t)n); c.run(); }
+  else { lz4hip::FastCore<hostsim::WaveHost, false, lz4hip::QueueOut<hostsim::WaveHost, VecQueue>> c(w, qo, src, (uint32_t)n); c.run(); }
+  hostsim::WaveHost w2;
+  w2.bounds(src, (size_t)n, dst, (size_t)cap);
+  lz4hip::DirectOut<hostsim::WaveHost> out(w2, src, (uint32_t)n, dst, (uint32_t)cap);
+  // drain in batches of up to `batch` SEQ descriptors (BatchEmitter), as the emitter wavefront does
+  int r = 0;
+  {
+    lz4hip::BatchEmitter<hostsim::WaveHost> be(out);
+    bool ok = true;
+    size_t i = 0;
+    uint64_t bs = rng_seed ? rng_seed : 12345;
+    while (i < q.v.size()) {
+      if ((q.v[i].lit & lz4hip::SEQ_KIND_MASK) == lz4hip::SEQ_KIND_LAST) { r = ok ? (int)out.emit_last(q.v[i].anchor) : 0; break; }
+      bs = bs * 6364136223846793005ull + 1442695040888963407ull;
+      size_t want = 1 + (size_t)((bs >> 33) % 64), m = 0;
+      hostsim::WaveHost::VU va, vl, vm, vo;
+      while (m < want && i + m < q.v.size() && (q.v[i + m].lit & lz4hip::SEQ_KIND_MASK) == lz4hip::SEQ_KIND_SEQ) {
+        va.v[m] = q.v[i + m].anchor; vl.v[m] = q.v[i + m].lit; vm.v[m] = q.v[i + m].mc; vo.v[m] = q.v[i + m].offset; m++;
+      }
+      if (ok) ok = be.emit_batch(va, vl, vm, vo, (uint32_t)m);
+      i += m;
+    }
+  }
+  if (w.oob || w2.oob) return -1000;
   return r;
 }
 

@@ -89,6 +89,8 @@ struct WaveHost {
   VU ldu32(const uint8_t* b, const VU& i) { return ld32(b, i, VB(true)); }
   VU64 ldu64(const uint8_t* b, const VU& i) { return ld64(b, i, VB(true)); }
   static VU vmin(const VU& a, const VU& b) { VU r; for (int l = 0; l < 64; l++) r.v[l] = a.v[l] < b.v[l] ? a.v[l] : b.v[l]; return r; }
+  static VU div255(const VU& a) { VU r; for (int l = 0; l < 64; l++) r.v[l] = a.v[l] / 255u; return r; }
+  static VU excl_scan(const VU& a) { VU r; uint32_t acc = 0; for (int l = 0; l < 64; l++) { r.v[l] = acc; acc += a.v[l]; } return r; }
   static VU shr(const VU& a, const VU& k) { VU r; for (int l = 0; l < 64; l++) r.v[l] = a.v[l] >> (k.v[l] & 31u); return r; }
   static VU shfl_up1(const VU& v) { VU r; r.v[0] = v.v[0]; for (int l = 1; l < 64; l++) r.v[l] = v.v[l - 1]; return r; }
   uint32_t sld32(const uint8_t* b, uint32_t i) { uint32_t v = 0; if (in_ok(b + i, 4)) memcpy(&v, b + i, 4); return v; }

@@ -277,3 +277,23 @@ def test_cpp_host_mirror_runs():
                            "-L" + os.path.join(ROOT, "lz4-java_amd"), "-llz4hip", "-Wl,-rpath," + os.path.join(ROOT, "lz4-java_amd"),
                            "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
     assert subprocess.call([exe]) == 0
+
+
+def test_two_wave_compress_kernel_same_bytes(amd, ref, O, corpus):
+    """compress_waves=2 (match-finder wavefront + emitter wavefront, descriptor ring) must produce the same bytes"""
+    import random as _r
+    rng = _r.Random(303)
+    blocks, caps = [], []
+    for v in list(corpus.values()) + rnd_inputs(O, corpus, 91, 600):
+        full = ref.compress_bound(len(v))
+        er, _ = ref.compress_fast_raw(v, full)
+        for cap in (full, max(0, er + rng.choice([-1, 0, 1, -7, 9]))):
+            blocks.append(v); caps.append(cap)
+    amd.set_option("compress_waves", 2)
+    try:
+        res = gpu_compress_many(amd, blocks, caps)
+    finally:
+        amd.set_option("compress_waves", 1)
+    for v, cap, (r, c) in zip(blocks, caps, res):
+        er, eb = ref.compress_fast_raw(v, cap)
+        assert r == er and (er <= 0 or c == eb), (len(v), cap, r, er)

@@ -143,3 +143,19 @@ def test_hc_core_fuzz(sim, ref, O, corpus):
             v = bytes(v)
             assert sim_hc(sim, v, 9, ref.compress_bound(n))[1] == ref.compress_hc(v, 9), (period, n)
     assert sim_hc(sim, b"x" * 100, 10, 200)[0] == -1  # optimal-parser levels are not implemented
+
+
+def test_compress_queue_variant(sim, ref, O, corpus):
+    """match finder -> descriptor queue -> drain (the two-wave kernel's split) gives the same bytes"""
+    sim.sim_compress_fast_queue.restype = C.c_int
+    sim.sim_compress_fast_queue.argtypes = [C.c_char_p, C.c_int, _u8p, C.c_int, C.c_uint64]
+    rng = random.Random(77)
+    cases = list(corpus.values()) + rnd_inputs(O, corpus, 81, 300)
+    for v in cases:
+        full = ref.compress_bound(len(v))
+        er, _ = ref.compress_fast_raw(v, full)
+        for cap in (full, max(0, er + rng.choice([-1, 0, 1, -7, 9])), rng.randrange(0, full + 1)):
+            out = (C.c_uint8 * max(cap, 1))()
+            r = sim.sim_compress_fast_queue(bytes(v), len(v), out, cap, rng.getrandbits(63) | 1)
+            a = ref.compress_fast_raw(v, cap)
+            assert r == a[0] and (r <= 0 or bytes(out[:r]) == a[1]), (len(v), cap, r, a[0])

@@ -31,6 +31,10 @@ back = torch.zeros(n * blk, dtype=torch.uint8, device=dev)
 dlen = torch.zeros(n, dtype=torch.int32, device=dev)
 if lanes:
     amd.set_option("decode_lanes", lanes)
+if os.environ.get("DBG"):
+    amd.set_option("dbg_flags", int(os.environ["DBG"]))
+if os.environ.get("CW"):
+    amd.set_option("compress_waves", int(os.environ["CW"]))
 for _ in range(reps):
     a, b, c = (torch.cuda.Event(enable_timing=True) for _ in range(3))
     a.record(); amd.DeviceBatch.compress_fast(src, so, sl, comp, co, cc, clen); b.record()
