@@ -30,7 +30,21 @@ LZ4HIP_DEV uint32_t xxh32_one(const uint8_t* p, uint32_t len, uint32_t seed) {
   if (len >= 16u) {
     const uint8_t* const limit = end - 16;
     uint32_t v1 = seed + P1 + P2, v2 = seed + P2, v3 = seed, v4 = seed - P1;
-    do {
+    // four stripes per trip while they last: the 4 x 16-byte loads are issued back to back, so each thread keeps
+    // 64 bytes in flight (one thread per buffer means one cache line per lane per load: more bytes per request pays)
+    while (p + 64 <= end) {
+      uint32_t w[16];
+      __builtin_memcpy(w, p, 64);
+#pragma unroll
+      for (int k = 0; k < 16; k += 4) {
+        v1 = xrotl32(v1 + w[k + 0] * P2, 13) * P1;
+        v2 = xrotl32(v2 + w[k + 1] * P2, 13) * P1;
+        v3 = xrotl32(v3 + w[k + 2] * P2, 13) * P1;
+        v4 = xrotl32(v4 + w[k + 3] * P2, 13) * P1;
+      }
+      p += 64;
+    }
+    while (p <= limit) {
       uint32_t w[4];
       __builtin_memcpy(w, p, 16);
       v1 = xrotl32(v1 + w[0] * P2, 13) * P1;
@@ -38,7 +52,7 @@ LZ4HIP_DEV uint32_t xxh32_one(const uint8_t* p, uint32_t len, uint32_t seed) {
       v3 = xrotl32(v3 + w[2] * P2, 13) * P1;
       v4 = xrotl32(v4 + w[3] * P2, 13) * P1;
       p += 16;
-    } while (p <= limit);
+    }
     h = xrotl32(v1, 1) + xrotl32(v2, 7) + xrotl32(v3, 12) + xrotl32(v4, 18);
   } else {
     h = seed + P5;
@@ -62,7 +76,19 @@ LZ4HIP_DEV uint64_t xxh64_one(const uint8_t* p, uint32_t len, uint64_t seed) {
   if (len >= 32u) {
     const uint8_t* const limit = end - 32;
     uint64_t v1 = seed + P1 + P2, v2 = seed + P2, v3 = seed, v4 = seed - P1;
-    do {
+    while (p + 128 <= end) {  // four stripes per trip: 128 bytes in flight per thread
+      uint64_t w[16];
+      __builtin_memcpy(w, p, 128);
+#pragma unroll
+      for (int k = 0; k < 16; k += 4) {
+        v1 = xxh64_round(v1, w[k + 0]);
+        v2 = xxh64_round(v2, w[k + 1]);
+        v3 = xxh64_round(v3, w[k + 2]);
+        v4 = xxh64_round(v4, w[k + 3]);
+      }
+      p += 128;
+    }
+    while (p <= limit) {
       uint64_t w[4];
       __builtin_memcpy(w, p, 32);
       v1 = xxh64_round(v1, w[0]);
@@ -70,7 +96,7 @@ LZ4HIP_DEV uint64_t xxh64_one(const uint8_t* p, uint32_t len, uint64_t seed) {
       v3 = xxh64_round(v3, w[2]);
       v4 = xxh64_round(v4, w[3]);
       p += 32;
-    } while (p <= limit);
+    }
     h = xrotl64(v1, 1) + xrotl64(v2, 7) + xrotl64(v3, 12) + xrotl64(v4, 18);
     h = (h ^ xxh64_round(0, v1)) * P1 + P4;
     h = (h ^ xxh64_round(0, v2)) * P1 + P4;
