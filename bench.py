@@ -29,6 +29,20 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
+def measured_traffic(n_blocks, block):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/traffic.json, produced by tools/traffic_passes.sh + tools/traffic_json.py): FETCH_SIZE and
+    WRITE_SIZE collected in separate --pmc runs, KiB -> bytes, FETCH_SIZE doubled as the gfx950 note of
+    MI355X_MICROARCH.md (HBM section) prescribes.  None when no pass exists for this workload."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        if t.get("blocks_per_gpu") == n_blocks and t.get("block_bytes") == block:
+            return t
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(n_blocks, block, litmax, win):
     """oracle leg: the reference liblz4 (kind "reference") or the C port, all host cores, bounded sample"""
     from oracle import oracle as O
@@ -148,6 +162,7 @@ def main():
         nbytes = float(n) * blk
         ratio = nbytes / csum
         value = world * nbytes * args.steps / dt / 1e9
+        tr = measured_traffic(n, blk) or {}
         alg_c = (nbytes + csum) / 1e9   # compress: reads N, writes C  (1 + 1/ratio B/B)
         alg_d = (csum + nbytes) / 1e9   # decompress: reads C, writes N
         out = {
@@ -162,12 +177,14 @@ def main():
             "verified": ok,
             "compress_GBps": round(nbytes / t_c / 1e9, 3), "decompress_GBps": round(nbytes / t_d / 1e9, 3),
             "roofline": {"kernel": "compress_fast_kernel", "bound": "hbm", "achieved": round(alg_c / t_c, 3), "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": round(alg_c / t_c / HBM_PEAK_GBPS, 5), "traffic": None,
+                         "unit": "GB/s", "frac": round(alg_c / t_c / HBM_PEAK_GBPS, 5), "traffic": tr.get("compress_fast_kernel"),
                          "algorithmic_bytes_per_launch": int(nbytes + csum), "avg_launch_ms": round(t_c * 1e3, 4)},
             "roofline_decode": {"kernel": "decode_kernel", "bound": "hbm", "achieved": round(alg_d / t_d, 3), "peak": HBM_PEAK_GBPS,
-                                "unit": "GB/s", "frac": round(alg_d / t_d / HBM_PEAK_GBPS, 5), "traffic": None,
+                                "unit": "GB/s", "frac": round(alg_d / t_d / HBM_PEAK_GBPS, 5), "traffic": tr.get("decode_kernel"),
                                 "algorithmic_bytes_per_launch": int(nbytes + csum), "avg_launch_ms": round(t_d * 1e3, 4)},
         }
+        if tr:
+            out["traffic_source"] = tr.get("source")
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(n, blk, args.litmax, args.win)

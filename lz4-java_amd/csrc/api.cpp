@@ -348,6 +348,7 @@ int lz4hip_set_option(const char* name, int value) {
     g_decode_lanes = value;
     return LZ4HIP_OK;
   }
+  if (name && strcmp(name, "dbg_extra_lds") == 0) { lz4hip::set_dbg_extra_lds((uint32_t)value); return LZ4HIP_OK; }
   if (name && strcmp(name, "dbg_flags") == 0) { lz4hip::set_dbg_flags((uint32_t)value); return LZ4HIP_OK; }
   if (name && strcmp(name, "compress_waves") == 0) {
     if (value != 1 && value != 2) return fail(LZ4HIP_E_ARG, "compress_waves must be 1 or 2");

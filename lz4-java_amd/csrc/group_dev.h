@@ -30,6 +30,32 @@ struct GroupDev {
     }
   }
 
+  // Wide variants for the decoder's interior loop (>= 300 bytes of slack on every side): each lane moves
+  // LB = 64/GL bytes per step, so a step always covers 64 bytes whatever the group size -- smaller groups put more
+  // blocks behind every instruction of the (issue-bound) loop.  May touch up to LB-1 bytes past len.
+  static constexpr uint32_t LB = 64u / GL < 4u ? 4u : 64u / GL;
+  template <int N> struct Chunk { uint32_t w[N]; };
+  __device__ __forceinline__ void copy_lits_wide(uint8_t* d, const uint8_t* s, uint32_t len) const {
+    for (uint32_t i = l * LB; i < len; i += LB * GL) {
+      Chunk<LB / 4> v;
+      __builtin_memcpy(&v, s + i, LB);
+      __builtin_memcpy(d + i, &v, LB);
+    }
+  }
+  __device__ __forceinline__ void copy_match_wide(uint8_t* dst, uint32_t op, uint32_t offset, uint32_t len) const {
+    if (offset >= LB * GL) {  // a step reads [m+i0, m+i0+64) <= d+i0: only bytes stored by earlier instructions
+      uint8_t* d = dst + op;
+      const uint8_t* m = d - offset;
+      for (uint32_t i = l * LB; i < len; i += LB * GL) {
+        Chunk<LB / 4> v;
+        __builtin_memcpy(&v, m + i, LB);
+        __builtin_memcpy(d + i, &v, LB);
+      }
+    } else {
+      copy_match(dst, op, offset, len, true);
+    }
+  }
+
   // dst[op+i] = dst[op-offset+i] for i in [0,len), byte-forward (overlap replicates the pattern)
   __device__ __forceinline__ void copy_match(uint8_t* dst, uint32_t op, uint32_t offset, uint32_t len, bool wild) const {
     uint8_t* d = dst + op;

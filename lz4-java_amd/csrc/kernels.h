@@ -14,6 +14,7 @@ struct BatchArgs {
 
 int launch_compress_fast(const BatchArgs& a, void* stream);
 void set_dbg_flags(uint32_t f);  // developer diagnostics
+void set_dbg_extra_lds(uint32_t bytes);
 // two-wave variant: `ws` = zeroed device workspace of compress_fast2_ws_bytes(grid) bytes
 uint32_t compress_fast2_grid(uint32_t n_blocks, uint32_t n_cus);
 size_t compress_fast2_ws_bytes(uint32_t grid);

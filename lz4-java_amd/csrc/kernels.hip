@@ -10,6 +10,8 @@
 // No MFMA anywhere: this is byte shuffling, not a contraction.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include "kernels.h"
 #include "wave_dev.h"
 #include "group_dev.h"
@@ -20,6 +22,8 @@
 
 namespace lz4hip {
 
+uint32_t g_dbg_extra_lds = 0;  // developer diagnostics: extra dynamic LDS per workgroup (lowers residency, for scaling studies)
+void set_dbg_extra_lds(uint32_t b) { g_dbg_extra_lds = b; }
 uint32_t g_dbg_flags = 0;  // developer diagnostics (lz4hip_set_option "dbg_flags"): bit 0 = skip emission (timing only)
 void set_dbg_flags(uint32_t f) { g_dbg_flags = f; }
 
@@ -226,7 +230,14 @@ size_t compress_fast2_ws_bytes(uint32_t grid) { return (size_t)grid * RING_WG_BY
 
 int launch_compress_fast(const BatchArgs& a, void* stream) {
   if (a.n == 0) return 0;
-  hipLaunchKernelGGL(compress_fast_kernel, dim3(a.n), dim3(64), 0, (hipStream_t)stream, a, g_dbg_flags);
+  if (getenv("LZ4HIP_DEBUG")) {
+    int nb = -1;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, compress_fast_kernel, 64, g_dbg_extra_lds);
+    hipDeviceProp_t pr; int dev = 0; (void)hipGetDevice(&dev); (void)hipGetDeviceProperties(&pr, dev);
+    fprintf(stderr, "[lz4hip] compress_fast_kernel: occupancy API says %d workgroups/CU (err %d), extra LDS %u, sharedMemPerMultiprocessor %zu, maxSharedMemoryPerMultiProcessor %zu, sharedMemPerBlock %zu\n",
+            nb, (int)e, g_dbg_extra_lds, (size_t)pr.sharedMemPerMultiprocessor, (size_t)pr.maxSharedMemoryPerMultiProcessor, (size_t)pr.sharedMemPerBlock);
+  }
+  hipLaunchKernelGGL(compress_fast_kernel, dim3(a.n), dim3(64), g_dbg_extra_lds, (hipStream_t)stream, a, g_dbg_flags);
   return (int)hipGetLastError();
 }
 
@@ -299,12 +310,12 @@ int launch_decompress(const BatchArgs& a, bool safe, int lanes_per_block, void* 
   hipStream_t st = (hipStream_t)stream;
   switch (lanes_per_block) {
     case 4: return launch_decode_gl<4>(a, safe, st);
-    case 8: return launch_decode_gl<8>(a, safe, st);
+    case 16: return launch_decode_gl<16>(a, safe, st);
     case 32: return launch_decode_gl<32>(a, safe, st);
     case 64: return launch_decode_gl<64>(a, safe, st);
-    case 0:
-    case 16:
-    default: return launch_decode_gl<16>(a, safe, st);
+    case 0:   // default: 8 lanes x 8 bytes per block, 8 blocks per wavefront (measured best on 64 KiB blocks)
+    case 8:
+    default: return launch_decode_gl<8>(a, safe, st);
   }
 }
 

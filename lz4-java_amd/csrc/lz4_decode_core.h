@@ -76,7 +76,7 @@ LZ4HIP_DEV int decode_block(Grp& g, const uint8_t* src, int src_size, uint8_t* d
           hdr = 2;
         }
         const uint64_t o8 = g.ld64(src + ip + hdr + lit);  // {offset lo, hi, [match-length byte], next token, ...}
-        g.copy_lits(dst + op, src + ip + hdr, (uint32_t)lit, true);
+        g.copy_lits_wide(dst + op, src + ip + hdr, (uint32_t)lit);
         const int off = (int)((uint32_t)o8 & 0xFFFFu);
         int adv = hdr + lit + 2;
         uint32_t nxt = (uint32_t)(o8 >> 16);
@@ -90,7 +90,7 @@ LZ4HIP_DEV int decode_block(Grp& g, const uint8_t* src, int src_size, uint8_t* d
         ml += 4;
         if (off > op + lit) break;  // invalid offset: let the exact path produce liblz4's error code
         op += lit;
-        g.copy_match(dst, (uint32_t)op, (uint32_t)off, (uint32_t)ml, true);
+        g.copy_match_wide(dst, (uint32_t)op, (uint32_t)off, (uint32_t)ml);
         op += ml;
         ip += adv;
         t4 = nxt;

@@ -44,6 +44,30 @@ struct GroupHost {
     }
   }
 
+  // wide variants (interior loop): LB = 64/GL bytes per lane and step, lock-step loads then stores
+  void copy_lits_wide(uint8_t* d, const uint8_t* s, uint32_t len) {
+    const uint32_t LB = 64u / GL < 4u ? 4u : 64u / GL;
+    for (uint32_t base = 0; base < len; base += LB * GL) {
+      uint8_t v[64][16]; bool act[64];
+      for (int l = 0; l < GL; l++) { uint32_t i = base + LB * l; act[l] = i < len; if (act[l] && rd_ok(s + i, LB)) memcpy(v[l], s + i, LB); }
+      for (int l = 0; l < GL; l++) { uint32_t i = base + LB * l; if (act[l] && wr_ok(d + i, LB)) memcpy(d + i, v[l], LB); }
+    }
+  }
+  void copy_match_wide(uint8_t* dst, uint32_t op, uint32_t offset, uint32_t len) {
+    const uint32_t LB = 64u / GL < 4u ? 4u : 64u / GL;
+    if (offset >= LB * GL) {
+      uint8_t* d = dst + op;
+      const uint8_t* m = d - offset;
+      for (uint32_t base = 0; base < len; base += LB * GL) {
+        uint8_t v[64][16]; bool act[64];
+        for (int l = 0; l < GL; l++) { uint32_t i = base + LB * l; act[l] = i < len; if (act[l] && rd_ok(m + i, LB)) memcpy(v[l], m + i, LB); }
+        for (int l = 0; l < GL; l++) { uint32_t i = base + LB * l; if (act[l] && wr_ok(d + i, LB)) memcpy(d + i, v[l], LB); }
+      }
+    } else {
+      copy_match(dst, op, offset, len, true);
+    }
+  }
+
   void copy_match(uint8_t* dst, uint32_t op, uint32_t offset, uint32_t len, bool wild) {
     uint8_t* d = dst + op;
     const uint8_t* m = d - offset;

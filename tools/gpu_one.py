@@ -31,6 +31,8 @@ back = torch.zeros(n * blk, dtype=torch.uint8, device=dev)
 dlen = torch.zeros(n, dtype=torch.int32, device=dev)
 if lanes:
     amd.set_option("decode_lanes", lanes)
+if os.environ.get("XLDS"):
+    amd.set_option("dbg_extra_lds", int(os.environ["XLDS"]))
 if os.environ.get("DBG"):
     amd.set_option("dbg_flags", int(os.environ["DBG"]))
 if os.environ.get("CW"):
