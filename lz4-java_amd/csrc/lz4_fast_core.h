@@ -476,7 +476,7 @@ struct FastCore {
       bool hit_post = post && k0 == 1u;
       uint32_t maxback = (!have_hit || hit_post) ? 0u : ((hpos - anchor) < mpos ? (hpos - anchor) : mpos);
       VU64 fa = w.ldu64(src, W::vmin(o8 + hpos, n - 8u));   // kept apart from fb: xor-ing here would wait for the loads
-      VU64 fb = w.ldu64(src, W::vmin(o8 + mpos, n - 8u));
+      VU64 fb = w.ldu64_cand(src, W::vmin(o8 + mpos, n - 8u));
       VU ba, bb;
       {
         const VB bact = j < maxback;
@@ -530,7 +530,7 @@ struct FastCore {
             hit_post = post && k0 == 1u;
             maxback = hit_post ? 0u : ((hpos - anchor) < mpos ? (hpos - anchor) : mpos);
             fa = w.ldu64(src, W::vmin(o8 + hpos, n - 8u));
-            fb = w.ldu64(src, W::vmin(o8 + mpos, n - 8u));
+            fb = w.ldu64_cand(src, W::vmin(o8 + mpos, n - 8u));
             const VB bact = j < maxback;
             ba = w.ldu8(src, W::select(bact, (hpos - 1u) - j, VU(0u)));
             bb = w.ldu8(src, W::select(bact, (mpos - 1u) - j, VU(0u)));

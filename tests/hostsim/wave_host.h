@@ -88,6 +88,7 @@ struct WaveHost {
   VU ldu8(const uint8_t* b, const VU& i) { return ld8(b, i, VB(true)); }
   VU ldu32(const uint8_t* b, const VU& i) { return ld32(b, i, VB(true)); }
   VU64 ldu64(const uint8_t* b, const VU& i) { return ld64(b, i, VB(true)); }
+  VU64 ldu64_cand(const uint8_t* b, const VU& i) { return ld64(b, i, VB(true)); }
   static VU vmin(const VU& a, const VU& b) { VU r; for (int l = 0; l < 64; l++) r.v[l] = a.v[l] < b.v[l] ? a.v[l] : b.v[l]; return r; }
   static VU div255(const VU& a) { VU r; for (int l = 0; l < 64; l++) r.v[l] = a.v[l] / 255u; return r; }
   static VU excl_scan(const VU& a) { VU r; uint32_t acc = 0; for (int l = 0; l < 64; l++) { r.v[l] = acc; acc += a.v[l]; } return r; }
