@@ -41,12 +41,8 @@ __global__ __launch_bounds__(64) void compress_fast_kernel(BatchArgs a, uint32_t
     uint8_t* d = a.dst + a.dst_off[b];
     WaveDev w(table);
     DirectOut<WaveDev> out(w, s, (uint32_t)n, d, (uint32_t)cap);
-    if (dbg_flags & 1u) {  // developer diagnostics: match finder only (descriptors dropped; output is NOT written)
-      struct NullQ { __device__ void push(const SeqDesc&) {} } nq;
-      QueueOut<WaveDev, NullQ> qo(nq);
-      if (n < 65547) { FastCore<WaveDev, true, QueueOut<WaveDev, NullQ>> c(w, qo, s, (uint32_t)n); r = c.run(); }
-      else { FastCore<WaveDev, false, QueueOut<WaveDev, NullQ>> c(w, qo, s, (uint32_t)n); r = c.run(); }
-    } else if (n < 65547) {
+    (void)dbg_flags;
+    if (n < 65547) {
       FastCore<WaveDev, true> c(w, out, s, (uint32_t)n);
       r = c.run();
     } else {

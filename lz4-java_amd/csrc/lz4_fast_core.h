@@ -122,12 +122,15 @@ struct DirectOut {
     if (!pend.have) return true;
     pend.have = false;
     const uint32_t lit = pend.lit, mc = pend.mc, offset = pend.offset;
-    const uint32_t nlx = ext_count(lit), nmx = ext_count(mc);
     if (LZ4HIP_UNLIKELY(limited)) {
+      const uint32_t nlx_ = ext_count(lit);
       if (pend.check_lits && (uint64_t)op + 1u + lit + (2u + 1u + 5u) + lit / 255u > cap) return false;
-      if ((uint64_t)op + 1u + nlx + lit + 2u + (1u + 5u) + (mc + 240u) / 255u > cap) return false;
+      if ((uint64_t)op + 1u + nlx_ + lit + 2u + (1u + 5u) + (mc + 240u) / 255u > cap) return false;
     }
     const uint32_t token = ((lit < 15u ? lit : 15u) << 4) | (mc < 15u ? mc : 15u);
+    // (regs implies at most one length byte each: no division on the hot path)
+    const uint32_t nlx = pend.regs ? (lit >= 15u ? 1u : 0u) : ext_count(lit);
+    const uint32_t nmx = pend.regs ? (mc >= 15u ? 1u : 0u) : ext_count(mc);
     const uint32_t total = 1u + nlx + lit + 2u + nmx;
     const VU i = w.lane();
     if (LZ4HIP_LIKELY(pend.regs)) {
@@ -391,20 +394,22 @@ struct FastCore {
 
   // ---- per-step inputs, prepared one step ahead so the window load overlaps bookkeeping ----------
   VU sp_pos;      // position of each of the 64 slots
-  VB sp_valid, sp_isrun;
+  uint64_t sp_validm = 0, sp_probem = 0;  // lane masks (wave-uniform scalars): slot is valid / slot probes the table
   VU64 sp_x64;    // window word at the slot position (U32 mode: 8 bytes; U16 mode: low 4 bytes used)
   VU sp_x32;
 
   LZ4HIP_DEV void prepare_step(bool post, uint32_t S, uint32_t r, uint32_t ip) {
     const VU j = w.lane();
     const uint32_t nspecial = post ? 2u : 0u;
-    sp_isrun = j >= nspecial;
+    const VB sp_isrun = j >= nspecial;
     const VU k = j - nspecial + r;
     VU prun, pnext;
     if (LZ4HIP_LIKELY(r + 64u - nspecial <= 65u)) { prun = k + S; pnext = prun + 1u; }  // probes 0..65 of a run are consecutive
     else { prun = g(k) + S; pnext = g(k + 1u) + S; }
     sp_pos = W::select(sp_isrun, prun, W::select(j == 0u, VU(ip - 2u), VU(ip)));
-    sp_valid = (!sp_isrun) | (pnext <= mfl1);
+    // special lanes (0,1 of a post step) are always valid; lane 0 of a post step only inserts
+    sp_validm = w.ballot(pnext <= mfl1) | (uint64_t)(post ? 3u : 0u);
+    sp_probem = sp_validm & ~(uint64_t)(post ? 1u : 0u);
     // invalid lanes read a clamped, harmless address: no exec-mask branch around the load
     if constexpr (U16) sp_x32 = w.ldu32(src, W::vmin(sp_pos, n - 8u));
     else sp_x64 = w.ldu64(src, W::vmin(sp_pos, n - 8u));
@@ -438,7 +443,7 @@ struct FastCore {
 #define LZ4HIP_PHASE(i, dep) do { if (st) { const uint64_t t_ = w.tick(dep); st->t[i] += t_ - tk; tk = t_; } } while (0)
       // ---- [1] this step's slots were prepared (and their window words requested) one step ahead ----
       const VU pos = sp_pos;
-      const VB valid = sp_valid, isrun = sp_isrun;
+      const uint64_t validm = sp_validm, probem = sp_probem;
       VU x32, h, fp;
       if constexpr (U16) {
         x32 = sp_x32;
@@ -454,19 +459,17 @@ struct FastCore {
       // ---- [2] table lookup, tentative hits, commit ----
       const VE e = w.template lds_rdu<U16>(h);
       const VE newe = mk_entry(pos, fp);
-      const VB probe = valid & (isrun | (j == 1u));  // lane 0 of a post step only inserts
-      VB tent = probe & (e_fp(e) == fp);
-      if constexpr (!U16) tent = tent & (e_pos(e) + MAXD >= pos);
-
-      const uint64_t tmask = w.ballot(tent);
-      const uint64_t imask = w.ballot(!valid);
+      // (ballots of plain compares are free -- the compare already writes the lane mask; the masks are combined on the scalar side)
+      uint64_t tmask = w.ballot(e_fp(e) == fp) & probem;
+      if constexpr (!U16) tmask &= w.ballot(e_pos(e) + MAXD >= pos);
+      const uint64_t imask = ~validm;
       uint32_t k0 = tmask ? (uint32_t)ctz64(tmask) : 64u;
       const uint32_t kinv = imask ? (uint32_t)ctz64(imask) : 64u;
       uint32_t ncommit = (k0 + 1u < kinv) ? k0 + 1u : kinv;
       bool have_hit = k0 < kinv;
-      VB inrange = j < ncommit;
+      uint64_t inm = ncommit >= 64u ? ~0ull : ((1ull << ncommit) - 1ull);  // lanes that commit their insert
       LZ4HIP_PHASE(1, ncommit);          // t[1]: table read + ballots
-      const VE old = w.template lds_max<U16>(h, newe, inrange);
+      const VE old = w.template lds_max<U16>(h, newe, w.lanes(inm));
 
       // ---- [3] speculative candidate fetch: verify + forward + backward extension in ONE round trip.
       // Branch-free: without a tentative hit the loads still go out (lane 0's slot vs position 0, L1 hits). ----
@@ -478,8 +481,9 @@ struct FastCore {
       VU64 fa = w.ldu64(src, W::vmin(o8 + hpos, n - 8u));   // kept apart from fb: xor-ing here would wait for the loads
       VU64 fb = w.ldu64_cand(src, W::vmin(o8 + mpos, n - 8u));
       VU ba, bb;
+      uint64_t bactm = maxback >= 64u ? ~0ull : ((1ull << maxback) - 1ull);
       {
-        const VB bact = j < maxback;
+        const VB bact = w.lanes(bactm);
         ba = w.ldu8(src, W::select(bact, (hpos - 1u) - j, VU(0u)));
         bb = w.ldu8(src, W::select(bact, (mpos - 1u) - j, VU(0u)));
       }
@@ -490,9 +494,10 @@ struct FastCore {
       LZ4HIP_PHASE(3, hpos);             // t[3]: emission of the previous sequence
 
       // ---- [5] intra-step bucket collisions (rare): undo, resolve exactly, commit again ----
-      const uint64_t det = w.ballot(inrange & (old != e));
+      const uint64_t det = w.ballot(old != e) & inm;
       if (LZ4HIP_UNLIKELY(det != 0)) {
         if (st) st->slow_steps++;
+        const VB inrange = w.lanes(inm);
         w.template lds_wr<U16>(h, e, inrange);
         w.sync();
         VE se = e;  // candidate each lane sees under sequential semantics
@@ -509,9 +514,8 @@ struct FastCore {
           se = W::select(has, pe, se);
           pendm &= ~gm;
         }
-        VB tent2 = inrange & probe & (e_fp(se) == fp);
-        if constexpr (!U16) tent2 = tent2 & (e_pos(se) + MAXD >= pos);
-        const uint64_t t2 = w.ballot(tent2);
+        uint64_t t2 = w.ballot(e_fp(se) == fp) & inm & probem;
+        if constexpr (!U16) t2 &= w.ballot(e_pos(se) + MAXD >= pos);
         const bool had = have_hit;
         const uint32_t hpos_old = hpos, mpos_old = mpos;
         if (t2) {
@@ -521,8 +525,8 @@ struct FastCore {
         } else {
           have_hit = false;  // the tentative lane (if any) no longer matches under the sequential candidates
         }
-        inrange = j < ncommit;
-        (void)w.template lds_max<U16>(h, newe, inrange);
+        inm = ncommit >= 64u ? ~0ull : ((1ull << ncommit) - 1ull);
+        (void)w.template lds_max<U16>(h, newe, w.lanes(inm));
         if (have_hit) {
           hpos = w.bcast(pos, (int)k0);
           mpos = se_pos(w.template bcast_e<U16>(se, (int)k0));
@@ -531,7 +535,8 @@ struct FastCore {
             maxback = hit_post ? 0u : ((hpos - anchor) < mpos ? (hpos - anchor) : mpos);
             fa = w.ldu64(src, W::vmin(o8 + hpos, n - 8u));
             fb = w.ldu64_cand(src, W::vmin(o8 + mpos, n - 8u));
-            const VB bact = j < maxback;
+            bactm = maxback >= 64u ? ~0ull : ((1ull << maxback) - 1ull);
+            const VB bact = w.lanes(bactm);
             ba = w.ldu8(src, W::select(bact, (hpos - 1u) - j, VU(0u)));
             bb = w.ldu8(src, W::select(bact, (mpos - 1u) - j, VU(0u)));
           }
@@ -558,10 +563,10 @@ struct FastCore {
       if (st) st->sequences++;
       uint32_t cnt;  // equal bytes from hpos on (>= 4)
       {
-        const VB full = o8 + (hpos + 8u) <= matchlimit;
+        const uint64_t fullm = w.ballot(o8 + (hpos + 8u) <= matchlimit);
         const VU64 xz = W::select(j == 0u, fx & VU64(0xFFFFFFFF00000000ull), fx);
-        const uint64_t dm = w.ballot(full & (xz != VU64(0)));
-        const uint64_t stop = dm | w.ballot(!full);
+        const uint64_t dm = w.ballot(xz != VU64(0)) & fullm;
+        const uint64_t stop = dm | ~fullm;
         if (LZ4HIP_UNLIKELY(stop == 0)) {
           cnt = 512u + count_fwd(hpos + 512u, mpos + 512u, matchlimit);
         } else {
@@ -586,7 +591,7 @@ struct FastCore {
       // ---- [8] catch-up, pending-sequence record ----
       uint32_t back = 0;
       if (maxback) {
-        const uint64_t bad = w.ballot((j < maxback) & (ba != bb));
+        const uint64_t bad = w.ballot(ba != bb) & bactm;
         if (bad) back = (uint32_t)ctz64(bad);
         else if (LZ4HIP_LIKELY(maxback <= 64u)) back = maxback;
         else back = 64u + count_back(hpos - 64u, mpos - 64u, maxback - 64u);

@@ -30,7 +30,10 @@ struct WaveDev {
   }
   __device__ __forceinline__ static VU lane() { return __lane_id(); }
   __device__ __forceinline__ static VU64 lanemask_lt() { return (1ull << __lane_id()) - 1ull; }
-  __device__ __forceinline__ static uint64_t ballot(bool b) { return __ballot(b); }
+  // (the i1 form folds straight into the compare that produced `b`; HIP's __ballot(int) costs a v_cndmask + v_cmp on top)
+  __device__ __forceinline__ static uint64_t ballot(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+  // per-lane predicate from a wave-uniform lane mask (the SGPR pair is used as the lane mask directly)
+  __device__ __forceinline__ static bool lanes(uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
   template <class T> __device__ __forceinline__ static T select(bool c, T a, T b) { return c ? a : b; }
   __device__ __forceinline__ static VU64 u64(VU v) { return (uint64_t)v; }
   __device__ __forceinline__ static VU lo32(VU64 v) { return (uint32_t)v; }

@@ -58,6 +58,7 @@ struct WaveHost {
   static VU lane() { VU r; for (int i = 0; i < 64; i++) r.v[i] = (uint32_t)i; return r; }
   static VU64 lanemask_lt() { VU64 r; for (int i = 0; i < 64; i++) r.v[i] = (1ull << i) - 1ull; return r; }
   static uint64_t ballot(const VB& b) { uint64_t m = 0; for (int i = 0; i < 64; i++) if (b.v[i]) m |= 1ull << i; return m; }
+  static VB lanes(uint64_t m) { VB r; for (int i = 0; i < 64; i++) r.v[i] = (m >> i) & 1u; return r; }
   template <class T> static V<T> select(const VB& c, const V<T>& a, const V<T>& b) {
     V<T> r; for (int i = 0; i < 64; i++) r.v[i] = c.v[i] ? a.v[i] : b.v[i]; return r;
   }
