@@ -1,0 +1,411 @@
+"""Shared cases for the stream/container twins (lz4-java_amd/streams.py).  The same case functions run with the
+oracle-backed engine on CPU (tests/test_streams_host.py: container logic only) and with the GPU engine
+(tests/test_gpu_streams.py: the product path).  TEST INFRASTRUCTURE: OracleEngine wraps oracle/ and exists only so
+the container logic can be checked without a GPU."""
+import io
+import os
+import shutil
+import struct
+import subprocess
+import tempfile
+
+LZ4_CLI = shutil.which("lz4") or ("/opt/conda/bin/lz4" if os.path.exists("/opt/conda/bin/lz4") else None)
+
+
+class OracleEngine:
+    """same interface as streams.HIPEngine, served by the CPU oracle (tests only)"""
+
+    def __init__(self, port, O, hcLevel=None):
+        self.port, self.O, self.hcLevel = port, O, hcLevel
+
+    def compress(self, src, srcOff, srcLen, dst, dstOff, dstCap):
+        out = []
+        for so, sl, do, dc in zip(srcOff, srcLen, dstOff, dstCap):
+            blk = bytes(src[so:so + sl])
+            r, b = (self.port.compress_fast_raw(blk, dc) if self.hcLevel is None
+                    else self.port.compress_hc_raw(blk, self.hcLevel, dc))
+            if r > 0:
+                dst[do:do + r] = b[:r]
+            out.append(r)
+        return out
+
+    def decompressSafe(self, src, srcOff, srcLen, dst, dstOff, dstCap):
+        out = []
+        for so, sl, do, dc in zip(srcOff, srcLen, dstOff, dstCap):
+            r, b = self.port.decompress_safe_raw(bytes(src[so:so + sl]), dc)
+            if r > 0:
+                dst[do:do + r] = b[:r]
+            out.append(r)
+        return out
+
+    def decompressFast(self, src, srcOff, srcCap, dst, dstOff, dstLen):
+        out = []
+        for so, sc, do, dl in zip(srcOff, srcCap, dstOff, dstLen):
+            r, b = self.O.decompress_fast_bounded(bytes(src[so:so + sc]), sc, dl)
+            if r >= 0:
+                dst[do:do + dl] = b[:dl]
+            out.append(r)
+        return out
+
+    def xxh32(self, buf, off, length, seed=0):
+        return [self.port.xxh32(bytes(buf[o:o + n]), seed) for o, n in zip(off, length)]
+
+
+def payload(corpus, O):
+    """~1.1 MB mixed: text, synthetic LZ blocks, an incompressible stretch, zeros, a ragged tail"""
+    import random
+    rng = random.Random(77)
+    noise = bytes(rng.getrandbits(8) for _ in range(70000))
+    return (corpus["book1[:200000]"] + O.gen_block(300000, 5) + noise + bytes(200000) + corpus["geo[:65536]"]
+            + corpus["pic[:65536]"] + corpus["book1[:200000]"][:12345])
+
+
+def frame_bytes(S, data, engine, blockSize, bits, knownSize=-1, chunk=100000, batchBlocks=3, flush_at=None):
+    sink = io.BytesIO()
+    f = S.LZ4FrameOutputStream(sink, blockSize, knownSize, *bits, engine=engine, batchBlocks=batchBlocks)
+    for i in range(0, len(data), chunk):
+        f.write(data[i:i + chunk])
+        if flush_at is not None and i // chunk == flush_at:
+            f.flush()
+    f.close()
+    return sink.getvalue()
+
+
+def parse_frame(buf):
+    """independent structural walk of one frame -> (flg, bd, content_size, [(stored_raw, payload, checksum)], content_checksum, end)"""
+    assert struct.unpack_from("<I", buf, 0)[0] == 0x184D2204
+    flg, bd = buf[4], buf[5]
+    p = 6
+    csize = None
+    if flg & 8:
+        csize = struct.unpack_from("<Q", buf, p)[0]
+        p += 8
+    hc = buf[p]
+    p += 1
+    blocks = []
+    while True:
+        w = struct.unpack_from("<I", buf, p)[0]
+        p += 4
+        if w == 0:
+            break
+        n = w & 0x7FFFFFFF
+        body = buf[p:p + n]
+        p += n
+        ck = None
+        if flg & 16:
+            ck = struct.unpack_from("<I", buf, p)[0]
+            p += 4
+        blocks.append((bool(w >> 31), body, ck))
+    cck = None
+    if flg & 4:
+        cck = struct.unpack_from("<I", buf, p)[0]
+        p += 4
+    return flg, bd, csize, hc, blocks, cck, p
+
+
+def cli(args, data):
+    with tempfile.TemporaryDirectory() as d:
+        a, b = os.path.join(d, "in"), os.path.join(d, "out")
+        open(a, "wb").write(data)
+        subprocess.run([LZ4_CLI, "-q", "-f"] + args + [a, b], check=True)
+        return open(b, "rb").read()
+
+
+# ---------------------------------------------------------------------------------------------------
+# cases (engine-agnostic)
+# ---------------------------------------------------------------------------------------------------
+def case_frame_layout_and_roundtrip(S, engine, port, data):
+    B = S.FLG.Bits
+    for blockSize, bits in ((S.BLOCKSIZE.SIZE_64KB, (B.BLOCK_INDEPENDENCE,)),
+                            (S.BLOCKSIZE.SIZE_64KB, (B.BLOCK_INDEPENDENCE, B.BLOCK_CHECKSUM, B.CONTENT_CHECKSUM, B.CONTENT_SIZE)),
+                            (S.BLOCKSIZE.SIZE_256KB, (B.BLOCK_INDEPENDENCE, B.CONTENT_CHECKSUM)),
+                            (S.BLOCKSIZE.SIZE_1MB, (B.BLOCK_INDEPENDENCE, B.BLOCK_CHECKSUM)),
+                            (S.BLOCKSIZE.SIZE_4MB, (B.BLOCK_INDEPENDENCE, B.CONTENT_SIZE))):
+        known = len(data) if B.CONTENT_SIZE in bits else -1
+        fr = frame_bytes(S, data, engine, blockSize, bits, known)
+        flg, bd, csize, hc, blocks, cck, end = parse_frame(fr)
+        assert end == len(fr)
+        assert flg == (1 << 6) | sum(1 << b for b in bits) and bd == blockSize << 4
+        desc = fr[4:6] + (struct.pack("<Q", csize) if csize is not None else b"")
+        assert hc == (port.xxh32(desc, 0) >> 8) & 0xFF
+        assert csize == (len(data) if known >= 0 else None)
+        mbs = 1 << (2 * blockSize + 8)
+        assert len(blocks) == -(-len(data) // mbs)
+        for i, (stored_raw, body, ck) in enumerate(blocks):
+            raw = data[i * mbs:(i + 1) * mbs]
+            comp = port.compress_fast(raw)
+            if len(comp) >= len(raw):            # LZ4FrameOutputStream.java:216-224
+                assert stored_raw and body == raw
+            else:
+                assert not stored_raw and body == comp   # bit-exact liblz4 block inside the container
+            if ck is not None:
+                assert ck == port.xxh32(body, 0)
+        if cck is not None:
+            assert cck == port.xxh32(data, 0)
+        for bb in (1, 5):
+            got = S.LZ4FrameInputStream(io.BytesIO(fr), engine=engine, batchBlocks=bb).read()
+            assert got == data
+
+
+def case_frame_known_header_bytes(S, engine):
+    # known descriptor checksums: FLG 0x60 / BD 0x70 -> HC 0x73 (what `lz4 --no-frame-crc` writes), BD 0x40 -> 0x82;
+    # XXH32("", 0) = 0x02CC5D05 is the content checksum of an empty frame
+    sink = io.BytesIO()
+    S.LZ4FrameOutputStream(sink, engine=engine).close()
+    assert sink.getvalue() == bytes.fromhex("04224d18" "60" "70" "73" "00000000")
+    sink = io.BytesIO()
+    S.LZ4FrameOutputStream(sink, S.BLOCKSIZE.SIZE_64KB, -1, engine=engine).close()
+    assert sink.getvalue() == bytes.fromhex("04224d18" "60" "40" "82" "00000000")
+    sink = io.BytesIO()
+    S.LZ4FrameOutputStream(sink, S.BLOCKSIZE.SIZE_64KB, -1, S.FLG.Bits.BLOCK_INDEPENDENCE, S.FLG.Bits.CONTENT_CHECKSUM,
+                           engine=engine).close()
+    v = sink.getvalue()
+    assert v[:6] == bytes.fromhex("04224d18" "64" "40") and v[7:] == bytes.fromhex("00000000" "055dcc02")
+
+
+def case_frame_flush_and_bytewise(S, engine, port, data):
+    B = S.FLG.Bits
+    small = data[:150000]
+    fr = frame_bytes(S, small, engine, S.BLOCKSIZE.SIZE_64KB, (B.BLOCK_INDEPENDENCE,), chunk=50000, flush_at=0)
+    _, _, _, _, blocks, _, _ = parse_frame(fr)
+    # flush() after the first 50000 bytes cuts a short block there (LZ4FrameOutputStream.java:279-286)
+    assert [len(b) if r else len(port.decompress_safe(b, 65536)) for r, b, _ in blocks] == [50000, 65536, 150000 - 50000 - 65536]
+    rd = S.LZ4FrameInputStream(io.BytesIO(fr), engine=engine, batchBlocks=2)
+    got = bytearray()
+    while True:
+        c = rd.read(7777)
+        if not c:
+            break
+        got += c
+    assert bytes(got) == small
+    sink = io.BytesIO()
+    f = S.LZ4FrameOutputStream(sink, S.BLOCKSIZE.SIZE_64KB, -1, engine=engine)
+    for b in small[:300]:
+        f.write(b)          # write(int)
+    f.close()
+    assert S.LZ4FrameInputStream(io.BytesIO(sink.getvalue()), engine=engine).read() == small[:300]
+    try:
+        f.write(b"x")
+        assert False
+    except S.IllegalStateException:
+        pass
+
+
+def case_frame_concat_skippable_single(S, engine, data):
+    B = S.FLG.Bits
+    a = frame_bytes(S, data[:100000], engine, S.BLOCKSIZE.SIZE_64KB, (B.BLOCK_INDEPENDENCE, B.CONTENT_CHECKSUM))
+    b = frame_bytes(S, data[100000:260000], engine, S.BLOCKSIZE.SIZE_256KB, (B.BLOCK_INDEPENDENCE, B.BLOCK_CHECKSUM))
+    skip = struct.pack("<II", 0x184D2A53, 11) + b"skip me pls"
+    empty = frame_bytes(S, b"", engine, S.BLOCKSIZE.SIZE_64KB, (B.BLOCK_INDEPENDENCE,))
+    cat = skip + a + skip + empty + b
+    assert S.LZ4FrameInputStream(io.BytesIO(cat), engine=engine).read() == data[:260000]
+    one = S.LZ4FrameInputStream(io.BytesIO(a + b), readSingleFrame=True, engine=engine)
+    assert one.read() == data[:100000]
+    f = S.LZ4FrameInputStream(io.BytesIO(frame_bytes(S, data[:5000], engine, S.BLOCKSIZE.SIZE_64KB,
+                                                    (B.BLOCK_INDEPENDENCE, B.CONTENT_SIZE), 5000)), engine=engine)
+    assert f.isExpectedContentSizeDefined() and f.getExpectedContentSize() == 5000
+    assert f.read() == data[:5000]
+
+
+def _expect(S, buf, msg, engine, delivered=None, **kw):
+    rd = S.LZ4FrameInputStream(io.BytesIO(buf), engine=engine, **kw)
+    got = bytearray()
+    try:
+        while True:
+            c = rd.read(1 << 20)
+            if not c:
+                break
+            got += c
+    except (S.IOException, RuntimeError) as e:
+        assert msg in str(e), (msg, str(e))
+        if delivered is not None:
+            assert bytes(got) == delivered
+        return
+    raise AssertionError("no error, wanted " + msg)
+
+
+def case_frame_errors(S, engine, data):
+    B = S.FLG.Bits
+    d = data[:200000]
+    fr = bytearray(frame_bytes(S, d, engine, S.BLOCKSIZE.SIZE_64KB,
+                               (B.BLOCK_INDEPENDENCE, B.BLOCK_CHECKSUM, B.CONTENT_CHECKSUM, B.CONTENT_SIZE), len(d)))
+    _, _, _, _, blocks, _, _ = parse_frame(bytes(fr))
+    _expect(S, b"\x01\x02\x03\x04" + bytes(fr[4:]), S.NOT_SUPPORTED, engine)
+    _expect(S, bytes(fr[:3]), S.PREMATURE_EOS, engine)
+    _expect(S, b"", S.PREMATURE_EOS, engine)
+    bad = bytearray(fr); bad[14] ^= 1
+    _expect(S, bytes(bad), S.DESCRIPTOR_HASH_MISMATCH, engine)
+    bad = bytearray(fr); bad[4] = 0x40 | 0x1C  # block independence cleared
+    _expect(S, bytes(bad), "BLOCK_INDEPENDENCE", engine)
+    bad = bytearray(fr); bad[4] = 0x80 | 0x3C
+    _expect(S, bytes(bad), "Version 2 is unsupported", engine)
+    bad = bytearray(fr); bad[5] |= 1
+    _expect(S, bytes(bad), "Reserved fields must be 0", engine)
+    # corrupt a byte inside block 2's payload: blocks 0,1 are delivered, then the block checksum trips
+    off2 = 15 + sum(4 + len(b) + 4 for _, b, _ in blocks[:2])
+    bad = bytearray(fr); bad[off2 + 4 + 10] ^= 0x55
+    _expect(S, bytes(bad), S.BLOCK_HASH_MISMATCH, engine, delivered=d[:131072], batchBlocks=8)
+    _expect(S, bytes(bad), S.BLOCK_HASH_MISMATCH, engine, delivered=d[:131072], batchBlocks=1)
+    bad = bytearray(fr); bad[-1] ^= 1
+    _expect(S, bytes(bad), "Content checksum mismatch", engine, delivered=d)
+    bad = bytearray(fr); bad[6] ^= 1  # content size; fix the descriptor checksum by brute force
+    for hc in range(256):
+        bad[14] = hc
+        try:
+            S.LZ4FrameInputStream(io.BytesIO(bytes(bad)), engine=engine).getExpectedContentSize()
+            break
+        except S.IOException:
+            continue
+    _expect(S, bytes(bad), "Size check mismatch", engine, delivered=d)
+    _expect(S, bytes(fr[:-6]), S.PREMATURE_EOS, engine, delivered=d)
+    _expect(S, bytes(fr[:off2 + 100]), S.PREMATURE_EOS, engine, delivered=d[:131072])
+    big = bytearray(fr[:15]) + struct.pack("<I", 65537) + bytes(70000)
+    _expect(S, bytes(big), "Block size 65537 exceeded max: 65536", engine)
+    # no block checksum: a corrupted LZ4 block is caught by the safe decompressor
+    fr2 = bytearray(frame_bytes(S, d, engine, S.BLOCKSIZE.SIZE_64KB, (B.BLOCK_INDEPENDENCE,)))
+    _, _, _, _, blocks2, _, _ = parse_frame(bytes(fr2))
+    assert not blocks2[1][0]
+    off1 = 7 + 4 + len(blocks2[0][1])
+    fr2[off1 + 4] = 0xFF  # token: huge literal+match lengths
+    fr2[off1 + 5:off1 + 9] = b"\xff\xff\xff\xff"
+    _expect(S, bytes(fr2), "Error decoding offset", engine, delivered=d[:65536])
+    try:
+        S.LZ4FrameOutputStream(io.BytesIO(), S.BLOCKSIZE.SIZE_64KB, -1, B.BLOCK_INDEPENDENCE, B.CONTENT_SIZE, engine=engine)
+        assert False
+    except ValueError:
+        pass
+    try:
+        S.LZ4FrameOutputStream(io.BytesIO(), S.BLOCKSIZE.SIZE_64KB, -1, B.CONTENT_CHECKSUM, engine=engine)
+        assert False
+    except RuntimeError as e:
+        assert "BLOCK_INDEPENDENCE" in str(e)
+
+
+def case_frame_cli_interop(S, engine, data):
+    """frames from the lz4 1.9.3 CLI decode here; frames written here decode with the CLI; and for matching flags
+    the two byte streams are identical (the CLI's frame blocks are liblz4 fast-compressor output as well)"""
+    B = S.FLG.Bits
+    for args, blockSize, bits in ((["-1", "-B4", "--no-frame-crc"], S.BLOCKSIZE.SIZE_64KB, (B.BLOCK_INDEPENDENCE,)),
+                                  (["-1", "-B5"], S.BLOCKSIZE.SIZE_256KB, (B.BLOCK_INDEPENDENCE, B.CONTENT_CHECKSUM)),
+                                  (["-1", "-B7", "-BX"], S.BLOCKSIZE.SIZE_4MB,
+                                   (B.BLOCK_INDEPENDENCE, B.CONTENT_CHECKSUM, B.BLOCK_CHECKSUM)),
+                                  (["-1", "-B6", "--content-size"], S.BLOCKSIZE.SIZE_1MB,
+                                   (B.BLOCK_INDEPENDENCE, B.CONTENT_CHECKSUM, B.CONTENT_SIZE))):
+        d = data * 5 if blockSize == S.BLOCKSIZE.SIZE_4MB else data  # the CLI lowers the block-size id for small inputs
+        theirs = cli(args, d)
+        assert S.LZ4FrameInputStream(io.BytesIO(theirs), engine=engine).read() == d
+        ours = frame_bytes(S, d, engine, blockSize, bits, len(d) if B.CONTENT_SIZE in bits else -1)
+        assert cli(["-d"], ours) == d
+        assert ours == theirs
+    # block-dependent CLI frames are refused like the reference refuses them
+    _expect(S, cli(["-1", "-B4", "-BD"], data), "BLOCK_INDEPENDENCE", engine)
+
+
+def block_stream_bytes(S, data, engine, blockSize, chunk=70000, batchBlocks=4, syncFlush=False, flush_at=None):
+    sink = io.BytesIO()
+    f = S.LZ4BlockOutputStream(sink, blockSize, engine=engine, syncFlush=syncFlush, batchBlocks=batchBlocks)
+    for i in range(0, len(data), chunk):
+        f.write(data[i:i + chunk])
+        if flush_at is not None and i // chunk == flush_at:
+            f.flush()
+    f.close()
+    return sink.getvalue()
+
+
+def case_block_stream(S, engine, port, data):
+    d = data[:400000]
+    for blockSize in (64, 1000, 1 << 16, 1 << 20):
+        dd = d[:5000] if blockSize == 64 else d
+        st = block_stream_bytes(S, dd, engine, blockSize)
+        level = max(0, (blockSize - 1).bit_length() - 10)
+        p, i = 0, 0
+        while True:
+            assert st[p:p + 8] == b"LZ4Block"
+            token = st[p + 8]
+            clen, olen, check = struct.unpack_from("<iii", st, p + 9)
+            assert token & 0x0F == level
+            p += 21
+            if olen == 0:
+                assert token & 0xF0 == 0x10 and clen == 0 and check == 0 and p == len(st)
+                break
+            raw = dd[i:i + olen]
+            assert olen == min(blockSize, len(dd) - i)
+            comp = port.compress_fast(raw)
+            if len(comp) >= olen:
+                assert token & 0xF0 == 0x10 and st[p:p + clen] == raw
+            else:
+                assert token & 0xF0 == 0x20 and st[p:p + clen] == comp
+            assert check == port.xxh32(raw, 0x9747B28C) & 0x0FFFFFFF
+            p += clen
+            i += olen
+        assert i == len(dd)
+        for bb in (1, 7):
+            assert S.LZ4BlockInputStream(io.BytesIO(st), engine=engine, batchBlocks=bb).read() == dd
+    # syncFlush cuts a block at flush(); concatenated streams need stopOnEmptyBlock=False
+    st = block_stream_bytes(S, d[:100000], engine, 1 << 16, chunk=30000, syncFlush=True, flush_at=0)
+    assert struct.unpack_from("<i", st, 13)[0] == 30000
+    two = st + block_stream_bytes(S, d[100000:150000], engine, 1 << 12)
+    assert S.LZ4BlockInputStream(io.BytesIO(two), engine=engine).read() == d[:100000]
+    assert S.LZ4BlockInputStream(io.BytesIO(two), stopOnEmptyBlock=False, engine=engine).read() == d[:150000]
+
+    def expect(buf, delivered=None, exc=S.IOException, **kw):
+        rd = S.LZ4BlockInputStream(io.BytesIO(buf), engine=engine, **kw)
+        got = bytearray()
+        try:
+            while True:
+                c = rd.read(50000)
+                if not c:
+                    break
+                got += c
+        except exc as e:
+            if delivered is not None:
+                assert bytes(got) == delivered
+            return str(e)
+        raise AssertionError("no error")
+
+    st = bytearray(block_stream_bytes(S, d[:200000], engine, 1 << 16))
+    assert expect(bytes(st[:-1]), d[:200000], S.EOFException) == S.PREMATURE_EOS
+    bad = bytearray(st); bad[3] ^= 1
+    assert expect(bytes(bad)) == "Stream is corrupted"
+    clen0 = struct.unpack_from("<i", st, 9)[0]
+    second = 21 + clen0
+    bad = bytearray(st); bad[second + 8] = 0x30 | 6
+    assert expect(bytes(bad), d[:65536]) == "Stream is corrupted"
+    bad = bytearray(st); bad[second + 17] ^= 4  # checksum field of block 1
+    assert expect(bytes(bad), d[:65536], batchBlocks=8) == "Stream is corrupted"
+    bad = bytearray(st); bad[second + 21 + 30] ^= 0x10  # payload of block 1
+    assert expect(bytes(bad), d[:65536], batchBlocks=8) == "Stream is corrupted"
+    bad = bytearray(st); struct.pack_into("<i", bad, second + 13, 65537)  # originalLen > 1 << level
+    assert expect(bytes(bad), d[:65536]) == "Stream is corrupted"
+    for bs in (63, (1 << 25) + 1):
+        try:
+            S.LZ4BlockOutputStream(io.BytesIO(), bs, engine=engine)
+            assert False
+        except ValueError as e:
+            assert "blockSize must be" in str(e)
+
+
+def case_with_length(S, engine, port, data, hc_engine=None):
+    bufs = [data[:0], data[:1], data[:13], data[1000:70000], data[200000:500000], bytes(5000)]
+    cw = S.LZ4CompressorWithLength(engine=engine)
+    outs = cw.compressMany(bufs)
+    for b, o in zip(bufs, outs):
+        assert o == struct.pack("<i", len(b)) + port.compress_fast(b)
+        assert S.LZ4DecompressorWithLength.getDecompressedLength(o) == len(b)
+        assert S.LZ4DecompressorWithLength.getDecompressedLength(b"zz" + o, 2) == len(b)
+    assert cw.maxCompressedLength(1000) == 1000 + 1000 // 255 + 16 + 4
+    assert cw.compress(b"ab" + bufs[3] + b"cd", 2, len(bufs[3])) == outs[3]
+    for fast in (True, False):
+        dw = S.LZ4DecompressorWithLength(fast=fast, engine=engine)
+        assert dw.decompressMany(outs) == bufs
+        assert dw.decompress(b"q" + outs[4], 1) == bufs[4]
+        bad = bytearray(outs[3]); bad[4] = 0xFF; bad[5:9] = b"\xff" * 4
+        try:
+            dw.decompress(bytes(bad))
+            assert False
+        except Exception as e:
+            assert "Error decoding offset" in str(e)
+    if hc_engine is not None:
+        o = S.LZ4CompressorWithLength(engine=hc_engine).compressMany(bufs[3:5])
+        assert [x[4:] for x in o] == [port.compress_hc(b, 9) for b in bufs[3:5]]
+        assert S.LZ4DecompressorWithLength(engine=engine).decompressMany(o) == bufs[3:5]
