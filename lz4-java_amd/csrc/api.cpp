@@ -63,6 +63,11 @@ struct DeviceGuard {  // callers (e.g. PyTorch) own the thread's current device:
 
 enum Op { OP_COMPRESS_FAST, OP_DECODE_SAFE, OP_DECODE_FAST, OP_COMPRESS_HC };
 int g_decode_lanes = 0;  // tuning knob (lz4hip_set_option "decode_lanes"); 0 = kernel default
+// lz4hip_set_option "compress_core": 2 = adaptive two-pass (default), 1 = window-parallel core only (lz4_fast_ms_core.h),
+// 0 = one-sequence-per-step core only (lz4_fast_core.h); "compress_switch" = bytes per sequence below which a block counts
+// as dense and goes to the window-parallel core (probe: sequences 32..95 of the block)
+int g_compress_core = 2;
+int g_compress_switch = 20;
 int g_compress_waves = 1; // 1 = single-wave kernel (default, fastest so far), 2 = match-finder wave + emitter wave per block
 
 // liblz4's level handling: < 1 -> 9, > 12 -> 12; 10..12 are the optimal parser,
@@ -111,7 +116,17 @@ uint32_t cu_count() {
 
 // fast compress: single-wave kernel, or (default) the two-wave kernel with its zeroed ring workspace
 int launch_fast(const lz4hip::BatchArgs& a, hipStream_t st) {
-  if (g_compress_waves != 2) return lz4hip::launch_compress_fast(a, st);
+  if (g_compress_waves != 2) {
+    if (g_compress_core == 0) return lz4hip::launch_compress_fast(a, nullptr, 0u, st);
+    if (g_compress_core == 1) return lz4hip::launch_compress_fast_ms(a, nullptr, st);
+    uint8_t* route = nullptr;
+    hipError_t e = hipMallocAsync((void**)&route, a.n, st);
+    if (e != hipSuccess) return (int)e;
+    int le = lz4hip::launch_compress_fast(a, route, 64u * (uint32_t)g_compress_switch, st);
+    if (le == 0) le = lz4hip::launch_compress_fast_ms(a, route, st);
+    (void)hipFreeAsync(route, st);
+    return le;
+  }
   const uint32_t grid = lz4hip::compress_fast2_grid(a.n, cu_count());
   const size_t bytes = lz4hip::compress_fast2_ws_bytes(grid);
   uint8_t* ws = nullptr;
@@ -350,6 +365,16 @@ int lz4hip_set_option(const char* name, int value) {
   }
   if (name && strcmp(name, "dbg_extra_lds") == 0) { lz4hip::set_dbg_extra_lds((uint32_t)value); return LZ4HIP_OK; }
   if (name && strcmp(name, "dbg_flags") == 0) { lz4hip::set_dbg_flags((uint32_t)value); return LZ4HIP_OK; }
+  if (name && strcmp(name, "compress_core") == 0) {
+    if (value < 0 || value > 2) return fail(LZ4HIP_E_ARG, "compress_core must be 0, 1 or 2");
+    g_compress_core = value;
+    return LZ4HIP_OK;
+  }
+  if (name && strcmp(name, "compress_switch") == 0) {
+    if (value < 0 || value > 1024) return fail(LZ4HIP_E_ARG, "compress_switch must be 0..1024");
+    g_compress_switch = value;
+    return LZ4HIP_OK;
+  }
   if (name && strcmp(name, "compress_waves") == 0) {
     if (value != 1 && value != 2) return fail(LZ4HIP_E_ARG, "compress_waves must be 1 or 2");
     g_compress_waves = value;
@@ -443,7 +468,7 @@ int lz4hip_dbg_compress_fast_profile_dev(const uint8_t* src, const uint64_t* src
   if (ordinal(device, &ord)) return fail(LZ4HIP_E_ARG, "bad device index");
   DeviceGuard g(ord);
   lz4hip::BatchArgs a{src, src_off, src_len, dst, dst_off, dst_cap, out_len, n};
-  int e = lz4hip::launch_compress_fast_prof(a, prof, stream);
+  int e = lz4hip::launch_compress_fast_prof(a, prof, g_compress_core >= 1, stream);
   return e ? fail(LZ4HIP_E_HIP, "kernel launch", (hipError_t)e) : LZ4HIP_OK;
 }
 

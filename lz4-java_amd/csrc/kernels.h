@@ -12,14 +12,21 @@ struct BatchArgs {
   int32_t* out; uint32_t n;
 };
 
-int launch_compress_fast(const BatchArgs& a, void* stream);
+// Fast compress, two cores (same bytes):
+//   launch_compress_fast     one sequence per step (lz4_fast_core.h): best when sequences are long
+//   launch_compress_fast_ms  every sequence of a 64-position window per step (lz4_fast_ms_core.h): best when they are short
+// Adaptive two-pass use: launch_compress_fast(route = n-byte device buffer, dense64) finishes the blocks with long sequences
+// and marks the others (route[b] = 1: sequences 32..95 cover fewer than dense64 bytes); launch_compress_fast_ms(route) then
+// does exactly those.  route == nullptr: the kernel does every block.
+int launch_compress_fast(const BatchArgs& a, uint8_t* route, uint32_t dense64, void* stream);
+int launch_compress_fast_ms(const BatchArgs& a, const uint8_t* route, void* stream);
 void set_dbg_flags(uint32_t f);  // developer diagnostics
 void set_dbg_extra_lds(uint32_t bytes);
 // two-wave variant: `ws` = zeroed device workspace of compress_fast2_ws_bytes(grid) bytes
 uint32_t compress_fast2_grid(uint32_t n_blocks, uint32_t n_cus);
 size_t compress_fast2_ws_bytes(uint32_t grid);
 int launch_compress_fast2(const BatchArgs& a, uint8_t* ws, uint32_t grid, void* stream);
-int launch_compress_fast_prof(const BatchArgs& a, uint64_t* prof, void* stream);  // developer diagnostics
+int launch_compress_fast_prof(const BatchArgs& a, uint64_t* prof, bool ms, void* stream);  // developer diagnostics
 // HC levels 1..9: `ws` = device workspace of u16[max(src_off+src_len)] (see launch_hc_span)
 int launch_hc_span(const uint64_t* src_off, const int32_t* src_len, uint32_t n, uint64_t* out_dev, void* stream);
 int launch_compress_hc(const BatchArgs& a, int level, uint16_t* ws, void* stream);

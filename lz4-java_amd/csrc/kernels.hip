@@ -16,6 +16,7 @@
 #include "wave_dev.h"
 #include "group_dev.h"
 #include "lz4_fast_core.h"
+#include "lz4_fast_ms_core.h"
 #include "lz4_decode_core.h"
 #include "lz4_hc_core.h"
 #include "xxh_core.h"
@@ -30,7 +31,9 @@ void set_dbg_flags(uint32_t f) { g_dbg_flags = f; }
 // ------------------------------------------------------------------------------------------------
 // fast compress
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void compress_fast_kernel(BatchArgs a, uint32_t dbg_flags) {
+// `route` (may be null): per-block routing byte of the adaptive two-pass scheme.  This kernel probes the density of each
+// block (lz4_fast_core.h, dense64); a block of short sequences is left unfinished with route[b] = 1 for compress_fast_ms_kernel.
+__global__ __launch_bounds__(64) void compress_fast_kernel(BatchArgs a, uint32_t dbg_flags, uint8_t* route, uint32_t dense64) {
   __shared__ __attribute__((aligned(16))) uint64_t table[4096];  // 32 KB: 8192 x u32 (byU16) or 4096 x u64 (byU32)
   const uint32_t b = blockIdx.x;
   const int32_t n = a.src_len[b];
@@ -42,19 +45,62 @@ __global__ __launch_bounds__(64) void compress_fast_kernel(BatchArgs a, uint32_t
     WaveDev w(table);
     DirectOut<WaveDev> out(w, s, (uint32_t)n, d, (uint32_t)cap);
     (void)dbg_flags;
+    bool bailed;
     if (n < 65547) {
       FastCore<WaveDev, true> c(w, out, s, (uint32_t)n);
+      c.dense64 = route ? dense64 : 0u;
       r = c.run();
+      bailed = c.bailed;
     } else {
       FastCore<WaveDev, false> c(w, out, s, (uint32_t)n);
+      c.dense64 = route ? dense64 : 0u;
+      r = c.run();
+      bailed = c.bailed;
+    }
+    if (bailed) {
+      if (threadIdx.x == 0) route[b] = 1;
+      return;
+    }
+  }
+  if (threadIdx.x == 0) {
+    a.out[b] = (int32_t)r;
+    if (route) route[b] = 0;
+  }
+}
+
+// window-parallel core (lz4_fast_ms_core.h): every sequence of a 64-position window per step
+// `route` (may be null): only blocks with route[b] != 0 are processed (second pass of the adaptive scheme)
+__global__ __launch_bounds__(64) void compress_fast_ms_kernel(BatchArgs a, const uint8_t* route) {
+  __shared__ __attribute__((aligned(16))) uint64_t table[4096];
+  const uint32_t b = blockIdx.x;
+  if (route && !route[b]) return;
+  const int32_t n = a.src_len[b];
+  const int32_t cap = a.dst_cap[b];
+  uint32_t r = 0;
+  if (n >= 0 && (uint32_t)n <= 0x7E000000u && cap >= 0) {
+    const uint8_t* s = a.src + a.src_off[b];
+    uint8_t* d = a.dst + a.dst_off[b];
+    WaveDev w(table);
+    DirectOut<WaveDev> out(w, s, (uint32_t)n, d, (uint32_t)cap);
+    if (n < 65547) {
+      FastCoreMS<WaveDev, true> c(w, out, s, (uint32_t)n);
+      r = c.run();
+    } else {
+      FastCoreMS<WaveDev, false> c(w, out, s, (uint32_t)n);
       r = c.run();
     }
   }
   if (threadIdx.x == 0) a.out[b] = (int32_t)r;
 }
+int launch_compress_fast_ms(const BatchArgs& a, const uint8_t* route, void* stream) {
+  if (a.n == 0) return 0;
+  hipLaunchKernelGGL(compress_fast_ms_kernel, dim3(a.n), dim3(64), g_dbg_extra_lds, (hipStream_t)stream, a, route);
+  return (int)hipGetLastError();
+}
 
 // developer diagnostics: same algorithm with per-phase shader-clock accumulation; prof[b*12 + i] =
 // {steps, slow_steps, false_pos, sequences, t[0..7]} of block b
+template <bool MS>
 __global__ __launch_bounds__(64) void compress_fast_prof_kernel(BatchArgs a, uint64_t* prof) {
   __shared__ __attribute__((aligned(16))) uint64_t table[4096];
   const uint32_t b = blockIdx.x;
@@ -67,8 +113,13 @@ __global__ __launch_bounds__(64) void compress_fast_prof_kernel(BatchArgs a, uin
     uint8_t* d = a.dst + a.dst_off[b];
     WaveDev w(table);
     DirectOut<WaveDev> out(w, s, (uint32_t)n, d, (uint32_t)cap);
-    if (n < 65547) { FastCore<WaveDev, true> c(w, out, s, (uint32_t)n, &st); r = c.run(); }
-    else { FastCore<WaveDev, false> c(w, out, s, (uint32_t)n, &st); r = c.run(); }
+    if constexpr (MS) {
+      if (n < 65547) { FastCoreMS<WaveDev, true> c(w, out, s, (uint32_t)n, &st); r = c.run(); }
+      else { FastCoreMS<WaveDev, false> c(w, out, s, (uint32_t)n, &st); r = c.run(); }
+    } else {
+      if (n < 65547) { FastCore<WaveDev, true> c(w, out, s, (uint32_t)n, &st); r = c.run(); }
+      else { FastCore<WaveDev, false> c(w, out, s, (uint32_t)n, &st); r = c.run(); }
+    }
   }
   if (threadIdx.x == 0) {
     a.out[b] = (int32_t)r;
@@ -77,9 +128,10 @@ __global__ __launch_bounds__(64) void compress_fast_prof_kernel(BatchArgs a, uin
     for (int i = 0; i < 8; i++) p[4 + i] = st.t[i];
   }
 }
-int launch_compress_fast_prof(const BatchArgs& a, uint64_t* prof, void* stream) {
+int launch_compress_fast_prof(const BatchArgs& a, uint64_t* prof, bool ms, void* stream) {
   if (a.n == 0) return 0;
-  hipLaunchKernelGGL(compress_fast_prof_kernel, dim3(a.n), dim3(64), 0, (hipStream_t)stream, a, prof);
+  if (ms) hipLaunchKernelGGL(compress_fast_prof_kernel<true>, dim3(a.n), dim3(64), 0, (hipStream_t)stream, a, prof);
+  else hipLaunchKernelGGL(compress_fast_prof_kernel<false>, dim3(a.n), dim3(64), 0, (hipStream_t)stream, a, prof);
   return (int)hipGetLastError();
 }
 
@@ -224,7 +276,7 @@ uint32_t compress_fast2_grid(uint32_t n_blocks, uint32_t n_cus) {
 }
 size_t compress_fast2_ws_bytes(uint32_t grid) { return (size_t)grid * RING_WG_BYTES + 64u; }
 
-int launch_compress_fast(const BatchArgs& a, void* stream) {
+int launch_compress_fast(const BatchArgs& a, uint8_t* route, uint32_t dense64, void* stream) {
   if (a.n == 0) return 0;
   if (getenv("LZ4HIP_DEBUG")) {
     int nb = -1;
@@ -233,7 +285,7 @@ int launch_compress_fast(const BatchArgs& a, void* stream) {
     fprintf(stderr, "[lz4hip] compress_fast_kernel: occupancy API says %d workgroups/CU (err %d), extra LDS %u, sharedMemPerMultiprocessor %zu, maxSharedMemoryPerMultiProcessor %zu, sharedMemPerBlock %zu\n",
             nb, (int)e, g_dbg_extra_lds, (size_t)pr.sharedMemPerMultiprocessor, (size_t)pr.maxSharedMemoryPerMultiProcessor, (size_t)pr.sharedMemPerBlock);
   }
-  hipLaunchKernelGGL(compress_fast_kernel, dim3(a.n), dim3(64), g_dbg_extra_lds, (hipStream_t)stream, a, g_dbg_flags);
+  hipLaunchKernelGGL(compress_fast_kernel, dim3(a.n), dim3(64), g_dbg_extra_lds, (hipStream_t)stream, a, g_dbg_flags, route, dense64);
   return (int)hipGetLastError();
 }
 

@@ -316,6 +316,12 @@ struct FastCore {
   uint32_t anchor = 0;
   uint32_t mfl1, matchlimit;  // mflimitPlusOne = n-11, matchlimit = n-5
   FastStats* st;
+  // Density probe (0 = off): if sequences 32..95 of the block cover fewer than `dense64` input bytes, the block is made of
+  // short sequences -- the window-parallel core (lz4_fast_ms_core.h) is the faster one for it; loop() then stops with
+  // `bailed` set and the caller leaves the block to that core.
+  uint32_t dense64 = 0;
+  bool bailed = false, probe_done = false;
+  uint32_t p_S = 0, p_ip = 0;
 
   LZ4HIP_DEV FastCore(W& w_, Out& out_, const uint8_t* s, uint32_t n_, FastStats* st_ = nullptr)
       : w(w_), out(out_), src(s), n(n_), st(st_) {
@@ -429,10 +435,20 @@ struct FastCore {
     }
     w.template lds_fill<U16>(1u << HLOG, (E)fp0);
     w.sync();
+    if (dense64 == 0u) return loop<false>(false, 1u, 0u, 0u);
+    // density probe: a second copy of the loop counts the first 96 sequences, so the main loop stays untouched
+    const uint32_t res = loop<true>(false, 1u, 0u, 0u);
+    if (!probe_done) return res;   // the block ended (or ran out of output) before the probe did
+    if (bailed) return 0u;
+    return loop<false>(true, p_S, 0u, p_ip);
+  }
 
-    bool post = false;       // step kind: false = run probes only; true = {insert ip-2, probe ip, run from ip+1}
-    uint32_t S = 1, r = 0;   // run start, index of the first run probe of this step
-    uint32_t ip = 0;         // post-match position (== anchor) when post
+  // the step loop from a given parser state (also entered mid-block by lz4_fast_ms_core.h when it hands a block over):
+  //   post: step kind: false = run probes only; true = {insert ip-2, probe ip, run from ip+1}
+  //   S, r: run start, index of the first run probe of this step;  ip: post-match position (== anchor) when post
+  template <bool PROBE>
+  LZ4HIP_DEV uint32_t loop(bool post, uint32_t S, uint32_t r, uint32_t ip) {
+    uint32_t probe_cd = 32u, probe_anchor = 0;  // (PROBE only) countdown to the next density-probe event
     const VU j = w.lane();
     const VU o8 = j * 8u;
     prepare_step(post, S, r, ip);
@@ -608,6 +624,18 @@ struct FastCore {
       anchor = ip_new;
       LZ4HIP_PHASE(6, ip_new);           // t[6]: match length + catch-up + bookkeeping
       if (done) return out.last(anchor);
+      if constexpr (PROBE) {
+        if (--probe_cd == 0u) {
+          if (probe_anchor == 0u) { probe_anchor = anchor; probe_cd = 64u; }
+          else {  // sequence 96 done: the next step is a post step at ip_new
+            if (!out.overlap_point()) return 0u;
+            probe_done = true;
+            bailed = anchor - probe_anchor < dense64;
+            p_S = S; p_ip = ip;
+            return 0u;
+          }
+        }
+      }
     }
 #undef LZ4HIP_PHASE
   }

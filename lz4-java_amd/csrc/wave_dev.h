@@ -76,16 +76,29 @@ struct WaveDev {
   __device__ __forceinline__ static VU64 ldu64(const uint8_t* b, VU i) { uint64_t v; __builtin_memcpy(&v, b + i, 8); return v; }
   // candidate side of the match fetch (a non-temporal load here measured 4 % SLOWER: ~half of these hit L2)
   __device__ __forceinline__ static VU64 ldu64_cand(const uint8_t* b, VU i) { return ldu64(b, i); }
+  __device__ __forceinline__ static void consume(VU v) { asm volatile("" ::"v"(v)); }  // keeps a prefetch load alive
   __device__ __forceinline__ static VU vmin(VU a, VU b) { return a < b ? a : b; }
+  __device__ __forceinline__ static VU vmax(VU a, VU b) { return a > b ? a : b; }
+  __device__ __forceinline__ static VU ctz64v(VU64 v) { return v ? (uint32_t)__builtin_ctzll(v) : 64u; }  // per-lane
+  // lane `l` (wave-uniform) of v replaced by the scalar s
+  // (v_writelane_b32 has no builtin in this toolchain and needs M0 for a second scalar operand; compare + select it is)
+  __device__ __forceinline__ static VU set_lane(VU v, int l, uint32_t s) { return (int)__lane_id() == l ? s : v; }
+  // number of set bits of the wave-uniform mask m below this lane
+  __device__ __forceinline__ static VU mbcnt(uint64_t m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+  }
+  __device__ __forceinline__ static VU shfl(VU v, VU srcl) { return (uint32_t)__shfl((int)v, (int)srcl, 64); }
   __device__ __forceinline__ static VU div255(VU a) { return a / 255u; }
-  // exclusive prefix sum across the wavefront (6 shuffle steps)
+  // exclusive prefix sum across the wavefront: 4 row_shr DPP adds + row_bcast15/31 (no LDS crossbar round trips)
   __device__ __forceinline__ static VU excl_scan(VU a) {
-    VU x = a;
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t y = (uint32_t)__shfl_up((int)x, d, 64);
-      if ((int)__lane_id() >= d) x += y;
-    }
-    return x - a;
+    int x = (int)a;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);  // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);  // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);  // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);  // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1,3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2,3
+    return (uint32_t)x - a;
   }
   __device__ __forceinline__ static VU shr(VU a, VU k) { return a >> (k & 31u); }  // per-lane shift amount
   __device__ __forceinline__ static VU shfl_up1(VU v) { return (uint32_t)__shfl_up((int)v, 1, 64); }  // lane l <- lane l-1

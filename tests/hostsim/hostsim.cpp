@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include "../../lz4-java_amd/csrc/lz4_fast_core.h"
+#include "../../lz4-java_amd/csrc/lz4_fast_ms_core.h"
 #include "wave_host.h"
 #include "../../lz4-java_amd/csrc/lz4_decode_core.h"
 #include "group_host.h"
@@ -28,6 +29,42 @@ int sim_compress_fast(const uint8_t* src, int n, uint8_t* dst, int cap, uint64_t
     r = c.run();
   } else {
     lz4hip::FastCore<hostsim::WaveHost, false> c(w, out, src, (uint32_t)n, &st);
+    r = c.run();
+  }
+  if (stats4) { stats4[0] = st.steps; stats4[1] = st.slow_steps; stats4[2] = st.false_pos; stats4[3] = st.sequences; }
+  if (w.oob) return -1000;
+  return (int)r;
+}
+
+// one-sequence-per-step core with the density probe of the adaptive scheme: -2 = the core left the block to the
+// window-parallel core (sequences 32..95 cover fewer than dense64 bytes)
+int sim_compress_fast_probe(const uint8_t* src, int n, uint8_t* dst, int cap, uint32_t dense64) {
+  if (n < 0 || (uint32_t)n > 0x7E000000u || cap < 0) return 0;
+  hostsim::WaveHost w;
+  w.bounds(src, (size_t)n, dst, (size_t)cap);
+  lz4hip::DirectOut<hostsim::WaveHost> out(w, src, (uint32_t)n, dst, (uint32_t)cap);
+  uint32_t r;
+  bool bailed;
+  if (n < 65547) { lz4hip::FastCore<hostsim::WaveHost, true> c(w, out, src, (uint32_t)n); c.dense64 = dense64; r = c.run(); bailed = c.bailed; }
+  else { lz4hip::FastCore<hostsim::WaveHost, false> c(w, out, src, (uint32_t)n); c.dense64 = dense64; r = c.run(); bailed = c.bailed; }
+  if (w.oob) return -1000;
+  return bailed ? -2 : (int)r;
+}
+
+// window-parallel core (lz4_fast_ms_core.h): every sequence of a 64-position window per step
+int sim_compress_fast_ms(const uint8_t* src, int n, uint8_t* dst, int cap, uint64_t* stats4, uint64_t rng_seed) {
+  if (n < 0 || (uint32_t)n > 0x7E000000u || cap < 0) return 0;
+  hostsim::WaveHost w;
+  if (rng_seed) w.rng = rng_seed;
+  w.bounds(src, (size_t)n, dst, (size_t)cap);
+  lz4hip::FastStats st = {0, 0, 0, 0};
+  uint32_t r;
+  lz4hip::DirectOut<hostsim::WaveHost> out(w, src, (uint32_t)n, dst, (uint32_t)cap);
+  if (n < 65547) {
+    lz4hip::FastCoreMS<hostsim::WaveHost, true> c(w, out, src, (uint32_t)n, &st);
+    r = c.run();
+  } else {
+    lz4hip::FastCoreMS<hostsim::WaveHost, false> c(w, out, src, (uint32_t)n, &st);
     r = c.run();
   }
   if (stats4) { stats4[0] = st.steps; stats4[1] = st.slow_steps; stats4[2] = st.false_pos; stats4[3] = st.sequences; }

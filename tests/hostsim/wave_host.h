@@ -35,6 +35,7 @@ struct V {
 #undef HS_CMP
   friend V operator<<(const V& a, int s) { V r; for (int i = 0; i < 64; i++) r.v[i] = (T)(a.v[i] << s); return r; }
   friend V operator>>(const V& a, int s) { V r; for (int i = 0; i < 64; i++) r.v[i] = (T)(a.v[i] >> s); return r; }
+  V operator~() const { V r; for (int i = 0; i < 64; i++) r.v[i] = (T)~v[i]; return r; }
   V<bool> operator!() const { V<bool> r; for (int i = 0; i < 64; i++) r.v[i] = !v[i]; return r; }
 };
 
@@ -91,6 +92,12 @@ struct WaveHost {
   VU64 ldu64(const uint8_t* b, const VU& i) { return ld64(b, i, VB(true)); }
   VU64 ldu64_cand(const uint8_t* b, const VU& i) { return ld64(b, i, VB(true)); }
   static VU vmin(const VU& a, const VU& b) { VU r; for (int l = 0; l < 64; l++) r.v[l] = a.v[l] < b.v[l] ? a.v[l] : b.v[l]; return r; }
+  static void consume(const VU&) {}
+  static VU vmax(const VU& a, const VU& b) { VU r; for (int l = 0; l < 64; l++) r.v[l] = a.v[l] > b.v[l] ? a.v[l] : b.v[l]; return r; }
+  static VU ctz64v(const VU64& v) { VU r; for (int i = 0; i < 64; i++) r.v[i] = v.v[i] ? (uint32_t)__builtin_ctzll(v.v[i]) : 64u; return r; }
+  static VU set_lane(const VU& v, int l, uint32_t s) { VU r = v; r.v[l] = s; return r; }
+  static VU mbcnt(uint64_t m) { VU r; for (int i = 0; i < 64; i++) r.v[i] = (uint32_t)__builtin_popcountll(m & ((1ull << i) - 1ull)); return r; }
+  static VU shfl(const VU& v, const VU& srcl) { VU r; for (int i = 0; i < 64; i++) r.v[i] = v.v[srcl.v[i] & 63u]; return r; }
   static VU div255(const VU& a) { VU r; for (int l = 0; l < 64; l++) r.v[l] = a.v[l] / 255u; return r; }
   static VU excl_scan(const VU& a) { VU r; uint32_t acc = 0; for (int l = 0; l < 64; l++) { r.v[l] = acc; acc += a.v[l]; } return r; }
   static VU shr(const VU& a, const VU& k) { VU r; for (int l = 0; l < 64; l++) r.v[l] = a.v[l] >> (k.v[l] & 31u); return r; }

@@ -297,3 +297,27 @@ def test_two_wave_compress_kernel_same_bytes(amd, ref, O, corpus):
     for v, cap, (r, c) in zip(blocks, caps, res):
         er, eb = ref.compress_fast_raw(v, cap)
         assert r == er and (er <= 0 or c == eb), (len(v), cap, r, er)
+
+
+@pytest.mark.parametrize("core,switch", [(0, 20), (1, 20), (2, 0), (2, 1024)])
+def test_compress_core_variants_same_bytes(amd, ref, O, corpus, core, switch):
+    """compress_core 0 (one sequence per step only), 1 (window-parallel only) and 2 (adaptive two-pass) with extreme routing
+    thresholds produce the same bytes as the default (2, threshold 20 bytes per sequence)"""
+    import random as _r
+    rng = _r.Random(304)
+    blocks, caps = [], []
+    for v in list(corpus.values()) + rnd_inputs(O, corpus, 92, 400):
+        full = ref.compress_bound(len(v))
+        er, _ = ref.compress_fast_raw(v, full)
+        for cap in (full, max(0, er + rng.choice([-1, 0, 1, -7, 9]))):
+            blocks.append(v); caps.append(cap)
+    amd.set_option("compress_core", core)
+    amd.set_option("compress_switch", switch)
+    try:
+        res = gpu_compress_many(amd, blocks, caps)
+    finally:
+        amd.set_option("compress_core", 2)
+        amd.set_option("compress_switch", 20)
+    for v, cap, (r, c) in zip(blocks, caps, res):
+        er, eb = ref.compress_fast_raw(v, cap)
+        assert r == er and (er <= 0 or c == eb), (len(v), cap, r, er)

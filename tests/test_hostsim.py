@@ -19,21 +19,25 @@ def sim():
     d = os.path.join(ROOT, "tests", "hostsim")
     so = os.path.join(d, "libhostsim.so")
     srcs = [os.path.join(d, f) for f in ("hostsim.cpp", "wave_host.h", "group_host.h")] + \
-           [os.path.join(ROOT, "lz4-java_amd", "csrc", f) for f in ("lz4_fast_core.h", "lz4_decode_core.h")]
+           [os.path.join(ROOT, "lz4-java_amd", "csrc", f) for f in ("lz4_fast_core.h", "lz4_fast_ms_core.h", "lz4_decode_core.h", "lz4_hc_core.h")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, os.path.join(d, "hostsim.cpp")])
     l = C.CDLL(so)
     l.sim_compress_fast.restype = C.c_int
     l.sim_compress_fast.argtypes = [C.c_char_p, C.c_int, _u8p, C.c_int, C.POINTER(C.c_uint64), C.c_uint64]
+    l.sim_compress_fast_ms.restype = C.c_int
+    l.sim_compress_fast_ms.argtypes = [C.c_char_p, C.c_int, _u8p, C.c_int, C.POINTER(C.c_uint64), C.c_uint64]
+    l.sim_compress_fast_probe.restype = C.c_int
+    l.sim_compress_fast_probe.argtypes = [C.c_char_p, C.c_int, _u8p, C.c_int, C.c_uint32]
     l.sim_decompress.restype = C.c_int
     l.sim_decompress.argtypes = [C.c_char_p, C.c_int, _u8p, C.c_int, C.c_int, C.c_int]
     return l
 
 
-def sim_compress(sim, v, cap, seed=0):
+def sim_compress(sim, v, cap, seed=0, ms=False):
     out = (C.c_uint8 * max(cap, 1))()
     st = (C.c_uint64 * 4)()
-    r = sim.sim_compress_fast(bytes(v), len(v), out, cap, st, seed)
+    r = (sim.sim_compress_fast_ms if ms else sim.sim_compress_fast)(bytes(v), len(v), out, cap, st, seed)
     return r, bytes(out[:max(r, 0)]), list(st)
 
 
@@ -64,6 +68,76 @@ def test_compress_core_fuzz(sim, ref, O, corpus):
             a = ref.compress_fast_raw(v, cap)
             r, b, _ = sim_compress(sim, v, cap, seed=rng.getrandbits(63) | 1)
             assert r == a[0] and (r <= 0 or b == a[1]), (len(v), cap, r, a[0])
+
+
+def test_compress_ms_core_golden(sim, ref, corpus):
+    """window-parallel core (lz4_fast_ms_core.h): all sequences of a 64-position window per step"""
+    slow = steps = seqs = 0
+    for name, v in corpus.items():
+        cap = ref.compress_bound(len(v))
+        r, b, st = sim_compress(sim, v, cap, ms=True)
+        assert b == ref.compress_fast(v), name
+        steps += st[0]; slow += st[1]; seqs += st[3]
+    assert slow > 0           # the roll-back path was exercised
+    assert seqs > 2 * steps   # and the point of the design: several sequences per step
+
+
+def test_compress_ms_core_fuzz(sim, ref, O, corpus):
+    rng = random.Random(4)
+    for v in rnd_inputs(O, corpus, 22, 500):
+        full = ref.compress_bound(len(v))
+        er, _ = ref.compress_fast_raw(v, full)
+        for cap in (full, max(0, er + rng.choice([-1, 0, 1, 2, -5, 5, -20, 20])), rng.randrange(0, full + 1)):
+            a = ref.compress_fast_raw(v, cap)
+            r, b, _ = sim_compress(sim, v, cap, seed=rng.getrandbits(63) | 1, ms=True)
+            assert r == a[0] and (r <= 0 or b == a[1]), (len(v), cap, r, a[0])
+
+
+def lz4_sequence_ends(c):
+    """input position after each sequence of an LZ4 block (independent walk of the format)"""
+    i = pos = 0
+    ends = []
+    while i < len(c):
+        t = c[i]; i += 1
+        l = t >> 4
+        if l == 15:
+            while True:
+                b = c[i]; i += 1; l += b
+                if b != 255:
+                    break
+        i += l; pos += l
+        if i >= len(c):
+            break
+        i += 2
+        m = t & 15
+        if m == 15:
+            while True:
+                b = c[i]; i += 1; m += b
+                if b != 255:
+                    break
+        pos += m + 4
+        ends.append(pos)
+    return ends
+
+
+def test_density_probe_routes_blocks(sim, ref, O, corpus):
+    """adaptive two-pass scheme, pass 1: the one-sequence-per-step core leaves a block to the window-parallel core exactly
+    when its sequences 32..95 cover fewer than dense64 bytes; otherwise it finishes it with the usual bytes"""
+    routed = {}
+    for name, v in list(corpus.items()) + [("rnd%d" % i, x) for i, x in enumerate(rnd_inputs(O, corpus, 24, 120))]:
+        cap = ref.compress_bound(len(v))
+        expect = ref.compress_fast(v)
+        ends = lz4_sequence_ends(expect)
+        for dense64 in (64 * 20, 64 * 40):
+            out = (C.c_uint8 * max(cap, 1))()
+            r = sim.sim_compress_fast_probe(bytes(v), len(v), out, cap, dense64)
+            dense = len(ends) >= 96 and ends[95] - ends[31] < dense64
+            if dense:
+                assert r == -2, (name, dense64)
+            else:
+                assert r == len(expect) and bytes(out[:r]) == expect, (name, dense64)
+            routed[(name, dense64)] = dense
+    assert routed[("book1[:65536]", 1280)] and not routed[("gen_block(65536,0)", 1280)] and routed[("gen_block(65536,0)", 2560)]
 
 
 def test_decode_core_fuzz(sim, ref, O, corpus):

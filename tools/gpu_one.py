@@ -16,6 +16,8 @@ else:
     import numpy as np
     if data == "book1":
         b = open(os.path.join(ROOT, "tests/golden/book1_200000.bin"), "rb").read()[:blk]
+    elif data in ("geo", "pic"):
+        b = open(os.path.join(ROOT, "tests/golden/%s_65536.bin" % data), "rb").read()
     elif data == "zeros":
         b = bytes(blk)
     else:
@@ -35,6 +37,10 @@ if os.environ.get("XLDS"):
     amd.set_option("dbg_extra_lds", int(os.environ["XLDS"]))
 if os.environ.get("DBG"):
     amd.set_option("dbg_flags", int(os.environ["DBG"]))
+if os.environ.get("CC"):
+    amd.set_option("compress_core", int(os.environ["CC"]))
+if os.environ.get("CS"):
+    amd.set_option("compress_switch", int(os.environ["CS"]))
 if os.environ.get("CW"):
     amd.set_option("compress_waves", int(os.environ["CW"]))
 for _ in range(reps):

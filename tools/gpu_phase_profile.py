@@ -8,6 +8,10 @@ import torch, numpy as np
 amd = importlib.import_module("lz4-java_amd")
 n = int(sys.argv[1]); kinds = sys.argv[2:] or ["synth", "book1"]
 dev = torch.device("cuda:0"); blk = 65536; cap = amd.maxCompressedLength(blk)
+if os.environ.get("CC"):
+    amd.set_option("compress_core", int(os.environ["CC"]))
+ms = os.environ.get("CC", "1") == "1"
+names_ms = ["window+hash", "bucket+fp ballot", "cand fetch issue", "emit prev window", "wait cand+verdict", "chain walk", "commit+collision", "handover+prepare"]
 names = ["window+hash", "table+ballot", "issue commit/fetch", "emit prev", "atomic/collision", "wait candidate", "extend+bookkeep", "-"]
 for data in kinds:
     if data == "synth":
@@ -25,7 +29,7 @@ for data in kinds:
     p = prof.double().mean(0).cpu().tolist()
     steps = p[0]
     print("== %s: %d blocks, kernel %.2f ms; per block: steps %.0f collision-steps %.0f false-pos %.1f sequences %.0f" % (data, n, a.elapsed_time(b2), p[0], p[1], p[2], p[3]))
-    tot = sum(p[4:11])
-    for i in range(7):
-        print("   %-20s %8.0f cycles/step  %5.1f%%" % (names[i], p[4 + i] / steps, 100 * p[4 + i] / tot))
+    tot = sum(p[4:12])
+    for i in range(8):
+        print("   %-20s %8.0f cycles/step  %5.1f%%" % ((names_ms if ms else names)[i], p[4 + i] / steps, 100 * p[4 + i] / tot))
     print("   %-20s %8.0f cycles/step" % ("total", tot / steps))
