@@ -187,6 +187,7 @@ struct FastCoreMS : FastCore<W, U16, DirectOut<W>> {
     prepare(post, S, r, ip);
 
     enum { K_RUN = 0, K_POST = 1, K_DONE = 2, K_LAST = 3 };
+    uint32_t pf_end = 0;  // source prefetched up to here
 
     for (;;) {
       if (st) st->steps++;
@@ -230,8 +231,7 @@ struct FastCoreMS : FastCore<W, U16, DirectOut<W>> {
       const uint32_t hp0 = w.bcast(pos, k0), mp0 = w.bcast(cpos, k0);
       const VU64 fa = w.ldu64(src, W::vmin(j * 8u + hp0, top));
       const VU64 fb = w.ldu64_cand(src, W::vmin(j * 8u + mp0, top));
-      // the source line two windows ahead (one request; consumed only to keep it alive): later window loads hit L2
-      const VU pf = w.ldu32(src, VU(wbase + 192u < top ? wbase + 192u : top));
+      if (LZ4HIP_UNLIKELY(wbase + 4096u > pf_end && pf_end < n && n >= 16u)) { w.prefetch4k(src, pf_end, n); pf_end += 4096u; }  // source -> L2, 4 KB ahead
       LZ4HIP_PHASE(2, (uint32_t)tmask);          // t[2]: candidate fetch issue
 
       // ---- [3] write the previous window's sequences while those loads are in flight ----
@@ -260,41 +260,55 @@ struct FastCoreMS : FastCore<W, U16, DirectOut<W>> {
       }
       LZ4HIP_PHASE(4, (uint32_t)M + w.bcast(lenv, 0));  // t[4]: candidate bytes arrived + per-lane verdicts
 
-      // ---- [5] link the sequences of this window (scalar, minimal) ----
+      // ---- [5] link the sequences of this window.  The scalar walk only hops hit -> match end -> next hit and notes
+      //          the hit lanes; which lanes lie inside matches, which insert, and every sequence's anchor follow in one vector pass ----
       const uint32_t anchor0 = anchor;
       const uint64_t inv = ~validm;
       const uint32_t kinv = inv ? (uint32_t)ctz64(inv) : 64u;  // valid lanes are a prefix
-      uint32_t cur = l0;
-      uint64_t cm = 0, covered = 0, e2m = 0;  // lanes that found a sequence / lie inside a match / only insert (liblz4's ip-2)
-      VU anchor_v = VU(anchor);               // anchor each sequence starts from, in the lane that found it
-      int kind;
+      const uint32_t wpb = wbase - l0;                         // position of lane x is wpb + x (consecutive windows)
+      // a match that ends at or beyond lane `lim` ends the window: the window edge, the end of the probing range
+      // (liblz4 stops at mflimitPlusOne), or -- non-consecutive window -- any match at all
+      const uint32_t lim = !multi ? 0u : (mfl1 - wpb < 64u ? mfl1 - wpb : 64u);
+      VU E = j + lenv;   // lane of the match end, were this lane's match taken
+      uint32_t cur = l0, jlast = 0, le = 0;
+      uint64_t cm = 0;   // lanes that found a sequence
+      bool broke = false;
       for (;;) {
         const uint64_t hm = M & (~0ull << cur);
-        if (hm == 0) { kind = kinv < 64u ? K_LAST : K_RUN; break; }
-        const uint32_t jh = (uint32_t)ctz64(hm);
-        uint32_t len = w.bcast(lenv, (int)jh);
-        if (LZ4HIP_UNLIKELY((longm >> jh) & 1u)) {
-          const uint32_t p = w.bcast(pos, (int)jh), c = w.bcast(cpos, (int)jh);
+        if (hm == 0) break;
+        jlast = (uint32_t)ctz64(hm);
+        if (LZ4HIP_UNLIKELY((longm >> jlast) & 1u)) {
+          const uint32_t p = w.bcast(pos, (int)jlast), c = w.bcast(cpos, (int)jlast);
+          uint32_t len = w.bcast(lenv, (int)jlast);
           len += Base::count_fwd(p + len, c + len, matchlimit);
-          lenv = w.set_lane(lenv, (int)jh, len);
+          lenv = w.set_lane(lenv, (int)jlast, len);
+          E = w.set_lane(E, (int)jlast, jlast + len);
         }
-        cm |= 1ull << jh;
-        anchor_v = w.set_lane(anchor_v, (int)jh, anchor);
-        const uint32_t e_ = (multi ? wbase - l0 + jh : w.bcast(pos, (int)jh)) + len;
-        anchor = e_;
-        const uint64_t after = (~0ull << jh) << 1;
-        if (e_ >= mfl1) { kind = K_DONE; covered |= after; break; }
-        const uint32_t le = jh + len;
-        if (!multi || le >= 64u) { kind = K_POST; covered |= after; break; }
-        covered |= after & ~(~0ull << le);
-        e2m |= 1ull << (le - 2u);
+        cm |= 1ull << jlast;
+        le = w.bcast(E, (int)jlast);
+        if (le >= lim) { broke = true; break; }
         cur = le;
       }
+      int kind;
+      if (broke) {
+        anchor = multi ? wpb + le : w.bcast(pos, (int)jlast) + w.bcast(lenv, (int)jlast);
+        kind = anchor >= mfl1 ? K_DONE : K_POST;
+      } else {
+        if (cm) anchor = wpb + le;
+        kind = kinv < 64u ? K_LAST : K_RUN;
+      }
+      // vector pass: EP = match-end lane of the nearest sequence found below this lane
+      const VU64 lowc = VU64(cm) & w.lanemask_lt();
+      const uint64_t haspm = w.ballot(lowc != VU64(0));
+      const VU EP = w.shfl(E, VU(63u) - W::clz64(lowc));
+      const VU anchor_v = W::select(w.lanes(haspm), EP + wpb, VU(anchor0));   // anchor each sequence starts from
+      uint64_t covered = w.ballot(EP > j) & haspm;                            // lanes inside a match: neither probed nor inserted
+      if (broke) covered |= (~0ull << jlast) << 1;
+      const uint64_t e2m = multi ? (w.ballot(EP == j + 2u) & haspm) : 0ull;    // lanes that only insert (liblz4's putPosition(ip-2))
       const uint32_t stop = (kind == K_LAST) ? kinv : 64u;
       uint64_t I = ((~0ull << l0) & (stop >= 64u ? ~0ull : ((1ull << stop) - 1ull)) & ~covered) | e2m;  // lanes liblz4 would insert
       LZ4HIP_PHASE(5, (uint32_t)I);              // t[5]: chain walk
 
-      w.consume(pf);
       // ---- [6] commit (the returned values are examined after the next window has been requested) ----
       const VE old = w.template lds_max<U16>(h, newe, w.lanes(I));
 
