@@ -67,7 +67,7 @@ int g_decode_lanes = 0;  // tuning knob (lz4hip_set_option "decode_lanes"); 0 = 
 // 0 = one-sequence-per-step core only (lz4_fast_core.h); "compress_switch" = bytes per sequence below which a block counts
 // as dense and goes to the window-parallel core (probe: sequences 32..95 of the block)
 int g_compress_core = 2;
-int g_compress_switch = 20;
+int g_compress_switch = 26;
 int g_compress_waves = 1; // 1 = single-wave kernel (default, fastest so far), 2 = match-finder wave + emitter wave per block
 
 // liblz4's level handling: < 1 -> 9, > 12 -> 12; 10..12 are the optimal parser,
