@@ -61,7 +61,7 @@ int lz4hip_version(void);
  * block in the decoder (0 = default, 4/8/16/32/64); "compress_core" = 2 (default: adaptive two-pass -- blocks of
  * long sequences are finished by the one-sequence-per-step core, blocks of short sequences by the window-parallel core),
  * 1 (window-parallel core only) or 0 (one-sequence-per-step core only); "compress_switch" = routing threshold of the
- * adaptive scheme in bytes per sequence (default 26); "compress_waves" = 1 (default: one wavefront per block) or
+ * adaptive scheme in bytes per sequence (default 20); "compress_waves" = 1 (default: one wavefront per block) or
  * 2 (experimental: a match-finder wavefront plus an emitter wavefront per block; same bytes, measured
  * slower so far -- see DESIGN.md).                                                                  */
 int lz4hip_set_option(const char* name, int value);

@@ -67,7 +67,7 @@ int g_decode_lanes = 0;  // tuning knob (lz4hip_set_option "decode_lanes"); 0 = 
 // 0 = one-sequence-per-step core only (lz4_fast_core.h); "compress_switch" = bytes per sequence below which a block counts
 // as dense and goes to the window-parallel core (probe: sequences 32..95 of the block)
 int g_compress_core = 2;
-int g_compress_switch = 26;
+int g_compress_switch = 20;
 int g_compress_waves = 1; // 1 = single-wave kernel (default, fastest so far), 2 = match-finder wave + emitter wave per block
 
 // liblz4's level handling: < 1 -> 9, > 12 -> 12; 10..12 are the optimal parser,
@@ -120,7 +120,7 @@ int launch_fast(const lz4hip::BatchArgs& a, hipStream_t st) {
     if (g_compress_core == 0) return lz4hip::launch_compress_fast(a, nullptr, 0u, st);
     if (g_compress_core == 1) return lz4hip::launch_compress_fast_ms(a, nullptr, st);
     uint8_t* route = nullptr;
-    hipError_t e = hipMallocAsync((void**)&route, a.n, st);
+    hipError_t e = hipMallocAsync((void**)&route, ((size_t)a.n + 7u) & ~(size_t)3u, st);
     if (e != hipSuccess) return (int)e;
     int le = lz4hip::launch_compress_fast(a, route, 64u * (uint32_t)g_compress_switch, st);
     if (le == 0) le = lz4hip::launch_compress_fast_ms(a, route, st);

@@ -299,10 +299,10 @@ def test_two_wave_compress_kernel_same_bytes(amd, ref, O, corpus):
         assert r == er and (er <= 0 or c == eb), (len(v), cap, r, er)
 
 
-@pytest.mark.parametrize("core,switch", [(0, 26), (1, 26), (2, 0), (2, 1024)])
+@pytest.mark.parametrize("core,switch", [(0, 20), (1, 20), (2, 0), (2, 1024)])
 def test_compress_core_variants_same_bytes(amd, ref, O, corpus, core, switch):
     """compress_core 0 (one sequence per step only), 1 (window-parallel only) and 2 (adaptive two-pass) with extreme routing
-    thresholds produce the same bytes as the default (2, threshold 26 bytes per sequence)"""
+    thresholds produce the same bytes as the default (2, threshold 20 bytes per sequence)"""
     import random as _r
     rng = _r.Random(304)
     blocks, caps = [], []
@@ -317,7 +317,7 @@ def test_compress_core_variants_same_bytes(amd, ref, O, corpus, core, switch):
         res = gpu_compress_many(amd, blocks, caps)
     finally:
         amd.set_option("compress_core", 2)
-        amd.set_option("compress_switch", 26)
+        amd.set_option("compress_switch", 20)
     for v, cap, (r, c) in zip(blocks, caps, res):
         er, eb = ref.compress_fast_raw(v, cap)
         assert r == er and (er <= 0 or c == eb), (len(v), cap, r, er)
