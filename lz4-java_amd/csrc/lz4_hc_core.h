@@ -273,9 +273,20 @@ struct HcParse {
   LZ4HIP_DEV int first_match(int ip, int mflimit, int matchlimit, int& ml, int& ref) {
     while (ip <= mflimit) {
       const HcSearch& sr = s;
-      const VU64 res = w.map_lanes64([&](uint32_t l) -> uint64_t {
+      // Stage 1 (a filter, no effect on the result): a lane whose MOST RECENT chain node already matches 4 bytes has a match
+      // of >= 4 for sure, so no lane behind the first such lane can be the answer -- and those are exactly the lanes with the
+      // long walks (they sit inside the coming match, where every 4-gram has been seen before).  Only lanes up to it search.
+      const uint64_t quick = w.ballot(w.map_lanes64([&](uint32_t l) -> uint64_t {
         const int p = ip + (int)l;
         if (p > mflimit) return 0ull;
+        const uint32_t d = sr.delta[p];
+        if (d == 0u) return 0ull;
+        return hc_rd32(sr.src + p - (int)d) == hc_rd32(sr.src + p) ? 1ull : 0ull;   // (d <= 65535 and p - d >= 0 by construction)
+      }) != VU64(0));
+      const uint32_t lmax = quick ? (uint32_t)ctz64(quick) : 63u;
+      const VU64 res = w.map_lanes64([&](uint32_t l) -> uint64_t {
+        const int p = ip + (int)l;
+        if (p > mflimit || l > lmax) return 0ull;
         int mp = 0, sp = p;
         const int m = sr.wider(p, p, matchlimit, 3, mp, sp);
         return m >= 4 ? (((uint64_t)(uint32_t)m << 32) | (uint32_t)mp) : 0ull;
