@@ -228,6 +228,69 @@ struct HcParse {
   bool limited;
   int op = 0, anchor = 0;
 
+  // LZ4HC_InsertAndGetWiderMatch for the wave-uniform searches of the lazy evaluation.  s.wider() spends three dependent
+  // loads per chain node (link, 2-byte pre-test, 4 bytes, then the counts); here the wave first walks the links alone (one
+  // dependent load per node) and parks up to 64 node positions in its lanes, then every lane evaluates its node at once.
+  // Same result as s.wider(): liblz4 keeps the FIRST node (most recent position) that beats the running `longest`, and only
+  // tests a node if two bytes at offset longest-1 agree (a node that would beat `longest` can fail that when the match may
+  // start before ip) -- so the nodes that could improve are replayed in chain order against the running `longest`.
+  // Repeated-byte patterns (level 9's pattern analysis may then jump along the chain) take the serial walk.
+  LZ4HIP_DEV int wider_wave(int ip, int ilow, int ihigh, int longest, int& mpos, int& spos) {
+    const uint32_t pattern = hc_rd32(src + ip);
+    const bool rep = ((pattern & 0xFFFFu) == (pattern >> 16)) & ((pattern & 0xFFu) == (pattern >> 24));
+    if (s.pattern_analysis && rep) return s.wider(ip, ilow, ihigh, longest, mpos, spos);
+    const uint32_t ip_idx = (uint32_t)ip + HC_BIAS;
+    const uint32_t lowest = (HC_BIAS + 65536u > ip_idx) ? HC_BIAS : ip_idx - (uint32_t)HC_MAXD;
+    const int look_back = ip - ilow;
+    const uint8_t* const sp = src;
+    int attempts = s.nb_searches;
+    uint32_t mi;
+    {
+      const uint32_t d0 = s.delta[ip];
+      mi = d0 ? ip_idx - d0 : 0u;
+    }
+    int L = longest;
+    const VU lane = w.lane();
+    while (mi >= lowest && attempts > 0) {
+      // walk: up to 64 nodes
+      VU node = VU(0u);
+      uint32_t cnt = 0;
+      while (mi >= lowest && attempts > 0 && cnt < 64u) {
+        attempts--;
+        node = w.set_lane(node, (int)cnt, mi - HC_BIAS);
+        cnt++;
+        mi -= s.chain(mi);
+      }
+      const int L0 = L;
+      const VU64 res = w.map_lanes64v(node, lane < cnt, [&](uint32_t, uint32_t c, bool a) -> uint64_t {
+        if (!a || hc_rd32(sp + c) != pattern) return 0ull;
+        int back = 0;
+        if (look_back) {
+          const int mn = -((int)look_back < (int)c ? look_back : (int)c);
+          while (back > mn && sp[ip + back - 1] == sp[(int)c + back - 1]) back--;
+        }
+        const int ml = 4 + HcSearch::count_fwd(sp, ip + 4, (int)c + 4, ihigh) - back;
+        const uint32_t pre0 = (hc_rd16(sp + ilow + L0 - 1) == hc_rd16(sp + (int)c - look_back + L0 - 1)) ? 1u : 0u;
+        return ((uint64_t)(uint32_t)ml << 32) | ((uint64_t)(uint32_t)(-back) << 1) | pre0;
+      });
+      uint64_t imp = w.ballot(W::lo32(res >> 32) > (uint32_t)L);   // nodes that would beat the `longest` this batch started with
+      while (imp) {
+        const int l = ctz64(imp);
+        imp &= imp - 1u;
+        const uint64_t r = w.bcast64(res, l);
+        const int ml = (int)(uint32_t)(r >> 32);
+        if (ml <= L) continue;
+        const int c = (int)w.bcast(node, l);
+        const bool pass = (L == L0) ? (r & 1u) != 0u : hc_rd16(sp + ilow + L - 1) == hc_rd16(sp + c - look_back + L - 1);
+        if (pass) {
+          const int back = -(int)((uint32_t)r >> 1);
+          L = ml; mpos = c + back; spos = ip + back;
+        }
+      }
+    }
+    return L;
+  }
+
   LZ4HIP_DEV HcParse(W& w_, const uint8_t* src_, int n_, const uint16_t* delta, uint8_t* dst_, int cap_, int level)
       : w(w_), src(src_), n(n_), dst(dst_), cap(cap_) {
     s.src = src_;
@@ -284,6 +347,7 @@ struct HcParse {
         return hc_rd32(sr.src + p - (int)d) == hc_rd32(sr.src + p) ? 1ull : 0ull;   // (d <= 65535 and p - d >= 0 by construction)
       }) != VU64(0));
       const uint32_t lmax = quick ? (uint32_t)ctz64(quick) : 63u;
+      // (handing the search of lane lmax to the whole wave -- wider_wave -- was measured: +13 % on 64 KiB blocks, -6 % on 1 MiB blocks)
       const VU64 res = w.map_lanes64([&](uint32_t l) -> uint64_t {
         const int p = ip + (int)l;
         if (p > mflimit || l > lmax) return 0ull;
@@ -313,7 +377,7 @@ struct HcParse {
         if (ip < 0) break;
         start0 = ip; ref0 = ref; ml0 = ml;
       search2:
-        if (ip + ml <= mflimit) ml2 = s.wider(ip + ml - 2, ip, matchlimit, ml, ref2, start2);
+        if (ip + ml <= mflimit) ml2 = wider_wave(ip + ml - 2, ip, matchlimit, ml, ref2, start2);
         else ml2 = ml;
         if (ml2 == ml) {  // no better match: encode ML1
           if (encode(ip, ml, ref)) return 0;
@@ -334,7 +398,7 @@ struct HcParse {
           const int correction = new_ml - (start2 - ip);
           if (correction > 0) { start2 += correction; ref2 += correction; ml2 -= correction; }
         }
-        if (start2 + ml2 <= mflimit) ml3 = s.wider(start2 + ml2 - 3, start2, matchlimit, ml2, ref3, start3);
+        if (start2 + ml2 <= mflimit) ml3 = wider_wave(start2 + ml2 - 3, start2, matchlimit, ml2, ref3, start3);
         else ml3 = ml2;
         if (ml3 == ml2) {  // no better match: encode ML1 and ML2
           if (start2 < ip + ml) ml = start2 - ip;

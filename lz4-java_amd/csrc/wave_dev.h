@@ -128,6 +128,8 @@ struct WaveDev {
   }
   // per-lane evaluation of a scalar function (lanes diverge freely inside f)
   template <class F> __device__ __forceinline__ static VU64 map_lanes64(F f) { return f((uint32_t)__lane_id()); }
+  // same, handing each lane its own element of a and m
+  template <class F> __device__ __forceinline__ static VU64 map_lanes64v(VU a, bool m, F f) { return f((uint32_t)__lane_id(), a, m); }
   // cooperative byte copy dst[dpos..+len) = src[spos..+len); regions never overlap
   __device__ __forceinline__ static void copy(uint8_t* dst, uint32_t dpos, const uint8_t* src, uint32_t spos, uint32_t len) {
     const uint32_t l = __lane_id();

@@ -110,6 +110,7 @@ struct WaveHost {
   void st16(uint16_t* b, const VU& i, const VU& v, const VB& m) {
     for (int l = 0; l < 64; l++) if (m.v[l]) b[i.v[l]] = (uint16_t)v.v[l];
   }
+  template <class F> static VU64 map_lanes64v(const VU& a, const VB& m, F f) { VU64 r; for (int l = 0; l < 64; l++) r.v[l] = f((uint32_t)l, a.v[l], m.v[l]); return r; }
   template <class F> static VU64 map_lanes64(F f) { VU64 r; for (int l = 0; l < 64; l++) r.v[l] = f((uint32_t)l); return r; }
   void copy(uint8_t* dst, uint32_t dpos, const uint8_t* src, uint32_t spos, uint32_t len) {
     if (len && in_ok(src + spos, len) && out_ok(dst + dpos, len)) memcpy(dst + dpos, src + spos, len);
