@@ -9,7 +9,8 @@
  * 64 KiB block) is not included.
  *
  *   cpu_bench <reference|port> <lib.so> <liblz4oracle.so> <n_blocks> <block_size> <threads> <reps> <first_idx> <litmax> <win>
- * prints one JSON line.
+ * prints one JSON line.  With LZ4_HC_LEVEL=<1..9> in the environment the compress leg is LZ4_compress_HC at that level
+ * (LZ4JNI.c:122; row a4) instead of LZ4_compress_default ("reference" kind only).
  */
 #define _GNU_SOURCE
 #include <dlfcn.h>
@@ -21,6 +22,7 @@
 #include <time.h>
 
 typedef int (*compress_fn)(const char*, char*, int, int);
+typedef int (*compress_hc_fn)(const char*, char*, int, int, int);
 typedef int (*dsafe_fn)(const char*, char*, int, int);
 typedef int (*dfast_fn)(const char*, char*, int);
 typedef int (*p_compress_fn)(const uint8_t*, int, uint8_t*, int);
@@ -28,7 +30,8 @@ typedef int (*p_dsafe_fn)(const uint8_t*, int, uint8_t*, int);
 typedef int (*p_dfast_fn)(const uint8_t*, uint8_t*, int);
 typedef void (*gen_fn)(uint8_t*, int64_t, uint64_t, uint64_t, uint32_t, uint32_t);
 
-static int is_ref;
+static int is_ref, hc_level;
+static compress_hc_fn r_hc;
 static compress_fn r_c; static dsafe_fn r_ds; static dfast_fn r_df;
 static p_compress_fn p_c; static p_dsafe_fn p_ds; static p_dfast_fn p_df;
 static gen_fn gen;
@@ -48,7 +51,9 @@ static void* worker(void* arg) {
     int r;
     switch (phase) {
       case 0: gen(s, block_size, 0x4C5A3447ull, first_idx + (uint64_t)i, litmax, win); break;
-      case 1: r = is_ref ? r_c((const char*)s, (char*)c, block_size, bound) : p_c(s, block_size, c, bound); clen[i] = r; if (r <= 0) bad = 1; break;
+      case 1: r = hc_level ? r_hc((const char*)s, (char*)c, block_size, bound, hc_level)
+                           : (is_ref ? r_c((const char*)s, (char*)c, block_size, bound) : p_c(s, block_size, c, bound));
+              clen[i] = r; if (r <= 0) bad = 1; break;
       case 2: r = is_ref ? r_ds((const char*)c, (char*)d, clen[i], block_size) : p_ds(c, clen[i], d, block_size); if (r != block_size) bad = 1; break;
       case 3: r = is_ref ? r_df((const char*)c, (char*)d, block_size) : p_df(c, d, block_size); if (r != clen[i]) bad = 1; break;
     }
@@ -78,6 +83,11 @@ int main(int argc, char** argv) {
   if (is_ref) {
     r_c = (compress_fn)dlsym(lib, "LZ4_compress_default"); r_ds = (dsafe_fn)dlsym(lib, "LZ4_decompress_safe"); r_df = (dfast_fn)dlsym(lib, "LZ4_decompress_fast");
     if (!r_c || !r_ds || !r_df) { fprintf(stderr, "missing LZ4_* symbols\n"); return 4; }
+    if (getenv("LZ4_HC_LEVEL")) {
+      hc_level = atoi(getenv("LZ4_HC_LEVEL"));
+      r_hc = (compress_hc_fn)dlsym(lib, "LZ4_compress_HC");
+      if (!r_hc || hc_level < 1 || hc_level > 12) { fprintf(stderr, "LZ4_compress_HC unavailable / bad level\n"); return 4; }
+    }
   } else {
     p_c = (p_compress_fn)dlsym(lib, "lz4o_compress_fast"); p_ds = (p_dsafe_fn)dlsym(lib, "lz4o_decompress_safe"); p_df = (p_dfast_fn)dlsym(lib, "lz4o_decompress_fast");
     if (!p_c || !p_ds || !p_df) { fprintf(stderr, "missing lz4o_* symbols\n"); return 4; }
@@ -94,7 +104,8 @@ int main(int argc, char** argv) {
   if (memcmp(src, back, (size_t)n_blocks * block_size) != 0) bad = 1;
   long long csum = 0; for (int i = 0; i < n_blocks; i++) csum += clen[i];
   double bytes = (double)n_blocks * block_size;
-  printf("{\"kind\": \"%s\", \"threads\": %d, \"n_blocks\": %d, \"block_size\": %d, \"ratio\": %.4f, \"ok\": %s, "
+  if (hc_level) printf("{\"hc_level\": %d, ", hc_level); else printf("{");
+  printf("\"kind\": \"%s\", \"threads\": %d, \"n_blocks\": %d, \"block_size\": %d, \"ratio\": %.4f, \"ok\": %s, "
          "\"compress_GBps\": %.4f, \"decompress_safe_GBps\": %.4f, \"decompress_fast_GBps\": %.4f, \"roundtrip_GBps\": %.4f}\n",
          argv[1], n_threads, n_blocks, block_size, bytes / (double)csum, bad ? "false" : "true",
          bytes / best[1] / 1e9, bytes / best[2] / 1e9, bytes / best[3] / 1e9, bytes / (best[1] + best[2]) / 1e9);
