@@ -3,7 +3,7 @@
 set -euo pipefail
 here="$(cd "$(dirname "$0")" && pwd)"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-"$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fvisibility=hidden \
+"$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 ${LZ4HIP_EXTRA_FLAGS:-} -fPIC -shared -fvisibility=hidden \
   -Wl,-rpath,/opt/rocm/lib -Wl,--exclude-libs,ALL \
   "$here/csrc/kernels.hip" "$here/csrc/api.cpp" -o "$here/liblz4hip.so"
 echo "built $here/liblz4hip.so"

@@ -449,7 +449,7 @@ struct FastCore {
   template <bool PROBE>
   LZ4HIP_DEV uint32_t loop(bool post, uint32_t S, uint32_t r, uint32_t ip) {
     uint32_t probe_cd = 32u, probe_anchor = 0;  // (PROBE only) countdown to the next density-probe event
-    uint32_t pf_end = PROBE ? 0u : (post ? ip : S) & ~4095u;  // source prefetched up to here (4 KB chunks, 4 KB ahead)
+    uint32_t pf_end = PROBE ? 0u : (post ? ip : S) & ~(W::kPrefetchBytes - 1u);  // source prefetched up to here (LZ4HIP_PF_KB KB chunks, as far ahead)
     const VU j = w.lane();
     const VU o8 = j * 8u;
     prepare_step(post, S, r, ip);
@@ -504,7 +504,7 @@ struct FastCore {
         ba = w.ldu8(src, W::select(bact, (hpos - 1u) - j, VU(0u)));
         bb = w.ldu8(src, W::select(bact, (mpos - 1u) - j, VU(0u)));
       }
-      if (LZ4HIP_UNLIKELY(hpos + 4096u > pf_end && pf_end < n && n >= 16u)) { w.prefetch4k(src, pf_end, n); pf_end += 4096u; }
+      if (LZ4HIP_UNLIKELY(hpos + W::kPrefetchBytes > pf_end && pf_end < n && n >= 16u)) { w.prefetch4k(src, pf_end, n); pf_end += W::kPrefetchBytes; }
       LZ4HIP_PHASE(2, hpos);             // t[2]: commit issue + candidate-fetch issue
 
       // ---- [4] write out the previous sequence while those loads are in flight ----

@@ -231,7 +231,7 @@ struct FastCoreMS : FastCore<W, U16, DirectOut<W>> {
       const uint32_t hp0 = w.bcast(pos, k0), mp0 = w.bcast(cpos, k0);
       const VU64 fa = w.ldu64(src, W::vmin(j * 8u + hp0, top));
       const VU64 fb = w.ldu64_cand(src, W::vmin(j * 8u + mp0, top));
-      if (LZ4HIP_UNLIKELY(wbase + 4096u > pf_end && pf_end < n && n >= 16u)) { w.prefetch4k(src, pf_end, n); pf_end += 4096u; }  // source -> L2, 4 KB ahead
+      if (LZ4HIP_UNLIKELY(wbase + W::kPrefetchBytes > pf_end && pf_end < n && n >= 16u)) { w.prefetch4k(src, pf_end, n); pf_end += W::kPrefetchBytes; }  // source -> L2, one chunk ahead
       LZ4HIP_PHASE(2, (uint32_t)tmask);          // t[2]: candidate fetch issue
 
       // ---- [3] write the previous window's sequences while those loads are in flight ----

@@ -76,19 +76,23 @@ struct WaveDev {
   __device__ __forceinline__ static VU64 ldu64(const uint8_t* b, VU i) { uint64_t v; __builtin_memcpy(&v, b + i, 8); return v; }
   // candidate side of the match fetch (a non-temporal load here measured 4 % SLOWER: ~half of these hit L2)
   __device__ __forceinline__ static VU64 ldu64_cand(const uint8_t* b, VU i) { return ldu64(b, i); }
-  // touches src[from, from + 4096) (clamped to n) so that later loads of that span hit L2: four 1 KB wave loads, waited for here
+#ifndef LZ4HIP_PF_KB
+#define LZ4HIP_PF_KB 1  /* source prefetch chunk in KB (1, 2 or 4): how far ahead of the parse position the source is touched */
+#endif
+  // touches src[from, from + LZ4HIP_PF_KB KB) (clamped to n) so that later loads of that span hit L2: 1 KB wave loads, waited for here
   __device__ __forceinline__ static void prefetch4k(const uint8_t* b, uint32_t from, uint32_t n) {
     const uint32_t top = n - 16u;  // n >= 16
-    uint4 v[4];
+    uint4 v[LZ4HIP_PF_KB];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < LZ4HIP_PF_KB; i++) {
       uint32_t a = from + (uint32_t)i * 1024u + __lane_id() * 16u;
       a = a < top ? a : top;
       __builtin_memcpy(&v[i], b + a, 16);
     }
 #pragma unroll
-    for (int i = 0; i < 4; i++) asm volatile("" ::"v"(v[i].x), "v"(v[i].y), "v"(v[i].z), "v"(v[i].w));
+    for (int i = 0; i < LZ4HIP_PF_KB; i++) asm volatile("" ::"v"(v[i].x), "v"(v[i].y), "v"(v[i].z), "v"(v[i].w));
   }
+  static constexpr uint32_t kPrefetchBytes = LZ4HIP_PF_KB * 1024u;
   __device__ __forceinline__ static void consume(VU v) { asm volatile("" ::"v"(v)); }  // keeps a prefetch load alive
   __device__ __forceinline__ static VU vmin(VU a, VU b) { return a < b ? a : b; }
   __device__ __forceinline__ static VU vmax(VU a, VU b) { return a > b ? a : b; }

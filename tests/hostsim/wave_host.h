@@ -94,6 +94,7 @@ struct WaveHost {
   static VU vmin(const VU& a, const VU& b) { VU r; for (int l = 0; l < 64; l++) r.v[l] = a.v[l] < b.v[l] ? a.v[l] : b.v[l]; return r; }
   static void consume(const VU&) {}
   static void prefetch4k(const uint8_t*, uint32_t, uint32_t) {}
+  static constexpr uint32_t kPrefetchBytes = 4096u;
   static VU vmax(const VU& a, const VU& b) { VU r; for (int l = 0; l < 64; l++) r.v[l] = a.v[l] > b.v[l] ? a.v[l] : b.v[l]; return r; }
   static VU ctz64v(const VU64& v) { VU r; for (int i = 0; i < 64; i++) r.v[i] = v.v[i] ? (uint32_t)__builtin_ctzll(v.v[i]) : 64u; return r; }
   static VU set_lane(const VU& v, int l, uint32_t s) { VU r = v; r.v[l] = s; return r; }
