@@ -373,7 +373,12 @@ class XXHashFactory:
 # batch helper (host memory)
 # ----------------------------------------------------------------------------------------------
 def _arr(ctype, values):
-    return (ctype * max(len(values), 1))(*values)
+    """ctypes array of the per-block offsets / lengths; a numpy array of the matching width is used in place (no copy)"""
+    n = len(values)
+    if hasattr(values, "ctypes") and hasattr(values, "dtype") and values.dtype.itemsize == C.sizeof(ctype) and \
+            values.dtype.kind in "iu" and values.flags["C_CONTIGUOUS"] and n:
+        return (ctype * n).from_address(values.ctypes.data)   # (the caller's array outlives the call)
+    return (ctype * max(n, 1))(*values)
 
 
 class LZ4HIPBatch:
@@ -384,14 +389,24 @@ class LZ4HIPBatch:
     @staticmethod
     def _call(fn, src, srcOff, srcLen, dst, dstOff, dstCap):
         n = len(srcOff)
-        for i in range(n):
-            _check_range(src, srcOff[i], srcLen[i]) if fn != "lz4hip_decompress_fast_batch" else None
-            _check_range(dst, dstOff[i], dstCap[i])
+        if hasattr(srcOff, "dtype"):   # numpy offsets/lengths: vectorised range checks (SafeUtils.checkRange per block)
+            import numpy as np
+            so, sl, do, dc = (np.asarray(x, dtype=np.int64) for x in (srcOff, srcLen, dstOff, dstCap))
+            if n and ((sl < 0).any() or (dc < 0).any() or (so < 0).any() or (do < 0).any()
+                      or (fn != "lz4hip_decompress_fast_batch" and ((so + sl) > len(src)).any()) or ((do + dc) > len(dst)).any()):
+                raise IndexError("block range outside its buffer")
+        else:
+            for i in range(n):
+                _check_range(src, srcOff[i], srcLen[i]) if fn != "lz4hip_decompress_fast_batch" else None
+                _check_range(dst, dstOff[i], dstCap[i])
         sp, sk = _ro_ptr(src)
         dp, dk = _rw_ptr(dst)
         out = (C.c_int32 * max(n, 1))()
         _chk(getattr(lib(), fn)(sp, _arr(C.c_uint64, srcOff), _arr(C.c_int32, srcLen), dp, _arr(C.c_uint64, dstOff),
                                 _arr(C.c_int32, dstCap), out, n))
+        if hasattr(srcOff, "dtype"):
+            import numpy as np
+            return np.frombuffer(out, dtype=np.int32, count=n).copy()
         return list(out[:n])
 
     @classmethod

@@ -9,6 +9,7 @@
 #include <limits.h>
 #include <mutex>
 #include <thread>
+#include <algorithm>
 #include <vector>
 #include <string>
 #include "../../include/lz4hip.h"
@@ -184,6 +185,87 @@ struct DevBuf {
   hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
 };
 
+// ---- staging of the host-pointer batch API --------------------------------------------------------------------------
+// A host batch is cut into chunks of <= CHUNK_SRC source bytes.  Each chunk is packed into a PINNED staging buffer (user
+// memory is pageable: hipMemcpyAsync from it would be staged by the runtime at a fraction of the link rate), copied to the
+// device, processed, and its destination slots are copied back into a second pinned buffer, from which the bytes each block
+// actually produced go to the caller's slots.  Two buffer sets per device alternate, so the CPU packs chunk c+1 and unpacks
+// chunk c-1 while the GPU works on chunk c.  Buffers, streams and events are created once per device and kept
+// (lz4hip_shutdown releases them) -- the per-call hipMalloc/hipFree/stream churn of the first version cost more than the
+// work for single blocks.
+constexpr size_t CHUNK_SRC = 128u << 20;   // source bytes per chunk
+constexpr uint32_t CHUNK_BLOCKS = 1u << 20;
+constexpr int COPY_THREADS = 16;           // host threads packing / unpacking a chunk
+
+struct GrowBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  bool pinned = false;
+  hipError_t reserve(size_t n) {
+    if (n <= cap) return hipSuccess;
+    release();
+    size_t want = n + n / 4 + 4096;
+    hipError_t e = pinned ? hipHostMalloc(&p, want, hipHostMallocDefault) : hipMalloc(&p, want);
+    if (e != hipSuccess) { p = nullptr; return e; }
+    cap = want;
+    return hipSuccess;
+  }
+  void release() {
+    if (p) { if (pinned) (void)hipHostFree(p); else (void)hipFree(p); }
+    p = nullptr; cap = 0;
+  }
+};
+
+struct ChunkSlot {
+  hipStream_t st = nullptr;
+  hipEvent_t done = nullptr;
+  GrowBuf h_src, h_dst, h_meta, d_src, d_dst, d_meta, d_ws, d_pack, d_poff;
+  bool packed = false;                // compress ops: only the useful bytes of the slots come back (device-side packing)
+  uint32_t i0 = 0, i1 = 0;            // blocks of the chunk in flight
+  size_t src_bytes = 0, dst_bytes = 0;
+  std::vector<uint64_t> so, dof;      // packed offsets of the chunk's blocks
+  ChunkSlot() { h_src.pinned = h_dst.pinned = h_meta.pinned = true; }
+};
+
+struct DevCtx {
+  std::mutex mu;   // one host batch at a time per device
+  bool ready = false;
+  ChunkSlot slot[2];
+  hipError_t init() {
+    if (ready) return hipSuccess;
+    for (auto& s : slot) {
+      hipError_t e;
+      if ((e = hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking)) != hipSuccess) return e;
+      if ((e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming)) != hipSuccess) return e;
+    }
+    ready = true;
+    return hipSuccess;
+  }
+  void release() {
+    for (auto& s : slot) {
+      if (s.st) (void)hipStreamDestroy(s.st);
+      if (s.done) (void)hipEventDestroy(s.done);
+      s.st = nullptr; s.done = nullptr;
+      for (GrowBuf* g : {&s.h_src, &s.h_dst, &s.h_meta, &s.d_src, &s.d_dst, &s.d_meta, &s.d_ws, &s.d_pack, &s.d_poff}) g->release();
+    }
+    ready = false;
+  }
+};
+DevCtx g_ctx[64];
+
+template <class F>
+void par_blocks(uint32_t i0, uint32_t i1, size_t bytes, F f) {  // f(i) for i in [i0, i1), on several threads when it is worth it
+  const uint32_t n = i1 - i0;
+  const int T = (bytes < (4u << 20) || n < 2) ? 1 : (int)std::min<uint32_t>(COPY_THREADS, n);
+  if (T == 1) { for (uint32_t i = i0; i < i1; i++) f(i); return; }
+  std::vector<std::thread> th;
+  for (int t = 0; t < T; t++) {
+    const uint32_t a = i0 + (uint32_t)((uint64_t)n * t / T), b = i0 + (uint32_t)((uint64_t)n * (t + 1) / T);
+    th.emplace_back([=] { for (uint32_t i = a; i < b; i++) f(i); });
+  }
+  for (auto& x : th) x.join();
+}
+
 // one device's share [b0, b1) of a host batch
 int host_shard(Op op, int level, int ord, const uint8_t* src, const uint64_t* src_off, const int32_t* src_len, uint8_t* dst,
                const uint64_t* dst_off, const int32_t* dst_cap, int32_t* out, uint32_t b0, uint32_t b1, std::string* err) {
@@ -191,62 +273,110 @@ int host_shard(Op op, int level, int ord, const uint8_t* src, const uint64_t* sr
     char buf[512];
     snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
     *err = buf;
-    return (int)LZ4HIP_E_HIP;
+    return e == hipErrorOutOfMemory ? (int)LZ4HIP_E_NOMEM : (int)LZ4HIP_E_HIP;
   };
-  const uint32_t n = b1 - b0;
-  if (n == 0) return LZ4HIP_OK;
+  if (b1 == b0) return LZ4HIP_OK;
+  if (ord < 0 || ord >= 64) { *err = "device ordinal out of range"; return LZ4HIP_E_ARG; }
   hipError_t e;
   if ((e = hipSetDevice(ord)) != hipSuccess) return bad("hipSetDevice", e);
-  const Span ss = span_of(src_off, src_len, b0, b1);
-  const Span ds = span_of(dst_off, dst_cap, b0, b1);
-  std::vector<uint64_t> so(n), dof(n);
-  for (uint32_t i = 0; i < n; i++) { so[i] = src_off[b0 + i] - ss.lo; dof[i] = dst_off[b0 + i] - ds.lo; }
-  DevBuf dsrc, ddst, dso, ddo, dsl, ddc, dout, dws;
-  const size_t slen = (size_t)(ss.hi - ss.lo), dlen = (size_t)(ds.hi - ds.lo);
-  if ((e = dsrc.alloc(slen + 16)) != hipSuccess || (e = ddst.alloc(dlen + 16)) != hipSuccess || (e = dso.alloc(n * 8)) != hipSuccess ||
-      (e = ddo.alloc(n * 8)) != hipSuccess || (e = dsl.alloc(n * 4)) != hipSuccess || (e = ddc.alloc(n * 4)) != hipSuccess ||
-      (e = dout.alloc(n * 4)) != hipSuccess || (op == OP_COMPRESS_HC && (e = dws.alloc(slen * 2 + 64)) != hipSuccess)) {
-    *err = std::string("hipMalloc: ") + hipGetErrorString(e);
-    return LZ4HIP_E_NOMEM;
-  }
-  hipStream_t st;
-  if ((e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) return bad("hipStreamCreate", e);
+  DevCtx& cx = g_ctx[ord];
+  std::lock_guard<std::mutex> lk(cx.mu);
+  if ((e = cx.init()) != hipSuccess) return bad("stream/event creation", e);
+  auto slen_of = [&](uint32_t i) -> size_t { return src_len[i] > 0 ? (size_t)src_len[i] : 0; };
+  auto dcap_of = [&](uint32_t i) -> size_t { return dst_cap[i] > 0 ? (size_t)dst_cap[i] : 0; };
+
+  // hand the results of the chunk in `s` to the caller (waits for it)
+  auto finish = [&](ChunkSlot& s) -> int {
+    if (s.i1 == s.i0) return LZ4HIP_OK;
+    if ((e = hipEventSynchronize(s.done)) != hipSuccess) return bad("hipEventSynchronize", e);
+    const uint32_t nb = s.i1 - s.i0;
+    const int32_t* hout = (const int32_t*)((const uint8_t*)s.h_meta.p + (size_t)nb * 24u);
+    memcpy(out + s.i0, hout, (size_t)nb * 4u);
+    const uint8_t* hd = (const uint8_t*)s.h_dst.p;
+    const uint32_t i0 = s.i0;
+    if (s.packed) {   // the sizes are here: fetch exactly the useful bytes (already packed on the device), then hand them out
+      uint64_t total = 0;
+      for (uint32_t t = 0; t < nb; t++) { s.dof[t] = total; total += hout[t] > 0 ? (uint64_t)hout[t] : 0ull; }
+      if (total && (e = hipMemcpyAsync(s.h_dst.p, s.d_pack.p, (size_t)total, hipMemcpyDeviceToHost, s.st)) != hipSuccess) return bad("D2H packed", e);
+      if ((e = hipStreamSynchronize(s.st)) != hipSuccess) return bad("hipStreamSynchronize", e);
+      s.dst_bytes = (size_t)total;
+    }
+    par_blocks(s.i0, s.i1, s.dst_bytes, [=, &s](uint32_t i) {
+      int64_t produced;   // (bytes past a result stay untouched in the caller's slot)
+      if (op == OP_DECODE_FAST) produced = out[i] > 0 ? dst_cap[i] : 0;
+      else produced = out[i] > 0 ? out[i] : 0;
+      if (produced > 0) memcpy(dst + dst_off[i], hd + s.dof[i - i0], (size_t)produced);
+    });
+    s.i0 = s.i1 = 0;
+    return LZ4HIP_OK;
+  };
+
   int rc = LZ4HIP_OK;
-  do {
-    if (slen && (e = hipMemcpyAsync(dsrc.p, src + ss.lo, slen, hipMemcpyHostToDevice, st)) != hipSuccess) { rc = bad("H2D src", e); break; }
-    if ((e = hipMemcpyAsync(dso.p, so.data(), n * 8, hipMemcpyHostToDevice, st)) != hipSuccess) { rc = bad("H2D", e); break; }
-    if ((e = hipMemcpyAsync(ddo.p, dof.data(), n * 8, hipMemcpyHostToDevice, st)) != hipSuccess) { rc = bad("H2D", e); break; }
-    if ((e = hipMemcpyAsync(dsl.p, src_len + b0, n * 4, hipMemcpyHostToDevice, st)) != hipSuccess) { rc = bad("H2D", e); break; }
-    if ((e = hipMemcpyAsync(ddc.p, dst_cap + b0, n * 4, hipMemcpyHostToDevice, st)) != hipSuccess) { rc = bad("H2D", e); break; }
-    lz4hip::BatchArgs a{(const uint8_t*)dsrc.p, (const uint64_t*)dso.p, (const int32_t*)dsl.p, (uint8_t*)ddst.p,
-                        (const uint64_t*)ddo.p, (const int32_t*)ddc.p, (int32_t*)dout.p, n};
+  uint32_t i = b0;
+  int k = 0;
+  while (i < b1 && rc == LZ4HIP_OK) {
+    ChunkSlot& s = cx.slot[k];
+    if ((rc = finish(s)) != LZ4HIP_OK) break;   // the chunk that used this buffer set two rounds ago
+    // the next chunk: blocks [i, j)
+    uint32_t j = i;
+    size_t sb = 0, db = 0;
+    while (j < b1 && j - i < CHUNK_BLOCKS) {
+      const size_t a = (slen_of(j) + 15u) & ~(size_t)15u, c = (dcap_of(j) + 15u) & ~(size_t)15u;
+      if (j > i && sb + a > CHUNK_SRC) break;
+      sb += a; db += c; j++;
+    }
+    const uint32_t nb = j - i;
+    s.so.resize(nb); s.dof.resize(nb);
+    { size_t so = 0, dofs = 0;
+      for (uint32_t t = 0; t < nb; t++) { s.so[t] = so; s.dof[t] = dofs; so += (slen_of(i + t) + 15u) & ~(size_t)15u; dofs += (dcap_of(i + t) + 15u) & ~(size_t)15u; } }
+    const size_t meta = (size_t)nb * 28u;   // so[nb] u64 | dof[nb] u64 | src_len[nb] | dst_cap[nb] | out[nb]
+    if ((e = s.h_src.reserve(sb + 64)) != hipSuccess || (e = s.h_dst.reserve(db + 64)) != hipSuccess || (e = s.h_meta.reserve(meta)) != hipSuccess ||
+        (e = s.d_src.reserve(sb + 64)) != hipSuccess || (e = s.d_dst.reserve(db + 64)) != hipSuccess || (e = s.d_meta.reserve(meta)) != hipSuccess ||
+        (op == OP_COMPRESS_HC && (e = s.d_ws.reserve(sb * 2 + 64)) != hipSuccess) ||
+        ((op == OP_COMPRESS_FAST || op == OP_COMPRESS_HC) && ((e = s.d_pack.reserve(db + 64)) != hipSuccess || (e = s.d_poff.reserve((size_t)nb * 8u)) != hipSuccess))) {
+      rc = bad("staging allocation", e);
+      break;
+    }
+    uint8_t* hs = (uint8_t*)s.h_src.p;
+    { const uint32_t base = i;
+      par_blocks(i, j, sb, [=, &s](uint32_t t) { if (src_len[t] > 0) memcpy(hs + s.so[t - base], src + src_off[t], (size_t)src_len[t]); }); }
+    uint8_t* hm = (uint8_t*)s.h_meta.p;
+    memcpy(hm, s.so.data(), (size_t)nb * 8u);
+    memcpy(hm + (size_t)nb * 8u, s.dof.data(), (size_t)nb * 8u);
+    memcpy(hm + (size_t)nb * 16u, src_len + i, (size_t)nb * 4u);
+    memcpy(hm + (size_t)nb * 20u, dst_cap + i, (size_t)nb * 4u);
+    uint8_t* dm = (uint8_t*)s.d_meta.p;
+    if (sb && (e = hipMemcpyAsync(s.d_src.p, hs, sb, hipMemcpyHostToDevice, s.st)) != hipSuccess) { rc = bad("H2D src", e); break; }
+    if ((e = hipMemcpyAsync(dm, hm, (size_t)nb * 24u, hipMemcpyHostToDevice, s.st)) != hipSuccess) { rc = bad("H2D meta", e); break; }
+    lz4hip::BatchArgs a{(const uint8_t*)s.d_src.p, (const uint64_t*)dm, (const int32_t*)(dm + (size_t)nb * 16u), (uint8_t*)s.d_dst.p,
+                        (const uint64_t*)(dm + (size_t)nb * 8u), (const int32_t*)(dm + (size_t)nb * 20u), (int32_t*)(dm + (size_t)nb * 24u), nb};
     int le = 0;
     switch (op) {
-      case OP_COMPRESS_FAST: le = launch_fast(a, st); break;
-      case OP_DECODE_SAFE: le = lz4hip::launch_decompress(a, true, g_decode_lanes, st); break;
-      case OP_DECODE_FAST: le = lz4hip::launch_decompress(a, false, g_decode_lanes, st); break;
-      case OP_COMPRESS_HC: le = lz4hip::launch_compress_hc(a, level, (uint16_t*)dws.p, st); break;
+      case OP_COMPRESS_FAST: le = launch_fast(a, s.st); break;
+      case OP_DECODE_SAFE: le = lz4hip::launch_decompress(a, true, g_decode_lanes, s.st); break;
+      case OP_DECODE_FAST: le = lz4hip::launch_decompress(a, false, g_decode_lanes, s.st); break;
+      case OP_COMPRESS_HC: le = lz4hip::launch_compress_hc(a, level, (uint16_t*)s.d_ws.p, s.st); break;
     }
     if (le) { rc = bad("kernel launch", (hipError_t)le); break; }
-    if ((e = hipMemcpyAsync(out + b0, dout.p, n * 4, hipMemcpyDeviceToHost, st)) != hipSuccess) { rc = bad("D2H out", e); break; }
-    if ((e = hipStreamSynchronize(st)) != hipSuccess) { rc = bad("hipStreamSynchronize", e); break; }
-    // bring the destination span back once, then hand each block exactly the bytes it produced
-    // (slots may be far larger than their content, and bytes past a result stay untouched)
-    {
-      std::vector<uint8_t> host(dlen ? dlen : 1);
-      if (dlen && (e = hipMemcpyAsync(host.data(), ddst.p, dlen, hipMemcpyDeviceToHost, st)) != hipSuccess) { rc = bad("D2H dst", e); break; }
-      if ((e = hipStreamSynchronize(st)) != hipSuccess) { rc = bad("hipStreamSynchronize", e); break; }
-      for (uint32_t i = 0; i < n; i++) {
-        int64_t produced;
-        if (op == OP_DECODE_FAST) produced = out[b0 + i] > 0 ? dst_cap[b0 + i] : 0;
-        else produced = out[b0 + i] > 0 ? out[b0 + i] : 0;
-        if (produced > 0) memcpy(dst + dst_off[b0 + i], host.data() + dof[i], (size_t)produced);
-      }
+    if ((e = hipMemcpyAsync(hm + (size_t)nb * 24u, dm + (size_t)nb * 24u, (size_t)nb * 4u, hipMemcpyDeviceToHost, s.st)) != hipSuccess) { rc = bad("D2H out", e); break; }
+    s.packed = (op == OP_COMPRESS_FAST || op == OP_COMPRESS_HC);
+    if (s.packed) {
+      if ((e = hipEventRecord(s.done, s.st)) != hipSuccess) { rc = bad("hipEventRecord", e); break; }   // sizes on the host
+      if ((le = lz4hip::launch_pack(a, (uint64_t*)s.d_poff.p, (uint8_t*)s.d_pack.p, s.st)) != 0) { rc = bad("kernel launch", (hipError_t)le); break; }
+    } else {
+      if (db && (e = hipMemcpyAsync(s.h_dst.p, s.d_dst.p, db, hipMemcpyDeviceToHost, s.st)) != hipSuccess) { rc = bad("D2H dst", e); break; }
+      if ((e = hipEventRecord(s.done, s.st)) != hipSuccess) { rc = bad("hipEventRecord", e); break; }
     }
-    if (rc) break;
-    if ((e = hipStreamSynchronize(st)) != hipSuccess) { rc = bad("hipStreamSynchronize", e); break; }
-  } while (0);
-  (void)hipStreamDestroy(st);
+    s.i0 = i; s.i1 = j; s.src_bytes = sb; s.dst_bytes = db;
+    i = j;
+    k ^= 1;
+  }
+  // drain (also after an error: nothing may stay in flight on the cached buffers)
+  for (int t = 0; t < 2; t++) {
+    ChunkSlot& s = cx.slot[(k + t) & 1];
+    if (rc == LZ4HIP_OK) rc = finish(s);
+    else { (void)hipStreamSynchronize(s.st); s.i0 = s.i1 = 0; }
+  }
   return rc;
 }
 
@@ -348,6 +478,14 @@ int lz4hip_init(const int* device_ids, int n_devices) {
 
 void lz4hip_shutdown(void) {
   std::lock_guard<std::mutex> lk(g_mu);
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  for (int ord : g_devs) {
+    if (ord < 0 || ord >= 64) continue;
+    std::lock_guard<std::mutex> lc(g_ctx[ord].mu);
+    if (g_ctx[ord].ready && hipSetDevice(ord) == hipSuccess) g_ctx[ord].release();
+  }
+  if (prev >= 0) (void)hipSetDevice(prev);
   g_devs.clear();
   g_inited = false;
 }

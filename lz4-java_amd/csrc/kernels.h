@@ -30,6 +30,8 @@ int launch_compress_fast_prof(const BatchArgs& a, uint64_t* prof, bool ms, void*
 // HC levels 1..9: `ws` = device workspace of u16[max(src_off+src_len)] (see launch_hc_span)
 int launch_hc_span(const uint64_t* src_off, const int32_t* src_len, uint32_t n, uint64_t* out_dev, void* stream);
 int launch_compress_hc(const BatchArgs& a, int level, uint16_t* ws, void* stream);
+// after a compress launch: moves the out[i] > 0 useful bytes of every slot to pack + sum(out[0..i)); poff: u64[n] scratch
+int launch_pack(const BatchArgs& a, uint64_t* poff, uint8_t* pack, void* stream);
 // lanes_per_block: lanes of a wavefront that share one block in the decoder (4..64); 0 = default
 int launch_decompress(const BatchArgs& a, bool safe, int lanes_per_block, void* stream);
 int launch_xxh32(const uint8_t* buf, const uint64_t* off, const int32_t* len, uint32_t seed, uint32_t* out, uint32_t n, void* stream);

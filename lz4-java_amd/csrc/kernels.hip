@@ -350,6 +350,50 @@ int launch_compress_hc(const BatchArgs& a, int level, uint16_t* ws, void* stream
 }
 
 // ------------------------------------------------------------------------------------------------
+// packing of compressed slots (host-pointer batch API): slot i holds out[i] > 0 useful bytes at dst + dst_off[i]; they are
+// moved to pack + sum(out[0..i)) so that only useful bytes cross PCIe
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void pack_scan_kernel(const int32_t* out, uint32_t n, uint64_t* poff) {
+  __shared__ uint64_t part[1024];
+  const uint32_t t = threadIdx.x;
+  const uint32_t per = (n + 1023u) / 1024u;
+  const uint32_t i0 = t * per, i1 = (i0 + per < n) ? i0 + per : n;
+  uint64_t s = 0;
+  for (uint32_t i = i0; i < i1; i++) s += out[i] > 0 ? (uint64_t)out[i] : 0ull;
+  part[t] = s;
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024u; d <<= 1) {   // inclusive scan of the 1024 partial sums
+    const uint64_t v = t >= d ? part[t - d] : 0ull;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  uint64_t run = part[t] - s;
+  for (uint32_t i = i0; i < i1; i++) { poff[i] = run; run += out[i] > 0 ? (uint64_t)out[i] : 0ull; }
+}
+__global__ __launch_bounds__(256) void pack_copy_kernel(BatchArgs a, const uint64_t* poff, uint8_t* pack) {
+  const uint32_t b = blockIdx.x;
+  const int32_t r = a.out[b];
+  if (r <= 0) return;
+  const uint8_t* s = a.dst + a.dst_off[b];   // (slots are 16-byte aligned in the staging layout; pack offsets are not)
+  uint8_t* d = pack + poff[b];
+  const uint32_t len = (uint32_t)r, body = len & ~15u;
+  for (uint32_t i = threadIdx.x * 16u; i < body; i += 256u * 16u) {
+    uint4 v;
+    __builtin_memcpy(&v, s + i, 16);
+    __builtin_memcpy(d + i, &v, 16);
+  }
+  const uint32_t i = body + threadIdx.x;
+  if (i < len) d[i] = s[i];
+}
+int launch_pack(const BatchArgs& a, uint64_t* poff, uint8_t* pack, void* stream) {
+  if (a.n == 0) return 0;
+  hipLaunchKernelGGL(pack_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const int32_t*)a.out, a.n, poff);
+  hipLaunchKernelGGL(pack_copy_kernel, dim3(a.n), dim3(256), 0, (hipStream_t)stream, a, (const uint64_t*)poff, pack);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // decode
 // ------------------------------------------------------------------------------------------------
 template <int GL, bool SAFE>
