@@ -417,12 +417,15 @@ static int launch_decode_gl(const BatchArgs& a, bool safe, hipStream_t st) {
 int launch_decompress(const BatchArgs& a, bool safe, int lanes_per_block, void* stream) {
   if (a.n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
+  // default: 8 lanes x 8 bytes per block (8 blocks per wavefront) while the batch cannot fill the GPU with 4-lane groups; from
+  // 32768 blocks on 4 lanes x 16 bytes (16 blocks per wavefront): a full GPU is issue-bound on short sequences (text: +13 %),
+  // and long-sequence data is bandwidth-bound either way (measured equal)
+  if (lanes_per_block == 0) lanes_per_block = a.n >= 32768u ? 4 : 8;
   switch (lanes_per_block) {
     case 4: return launch_decode_gl<4>(a, safe, st);
     case 16: return launch_decode_gl<16>(a, safe, st);
     case 32: return launch_decode_gl<32>(a, safe, st);
     case 64: return launch_decode_gl<64>(a, safe, st);
-    case 0:   // default: 8 lanes x 8 bytes per block, 8 blocks per wavefront (measured best on 64 KiB blocks)
     case 8:
     default: return launch_decode_gl<8>(a, safe, st);
   }
