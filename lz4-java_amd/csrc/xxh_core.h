@@ -64,6 +64,28 @@ LZ4HIP_DEV uint32_t xxh32_one(const uint8_t* p, uint32_t len, uint32_t seed) {
   return h;
 }
 
+// XXH32 of a buffer whose first (total_len - rem) bytes -- a multiple of 16, at least 16 -- are already in the four
+// accumulators: the remaining stripes, the tail and the avalanche (used by the wave-per-buffer kernel)
+LZ4HIP_DEV uint32_t xxh32_resume(uint32_t v1, uint32_t v2, uint32_t v3, uint32_t v4, const uint8_t* p, uint32_t rem, uint32_t total_len) {
+  const uint32_t P1 = 2654435761u, P2 = 2246822519u, P3 = 3266489917u, P4 = 668265263u, P5 = 374761393u;
+  const uint8_t* const end = p + rem;
+  while (p + 16 <= end) {
+    uint32_t w[4];
+    __builtin_memcpy(w, p, 16);
+    v1 = xrotl32(v1 + w[0] * P2, 13) * P1;
+    v2 = xrotl32(v2 + w[1] * P2, 13) * P1;
+    v3 = xrotl32(v3 + w[2] * P2, 13) * P1;
+    v4 = xrotl32(v4 + w[3] * P2, 13) * P1;
+    p += 16;
+  }
+  uint32_t h = xrotl32(v1, 1) + xrotl32(v2, 7) + xrotl32(v3, 12) + xrotl32(v4, 18);
+  h += total_len;
+  while (p + 4 <= end) { h = xrotl32(h + xrd32(p) * P3, 17) * P4; p += 4; }
+  while (p < end) { h = xrotl32(h + (uint32_t)(*p) * P5, 11) * P1; p++; }
+  h ^= h >> 15; h *= P2; h ^= h >> 13; h *= P3; h ^= h >> 16;
+  return h;
+}
+
 LZ4HIP_DEV uint64_t xxh64_round(uint64_t acc, uint64_t in) {
   return xrotl64(acc + in * 14029467366897019727ull, 31) * 11400714785074694791ull;
 }

@@ -60,3 +60,22 @@ def test_cfg5_shape_device(amd, O, ref):
         for i in range(0, n, 37):
             assert a[i] & 0xFFFFFFFF == ref.xxh32(host[i * sl:(i + 1) * sl], seed)
             assert b[i] & 0xFFFFFFFFFFFFFFFF == ref.xxh64(host[i * sl:(i + 1) * sl], seed)
+
+
+def test_few_long_buffers_wave_kernel(amd, ref):
+    """<= 512 buffers take the wave-per-buffer XXH32 kernel (LDS-streamed, lanes 0..3 own the accumulators): lengths around the
+    8192-byte switch and the 4 KiB chunk boundaries, unaligned offsets, the frame content-checksum shape (one long buffer)"""
+    rng = random.Random(23)
+    buf = rng.randbytes((3 << 20) + 77)
+    off, ln = [], []
+    for n in (0, 1, 15, 16, 8191, 8192, 8193, 12287, 12288, 12289, 16384 + 15, 65536, 65537, 100000, 1 << 20, (1 << 20) + 4095,
+              (3 << 20) + 70):
+        for o in (0, 1, 3, 7):
+            if o + n <= len(buf):
+                off.append(o); ln.append(n)
+    for seed in (0, 0x9747b28c, rng.getrandbits(32)):
+        got = amd.LZ4HIPBatch.xxh32(buf, off, ln, seed)
+        for o, n, g in zip(off, ln, got):
+            assert g == ref.xxh32(buf[o:o + n], seed), (o, n, seed)
+    h32 = amd.XXHashFactory.hipInstance().hash32()
+    assert h32.hash(buf, 5, len(buf) - 5, 1) == ref.xxh32(buf[5:], 1)
