@@ -95,3 +95,17 @@ def test_cpp_host_mirror_builds_and_jni_shim_typechecks():
     import torch
     if not torch.cuda.is_available():
         assert subprocess.call([exe], stderr=subprocess.DEVNULL) == 3   # loud failure, no CPU path
+
+
+def test_cpp_stream_mirror_builds():
+    """the C++ twins of the reference's stream / container classes (lz4-java_amd/host/lz4hip_streams.hpp) compile warning-free
+    and link against the C ABI; without a GPU they fail loudly like everything else"""
+    exe = os.path.join(ROOT, "tests", "cpp", "stream_mirror_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", os.path.join(ROOT, "tests", "cpp", "stream_mirror_test.cpp"),
+                           "-L" + os.path.join(ROOT, "lz4-java_amd"), "-llz4hip", "-Wl,-rpath," + os.path.join(ROOT, "lz4-java_amd"),
+                           "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    import torch
+    if not torch.cuda.is_available():
+        import tempfile
+        with tempfile.TemporaryDirectory() as d:
+            assert subprocess.call([exe, d], stderr=subprocess.DEVNULL) == 3

@@ -70,3 +70,36 @@ def test_block_stream(S, engine, port, data):
 
 def test_with_length(S, engine, port, data):
     sc.case_with_length(S, engine, port, data, hc_engine=S.HIPEngine(hcLevel=9))
+
+
+def test_cpp_stream_mirror_runs_and_interoperates(S, engine):
+    """the C++ twins (lz4-java_amd/host/lz4hip_streams.hpp): their own checks pass, and the containers they write are the
+    Python twin's byte for byte, decode with the lz4 CLI, and a CLI frame decodes with them"""
+    import os
+    import subprocess
+    import tempfile
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "tests", "cpp", "stream_mirror_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tests", "cpp", "stream_mirror_test.cpp"),
+                           "-L" + os.path.join(ROOT, "lz4-java_amd"), "-llz4hip", "-Wl,-rpath," + os.path.join(ROOT, "lz4-java_amd"),
+                           "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    with tempfile.TemporaryDirectory() as d:
+        cli_payload = bytes(range(256)) * 3000 + b"tail"
+        if sc.LZ4_CLI:
+            open(os.path.join(d, "cli_payload.bin"), "wb").write(cli_payload)
+            open(os.path.join(d, "cli.lz4"), "wb").write(sc.cli(["-1", "-B5", "-BX"], cli_payload))
+        assert subprocess.call([exe, d]) == 0
+        data = open(os.path.join(d, "cpp_payload.bin"), "rb").read()
+        B = S.FLG.Bits
+        for name, bs, bits, known in (("cpp_frame_default.lz4", S.BLOCKSIZE.SIZE_4MB, (B.BLOCK_INDEPENDENCE,), -1),
+                                      ("cpp_frame_all.lz4", S.BLOCKSIZE.SIZE_64KB,
+                                       (B.BLOCK_INDEPENDENCE, B.BLOCK_CHECKSUM, B.CONTENT_CHECKSUM, B.CONTENT_SIZE), len(data)),
+                                      ("cpp_frame_256k_cc.lz4", S.BLOCKSIZE.SIZE_256KB, (B.BLOCK_INDEPENDENCE, B.CONTENT_CHECKSUM), -1)):
+            fr = open(os.path.join(d, name), "rb").read()
+            assert fr == sc.frame_bytes(S, data, engine, bs, bits, known), name
+            assert S.LZ4FrameInputStream(io.BytesIO(fr), engine=engine).read() == data
+            if sc.LZ4_CLI:
+                assert sc.cli(["-d"], fr) == data
+        blk = open(os.path.join(d, "cpp_stream.blk"), "rb").read()
+        assert blk == sc.block_stream_bytes(S, data, engine, 1 << 16)
+        assert S.LZ4BlockInputStream(io.BytesIO(blk), engine=engine).read() == data
