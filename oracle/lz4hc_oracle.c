@@ -31,7 +31,7 @@ typedef struct {
   uint16_t chain[65536];
   const uint8_t* src;       /* block start; position p <-> index p + BIAS */
   uint32_t next_to_update;  /* index */
-  int nb_searches, pattern_analysis;
+  int nb_searches, pattern_analysis, chain_swap;
 } hc_t;
 
 static inline uint32_t hc_hash(const uint8_t* p) { return (rd32(p) * 2654435761u) >> 17; }
@@ -81,6 +81,7 @@ static int wider_match(hc_t* c, int ip, int ilow, int ihigh, int longest, int* m
   int repeat = 0; /* 0 untested, 1 not, 2 confirmed */
   int src_pat_len = 0;
   uint32_t mi;
+  uint32_t chain_pos = 0; /* matchChainPos: offset inside the current match whose chain is followed (chainSwap, optimal parser) */
 
   hc_insert(c, ip_idx);
   mi = c->hash[hc_hash(src + ip)];
@@ -107,9 +108,31 @@ static int wider_match(hc_t* c, int ip, int ilow, int ihigh, int longest, int* m
         }
       }
     }
+    if (c->chain_swap && ml == longest) { /* better match => select a better chain (forward-only searches) */
+      if (mi + (uint32_t)longest <= ip_idx) {
+        const int k_trigger = 4;
+        uint32_t dist_to_next = 1;
+        const int end = longest - MINMATCH + 1;
+        int step = 1, accel = 1 << k_trigger, pos;
+        for (pos = 0; pos < end; pos += step) {
+          const uint32_t cand_dist = c->chain[(mi + (uint32_t)pos) & 0xFFFF];
+          step = (accel++ >> k_trigger);
+          if (cand_dist > dist_to_next) {
+            dist_to_next = cand_dist;
+            chain_pos = (uint32_t)pos;
+            accel = 1 << k_trigger;
+          }
+        }
+        if (dist_to_next > 1) {
+          if (dist_to_next > mi) break; /* avoid overflow */
+          mi -= dist_to_next;
+          continue;
+        }
+      }
+    }
     {
       const uint32_t dist_next = c->chain[mi & 0xFFFF];
-      if (c->pattern_analysis && dist_next == 1) {
+      if (c->pattern_analysis && dist_next == 1 && chain_pos == 0) {
         const uint32_t cand = mi - 1;
         if (repeat == 0) {
           if (((pattern & 0xFFFF) == (pattern >> 16)) & ((pattern & 0xFF) == (pattern >> 24))) {
@@ -154,7 +177,7 @@ static int wider_match(hc_t* c, int ip, int ilow, int ihigh, int longest, int* m
         }
       }
     }
-    mi -= c->chain[mi & 0xFFFF];
+    mi -= c->chain[(mi + chain_pos) & 0xFFFF];
   }
   return longest;
 }
@@ -199,6 +222,153 @@ static int encode_sequence(enc_t* e, int* ip, int ml, int ref) {
   return 0;
 }
 
+/* ---- levels 10..12: LZ4HC_compress_optimal (liblz4 1.9.3 lz4hc.c) ------------------------------------------------ */
+#define LZ4_OPT_NUM (1 << 12)
+#define TRAILING_LITERALS 3
+typedef struct { int price, off, mlen, litlen; } opt_t;
+
+static int literals_price(int litlen) {
+  int price = litlen;
+  if (litlen >= 15) price += 1 + ((litlen - 15) / 255);
+  return price;
+}
+static int sequence_price(int litlen, int mlen) {
+  int price = 1 + 2; /* token + 16-bit offset */
+  price += literals_price(litlen);
+  if (mlen >= 15 + MINMATCH) price += 1 + ((mlen - (15 + MINMATCH)) / 255);
+  return price;
+}
+/* LZ4HC_FindLongerMatch: forward-only search with pattern analysis and chain swap; returns the length (0: none) */
+static int find_longer_match(hc_t* c, int ip, int ihigh, int min_len, int* off) {
+  int mpos = 0, spos = ip;
+  const int ml = wider_match(c, ip, ip, ihigh, min_len, &mpos, &spos);
+  if (ml <= min_len) return 0;
+  *off = ip - mpos;
+  return ml;
+}
+
+static int compress_optimal(hc_t* c, enc_t* e, int n, int sufficient_len, int full_update) {
+  opt_t* const opt = (opt_t*)malloc(sizeof(opt_t) * (LZ4_OPT_NUM + TRAILING_LITERALS));
+  const int mflimit = n - MFLIMIT, matchlimit = n - LASTLITERALS;
+  int ip = 0, overflow = 0;
+  if (!opt) return 1;
+  if (sufficient_len >= LZ4_OPT_NUM) sufficient_len = LZ4_OPT_NUM - 1;
+  while (ip <= mflimit) {
+    const int llen = ip - e->anchor;
+    int best_mlen, best_off, cur, last_match_pos = 0;
+    int first_off = 0;
+    const int first_len = find_longer_match(c, ip, matchlimit, MINMATCH - 1, &first_off);
+    if (first_len == 0) { ip++; continue; }
+    if (first_len > sufficient_len) { /* good enough: immediate encoding */
+      if (encode_sequence(e, &ip, first_len, ip - first_off)) { overflow = 1; break; }
+      continue;
+    }
+    { /* prices of the first positions (literals) */
+      int rpos;
+      for (rpos = 0; rpos < MINMATCH; rpos++) {
+        opt[rpos].mlen = 1; opt[rpos].off = 0; opt[rpos].litlen = llen + rpos; opt[rpos].price = literals_price(llen + rpos);
+      }
+    }
+    { /* prices using the initial match */
+      int mlen;
+      for (mlen = MINMATCH; mlen <= first_len; mlen++) {
+        opt[mlen].mlen = mlen; opt[mlen].off = first_off; opt[mlen].litlen = llen; opt[mlen].price = sequence_price(llen, mlen);
+      }
+    }
+    last_match_pos = first_len;
+    {
+      int add;
+      for (add = 1; add <= TRAILING_LITERALS; add++) {
+        opt[last_match_pos + add].mlen = 1; opt[last_match_pos + add].off = 0; opt[last_match_pos + add].litlen = add;
+        opt[last_match_pos + add].price = opt[last_match_pos].price + literals_price(add);
+      }
+    }
+    /* check further positions */
+    for (cur = 1; cur < last_match_pos; cur++) {
+      const int cur_pos = ip + cur;
+      int new_len, new_off = 0;
+      if (cur_pos > mflimit) break;
+      if (full_update) {
+        /* not useful to search here if the next position has the same (or lower) cost ... unless the cost rises sharply after */
+        if (opt[cur + 1].price <= opt[cur].price && opt[cur + MINMATCH].price < opt[cur].price + 3) continue;
+      } else {
+        if (opt[cur + 1].price <= opt[cur].price) continue;
+      }
+      if (full_update) new_len = find_longer_match(c, cur_pos, matchlimit, MINMATCH - 1, &new_off);
+      else new_len = find_longer_match(c, cur_pos, matchlimit, last_match_pos - cur, &new_off);
+      if (!new_len) continue;
+      if (new_len > sufficient_len || new_len + cur >= LZ4_OPT_NUM) { /* immediate encoding */
+        best_mlen = new_len; best_off = new_off; last_match_pos = cur + 1;
+        goto encode;
+      }
+      { /* before the match: prices with literals at the beginning */
+        const int base_litlen = opt[cur].litlen;
+        int litlen;
+        for (litlen = 1; litlen < MINMATCH; litlen++) {
+          const int price = opt[cur].price - literals_price(base_litlen) + literals_price(base_litlen + litlen);
+          const int pos = cur + litlen;
+          if (price < opt[pos].price) {
+            opt[pos].mlen = 1; opt[pos].off = 0; opt[pos].litlen = base_litlen + litlen; opt[pos].price = price;
+          }
+        }
+      }
+      { /* prices using the match at position cur */
+        int ml;
+        for (ml = MINMATCH; ml <= new_len; ml++) {
+          const int pos = cur + ml;
+          int price, ll;
+          if (opt[cur].mlen == 1) {
+            ll = opt[cur].litlen;
+            price = ((cur > ll) ? opt[cur - ll].price : 0) + sequence_price(ll, ml);
+          } else {
+            ll = 0;
+            price = opt[cur].price + sequence_price(0, ml);
+          }
+          if (pos > last_match_pos + TRAILING_LITERALS || price <= opt[pos].price) {
+            if (ml == new_len && last_match_pos < pos) last_match_pos = pos;
+            opt[pos].mlen = ml; opt[pos].off = new_off; opt[pos].litlen = ll; opt[pos].price = price;
+          }
+        }
+      }
+      { /* complete the following positions with literals */
+        int add;
+        for (add = 1; add <= TRAILING_LITERALS; add++) {
+          opt[last_match_pos + add].mlen = 1; opt[last_match_pos + add].off = 0; opt[last_match_pos + add].litlen = add;
+          opt[last_match_pos + add].price = opt[last_match_pos].price + literals_price(add);
+        }
+      }
+    }
+    best_mlen = opt[last_match_pos].mlen;
+    best_off = opt[last_match_pos].off;
+    cur = last_match_pos - best_mlen;
+  encode: /* cur, last_match_pos, best_mlen, best_off are set */
+    { /* reverse traversal: the shortest path */
+      int candidate_pos = cur, selected_ml = best_mlen, selected_off = best_off;
+      for (;;) {
+        const int next_ml = opt[candidate_pos].mlen, next_off = opt[candidate_pos].off;
+        opt[candidate_pos].mlen = selected_ml;
+        opt[candidate_pos].off = selected_off;
+        selected_ml = next_ml;
+        selected_off = next_off;
+        if (next_ml > candidate_pos) break; /* last match elected, first match to encode */
+        candidate_pos -= next_ml;
+      }
+    }
+    { /* encode all recorded sequences in order */
+      int rpos = 0;
+      while (rpos < last_match_pos) {
+        const int ml = opt[rpos].mlen, offset = opt[rpos].off;
+        if (ml == 1) { ip++; rpos++; continue; } /* literal */
+        rpos += ml;
+        if (encode_sequence(e, &ip, ml, ip - offset)) { overflow = 1; break; }
+      }
+      if (overflow) break;
+    }
+  }
+  free(opt);
+  return overflow;
+}
+
 int lz4o_compress_hc(const uint8_t* src, int n, uint8_t* dst, int cap, int level) {
   static const int searches[10] = {2, 2, 2, 4, 8, 16, 32, 64, 128, 256};
   hc_t* c;
@@ -208,15 +378,22 @@ int lz4o_compress_hc(const uint8_t* src, int n, uint8_t* dst, int cap, int level
   if (n < 0 || (unsigned)n > 0x7E000000u) return 0;
   if (level < 1) level = 9;
   if (level > 12) level = 12;
-  if (level > 9) return -1; /* optimal parser: not restated */
   c = (hc_t*)calloc(1, sizeof(hc_t));
   if (!c) return 0;
   c->src = src;
   c->next_to_update = BIAS;
-  c->nb_searches = searches[level];
-  c->pattern_analysis = c->nb_searches > 128;
   e.src = src; e.dst = dst; e.op = 0; e.oend = cap; e.anchor = 0;
   e.limited = cap < lz4o_compress_bound(n);
+  if (level > 9) { /* optimal parser: clTable {96, 64}, {512, 128}, {16384, LZ4_OPT_NUM}; level 12 = "ultra" (fullUpdate) */
+    static const int nb[3] = {96, 512, 16384}, target[3] = {64, 128, LZ4_OPT_NUM};
+    c->nb_searches = nb[level - 10];
+    c->pattern_analysis = 1;
+    c->chain_swap = 1;
+    if (compress_optimal(c, &e, n, target[level - 10], level == 12)) goto overflow;
+    goto last_literals;
+  }
+  c->nb_searches = searches[level];
+  c->pattern_analysis = c->nb_searches > 128;
   {
     const int mflimit = n - MFLIMIT, matchlimit = n - LASTLITERALS;
     if (n < MFLIMIT + 1) goto last_literals;

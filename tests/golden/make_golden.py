@@ -38,10 +38,13 @@ def main():
     for name, data in inputs.items():
         fast = R.compress_fast(data)
         hc = R.compress_hc(data, 9)
+        hc10, hc12 = R.compress_hc(data, 10), R.compress_hc(data, 12)
         table[name] = {
             "n": len(data), "md5": hashlib.md5(data).hexdigest(),
             "fast_size": len(fast), "fast_sha256": hashlib.sha256(fast).hexdigest(),
             "hc9_size": len(hc), "hc9_sha256": hashlib.sha256(hc).hexdigest(),
+            "hc10_size": len(hc10), "hc10_sha256": hashlib.sha256(hc10).hexdigest(),
+            "hc12_size": len(hc12), "hc12_sha256": hashlib.sha256(hc12).hexdigest(),
             "xxh32_seed0": "%08x" % R.xxh32(data, 0), "xxh64_seed0": "%016x" % R.xxh64(data, 0),
             "xxh32_seed9747b28c": "%08x" % R.xxh32(data, 0x9747b28c), "xxh64_seed9747b28c": "%016x" % R.xxh64(data, 0x9747b28c),
         }
