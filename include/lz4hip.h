@@ -99,8 +99,8 @@ int lz4hip_xxh64_batch(const uint8_t* buf, const uint64_t* off, const int32_t* l
 int lz4hip_compress_fast_batch_dev(const uint8_t* src, const uint64_t* src_off, const int32_t* src_len,
                                    uint8_t* dst, const uint64_t* dst_off, const int32_t* dst_cap,
                                    int32_t* out_len, uint32_t n_blocks, int device, void* stream);
-/* HC: levels follow liblz4 (< 1 -> 9, > 12 -> 12); levels 1..9 (hash chain) are implemented, 10..12 (the
- * optimal parser, i.e. lz4-java levels 10..17) return LZ4HIP_E_UNSUPPORTED.  The call sizes an internal
+/* HC: levels follow liblz4 (< 1 -> 9, > 12 -> 12): 1..9 = hash-chain strategy with lazy evaluation, 10..12 = optimal
+ * parser (lz4-java levels 10..17).  The call sizes an internal
  * u16 workspace (2 bytes per source byte, stream-ordered allocation) and therefore synchronises `stream`
  * once before it enqueues the two kernels.                                                          */
 int lz4hip_compress_hc_batch_dev(const uint8_t* src, const uint64_t* src_off, const int32_t* src_len,

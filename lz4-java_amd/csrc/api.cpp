@@ -71,12 +71,10 @@ int g_compress_core = 2;
 int g_compress_switch = 20;
 int g_compress_waves = 1; // 1 = single-wave kernel (default, fastest so far), 2 = match-finder wave + emitter wave per block
 
-// liblz4's level handling: < 1 -> 9, > 12 -> 12; 10..12 are the optimal parser,
-// which this build does not implement
+// liblz4's level handling: < 1 -> 9, > 12 -> 12; 10..12 are the optimal parser (lz4-java levels 10..17)
 int hc_level(int level, int* out) {
   if (level < 1) level = 9;
   if (level > 12) level = 12;
-  if (level > 9) return fail(LZ4HIP_E_UNSUPPORTED, "HC levels 10..12 (optimal parser; lz4-java levels 10..17) are not implemented yet");
   *out = level;
   return LZ4HIP_OK;
 }
@@ -92,9 +90,9 @@ int dev_hc(const lz4hip::BatchArgs& a, int level, hipStream_t st) {
   HIPCHK(hipMemcpyAsync(&span, d_span, 8, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   HIPCHK(hipFreeAsync(d_span, st));
-  uint16_t* ws = nullptr;
-  if (hipMallocAsync((void**)&ws, (size_t)span * 2 + 64, st) != hipSuccess) return fail(LZ4HIP_E_NOMEM, "HC workspace allocation failed");
-  e = lz4hip::launch_compress_hc(a, level, ws, st);
+  void* ws = nullptr;
+  if (hipMallocAsync(&ws, lz4hip::hc_ws_bytes(span, a.n, level), st) != hipSuccess) return fail(LZ4HIP_E_NOMEM, "HC workspace allocation failed");
+  e = lz4hip::launch_compress_hc(a, level, ws, span, st);
   (void)hipFreeAsync(ws, st);
   if (e) return fail(LZ4HIP_E_HIP, "kernel launch", (hipError_t)e);
   return LZ4HIP_OK;
@@ -332,7 +330,7 @@ int host_shard(Op op, int level, int ord, const uint8_t* src, const uint64_t* sr
     const size_t meta = (size_t)nb * 28u;   // so[nb] u64 | dof[nb] u64 | src_len[nb] | dst_cap[nb] | out[nb]
     if ((e = s.h_src.reserve(sb + 64)) != hipSuccess || (e = s.h_dst.reserve(db + 64)) != hipSuccess || (e = s.h_meta.reserve(meta)) != hipSuccess ||
         (e = s.d_src.reserve(sb + 64)) != hipSuccess || (e = s.d_dst.reserve(db + 64)) != hipSuccess || (e = s.d_meta.reserve(meta)) != hipSuccess ||
-        (op == OP_COMPRESS_HC && (e = s.d_ws.reserve(sb * 2 + 64)) != hipSuccess) ||
+        (op == OP_COMPRESS_HC && (e = s.d_ws.reserve(lz4hip::hc_ws_bytes(sb, nb, level))) != hipSuccess) ||
         ((op == OP_COMPRESS_FAST || op == OP_COMPRESS_HC) && ((e = s.d_pack.reserve(db + 64)) != hipSuccess || (e = s.d_poff.reserve((size_t)nb * 8u)) != hipSuccess))) {
       rc = bad("staging allocation", e);
       break;
@@ -355,7 +353,7 @@ int host_shard(Op op, int level, int ord, const uint8_t* src, const uint64_t* sr
       case OP_COMPRESS_FAST: le = launch_fast(a, s.st); break;
       case OP_DECODE_SAFE: le = lz4hip::launch_decompress(a, true, g_decode_lanes, s.st); break;
       case OP_DECODE_FAST: le = lz4hip::launch_decompress(a, false, g_decode_lanes, s.st); break;
-      case OP_COMPRESS_HC: le = lz4hip::launch_compress_hc(a, level, (uint16_t*)s.d_ws.p, s.st); break;
+      case OP_COMPRESS_HC: le = lz4hip::launch_compress_hc(a, level, s.d_ws.p, sb, s.st); break;
     }
     if (le) { rc = bad("kernel launch", (hipError_t)le); break; }
     if ((e = hipMemcpyAsync(hm + (size_t)nb * 24u, dm + (size_t)nb * 24u, (size_t)nb * 4u, hipMemcpyDeviceToHost, s.st)) != hipSuccess) { rc = bad("D2H out", e); break; }

@@ -27,9 +27,10 @@ uint32_t compress_fast2_grid(uint32_t n_blocks, uint32_t n_cus);
 size_t compress_fast2_ws_bytes(uint32_t grid);
 int launch_compress_fast2(const BatchArgs& a, uint8_t* ws, uint32_t grid, void* stream);
 int launch_compress_fast_prof(const BatchArgs& a, uint64_t* prof, bool ms, void* stream);  // developer diagnostics
-// HC levels 1..9: `ws` = device workspace of u16[max(src_off+src_len)] (see launch_hc_span)
+// HC levels 1..12: `ws` = device workspace of hc_ws_bytes(span, n, level) bytes, span = max(src_off+src_len) (launch_hc_span)
 int launch_hc_span(const uint64_t* src_off, const int32_t* src_len, uint32_t n, uint64_t* out_dev, void* stream);
-int launch_compress_hc(const BatchArgs& a, int level, uint16_t* ws, void* stream);
+size_t hc_ws_bytes(uint64_t span, uint32_t n_blocks, int level);
+int launch_compress_hc(const BatchArgs& a, int level, void* ws, uint64_t span, void* stream);
 // after a compress launch: moves the out[i] > 0 useful bytes of every slot to pack + sum(out[0..i)); poff: u64[n] scratch
 int launch_pack(const BatchArgs& a, uint64_t* poff, uint8_t* pack, void* stream);
 // lanes_per_block: lanes of a wavefront that share one block in the decoder (4..64); 0 = default

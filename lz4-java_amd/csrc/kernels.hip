@@ -318,7 +318,7 @@ __global__ __launch_bounds__(64) void hc_build_kernel(BatchArgs a, uint16_t* ws)
   WaveDev w(head);
   HcBuild<WaveDev>::run(w, a.src + a.src_off[b], (uint32_t)n, ws + a.src_off[b]);
 }
-__global__ __launch_bounds__(64) void hc_parse_kernel(BatchArgs a, const uint16_t* ws, int level) {
+__global__ __launch_bounds__(64) void hc_parse_kernel(BatchArgs a, const uint16_t* ws, int level, int* opt_ws) {
   const uint32_t b = blockIdx.x;
   const int32_t n = a.src_len[b];
   const int32_t cap = a.dst_cap[b];
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(64) void hc_parse_kernel(BatchArgs a, const uint16_
   if (n >= 0 && (uint32_t)n <= 0x7E000000u && cap >= 0) {
     WaveDev w(nullptr);
     HcParse<WaveDev> p(w, a.src + a.src_off[b], n, ws + a.src_off[b], a.dst + a.dst_off[b], cap, level);
-    r = p.run();
+    r = level >= 10 ? p.run_opt(level, opt_ws + (size_t)b * HC_OPT_INTS) : p.run();
   }
   if (threadIdx.x == 0) a.out[b] = r;
 }
@@ -342,10 +342,18 @@ int launch_hc_span(const uint64_t* src_off, const int32_t* src_len, uint32_t n, 
   hipLaunchKernelGGL(hc_span_kernel, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, src_off, src_len, n, (unsigned long long*)out_dev);
   return (int)hipGetLastError();
 }
-int launch_compress_hc(const BatchArgs& a, int level, uint16_t* ws, void* stream) {
+// workspace: u16 delta[span] (span = max(src_off + src_len) over the batch), then -- levels 10..12 only -- the price table of
+// the optimal parser, HC_OPT_INTS ints per block
+size_t hc_ws_bytes(uint64_t span, uint32_t n_blocks, int level) {
+  const size_t d = (((size_t)span * 2u + 64u) + 255u) & ~(size_t)255u;
+  return d + (level >= 10 ? (size_t)n_blocks * HC_OPT_INTS * sizeof(int) : 0u);
+}
+int launch_compress_hc(const BatchArgs& a, int level, void* ws, uint64_t span, void* stream) {
   if (a.n == 0) return 0;
-  hipLaunchKernelGGL(hc_build_kernel, dim3(a.n), dim3(64), 0, (hipStream_t)stream, a, ws);
-  hipLaunchKernelGGL(hc_parse_kernel, dim3(a.n), dim3(64), 0, (hipStream_t)stream, a, (const uint16_t*)ws, level);
+  const size_t d = (((size_t)span * 2u + 64u) + 255u) & ~(size_t)255u;
+  int* const opt = level >= 10 ? (int*)((uint8_t*)ws + d) : nullptr;
+  hipLaunchKernelGGL(hc_build_kernel, dim3(a.n), dim3(64), 0, (hipStream_t)stream, a, (uint16_t*)ws);
+  hipLaunchKernelGGL(hc_parse_kernel, dim3(a.n), dim3(64), 0, (hipStream_t)stream, a, (const uint16_t*)ws, level, opt);
   return (int)hipGetLastError();
 }
 

@@ -1,4 +1,5 @@
-// lz4_hc_core.h -- bit-exact LZ4 HC (hash-chain strategy, liblz4 levels 1..9) for one wavefront per block.
+// lz4_hc_core.h -- bit-exact LZ4 HC (liblz4 levels 1..9: hash-chain strategy with lazy evaluation; levels 10..12:
+// optimal parser) for one wavefront per block.
 //
 // Replaces, for the "HIP" family, LZ4_compress_HC as reached from LZ4HCJNICompressor.compress through
 // /root/reference/src/jni/net_jpountz_lz4_LZ4JNI.c:122 (liblz4 1.9.3).  Output is
@@ -48,10 +49,14 @@ LZ4HIP_DEV uint32_t hc_rd32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v,
 LZ4HIP_DEV uint32_t hc_rd16(const uint8_t* p) { uint16_t v; __builtin_memcpy(&v, p, 2); return v; }
 LZ4HIP_DEV uint64_t hc_rd64(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
 
-// nbSearches per level (liblz4 clTable); level already clamped to 1..9
+// nbSearches per level (liblz4 clTable); level already clamped to 1..12
 LZ4HIP_DEV int hc_nb_searches(int level) {
+  if (level >= 10) return level == 10 ? 96 : (level == 11 ? 512 : 16384);
   return level <= 2 ? 2 : (1 << (level - 1));
 }
+constexpr int HC_OPT_NUM = 1 << 12;          // LZ4_OPT_NUM: positions priced by one run of the optimal parser
+constexpr int HC_OPT_TRAILING = 3;           // TRAILING_LITERALS
+constexpr int HC_OPT_INTS = 4 * (HC_OPT_NUM + HC_OPT_TRAILING);  // per-block workspace of the optimal parser, in ints
 
 // ---------------------------------------------------------------------------------------------------
 // phase 1: delta[] builder (one wavefront, 128 KB LDS head table)
@@ -105,6 +110,8 @@ struct HcSearch {
   const uint16_t* delta;
   int nb_searches;
   bool pattern_analysis;
+  bool chain_swap = false;  // levels 10..12 (LZ4HC_FindLongerMatch): a match as long as the best so far re-anchors the walk on the
+                            // position inside it whose chain link is the longest
 
   LZ4HIP_DEV static int count_fwd(const uint8_t* s, int a, int b, int limit) {
     const int st = a;
@@ -148,9 +155,11 @@ struct HcSearch {
       const uint32_t d0 = delta[ip];
       mi = d0 ? ip_idx - d0 : 0u;
     }
+    uint32_t chain_pos = 0;  // liblz4's matchChainPos
     while (mi >= lowest && attempts > 0) {
       attempts--;
       const int mp = (int)(mi - HC_BIAS);
+      int ml = 0;
       if (hc_rd16(src + ilow + longest - 1) == hc_rd16(src + mp - look_back + longest - 1)) {
         if (hc_rd32(src + mp) == pattern) {
           int back = 0;
@@ -158,12 +167,29 @@ struct HcSearch {
             const int mn = -((ip - ilow) < mp ? (ip - ilow) : mp);
             while (back > mn && src[ip + back - 1] == src[mp + back - 1]) back--;
           }
-          const int ml = 4 + count_fwd(src, ip + 4, mp + 4, ihigh) - back;
+          ml = 4 + count_fwd(src, ip + 4, mp + 4, ihigh) - back;
           if (ml > longest) { longest = ml; mpos = mp + back; spos = ip + back; }
         }
       }
+      if (chain_swap && ml == longest) {  // forward-only searches: pick the chain of the position with the longest link
+        if (mi + (uint32_t)longest <= ip_idx) {
+          uint32_t dist_to_next = 1;
+          const int end = longest - 4 + 1;
+          int step = 1, accel = 1 << 4;
+          for (int pos = 0; pos < end; pos += step) {
+            const uint32_t cd = chain(mi + (uint32_t)pos);
+            step = (accel++ >> 4);
+            if (cd > dist_to_next) { dist_to_next = cd; chain_pos = (uint32_t)pos; accel = 1 << 4; }
+          }
+          if (dist_to_next > 1) {
+            if (dist_to_next > mi) break;  // avoid overflow
+            mi -= dist_to_next;
+            continue;
+          }
+        }
+      }
       const uint32_t dist_next = chain(mi);
-      if (pattern_analysis && dist_next == 1u) {
+      if (pattern_analysis && dist_next == 1u && chain_pos == 0u) {
         const uint32_t cand = mi - 1u;
         if (repeat == 0) {
           if (((pattern & 0xFFFFu) == (pattern >> 16)) & ((pattern & 0xFFu) == (pattern >> 24))) {
@@ -204,7 +230,7 @@ struct HcSearch {
           }
         }
       }
-      mi -= dist_next;
+      mi -= chain(mi + chain_pos);
     }
     return longest;
   }
@@ -296,7 +322,8 @@ struct HcParse {
     s.src = src_;
     s.delta = delta;
     s.nb_searches = hc_nb_searches(level);
-    s.pattern_analysis = s.nb_searches > 128;
+    s.pattern_analysis = level >= 10 || s.nb_searches > 128;
+    s.chain_swap = level >= 10;
     limited = (uint32_t)cap < (uint32_t)n + (uint32_t)n / 255u + 16u;
   }
 
@@ -366,6 +393,133 @@ struct HcParse {
       ip += 64;
     }
     return -1;
+  }
+
+  // ---- levels 10..12: liblz4's optimal parser (LZ4HC_compress_optimal, lz4-java levels 10..17) -----------------------------
+  // From a position with a match, the prices (output bytes) of reaching each of the next <= 4096 positions are relaxed with
+  // every match found on the way, then the cheapest path is walked backwards and its sequences are written.  The price table
+  // lives in a per-block workspace in HBM (`opt`: 4 ints per position -- price, offset, match length, literal length); the
+  // table walk is wave-uniform scalar work (all lanes redundantly, like the lazy parse of levels 1..9), the searches are
+  // s.wider() with liblz4's pattern analysis and chain swap, the sequence writer is the cooperative encode() above.
+  LZ4HIP_DEV int last_literals() {
+    const uint32_t last = (uint32_t)(n - anchor);
+    const uint32_t ll_add = (last + 255u - 15u) / 255u;
+    if (limited && (uint64_t)op + 1u + ll_add + last > (uint64_t)cap) return 0;
+    const uint32_t o = (uint32_t)op;
+    w.st8(dst, VU(o), VU((last < 15u ? last : 15u) << 4), w.lane() == 0u);
+    if (last >= 15u) put_run(o + 1u, last - 15u);
+    w.copy(dst, o + 1u + ll_add, src, (uint32_t)anchor, last);
+    return (int)(o + 1u + ll_add + last);
+  }
+
+  LZ4HIP_DEV static int lit_price(int litlen) { return litlen >= 15 ? litlen + 1 + (litlen - 15) / 255 : litlen; }
+  LZ4HIP_DEV static int seq_price(int litlen, int mlen) { return 3 + lit_price(litlen) + (mlen >= 19 ? 1 + (mlen - 19) / 255 : 0); }
+  // LZ4HC_FindLongerMatch: forward-only search; length (0: nothing longer than min_len) and offset
+  LZ4HIP_DEV int find_longer(int ip, int matchlimit, int min_len, int& off) const {
+    int mp = 0, sp = ip;
+    const int m = s.wider(ip, ip, matchlimit, min_len, mp, sp);
+    if (m <= min_len) return 0;
+    off = ip - mp;
+    return m;
+  }
+
+  LZ4HIP_DEV int run_opt(int level, int* opt) {
+    const int mflimit = n - 12, matchlimit = n - 5;
+    int sufficient = level == 10 ? 64 : (level == 11 ? 128 : HC_OPT_NUM);
+    if (sufficient >= HC_OPT_NUM) sufficient = HC_OPT_NUM - 1;
+    const bool full_update = level >= 12;
+    int* const price = opt;                                        // opt[p].price
+    int* const o_off = opt + (HC_OPT_NUM + HC_OPT_TRAILING);        // opt[p].off
+    int* const o_ml = opt + 2 * (HC_OPT_NUM + HC_OPT_TRAILING);     // opt[p].mlen (1 = literal)
+    int* const o_ll = opt + 3 * (HC_OPT_NUM + HC_OPT_TRAILING);     // opt[p].litlen
+    int ip = 0;
+    if (n >= 13) {
+      while (ip <= mflimit) {
+        const int llen = ip - anchor;
+        int first_off = 0;
+        const int first_len = find_longer(ip, matchlimit, 3, first_off);
+        if (first_len == 0) { ip++; continue; }
+        if (first_len > sufficient) {  // good enough: immediate encoding
+          if (encode(ip, first_len, ip - first_off)) return 0;
+          continue;
+        }
+        for (int r = 0; r < 4; r++) { o_ml[r] = 1; o_off[r] = 0; o_ll[r] = llen + r; price[r] = lit_price(llen + r); }
+        for (int m = 4; m <= first_len; m++) { o_ml[m] = m; o_off[m] = first_off; o_ll[m] = llen; price[m] = seq_price(llen, m); }
+        int last_match_pos = first_len;
+        for (int a = 1; a <= HC_OPT_TRAILING; a++) {
+          o_ml[last_match_pos + a] = 1; o_off[last_match_pos + a] = 0; o_ll[last_match_pos + a] = a;
+          price[last_match_pos + a] = price[last_match_pos] + lit_price(a);
+        }
+        int best_mlen = 0, best_off = 0, cur;
+        bool direct = false;
+        for (cur = 1; cur < last_match_pos; cur++) {
+          const int cur_pos = ip + cur;
+          if (cur_pos > mflimit) break;
+          if (full_update) {  // not useful to search here if the next position costs the same or less -- unless the cost rises sharply after
+            if (price[cur + 1] <= price[cur] && price[cur + 4] < price[cur] + 3) continue;
+          } else {
+            if (price[cur + 1] <= price[cur]) continue;
+          }
+          int new_off = 0;
+          const int new_len = find_longer(cur_pos, matchlimit, full_update ? 3 : last_match_pos - cur, new_off);
+          if (!new_len) continue;
+          if (new_len > sufficient || new_len + cur >= HC_OPT_NUM) {  // immediate encoding
+            best_mlen = new_len; best_off = new_off; last_match_pos = cur + 1;
+            direct = true;
+            break;
+          }
+          {  // before the match: prices with literals at the beginning
+            const int base_ll = o_ll[cur];
+            for (int ll = 1; ll < 4; ll++) {
+              const int pr = price[cur] - lit_price(base_ll) + lit_price(base_ll + ll);
+              const int pos = cur + ll;
+              if (pr < price[pos]) { o_ml[pos] = 1; o_off[pos] = 0; o_ll[pos] = base_ll + ll; price[pos] = pr; }
+            }
+          }
+          {  // prices using the match at position cur
+            const bool cur_is_lit = o_ml[cur] == 1;
+            const int ll = cur_is_lit ? o_ll[cur] : 0;
+            const int basep = cur_is_lit ? ((cur > ll) ? price[cur - ll] : 0) : price[cur];
+            for (int m = 4; m <= new_len; m++) {
+              const int pos = cur + m;
+              const int pr = basep + seq_price(ll, m);
+              if (pos > last_match_pos + HC_OPT_TRAILING || pr <= price[pos]) {
+                if (m == new_len && last_match_pos < pos) last_match_pos = pos;
+                o_ml[pos] = m; o_off[pos] = new_off; o_ll[pos] = ll; price[pos] = pr;
+              }
+            }
+          }
+          for (int a = 1; a <= HC_OPT_TRAILING; a++) {  // complete the following positions with literals
+            o_ml[last_match_pos + a] = 1; o_off[last_match_pos + a] = 0; o_ll[last_match_pos + a] = a;
+            price[last_match_pos + a] = price[last_match_pos] + lit_price(a);
+          }
+        }
+        if (!direct) {
+          best_mlen = o_ml[last_match_pos];
+          best_off = o_off[last_match_pos];
+          cur = last_match_pos - best_mlen;
+        }
+        {  // reverse traversal: the cheapest path, turned into a forward list in place
+          int cand = cur, sel_ml = best_mlen, sel_off = best_off;
+          for (;;) {
+            const int next_ml = o_ml[cand], next_off = o_off[cand];
+            o_ml[cand] = sel_ml;
+            o_off[cand] = sel_off;
+            sel_ml = next_ml;
+            sel_off = next_off;
+            if (next_ml > cand) break;  // last match elected, first match to encode
+            cand -= next_ml;
+          }
+        }
+        for (int r = 0; r < last_match_pos;) {  // encode all recorded sequences in order
+          const int m = o_ml[r], off = o_off[r];
+          if (m == 1) { ip++; r++; continue; }  // literal
+          r += m;
+          if (encode(ip, m, ip - off)) return 0;
+        }
+      }
+    }
+    return last_literals();
   }
 
   LZ4HIP_DEV int run() {
@@ -439,16 +593,7 @@ struct HcParse {
         goto search3;
       }
     }
-    {  // last literals
-      const uint32_t last = (uint32_t)(n - anchor);
-      const uint32_t ll_add = (last + 255u - 15u) / 255u;
-      if (limited && (uint64_t)op + 1u + ll_add + last > (uint64_t)cap) return 0;
-      const uint32_t o = (uint32_t)op;
-      w.st8(dst, VU(o), VU((last < 15u ? last : 15u) << 4), w.lane() == 0u);
-      if (last >= 15u) put_run(o + 1u, last - 15u);
-      w.copy(dst, o + 1u + ll_add, src, (uint32_t)anchor, last);
-      return (int)(o + 1u + ll_add + last);
-    }
+    return last_literals();
   }
 };
 

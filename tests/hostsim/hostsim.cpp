@@ -123,20 +123,20 @@ int sim_compress_fast_queue(const uint8_t* src, int n, uint8_t* dst, int cap, ui
   return r;
 }
 
-// LZ4 HC (levels 1..9): phase 1 (delta[] build) + phase 2 (lazy parse) in the lock-step simulator.
-// returns the compressed size, 0 (does not fit), -1 (level not implemented) or -1000 (out-of-slot access)
+// LZ4 HC (levels 1..12): phase 1 (delta[] build) + phase 2 (lazy parse, or the optimal parser for 10..12) in the lock-step
+// simulator.  returns the compressed size, 0 (does not fit) or -1000 (out-of-slot access)
 int sim_compress_hc(const uint8_t* src, int n, uint8_t* dst, int cap, int level, uint64_t rng_seed) {
   if (n < 0 || (uint32_t)n > 0x7E000000u || cap < 0) return 0;
   if (level < 1) level = 9;
   if (level > 12) level = 12;
-  if (level > 9) return -1;
   hostsim::WaveHost w;
   if (rng_seed) w.rng = rng_seed;
   w.bounds(src, (size_t)n, dst, (size_t)cap);
   std::vector<uint16_t> delta((size_t)n + 8, 0xFFFF);
   lz4hip::HcBuild<hostsim::WaveHost>::run(w, src, (uint32_t)n, delta.data());
   lz4hip::HcParse<hostsim::WaveHost> p(w, src, n, delta.data(), dst, cap, level);
-  const int r = p.run();
+  std::vector<int> opt(level >= 10 ? (size_t)lz4hip::HC_OPT_INTS : 1u, 0x55555555);
+  const int r = level >= 10 ? p.run_opt(level, opt.data()) : p.run();
   if (w.oob) return -1000;
   return r;
 }

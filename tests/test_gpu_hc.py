@@ -1,5 +1,5 @@
-"""LZ4 HC (levels 1..9) on the GPU vs the oracle: golden table, level sweep and clamps, dest-too-small,
-BASELINE.json configs[3] shape (1 MiB blocks, win 4096)."""
+"""LZ4 HC (levels 1..12 = lz4-java 1..17) on the GPU vs the oracle: golden table, level sweep and clamps, dest-too-small,
+optimal-parser levels, BASELINE.json configs[3] shape (1 MiB blocks, win 4096)."""
 import random
 
 import pytest
@@ -29,10 +29,47 @@ def test_hc_golden_and_factory(amd, golden, corpus, ref):
     assert f.safeDecompressor().decompress(hc.compress(corpus["book1[:65536]"]), 65536) == corpus["book1[:65536]"]
     with pytest.raises(amd.LZ4Exception):
         hc.compress(corpus["book1[:65536]"], 0, 65536, bytearray(1000), 0, 1000)
-    # LZ4Factory.highCompressor clamps: > 17 -> 17 (== native 12, not implemented), < 1 -> 9
+    # LZ4Factory.highCompressor clamps: > 17 -> 17 (== native 12), < 1 -> 9
     assert f.highCompressor(0).compressionLevel == 9 and f.highCompressor(99).compressionLevel == 17
-    with pytest.raises(amd.LZ4HIPError):
-        f.highCompressor(12).compress(b"hello hello hello hello")
+    data = corpus["book1[:65536]"]
+    assert f.highCompressor(17).compress(data) == ref.compress_hc(data, 12) == f.highCompressor(12).compress(data)
+    assert f.highCompressor(10).compress(data) == ref.compress_hc(data, 10)
+
+
+def test_hc_optimal_parser_levels(amd, golden, corpus, ref, O):
+    """levels 10..12 (LZ4HC_compress_optimal; lz4-java 10..17): golden table incl. the 1 MiB block, fuzz with tight capacities,
+    repeated-byte patterns"""
+    names = list(corpus)
+    blocks = [corpus[n] for n in names]
+    for lvl in (10, 12):
+        res = gpu_hc_many(amd, blocks, [ref.compress_bound(len(b)) for b in blocks], lvl)
+        for n, b, (r, c) in zip(names, blocks, res):
+            assert (r, sha(c)) == (golden["inputs"][n]["hc%d_size" % lvl], golden["inputs"][n]["hc%d_sha256" % lvl]), (n, lvl)
+    rng = random.Random(37)
+    inputs = rnd_inputs(O, corpus, 72, 300)
+    for lvl in (10, 11, 12):
+        blocks, caps = [], []
+        for v in inputs[(lvl - 10) * 100:(lvl - 10) * 100 + 100]:
+            full = ref.compress_bound(len(v))
+            er, _ = ref.compress_hc_raw(v, lvl, full)
+            for cap in (full, max(0, er + rng.choice([-1, 0, 1, -9, 9]))):
+                blocks.append(v); caps.append(cap)
+        res = gpu_hc_many(amd, blocks, caps, lvl)
+        for v, cap, (r, c) in zip(blocks, caps, res):
+            er, eb = ref.compress_hc_raw(v, lvl, cap)
+            assert r == er and (er <= 0 or c == eb), (lvl, len(v), cap, r, er)
+    pats = []
+    for period in (1, 2, 4, 7):
+        p = rng.randbytes(period)
+        for n in (3000, 70000):
+            v = bytearray((p * (n // period + 1))[:n])
+            for _ in range(n // 2500):
+                v[rng.randrange(n)] ^= 0x33
+            pats.append(bytes(v))
+    for lvl in (10, 12):
+        res = gpu_hc_many(amd, pats, [ref.compress_bound(len(b)) for b in pats], lvl)
+        for b, (r, c) in zip(pats, res):
+            assert c == ref.compress_hc(b, lvl), (len(b), lvl)
 
 
 def test_hc_levels_fuzz(amd, ref, O, corpus):

@@ -216,7 +216,35 @@ def test_hc_core_fuzz(sim, ref, O, corpus):
                 v[rng.randrange(n)] ^= 0x33
             v = bytes(v)
             assert sim_hc(sim, v, 9, ref.compress_bound(n))[1] == ref.compress_hc(v, 9), (period, n)
-    assert sim_hc(sim, b"x" * 100, 10, 200)[0] == -1  # optimal-parser levels are not implemented
+
+
+def test_hc_core_optimal_parser(sim, ref, golden, corpus, O):
+    """levels 10..12 (lz4-java 10..17): delta[] builder + optimal parser (price table, chain swap, pattern analysis) vs liblz4"""
+    from conftest import sha
+    for name, v in corpus.items():
+        if len(v) > 300000:
+            continue   # (the 1 MiB input takes the lock-step simulator minutes at level 12; the GPU suite covers it)
+        for lvl in (10, 12):
+            r, b = sim_hc(sim, v, lvl, ref.compress_bound(len(v)))
+            assert (r, sha(b)) == (golden["inputs"][name]["hc%d_size" % lvl], golden["inputs"][name]["hc%d_sha256" % lvl]), (name, lvl)
+    rng = random.Random(31)
+    for v in rnd_inputs(O, corpus, 62, 120):
+        lvl = rng.choice([10, 11, 12, 17])
+        full = ref.compress_bound(len(v))
+        er, _ = ref.compress_hc_raw(v, lvl, full)
+        for cap in (full, max(0, er + rng.choice([-1, 0, 1, -9, 9]))):
+            a = ref.compress_hc_raw(v, lvl, cap)
+            r, b = sim_hc(sim, v, lvl, cap, seed=rng.getrandbits(63) | 1)
+            assert r == a[0] and (r <= 0 or b == a[1]), (len(v), lvl, cap, r, a[0])
+    for period in (1, 2, 4, 7):
+        p = rng.randbytes(period)
+        n = 20000
+        v = bytearray((p * (n // period + 1))[:n])
+        for _ in range(8):
+            v[rng.randrange(n)] ^= 0x33
+        v = bytes(v)
+        for lvl in (10, 12):
+            assert sim_hc(sim, v, lvl, ref.compress_bound(n))[1] == ref.compress_hc(v, lvl), (period, lvl)
 
 
 def test_compress_queue_variant(sim, ref, O, corpus):
