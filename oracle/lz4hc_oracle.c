@@ -1,12 +1,12 @@
 /*
  * oracle/lz4hc_oracle.c -- TEST INFRASTRUCTURE ONLY (see lz4_oracle.h).
  *
- * Plain-C restatement of LZ4_compress_HC (liblz4 1.9.3, hash-chain strategy, levels 1..9) as reached
+ * Plain-C restatement of LZ4_compress_HC (liblz4 1.9.3: hash-chain strategy for levels 1..9, optimal
+ * parser for levels 10..12) as reached
  * from LZ4HCJNICompressor.compress through /root/reference/src/jni/net_jpountz_lz4_LZ4JNI.c:122.
  * The liblz4 sources are not in /root/reference (empty submodule src/lz4); this follows SURVEY.md
  * Appendix B and is pinned byte-for-byte against the reference's prebuilt library by
- * tests/test_oracle_hc.py.  Levels 10..12 (the optimal parser) are NOT restated: the function returns
- * -1 for them ("unsupported"), SURVEY.md section 8(f) item 3.
+ * tests/test_oracle_hc.py (all twelve levels).
  *
  * State: hashTable u32[32768] (position of the latest occurrence of a 4-byte hash), chainTable
  * u16[65536] (distance to the previous occurrence, capped at 65535), both zeroed; positions are
