@@ -130,6 +130,25 @@ int lz4hip_decompress_fast(const uint8_t* src, int src_cap, uint8_t* dst, int ds
 int lz4hip_xxh32(const uint8_t* buf, int len, uint32_t seed, uint32_t* out);
 int lz4hip_xxh64(const uint8_t* buf, int len, uint64_t seed, uint64_t* out);
 
+/* ---- streaming xxhash ---------------------------------------------------------------------------
+ * What StreamingXXHash32JNI / StreamingXXHash64JNI bind (XXHashJNI.java: XXH32_init / _update / _digest / _free,
+ * net_jpountz_xxhash_XXHashJNI.c:89-145; the XXH64 set :199-255).  A stream's state -- accumulators, the bytes of
+ * the incomplete stripe, the length so far and the digest of everything so far -- is a small record in DEVICE
+ * memory; every update is one kernel launch that continues from it (one wavefront: XXH is a serial chain per
+ * stream), so device-resident data (decoded blocks, say) is hashed where it lies.  digest == the one-shot hash
+ * of the concatenation of all updates since create / reset.  Calls on one handle are serialised (the
+ * reference's methods are `synchronized`).  Handles must be freed before lz4hip_shutdown().                   */
+typedef struct lz4hip_xxh_stream lz4hip_xxh_stream;
+int lz4hip_xxh32_stream_create(uint32_t seed, lz4hip_xxh_stream** out);  /* XXH32_init, XXHashJNI.c:90-101 */
+int lz4hip_xxh64_stream_create(uint64_t seed, lz4hip_xxh_stream** out);  /* XXH64_init, XXHashJNI.c:200-211 */
+int lz4hip_xxh_stream_reset(lz4hip_xxh_stream* st, uint64_t seed);       /* StreamingXXHash32JNI.reset()    */
+int lz4hip_xxh_stream_update(lz4hip_xxh_stream* st, const uint8_t* buf, int len);   /* host pointer; XXHashJNI.c:108-121 */
+/* device pointer (on the engine's first device), enqueued on `stream`, returns without synchronising */
+int lz4hip_xxh_stream_update_dev(lz4hip_xxh_stream* st, const uint8_t* dbuf, int len, void* stream);
+int lz4hip_xxh32_stream_digest(lz4hip_xxh_stream* st, uint32_t* out);    /* XXH32_digest, XXHashJNI.c:128-133 */
+int lz4hip_xxh64_stream_digest(lz4hip_xxh_stream* st, uint64_t* out);    /* XXH64_digest, XXHashJNI.c:238-243 */
+void lz4hip_xxh_stream_free(lz4hip_xxh_stream* st);                      /* XXH32_free / XXH64_free          */
+
 /* ---- workload helper (not part of the reference API) ------------------------------------------
  * Fills n_blocks slots of `block_len` bytes at dst + i*stride with the SURVEY.md App. F synthetic
  * blocks idx = first_idx + i (deterministic, seed-addressed).  Device pointer, async on stream.

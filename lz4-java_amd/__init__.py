@@ -61,6 +61,14 @@ C_ABI = {
     "lz4hip_decompress_fast": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "lz4hip_xxh32": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, _u32p]),
     "lz4hip_xxh64": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, _u64p]),
+    "lz4hip_xxh32_stream_create": (C.c_int, [C.c_uint32, C.POINTER(C.c_void_p)]),
+    "lz4hip_xxh64_stream_create": (C.c_int, [C.c_uint64, C.POINTER(C.c_void_p)]),
+    "lz4hip_xxh_stream_reset": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "lz4hip_xxh_stream_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "lz4hip_xxh_stream_update_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "lz4hip_xxh32_stream_digest": (C.c_int, [C.c_void_p, _u32p]),
+    "lz4hip_xxh64_stream_digest": (C.c_int, [C.c_void_p, _u64p]),
+    "lz4hip_xxh_stream_free": (None, [C.c_void_p]),
     "lz4hip_dbg_compress_fast_profile_dev": (C.c_int, [C.c_void_p] * 7 + [C.c_uint32, C.c_void_p, C.c_int, C.c_void_p]),
     "lz4hip_gen_blocks_dev": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
                                         C.c_uint32, C.c_int, C.c_void_p]),
@@ -351,8 +359,112 @@ class XXHash64:
         return out.value
 
 
+class _Checksum:
+    """java.util.zip.Checksum view of a streaming hash (StreamingXXHash32.java:96-126, StreamingXXHash64.java:96-126)"""
+
+    def __init__(self, h, mask):
+        self._h, self._mask = h, mask
+
+    def getValue(self):
+        return self._h.getValue() & self._mask
+
+    def reset(self):
+        self._h.reset()
+
+    def update(self, b, off=None, length=None):
+        if isinstance(b, int):
+            self._h.update(bytes([b & 0xFF]), 0, 1)
+        else:
+            self._h.update(b, 0 if off is None else off, (len(b) if off is None else len(b) - off) if length is None else length)
+
+
+class _StreamingXXHash:
+    """Common part of the streaming twins: the state is a record in device memory behind a lz4hip_xxh_stream handle;
+    update() continues it with one launch; getValue() may be called any number of times between updates."""
+
+    _IS64 = False
+
+    def __init__(self, seed):
+        self.seed = seed
+        self._state = C.c_void_p(None)
+        if self._IS64:
+            _chk(lib().lz4hip_xxh64_stream_create(seed & 0xFFFFFFFFFFFFFFFF, C.byref(self._state)))
+        else:
+            _chk(lib().lz4hip_xxh32_stream_create(seed & 0xFFFFFFFF, C.byref(self._state)))
+
+    def _check_state(self):  # StreamingXXHash32JNI.java:47-51
+        if not self._state:
+            raise AssertionError("Already finalized")
+
+    def reset(self):
+        self._check_state()
+        _chk(lib().lz4hip_xxh_stream_reset(self._state, self.seed & 0xFFFFFFFFFFFFFFFF))
+
+    def update(self, buf, off=0, length=None):
+        self._check_state()
+        length = len(buf) - off if length is None else length
+        _check_range(buf, off, length)
+        p, k = _ro_ptr(buf)
+        _chk(lib().lz4hip_xxh_stream_update(self._state, p + off, length))
+
+    def update_device(self, dptr, length, stream=None):
+        """Not in the reference: absorbs `length` bytes at DEVICE address `dptr` where they lie (asynchronous on `stream`)."""
+        self._check_state()
+        if length < 0:
+            raise IndexError("length must be >= 0")
+        _chk(lib().lz4hip_xxh_stream_update_dev(self._state, dptr, length, stream))
+
+    def close(self):
+        if self._state:
+            lib().lz4hip_xxh_stream_free(self._state)
+            self._state = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __repr__(self):
+        return "%s(seed=%d)" % (type(self).__name__, self.seed)
+
+
+class StreamingXXHash32(_StreamingXXHash):
+    """xxhash/StreamingXXHash32.java:38-129; JNI twin StreamingXXHash32JNI.java:28-104 (XXH32_init/_update/_digest/_free)"""
+
+    def getValue(self):
+        self._check_state()
+        out = C.c_uint32(0)
+        _chk(lib().lz4hip_xxh32_stream_digest(self._state, C.byref(out)))
+        return out.value
+
+    def asChecksum(self):
+        return _Checksum(self, 0xFFFFFFF)  # 28 bits: StreamingXXHash32.java:101-107
+
+
+class StreamingXXHash64(_StreamingXXHash):
+    """xxhash/StreamingXXHash64.java:38-129; JNI twin StreamingXXHash64JNI.java:28-104"""
+
+    _IS64 = True
+
+    def getValue(self):
+        self._check_state()
+        out = C.c_uint64(0)
+        _chk(lib().lz4hip_xxh64_stream_digest(self._state, C.byref(out)))
+        return out.value
+
+    def asChecksum(self):
+        return _Checksum(self, 0xFFFFFFFFFFFFFFFF)
+
+
 class XXHashFactory:
-    """xxhash/XXHashFactory.java (one-shot hashes only; streaming state is out of scope)"""
+    """xxhash/XXHashFactory.java: hash32() / hash64() one-shot hashes, newStreamingHash32/64(seed) streaming states"""
 
     _HIP = None
 
@@ -367,6 +479,12 @@ class XXHashFactory:
 
     def hash64(self):
         return XXHash64()
+
+    def newStreamingHash32(self, seed):  # XXHashFactory.java:230-232
+        return StreamingXXHash32(seed)
+
+    def newStreamingHash64(self, seed):  # XXHashFactory.java:240-242
+        return StreamingXXHash64(seed)
 
 
 # ----------------------------------------------------------------------------------------------

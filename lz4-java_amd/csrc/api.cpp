@@ -8,6 +8,7 @@
 #include <string.h>
 #include <limits.h>
 #include <mutex>
+#include <new>
 #include <thread>
 #include <algorithm>
 #include <vector>
@@ -445,6 +446,65 @@ int single(Op op, const uint8_t* src, int src_len, uint8_t* dst, int dst_cap) {
 
 }  // namespace
 
+// ---- streaming xxhash (StreamingXXHash32JNI / StreamingXXHash64JNI: XXHashJNI.c:89-145, :199-255) ------------------------
+struct lz4hip_xxh_stream {
+  bool is64;
+  int ord;                 // HIP ordinal the record lives on (the engine's first device, or the device of update_dev)
+  void* rec = nullptr;     // device record (kernels.h)
+  void* stage = nullptr;   // device staging for host-pointer updates
+  size_t stage_cap = 0;
+  uint64_t seed;
+  bool pending_reset = true;   // the record is (re)initialised by the next launch
+  hipStream_t last = nullptr;  // stream of the last launch (digest waits for it)
+  std::mutex mu;               // the reference's methods are `synchronized`
+};
+namespace {
+constexpr size_t XXH_STAGE_MAX = 64u << 20;
+int xxh_stream_create(bool is64, uint64_t seed, lz4hip_xxh_stream** out) {
+  int rc = ensure_init();
+  if (rc) return fail(rc, "no HIP device: liblz4hip has no CPU fallback");
+  if (!out) return fail(LZ4HIP_E_ARG, "null pointer argument");
+  int ord;
+  if (ordinal(0, &ord)) return fail(LZ4HIP_E_NO_DEVICE, "no device");
+  DeviceGuard g(ord);
+  auto* st = new (std::nothrow) lz4hip_xxh_stream();
+  if (!st) return fail(LZ4HIP_E_NOMEM, "out of memory");
+  st->is64 = is64;
+  st->ord = ord;
+  st->seed = seed;
+  if (hipMalloc(&st->rec, lz4hip::xxh_stream_rec_bytes(is64)) != hipSuccess) {
+    delete st;
+    return fail(LZ4HIP_E_NOMEM, "hipMalloc failed");
+  }
+  *out = st;
+  return LZ4HIP_OK;
+}
+// absorbs a DEVICE buffer (len may be 0: only applies a pending reset)
+int xxh_stream_launch(lz4hip_xxh_stream* st, const uint8_t* dbuf, uint32_t len, hipStream_t stream) {
+  if (st->last != stream && st->last) HIPCHK(hipStreamSynchronize(st->last));  // updates of one stream are ordered
+  const int reset = st->pending_reset ? 1 : 0;
+  int e = st->is64 ? lz4hip::launch_xxh64_stream(st->rec, dbuf, len, reset, st->seed, stream)
+                   : lz4hip::launch_xxh32_stream(st->rec, dbuf, len, reset, (uint32_t)st->seed, stream);
+  if (e) return fail(LZ4HIP_E_HIP, "kernel launch", (hipError_t)e);
+  st->pending_reset = false;
+  st->last = stream;
+  return LZ4HIP_OK;
+}
+template <class T>
+int xxh_stream_digest(lz4hip_xxh_stream* st, bool is64, T* out) {
+  if (!st || !out || st->is64 != is64) return fail(LZ4HIP_E_ARG, "bad stream handle");
+  std::lock_guard<std::mutex> lk(st->mu);
+  DeviceGuard g(st->ord);
+  if (st->pending_reset) {  // nothing absorbed since create/reset: the digest of the empty stream
+    int rc = xxh_stream_launch(st, (const uint8_t*)st->rec, 0, nullptr);
+    if (rc) return rc;
+  }
+  if (st->last) HIPCHK(hipStreamSynchronize(st->last));
+  HIPCHK(hipMemcpy(out, (const uint8_t*)st->rec + lz4hip::xxh_stream_digest_offset(is64), sizeof(T), hipMemcpyDeviceToHost));
+  return LZ4HIP_OK;
+}
+}  // namespace
+
 extern "C" {
 
 int lz4hip_version(void) { return LZ4HIP_VERSION; }
@@ -633,6 +693,63 @@ int lz4hip_xxh64(const uint8_t* buf, int len, uint64_t seed, uint64_t* out) {
   int32_t l = len;
   uint8_t dummy = 0;
   return lz4hip_xxh64_batch(buf ? buf : &dummy, &zero, &l, seed, out, 1);
+}
+
+// ---- streaming xxhash: thin wrappers over the helpers above the extern "C" block ----
+int lz4hip_xxh32_stream_create(uint32_t seed, lz4hip_xxh_stream** out) { return xxh_stream_create(false, seed, out); }
+int lz4hip_xxh64_stream_create(uint64_t seed, lz4hip_xxh_stream** out) { return xxh_stream_create(true, seed, out); }
+int lz4hip_xxh_stream_reset(lz4hip_xxh_stream* st, uint64_t seed) {
+  if (!st) return fail(LZ4HIP_E_ARG, "bad stream handle");
+  std::lock_guard<std::mutex> lk(st->mu);
+  st->seed = st->is64 ? seed : (uint64_t)(uint32_t)seed;
+  st->pending_reset = true;
+  return LZ4HIP_OK;
+}
+int lz4hip_xxh_stream_update(lz4hip_xxh_stream* st, const uint8_t* buf, int len) {
+  if (!st || len < 0 || (!buf && len)) return fail(LZ4HIP_E_ARG, "bad argument");
+  if (len == 0) return LZ4HIP_OK;
+  std::lock_guard<std::mutex> lk(st->mu);
+  DeviceGuard g(st->ord);
+  size_t done = 0;
+  while (done < (size_t)len) {
+    const size_t part = std::min((size_t)len - done, XXH_STAGE_MAX);
+    if (st->stage_cap < part) {
+      if (st->last) HIPCHK(hipStreamSynchronize(st->last));
+      if (st->stage) (void)hipFree(st->stage);
+      st->stage = nullptr;
+      st->stage_cap = 0;
+      size_t cap = 1u << 16;
+      while (cap < part) cap <<= 1;
+      if (hipMalloc(&st->stage, cap) != hipSuccess) return fail(LZ4HIP_E_NOMEM, "hipMalloc failed");
+      st->stage_cap = cap;
+    }
+    if (st->last) HIPCHK(hipStreamSynchronize(st->last));  // the staging buffer is reused
+    HIPCHK(hipMemcpy(st->stage, buf + done, part, hipMemcpyHostToDevice));
+    int rc = xxh_stream_launch(st, (const uint8_t*)st->stage, (uint32_t)part, nullptr);
+    if (rc) return rc;
+    done += part;
+  }
+  return LZ4HIP_OK;
+}
+int lz4hip_xxh_stream_update_dev(lz4hip_xxh_stream* st, const uint8_t* dbuf, int len, void* stream) {
+  if (!st || len < 0 || (!dbuf && len)) return fail(LZ4HIP_E_ARG, "bad argument");
+  if (len == 0) return LZ4HIP_OK;
+  std::lock_guard<std::mutex> lk(st->mu);
+  DeviceGuard g(st->ord);
+  return xxh_stream_launch(st, dbuf, (uint32_t)len, (hipStream_t)stream);
+}
+int lz4hip_xxh32_stream_digest(lz4hip_xxh_stream* st, uint32_t* out) { return xxh_stream_digest<uint32_t>(st, false, out); }
+int lz4hip_xxh64_stream_digest(lz4hip_xxh_stream* st, uint64_t* out) { return xxh_stream_digest<uint64_t>(st, true, out); }
+void lz4hip_xxh_stream_free(lz4hip_xxh_stream* st) {
+  if (!st) return;
+  {
+    std::lock_guard<std::mutex> lk(st->mu);
+    DeviceGuard g(st->ord);
+    if (st->last) (void)hipStreamSynchronize(st->last);
+    if (st->rec) (void)hipFree(st->rec);
+    if (st->stage) (void)hipFree(st->stage);
+  }
+  delete st;
 }
 
 int lz4hip_gen_blocks_dev(uint8_t* dst, uint64_t stride, int32_t block_len, uint64_t seed, uint64_t first_idx, uint32_t litmax,

@@ -37,6 +37,12 @@ int launch_pack(const BatchArgs& a, uint64_t* poff, uint8_t* pack, void* stream)
 int launch_decompress(const BatchArgs& a, bool safe, int lanes_per_block, void* stream);
 int launch_xxh32(const uint8_t* buf, const uint64_t* off, const int32_t* len, uint32_t seed, uint32_t* out, uint32_t n, void* stream);
 int launch_xxh64(const uint8_t* buf, const uint64_t* off, const int32_t* len, uint64_t seed, uint64_t* out, uint32_t n, void* stream);
+// streaming xxhash: `rec` = device record of xxh_stream_rec_bytes() bytes (the digest so far sits at xxh_stream_digest_offset());
+// reset != 0 restarts the stream with `seed` before absorbing data[0..len)
+int launch_xxh32_stream(void* rec, const uint8_t* data, uint32_t len, int reset, uint32_t seed, void* stream);
+int launch_xxh64_stream(void* rec, const uint8_t* data, uint32_t len, int reset, uint64_t seed, void* stream);
+size_t xxh_stream_rec_bytes(bool is64);
+size_t xxh_stream_digest_offset(bool is64);
 int launch_gen_blocks(uint8_t* dst, uint64_t stride, int32_t block_len, uint64_t seed, uint64_t first_idx,
                       uint32_t litmax, uint32_t win, uint32_t n_blocks, void* stream);
 

@@ -458,6 +458,59 @@ __global__ __launch_bounds__(256) void xxh64_kernel(const uint8_t* buf, const ui
 // buffers -- but a lone thread walking a LONG buffer pays a full memory round trip per 64 bytes (0.16 GB/s).  With few buffers
 // each gets a wavefront instead: all 64 lanes stream the buffer through LDS in 4 KB chunks (double-buffered, coalesced 1 KB
 // loads), lanes 0..3 each own one accumulator and read their word of every stripe from LDS; the chain itself is all that is left.
+// Generic in the word type: lane k (mod 4) folds word k of `nst` whole stripes starting at `bulk` into its accumulator v
+// (4 KB chunks through LDS, double-buffered).  Used by the long-buffer kernels and by the streaming kernels.
+template <class T>
+__device__ __forceinline__ T xxh_absorb(T v, const uint8_t* bulk, uint32_t nst, uint32_t (*stage)[1024], uint32_t lane) {
+  constexpr uint32_t STRIPE = 4u * sizeof(T), SPC = 4096u / STRIPE;
+  const uint32_t k = lane & 3u;
+  const uint64_t lim = (uint64_t)nst * STRIPE;
+  const uint32_t nchunks = (nst + SPC - 1u) / SPC;
+  uint4 r[4];
+  auto fetch = [&](uint32_t c) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const uint64_t o = (uint64_t)c * 4096u + (uint32_t)i * 1024u + lane * 16u;
+      if (o + 16u <= lim) __builtin_memcpy(&r[i], bulk + o, 16);
+    }
+  };
+  // the input half of the round (in * PRIME_2) does not depend on the accumulator: all 64 lanes do it here, 16 bytes each,
+  // so the 4-lane serial chain is left with add, rotate, one multiply per stripe (integer multiplies are quarter rate)
+  auto put = [&](uint32_t c) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      T w[16 / sizeof(T)];
+      __builtin_memcpy(w, &r[i], 16);
+#pragma unroll
+      for (uint32_t q = 0; q < 16 / sizeof(T); q++) w[q] = XxhOps<T>::premul(w[q]);
+      __builtin_memcpy(&stage[c & 1u][(uint32_t)i * 256u + lane * 4u], w, 16);
+    }
+  };
+  if (nchunks) { fetch(0); put(0); }
+  __syncthreads();
+  for (uint32_t c = 0; c < nchunks; c++) {
+    const bool more = c + 1u < nchunks;
+    if (more) fetch(c + 1u);
+    const uint8_t* st = (const uint8_t*)stage[c & 1u] + k * sizeof(T);
+    const uint32_t cnt = nst - c * SPC < SPC ? nst - c * SPC : SPC;
+#pragma unroll 8
+    for (uint32_t s = 0; s < cnt; s++) {
+      T x;
+      __builtin_memcpy(&x, st + s * STRIPE, sizeof(T));
+      v = XxhOps<T>::round_pre(v, x);
+    }
+    if (more) put(c + 1u);
+    __syncthreads();
+  }
+  return v;
+}
+template <class T> __device__ __forceinline__ T xxh_lane_get(T v, int l);
+template <> __device__ __forceinline__ uint32_t xxh_lane_get<uint32_t>(uint32_t v, int l) { return __builtin_amdgcn_readlane(v, l); }
+template <> __device__ __forceinline__ uint64_t xxh_lane_get<uint64_t>(uint64_t v, int l) {
+  // (the builtin returns int: go through uint32_t, or the low half sign-extends into the high one)
+  return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((uint32_t)v, l) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((uint32_t)(v >> 32), l) << 32);
+}
+
 __global__ __launch_bounds__(64) void xxh32_wave_kernel(const uint8_t* buf, const uint64_t* off, const int32_t* len, uint32_t seed, uint32_t* out) {
   __shared__ __attribute__((aligned(16))) uint32_t stage[2][1024];
   const uint32_t b = blockIdx.x, lane = threadIdx.x;
@@ -468,36 +521,10 @@ __global__ __launch_bounds__(64) void xxh32_wave_kernel(const uint8_t* buf, cons
     if (lane == 0) out[b] = xxh32_one(p, n, seed);
     return;
   }
-  const uint32_t P1 = 2654435761u, P2 = 2246822519u;
-  const uint32_t k = lane & 3u;
-  uint32_t v = k == 0u ? seed + P1 + P2 : (k == 1u ? seed + P2 : (k == 2u ? seed : seed - P1));
-  const uint32_t nchunks = n / 4096u;
-  uint4 r[4];
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    __builtin_memcpy(&r[i], p + (uint32_t)i * 1024u + lane * 16u, 16);
-    *(uint4*)&stage[0][(uint32_t)i * 256u + lane * 4u] = r[i];
-  }
-  __syncthreads();
-  for (uint32_t c = 0; c < nchunks; c++) {
-    const bool more = c + 1u < nchunks;
-    if (more) {
-      const uint8_t* q = p + (size_t)(c + 1u) * 4096u;
-#pragma unroll
-      for (int i = 0; i < 4; i++) __builtin_memcpy(&r[i], q + (uint32_t)i * 1024u + lane * 16u, 16);
-    }
-    const uint32_t* st = stage[c & 1u];
-#pragma unroll 8
-    for (uint32_t s = 0; s < 256u; s++) v = xrotl32(v + st[s * 4u + k] * P2, 13) * P1;
-    if (more) {
-#pragma unroll
-      for (int i = 0; i < 4; i++) *(uint4*)&stage[(c + 1u) & 1u][(uint32_t)i * 256u + lane * 4u] = r[i];
-    }
-    __syncthreads();
-  }
-  const uint32_t v1 = __builtin_amdgcn_readlane(v, 0), v2 = __builtin_amdgcn_readlane(v, 1), v3 = __builtin_amdgcn_readlane(v, 2),
-                 v4 = __builtin_amdgcn_readlane(v, 3);
-  if (lane == 0) out[b] = xxh32_resume(v1, v2, v3, v4, p + (size_t)nchunks * 4096u, n - nchunks * 4096u, n);
+  const uint32_t nst = n / 16u;
+  const uint32_t v = xxh_absorb<uint32_t>(XxhOps<uint32_t>::init(seed, lane & 3u), p, nst, stage, lane);
+  const uint32_t v1 = xxh_lane_get(v, 0), v2 = xxh_lane_get(v, 1), v3 = xxh_lane_get(v, 2), v4 = xxh_lane_get(v, 3);
+  if (lane == 0) out[b] = XxhOps<uint32_t>::finish(v1, v2, v3, v4, seed, p + (size_t)nst * 16u, n - nst * 16u, n);
 }
 int launch_xxh32(const uint8_t* buf, const uint64_t* off, const int32_t* len, uint32_t seed, uint32_t* out, uint32_t n, void* stream) {
   if (n == 0) return 0;
@@ -505,9 +532,80 @@ int launch_xxh32(const uint8_t* buf, const uint64_t* off, const int32_t* len, ui
   else hipLaunchKernelGGL(xxh32_kernel, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, buf, off, len, seed, out, n);
   return (int)hipGetLastError();
 }
+__global__ __launch_bounds__(64) void xxh64_wave_kernel(const uint8_t* buf, const uint64_t* off, const int32_t* len, uint64_t seed, uint64_t* out) {
+  __shared__ __attribute__((aligned(16))) uint32_t stage[2][1024];
+  const uint32_t b = blockIdx.x, lane = threadIdx.x;
+  const int32_t l = len[b];
+  const uint32_t n = l < 0 ? 0u : (uint32_t)l;
+  const uint8_t* p = buf + off[b];
+  if (n < 8192u) {
+    if (lane == 0) out[b] = xxh64_one(p, n, seed);
+    return;
+  }
+  const uint32_t nst = n / 32u;
+  const uint64_t v = xxh_absorb<uint64_t>(XxhOps<uint64_t>::init(seed, lane & 3u), p, nst, stage, lane);
+  const uint64_t v1 = xxh_lane_get(v, 0), v2 = xxh_lane_get(v, 1), v3 = xxh_lane_get(v, 2), v4 = xxh_lane_get(v, 3);
+  if (lane == 0) out[b] = XxhOps<uint64_t>::finish(v1, v2, v3, v4, seed, p + (size_t)nst * 32u, n - nst * 32u, n);
+}
+
+// StreamingXXHash32/64.update (XXHashJNI.c:108-121 / :218-231): one wavefront continues the stream `rec` over data[0..len).
+// reset != 0: the stream is (re)started with `seed` first (XXH32_init / XXH64_init + reset, XXHashJNI.c:90-101); len may be 0.
+template <class T>
+__global__ __launch_bounds__(64) void xxh_stream_kernel(XxhRec<T>* rec, const uint8_t* data, uint32_t len, int reset, T seed_in) {
+  constexpr uint32_t STRIPE = 4u * sizeof(T);
+  __shared__ __attribute__((aligned(16))) uint32_t stage[2][1024];
+  __shared__ __attribute__((aligned(16))) uint8_t memb[2 * STRIPE];
+  const uint32_t lane = threadIdx.x, k = lane & 3u;
+  const T seed = reset ? seed_in : rec->seed;
+  T v = reset ? XxhOps<T>::init(seed, k) : rec->v[k];
+  const uint32_t ms = reset ? 0u : rec->memsize;
+  const uint64_t total = (reset ? 0ull : rec->total) + len;
+  if (lane < ms) memb[lane] = rec->mem[lane];
+  uint32_t newms;
+  if (ms + len < STRIPE) {  // still no whole stripe: only buffer
+    if (lane < len) memb[ms + lane] = data[lane];
+    newms = ms + len;
+    __syncthreads();
+  } else {
+    const uint32_t head = ms ? STRIPE - ms : 0u;  // bytes that complete the buffered stripe
+    if (ms) {
+      if (lane < head) memb[ms + lane] = data[lane];
+      __syncthreads();
+      v = XxhOps<T>::round(v, ((const T*)memb)[k]);
+      __syncthreads();
+    }
+    const uint8_t* bulk = data + head;
+    const uint32_t blen = len - head, nst = blen / STRIPE;
+    v = xxh_absorb<T>(v, bulk, nst, stage, lane);
+    newms = blen - nst * STRIPE;
+    if (lane < newms) memb[lane] = bulk[(size_t)nst * STRIPE + lane];
+    __syncthreads();
+  }
+  const T v1 = xxh_lane_get(v, 0), v2 = xxh_lane_get(v, 1), v3 = xxh_lane_get(v, 2), v4 = xxh_lane_get(v, 3);
+  if (lane < 4u) rec->v[lane] = v;
+  if (lane < newms) rec->mem[lane] = memb[lane];
+  if (lane == 0) {
+    rec->total = total;
+    rec->seed = seed;
+    rec->memsize = newms;
+    rec->digest = XxhOps<T>::finish(v1, v2, v3, v4, seed, memb, newms, total);
+  }
+}
+int launch_xxh32_stream(void* rec, const uint8_t* data, uint32_t len, int reset, uint32_t seed, void* stream) {
+  hipLaunchKernelGGL(xxh_stream_kernel<uint32_t>, dim3(1), dim3(64), 0, (hipStream_t)stream, (XxhRec<uint32_t>*)rec, data, len, reset, seed);
+  return (int)hipGetLastError();
+}
+int launch_xxh64_stream(void* rec, const uint8_t* data, uint32_t len, int reset, uint64_t seed, void* stream) {
+  hipLaunchKernelGGL(xxh_stream_kernel<uint64_t>, dim3(1), dim3(64), 0, (hipStream_t)stream, (XxhRec<uint64_t>*)rec, data, len, reset, seed);
+  return (int)hipGetLastError();
+}
+size_t xxh_stream_rec_bytes(bool is64) { return is64 ? sizeof(XxhRec<uint64_t>) : sizeof(XxhRec<uint32_t>); }
+size_t xxh_stream_digest_offset(bool is64) { return is64 ? offsetof(XxhRec<uint64_t>, digest) : offsetof(XxhRec<uint32_t>, digest); }
+
 int launch_xxh64(const uint8_t* buf, const uint64_t* off, const int32_t* len, uint64_t seed, uint64_t* out, uint32_t n, void* stream) {
   if (n == 0) return 0;
-  hipLaunchKernelGGL(xxh64_kernel, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, buf, off, len, seed, out, n);
+  if (n <= 512u) hipLaunchKernelGGL(xxh64_wave_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, buf, off, len, seed, out);
+  else hipLaunchKernelGGL(xxh64_kernel, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, buf, off, len, seed, out, n);
   return (int)hipGetLastError();
 }
 

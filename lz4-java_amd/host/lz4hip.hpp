@@ -167,10 +167,54 @@ struct XXHash64 {
     return (int64_t)h;
   }
 };
+// StreamingXXHash32.java:38-129 / StreamingXXHash64.java (JNI twins StreamingXXHash32JNI.java:28-104): the state is a device
+// record behind a lz4hip_xxh_stream handle; update() continues it with one launch.
+namespace detail {
+inline void xchk(int rc) { if (rc != 0) throw std::runtime_error(std::string("liblz4hip: ") + lz4hip_last_error()); }
+class StreamingBase {
+ public:
+  StreamingBase(const StreamingBase&) = delete;
+  StreamingBase& operator=(const StreamingBase&) = delete;
+  ~StreamingBase() { close(); }
+  void update(const bytes& buf, int off, int len) {
+    checkState();
+    util::checkRange(buf, off, len);
+    xchk(lz4hip_xxh_stream_update(st_, buf.data() + off, len));
+  }
+  void update(const uint8_t* p, size_t n) {  // raw overload for the stream classes (pieces of <= 1 GiB)
+    checkState();
+    while (n) { const size_t part = n < (1u << 30) ? n : (1u << 30); xchk(lz4hip_xxh_stream_update(st_, p, (int)part)); p += part; n -= part; }
+  }
+  void close() { if (st_) { lz4hip_xxh_stream_free(st_); st_ = nullptr; } }
+ protected:
+  StreamingBase() = default;
+  void checkState() const { if (!st_) throw std::logic_error("Already finalized"); }  // StreamingXXHash32JNI.java:47-51
+  lz4hip_xxh_stream* st_ = nullptr;
+};
+}  // namespace detail
+class StreamingXXHash32 final : public detail::StreamingBase {
+ public:
+  explicit StreamingXXHash32(int32_t seed) : seed_(seed) { detail::xchk(lz4hip_xxh32_stream_create((uint32_t)seed, &st_)); }
+  int32_t getValue() { checkState(); uint32_t h = 0; detail::xchk(lz4hip_xxh32_stream_digest(st_, &h)); return (int32_t)h; }
+  void reset() { checkState(); detail::xchk(lz4hip_xxh_stream_reset(st_, (uint32_t)seed_)); }
+  int64_t checksumValue() { return (int64_t)((uint32_t)getValue() & 0xFFFFFFFu); }  // asChecksum().getValue(): 28 bits (:101-107)
+ private:
+  int32_t seed_;
+};
+class StreamingXXHash64 final : public detail::StreamingBase {
+ public:
+  explicit StreamingXXHash64(int64_t seed) : seed_(seed) { detail::xchk(lz4hip_xxh64_stream_create((uint64_t)seed, &st_)); }
+  int64_t getValue() { checkState(); uint64_t h = 0; detail::xchk(lz4hip_xxh64_stream_digest(st_, &h)); return (int64_t)h; }
+  void reset() { checkState(); detail::xchk(lz4hip_xxh_stream_reset(st_, (uint64_t)seed_)); }
+ private:
+  int64_t seed_;
+};
 struct XXHashFactory {
   static XXHashFactory& hipInstance() { static XXHashFactory f; return f; }
   XXHash32 hash32() const { return XXHash32(); }
   XXHash64 hash64() const { return XXHash64(); }
+  std::unique_ptr<StreamingXXHash32> newStreamingHash32(int32_t seed) const { return std::unique_ptr<StreamingXXHash32>(new StreamingXXHash32(seed)); }  // XXHashFactory.java:230
+  std::unique_ptr<StreamingXXHash64> newStreamingHash64(int64_t seed) const { return std::unique_ptr<StreamingXXHash64>(new StreamingXXHash64(seed)); }  // :240
 };
 }  // namespace xxhash
 

@@ -163,7 +163,7 @@ class LZ4FrameOutputStream {
     writeBlocks(buf_.size());
     bytes tail;
     detail::putLE32(tail, 0);
-    if (flg_.isEnabled(frame::CONTENT_CHECKSUM)) detail::putLE32(tail, e_.xxh32_one(content_.data(), content_.size(), 0));
+    if (flg_.isEnabled(frame::CONTENT_CHECKSUM)) detail::putLE32(tail, (uint32_t)content().getValue());
     out_.write((const char*)tail.data(), (std::streamsize)tail.size());
     out_.flush();
     finished_ = true;
@@ -175,7 +175,7 @@ class LZ4FrameOutputStream {
     if (nbytes == 0) return;
     bytes data(buf_.begin(), buf_.begin() + (std::ptrdiff_t)nbytes);
     buf_.erase(buf_.begin(), buf_.begin() + (std::ptrdiff_t)nbytes);
-    if (flg_.isEnabled(frame::CONTENT_CHECKSUM)) content_.insert(content_.end(), data.begin(), data.end());
+    if (flg_.isEnabled(frame::CONTENT_CHECKSUM)) content().update(data.data(), data.size());  // :211-213
     const detail::Compressed c = detail::compressBlocks(e_, data, maxBlockSize_);
     const bool bc = flg_.isEnabled(frame::BLOCK_CHECKSUM);
     bytes o;
@@ -209,7 +209,9 @@ class LZ4FrameOutputStream {
   int64_t knownSize_;
   size_t batch_;
   int maxBlockSize_ = 0;
-  bytes buf_, content_;
+  xxhash::StreamingXXHash32& content() { if (!content_) content_.reset(new xxhash::StreamingXXHash32(0)); return *content_; }
+  bytes buf_;
+  std::unique_ptr<xxhash::StreamingXXHash32> content_;  // LZ4FrameOutputStream.java:116
   bool finished_ = false;
 };
 
@@ -270,7 +272,7 @@ class LZ4FrameInputStream {
     uint8_t expected;
     readFully(&expected, 1);
     if (h != expected) throw IOException(frame::DESCRIPTOR_HASH_MISMATCH);
-    content_.clear();
+    content_.reset();
     headerRead_ = true;
     frameFinished_ = false;
     inFrame_ = true;
@@ -327,12 +329,14 @@ class LZ4FrameInputStream {
           outs[cidx[k]].assign(dst.begin() + (std::ptrdiff_t)d_o[k], dst.begin() + (std::ptrdiff_t)d_o[k] + res[k]);
         }
       }
+      bytes fresh;
       for (size_t i = 0; i < bad; i++) {
         const bytes& piece = blocks[i].compressed ? outs[i] : blocks[i].payload;
-        ready_.insert(ready_.end(), piece.begin(), piece.end());
-        if (bit(frame::CONTENT_CHECKSUM)) content_.insert(content_.end(), piece.begin(), piece.end());
-        totalContentSize_ += (int64_t)piece.size();
+        fresh.insert(fresh.end(), piece.begin(), piece.end());
       }
+      ready_.insert(ready_.end(), fresh.begin(), fresh.end());
+      totalContentSize_ += (int64_t)fresh.size();
+      if (bit(frame::CONTENT_CHECKSUM) && !fresh.empty()) content().update(fresh.data(), fresh.size());  // one update per batch
       if (!badExc.empty()) { pending_ = badExc; return; }
     }
     if (!exc.empty()) { pending_ = exc; return; }
@@ -341,7 +345,7 @@ class LZ4FrameInputStream {
         if (bit(frame::CONTENT_CHECKSUM)) {
           uint8_t w4[4];
           readFully(w4, 4);
-          if (detail::getLE32(w4) != e_.xxh32_one(content_.data(), content_.size(), 0)) throw IOException("Content checksum mismatch");
+          if (detail::getLE32(w4) != (uint32_t)content().getValue()) throw IOException("Content checksum mismatch");
         }
         if (bit(frame::CONTENT_SIZE) && expectedContentSize_ != totalContentSize_) throw IOException("Size check mismatch");
       } catch (const IOException& e) { pending_ = e.what(); return; }
@@ -368,7 +372,8 @@ class LZ4FrameInputStream {
   int flgBits_ = 0, maxBlockSize_ = 0;
   int64_t expectedContentSize_ = -1, totalContentSize_ = 0;
   std::deque<uint8_t> ready_;
-  bytes content_;
+  xxhash::StreamingXXHash32& content() { if (!content_) content_.reset(new xxhash::StreamingXXHash32(0)); return *content_; }
+  std::unique_ptr<xxhash::StreamingXXHash32> content_;
   std::string pending_;
 };
 

@@ -1,0 +1,72 @@
+package net.jpountz.xxhash;
+
+/**
+ * "HIP" family member of {@link StreamingXXHash32} (twin of StreamingXXHash32JNI.java:28-104).  The state lives in a device
+ * record behind a native handle; every update continues it with one launch.  {@code XXHashFactory.instance("HIP")} finds the
+ * nested Factory by name (XXHashFactory.java:179-182).  Methods are synchronized for the same reason as in the JNI twin:
+ * finalize() may free the native state concurrently.
+ */
+final class StreamingXXHash32HIP extends StreamingXXHash32 {
+
+  static class Factory implements StreamingXXHash32.Factory {
+
+    public static final StreamingXXHash32.Factory INSTANCE = new Factory();
+
+    @Override
+    public StreamingXXHash32 newStreamingHash(int seed) {
+      return new StreamingXXHash32HIP(seed);
+    }
+
+  }
+
+  private long state;
+
+  StreamingXXHash32HIP(int seed) {
+    super(seed);
+    state = XXHashHIPJNI.XXH32_init(seed);
+  }
+
+  private void checkState() {
+    if (state == 0) {
+      throw new AssertionError("Already finalized");
+    }
+  }
+
+  @Override
+  public synchronized void reset() {
+    checkState();
+    XXHashHIPJNI.XXH32_reset(state, seed);   // keeps the device record, restarts it with the same seed
+  }
+
+  @Override
+  public synchronized int getValue() {
+    checkState();
+    return XXHashHIPJNI.XXH32_digest(state);
+  }
+
+  @Override
+  public synchronized void update(byte[] bytes, int off, int len) {
+    checkState();
+    net.jpountz.util.SafeUtils.checkRange(bytes, off, len);
+    XXHashHIPJNI.XXH32_update(state, bytes, off, len);
+  }
+
+  @Override
+  public synchronized void close() {
+    if (state != 0) {
+      super.close();
+      XXHashHIPJNI.XXH_free(state);
+      state = 0;
+    }
+  }
+
+  @Override
+  protected synchronized void finalize() throws Throwable {
+    super.finalize();
+    if (state != 0) {
+      XXHashHIPJNI.XXH_free(state);
+      state = 0;
+    }
+  }
+
+}

@@ -2,7 +2,7 @@ package net.jpountz.xxhash;
 
 import java.nio.ByteBuffer;
 
-/** JNI bindings to liblz4hip's one-shot hashes (twin of XXHashJNI.java; streaming state is out of scope). */
+/** JNI bindings to liblz4hip's hashes (twin of XXHashJNI.java:24-48): one-shot, streaming state, and the batch calls. */
 enum XXHashHIPJNI {
   ;
 
@@ -12,6 +12,16 @@ enum XXHashHIPJNI {
 
   static native int XXH32(byte[] input, int offset, int len, int seed);
   static native int XXH32BB(ByteBuffer input, int offset, int len, int seed);
+  /** streaming state (XXHashJNI.java:33-36, :40-43): a native handle; 0 + a pending OutOfMemoryError when it cannot be created */
+  static native long XXH32_init(int seed);
+  static native void XXH32_reset(long state, int seed);
+  static native void XXH32_update(long state, byte[] input, int offset, int len);
+  static native int XXH32_digest(long state);
+  static native long XXH64_init(long seed);
+  static native void XXH64_reset(long state, long seed);
+  static native void XXH64_update(long state, byte[] input, int offset, int len);
+  static native long XXH64_digest(long state);
+  static native void XXH_free(long state);
   static native long XXH64(byte[] input, int offset, int len, long seed);
   static native long XXH64BB(ByteBuffer input, int offset, int len, long seed);
   /** n buffers of a direct ByteBuffer in one launch: out32/out64 receive the hashes */

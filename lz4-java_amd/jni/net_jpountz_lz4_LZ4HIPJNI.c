@@ -210,3 +210,40 @@ JNIEXPORT jint JNICALL Java_net_jpountz_xxhash_XXHashHIPJNI_XXH64Batch(JNIEnv* e
   if (h) (*env)->ReleaseLongArrayElements(env, out64, h, 0);
   return rc;
 }
+
+/* ---- streaming xxhash (XXHashJNI.c:89-145, :199-255 counterparts): the jlong is a lz4hip_xxh_stream* ---- */
+static jlong stream_init(JNIEnv* env, int is64, uint64_t seed) {
+  lz4hip_xxh_stream* st = NULL;
+  const int rc = is64 ? lz4hip_xxh64_stream_create(seed, &st) : lz4hip_xxh32_stream_create((uint32_t)seed, &st);
+  if (rc != 0) { throw_OOM(env); return 0; }   /* same surface as the reference: XXHashJNI.c:94-98 */
+  return (jlong)(intptr_t)st;
+}
+static void stream_update(JNIEnv* env, jlong state, jbyteArray src, jint off, jint len) {
+  region_t in;   /* staged copy: the GC lock is not held across the launch */
+  if (region_in(env, src, NULL, off, len, 1, &in) != 0) { throw_OOM(env); return; }
+  (void)lz4hip_xxh_stream_update((lz4hip_xxh_stream*)(intptr_t)state, in.p, len);
+  region_out(env, NULL, 0, 0, &in);
+}
+JNIEXPORT jlong JNICALL Java_net_jpountz_xxhash_XXHashHIPJNI_XXH32_1init(JNIEnv* env, jclass cls, jint seed) { (void)cls; return stream_init(env, 0, (uint32_t)seed); }
+JNIEXPORT jlong JNICALL Java_net_jpountz_xxhash_XXHashHIPJNI_XXH64_1init(JNIEnv* env, jclass cls, jlong seed) { (void)cls; return stream_init(env, 1, (uint64_t)seed); }
+JNIEXPORT void JNICALL Java_net_jpountz_xxhash_XXHashHIPJNI_XXH32_1reset(JNIEnv* env, jclass cls, jlong state, jint seed) {
+  (void)env; (void)cls; (void)lz4hip_xxh_stream_reset((lz4hip_xxh_stream*)(intptr_t)state, (uint32_t)seed);
+}
+JNIEXPORT void JNICALL Java_net_jpountz_xxhash_XXHashHIPJNI_XXH64_1reset(JNIEnv* env, jclass cls, jlong state, jlong seed) {
+  (void)env; (void)cls; (void)lz4hip_xxh_stream_reset((lz4hip_xxh_stream*)(intptr_t)state, (uint64_t)seed);
+}
+JNIEXPORT void JNICALL Java_net_jpountz_xxhash_XXHashHIPJNI_XXH32_1update(JNIEnv* env, jclass cls, jlong state, jbyteArray src, jint off, jint len) {
+  (void)cls; stream_update(env, state, src, off, len);
+}
+JNIEXPORT void JNICALL Java_net_jpountz_xxhash_XXHashHIPJNI_XXH64_1update(JNIEnv* env, jclass cls, jlong state, jbyteArray src, jint off, jint len) {
+  (void)cls; stream_update(env, state, src, off, len);
+}
+JNIEXPORT jint JNICALL Java_net_jpountz_xxhash_XXHashHIPJNI_XXH32_1digest(JNIEnv* env, jclass cls, jlong state) {
+  (void)env; (void)cls; uint32_t h = 0; (void)lz4hip_xxh32_stream_digest((lz4hip_xxh_stream*)(intptr_t)state, &h); return (jint)h;
+}
+JNIEXPORT jlong JNICALL Java_net_jpountz_xxhash_XXHashHIPJNI_XXH64_1digest(JNIEnv* env, jclass cls, jlong state) {
+  (void)env; (void)cls; uint64_t h = 0; (void)lz4hip_xxh64_stream_digest((lz4hip_xxh_stream*)(intptr_t)state, &h); return (jlong)h;
+}
+JNIEXPORT void JNICALL Java_net_jpountz_xxhash_XXHashHIPJNI_XXH_1free(JNIEnv* env, jclass cls, jlong state) {
+  (void)env; (void)cls; lz4hip_xxh_stream_free((lz4hip_xxh_stream*)(intptr_t)state);
+}

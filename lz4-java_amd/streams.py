@@ -48,6 +48,12 @@ class HIPEngine:
     decompressFast = staticmethod(LZ4HIPBatch.decompressFast)
     xxh32 = staticmethod(LZ4HIPBatch.xxh32)
 
+    @staticmethod
+    def newStreamingHash32(seed):
+        """content checksum state (LZ4FrameOutputStream.java:116: `XXHashFactory...newStreamingHash32(0)`)"""
+        from . import StreamingXXHash32
+        return StreamingXXHash32(seed)
+
 
 def _compress_batch(engine, data, blockSize):
     """compress data[i*blockSize : +blockSize] for all i in one launch -> (dst, bound, [compressedLength])"""
@@ -171,7 +177,7 @@ class LZ4FrameOutputStream(io.RawIOBase):
         self.knownSize = knownSize
         self.batchBlocks = max(1, batchBlocks)
         self.buffer = bytearray()
-        self.content = bytearray() if self.flg.isEnabled(FLG.Bits.CONTENT_CHECKSUM) else None
+        self.content = self.engine.newStreamingHash32(0) if self.flg.isEnabled(FLG.Bits.CONTENT_CHECKSUM) else None
         self.finished = False
         self._closed = False
         if self.flg.isEnabled(FLG.Bits.CONTENT_SIZE) and knownSize < 0:
@@ -212,7 +218,7 @@ class LZ4FrameOutputStream(io.RawIOBase):
         data = bytes(self.buffer[:nbytes])
         del self.buffer[:nbytes]
         if self.content is not None:
-            self.content += data  # the content checksum is a hash of the whole stream: taken at the end mark
+            self.content.update(data, 0, len(data))  # :211-213: the content checksum streams over the uncompressed bytes
         dst, bound, lens, sizes = _compress_batch(self.engine, data, self.maxBlockSize)
         block_checksum = self.flg.isEnabled(FLG.Bits.BLOCK_CHECKSUM)
         outb = bytearray()
@@ -237,7 +243,8 @@ class LZ4FrameOutputStream(io.RawIOBase):
     def _writeEndMark(self):  # :244-252
         tail = bytearray(_U32.pack(0))
         if self.content is not None:
-            tail += _U32.pack(self.engine.xxh32(bytes(self.content), [0], [len(self.content)], 0)[0])
+            tail += _U32.pack(self.content.getValue())
+            self.content.close()
         self.out.write(bytes(tail))
         self.finished = True
 
@@ -346,7 +353,9 @@ class LZ4FrameInputStream(io.RawIOBase):
         if h != expected:
             raise IOException(DESCRIPTOR_HASH_MISMATCH)
         self.maxBlockSize = self.bd.getBlockMaximumSize()
-        self.content = bytearray() if self.flg.isEnabled(FLG.Bits.CONTENT_CHECKSUM) else None
+        if self.content is not None:
+            self.content.close()
+        self.content = self.engine.newStreamingHash32(0) if self.flg.isEnabled(FLG.Bits.CONTENT_CHECKSUM) else None
         self.firstFrameHeaderRead = True
         self.frame_finished = False
 
@@ -401,12 +410,13 @@ class LZ4FrameInputStream(io.RawIOBase):
                         bad, bad_exc = i, IOException(LZ4Exception("Error decoding offset %d of input buffer" % (-res[k])))
                         break
                     outs[i] = dst[k * self.maxBlockSize: k * self.maxBlockSize + res[k]]
+            first = len(self.ready)
             for i in range(bad):
                 piece = outs[i] if blocks[i][0] else blocks[i][1]
                 self.ready += piece
-                if self.content is not None:
-                    self.content += piece
                 self.totalContentSize += len(piece)
+            if self.content is not None and len(self.ready) > first:  # one update per batch of decoded blocks
+                self.content.update(self.ready, first, len(self.ready) - first)
             if bad_exc is not None:
                 self.pending_exc = bad_exc
                 return
@@ -417,7 +427,7 @@ class LZ4FrameInputStream(io.RawIOBase):
             try:
                 if self.flg.isEnabled(FLG.Bits.CONTENT_CHECKSUM):
                     stored = _U32.unpack(self.r.read_fully(4))[0]
-                    if stored != self.engine.xxh32(bytes(self.content), [0], [len(self.content)], 0)[0]:
+                    if stored != self.content.getValue():
                         raise IOException("Content checksum mismatch")
                 if self.flg.isEnabled(FLG.Bits.CONTENT_SIZE) and self.expectedContentSize != self.totalContentSize:
                     raise IOException("Size check mismatch")

@@ -119,6 +119,29 @@ int main(int argc, char** argv) {
       const std::vector<bytes> h = LZ4CompressorWithLength(BatchEngine{9}).compressMany({bufs[2]});
       CHECK(LZ4DecompressorWithLength().decompressMany(h)[0] == bufs[2] && h[0].size() <= c[2].size());
     }
+    // ---- streaming xxhash (XXHashFactory.java:186-203 self-test shape): any split == the one-shot hash; reset(); closed state ----
+    {
+      auto& xf = xxhash::XXHashFactory::hipInstance();
+      auto h32 = xf.newStreamingHash32((int32_t)0x9747b28c);
+      auto h64 = xf.newStreamingHash64(-7);
+      CHECK(h32->getValue() == xf.hash32().hash(data, 0, 0, (int32_t)0x9747b28c));
+      size_t pos = 0, step = 1;
+      while (pos < data.size()) {
+        const size_t n = std::min(step, data.size() - pos);
+        h32->update(data, (int)pos, (int)n);
+        h64->update(data, (int)pos, (int)n);
+        pos += n;
+        step = step * 3 + 5;
+      }
+      CHECK(h32->getValue() == xf.hash32().hash(data, 0, (int)data.size(), (int32_t)0x9747b28c));
+      CHECK(h64->getValue() == xf.hash64().hash(data, 0, (int)data.size(), -7));
+      CHECK(h32->checksumValue() == (int64_t)((uint32_t)h32->getValue() & 0xFFFFFFFu));
+      h32->reset();
+      h32->update(data, 5, 100);
+      CHECK(h32->getValue() == xf.hash32().hash(data, 5, 100, (int32_t)0x9747b28c));
+      h32->close();
+      CHECK(thrown([&] { h32->getValue(); }) == "Already finalized");
+    }
     printf("stream mirror ok (%zu payload bytes)\n", data.size());
     return 0;
   } catch (const LZ4Exception& e) {

@@ -50,6 +50,26 @@ class OracleEngine:
     def xxh32(self, buf, off, length, seed=0):
         return [self.port.xxh32(bytes(buf[o:o + n]), seed) for o, n in zip(off, length)]
 
+    def newStreamingHash32(self, seed):
+        port = self.port
+
+        class H:  # the oracle has no streaming state: hash the concatenation
+            def __init__(self):
+                self.data = bytearray()
+
+            def update(self, buf, off, length):
+                self.data += bytes(buf[off:off + length])
+
+            def getValue(self):
+                return port.xxh32(bytes(self.data), seed)
+
+            def reset(self):
+                self.data = bytearray()
+
+            def close(self):
+                pass
+        return H()
+
 
 def payload(corpus, O):
     """~1.1 MB mixed: text, synthetic LZ blocks, an incompressible stretch, zeros, a ragged tail"""

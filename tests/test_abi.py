@@ -109,3 +109,25 @@ def test_cpp_stream_mirror_builds():
         import tempfile
         with tempfile.TemporaryDirectory() as d:
             assert subprocess.call([exe, d], stderr=subprocess.DEVNULL) == 3
+
+
+def test_java_natives_match_jni_shim():
+    """every `static native` method of the Java binding classes has its Java_* function in the shim and vice versa
+    (JNI name mangling: '_' -> '_1'); the factory-by-name classes XXHashFactory.instance("HIP") looks up exist."""
+    import glob
+    import re
+    shim = open(os.path.join(ROOT, "lz4-java_amd", "jni", "net_jpountz_lz4_LZ4HIPJNI.c")).read()
+    exported = set(re.findall(r"JNICALL\s+(Java_\w+)\s*\(", shim))
+    declared = set()
+    for path in glob.glob(os.path.join(ROOT, "lz4-java_amd", "java", "net", "jpountz", "*", "*HIPJNI.java")):
+        src = open(path).read()
+        pkg = re.search(r"package\s+([\w.]+);", src).group(1)
+        cls = os.path.basename(path)[:-5]
+        for name in re.findall(r"static\s+native\s+[\w\[\]]+\s+(\w+)\s*\(", src):
+            declared.add("Java_%s_%s_%s" % (pkg.replace(".", "_"), cls, name.replace("_", "_1")))
+    assert declared and declared == exported, (sorted(declared - exported), sorted(exported - declared))
+    xx = os.path.join(ROOT, "lz4-java_amd", "java", "net", "jpountz", "xxhash")
+    for cls in ("XXHash32HIP", "XXHash64HIP", "StreamingXXHash32HIP", "StreamingXXHash64HIP"):   # XXHashFactory.java:178-182
+        assert os.path.exists(os.path.join(xx, cls + ".java")), cls
+    for cls in ("StreamingXXHash32HIP", "StreamingXXHash64HIP"):
+        assert "static class Factory implements" in open(os.path.join(xx, cls + ".java")).read()

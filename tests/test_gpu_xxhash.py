@@ -79,3 +79,57 @@ def test_few_long_buffers_wave_kernel(amd, ref):
             assert g == ref.xxh32(buf[o:o + n], seed), (o, n, seed)
     h32 = amd.XXHashFactory.hipInstance().hash32()
     assert h32.hash(buf, 5, len(buf) - 5, 1) == ref.xxh32(buf[5:], 1)
+
+
+def test_streaming_equals_one_shot(amd, ref):
+    """XXHash32Test / XXHash64Test streaming cases: any split of the input into update() calls gives the one-shot
+    hash of the whole; getValue() between updates is the hash of the prefix; reset() starts over with the same seed."""
+    rng = random.Random(23)
+    f = amd.XXHashFactory.hipInstance()
+    data = rng.randbytes(300000)
+    for seed32, seed64 in ((0, 0), (0x9747b28c, 0x9747b28c), (rng.getrandbits(32), rng.getrandbits(64))):
+        with f.newStreamingHash32(seed32) as h32, f.newStreamingHash64(seed64) as h64:
+            assert h32.getValue() == ref.xxh32(b"", seed32) and h64.getValue() == ref.xxh64(b"", seed64)
+            for trial in range(6):
+                n = rng.choice([0, 1, 15, 16, 17, 31, 32, 33, 100, 4096 + 7, 8192 * 3 + 5, len(data)])
+                pos = 0
+                while pos < n:
+                    step = min(n - pos, rng.choice([1, 2, 3, 5, 11, 15, 16, 17, 31, 32, 33, 63, 64, 1000, 4096, 8192, 50000]))
+                    h32.update(data, pos, step)
+                    h64.update(data, pos, step)
+                    pos += step
+                    if rng.random() < 0.3:
+                        assert h32.getValue() == ref.xxh32(data[:pos], seed32), (n, pos)
+                        assert h64.getValue() == ref.xxh64(data[:pos], seed64), (n, pos)
+                assert h32.getValue() == ref.xxh32(data[:n], seed32), n
+                assert h64.getValue() == ref.xxh64(data[:n], seed64), n
+                assert h32.asChecksum().getValue() == ref.xxh32(data[:n], seed32) & 0xFFFFFFF
+                h32.reset()
+                h64.reset()
+        with pytest.raises(AssertionError):
+            h32.getValue()  # closed: "Already finalized" (StreamingXXHash32JNI.java:47-51)
+    with f.newStreamingHash32(1) as h:
+        with pytest.raises(IndexError):
+            h.update(b"abc", 2, 5)
+
+
+def test_streaming_device_updates_and_long_xxh64(amd, ref):
+    """update_device hashes device-resident bytes where they lie; a long single XXH64 buffer takes the wave kernel"""
+    import torch
+    rng = random.Random(29)
+    data = rng.randbytes((1 << 20) + 13)
+    t = torch.frombuffer(bytearray(data), dtype=torch.uint8).to("cuda:0")
+    f = amd.XXHashFactory.hipInstance()
+    with f.newStreamingHash32(7) as h32, f.newStreamingHash64(7) as h64:
+        pos = 0
+        for step in (5, 4096, 100000, 31, len(data)):
+            step = min(step, len(data) - pos)
+            h32.update_device(t.data_ptr() + pos, step)
+            h64.update_device(t.data_ptr() + pos, step)
+            pos += step
+        assert pos == len(data)
+        assert h32.getValue() == ref.xxh32(data, 7) and h64.getValue() == ref.xxh64(data, 7)
+    assert f.hash64().hash(data, 0, len(data), 99) == ref.xxh64(data, 99)
+    assert f.hash64().hash(data, 3, 8192, 99) == ref.xxh64(data[3:3 + 8192], 99)
+    got = amd.LZ4HIPBatch.xxh64(data, [0, 1, 100], [len(data), 70000, 8191], 5)
+    assert list(got) == [ref.xxh64(data, 5), ref.xxh64(data[1:70001], 5), ref.xxh64(data[100:100 + 8191], 5)]
