@@ -122,24 +122,17 @@ struct DirectOut {
     if (!pend.have) return true;
     pend.have = false;
     const uint32_t lit = pend.lit, mc = pend.mc, offset = pend.offset;
-    if (LZ4HIP_UNLIKELY(limited)) {
-      const uint32_t nlx_ = ext_count(lit);
-      if (pend.check_lits && (uint64_t)op + 1u + lit + (2u + 1u + 5u) + lit / 255u > cap) return false;
-      if ((uint64_t)op + 1u + nlx_ + lit + 2u + (1u + 5u) + (mc + 240u) / 255u > cap) return false;
-    }
     const uint32_t token = ((lit < 15u ? lit : 15u) << 4) | (mc < 15u ? mc : 15u);
-    // (regs implies at most one length byte each: no division on the hot path)
-    const uint32_t nlx = pend.regs ? (lit >= 15u ? 1u : 0u) : ext_count(lit);
-    const uint32_t nmx = pend.regs ? (mc >= 15u ? 1u : 0u) : ext_count(mc);
-    const uint32_t total = 1u + nlx + lit + 2u + nmx;
-    const VU i = w.lane();
-    if (LZ4HIP_LIKELY(pend.regs)) {
-      // The common case, branch-free, ONE store instruction, no cross-lane traffic (nlx, nmx <= 1, total <= 63):
-      // lane 0 writes the token; lane l >= 1 writes output byte l + nlx, so the literal it needs (literal l-1)
-      // is byte 0 of its own window word; when a literal-length byte exists (nlx == 1) the otherwise idle lane
-      // 63 writes it at index 1; bytes past the literals come from the 3-byte trailer word {offset, ml-15}.
-      const uint32_t off0 = 1u + nlx + lit;
+    if (LZ4HIP_LIKELY(pend.regs && !limited)) {
+      // The common case, branch-free, ONE store instruction, no cross-lane traffic (regs implies at most one length byte
+      // each and total <= 63: no division, no loop): lane 0 writes the token; lane l >= 1 writes output byte l + nlx, so
+      // the literal it needs (literal l-1) is byte 0 of its own window word; when a literal-length byte exists (nlx == 1)
+      // the otherwise idle lane 63 writes it at index 1; bytes past the literals come from the 3-byte trailer word
+      // {offset, ml-15}.
+      const uint32_t nlx = lit >= 15u ? 1u : 0u, nmx = mc >= 15u ? 1u : 0u;
+      const uint32_t off0 = 1u + nlx + lit, total = off0 + 2u + nmx;
       const uint32_t trl = offset | ((mc - 15u) << 16);  // third byte only used when nmx == 1
+      const VU i = w.lane();
       const VB ext_lane = (i == 63u) & VB(nlx != 0u);
       const VU oi = W::select(ext_lane, VU(1u), W::select(i == 0u, VU(0u), i + nlx));
       const VU tb = W::shr(VU(trl), ((oi - off0) * 8u) & 31u) & 0xFFu;  // garbage for oi < off0 (never selected)
@@ -147,9 +140,22 @@ struct DirectOut {
       b = W::select(i == 0u, VU(token), b);
       b = W::select(ext_lane, VU(lit - 15u), b);
       w.st8(dst, oi + op, b, (oi < total));
-    } else {
-      emit_generic(lit, mc, offset, nlx, nmx, token, total);
+      op += total;
+      return true;
     }
+    return emit_checked(lit, mc, offset, token);
+  }
+
+  // everything else: a limited output buffer (liblz4's two capacity checks), literals that are not in the window registers,
+  // long length runs
+  LZ4HIP_COLD bool emit_checked(uint32_t lit, uint32_t mc, uint32_t offset, uint32_t token) {
+    const uint32_t nlx = ext_count(lit), nmx = ext_count(mc);
+    if (limited) {
+      if (pend.check_lits && (uint64_t)op + 1u + lit + (2u + 1u + 5u) + lit / 255u > cap) return false;
+      if ((uint64_t)op + 1u + nlx + lit + 2u + (1u + 5u) + (mc + 240u) / 255u > cap) return false;
+    }
+    const uint32_t total = 1u + nlx + lit + 2u + nmx;
+    emit_generic(lit, mc, offset, nlx, nmx, token, total);
     op += total;
     return true;
   }
