@@ -117,14 +117,23 @@ uint32_t cu_count() {
 // fast compress: single-wave kernel, or (default) the two-wave kernel with its zeroed ring workspace
 int launch_fast(const lz4hip::BatchArgs& a, hipStream_t st) {
   if (g_compress_waves != 2) {
-    if (g_compress_core == 0) return lz4hip::launch_compress_fast(a, nullptr, 0u, st);
-    if (g_compress_core == 1) return lz4hip::launch_compress_fast_ms(a, nullptr, st);
-    uint8_t* route = nullptr;
-    hipError_t e = hipMallocAsync((void**)&route, ((size_t)a.n + 7u) & ~(size_t)3u, st);
+    // scratch: the route bytes of the adaptive scheme (padded to 4 bytes) + the two block-queue words of the CU-filling kernels
+    const size_t route_bytes = ((size_t)a.n + 7u) & ~(size_t)3u;
+    uint8_t* scratch = nullptr;
+    hipError_t e = hipMallocAsync((void**)&scratch, route_bytes + 2 * sizeof(uint32_t), st);
     if (e != hipSuccess) return (int)e;
-    int le = lz4hip::launch_compress_fast(a, route, 64u * (uint32_t)g_compress_switch, st);
-    if (le == 0) le = lz4hip::launch_compress_fast_ms(a, route, st);
-    (void)hipFreeAsync(route, st);
+    uint32_t* queue = (uint32_t*)(scratch + route_bytes);
+    const uint32_t cus = cu_count();
+    int le;
+    if (g_compress_core == 0) {
+      le = lz4hip::launch_compress_fast(a, nullptr, 0u, queue, cus, st);
+    } else if (g_compress_core == 1) {
+      le = lz4hip::launch_compress_fast_ms(a, nullptr, queue + 1, cus, st);
+    } else {
+      le = lz4hip::launch_compress_fast(a, scratch, 64u * (uint32_t)g_compress_switch, queue, cus, st);
+      if (le == 0) le = lz4hip::launch_compress_fast_ms(a, scratch, queue + 1, cus, st);
+    }
+    (void)hipFreeAsync(scratch, st);
     return le;
   }
   const uint32_t grid = lz4hip::compress_fast2_grid(a.n, cu_count());

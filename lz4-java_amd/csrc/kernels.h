@@ -18,8 +18,10 @@ struct BatchArgs {
 // Adaptive two-pass use: launch_compress_fast(route = n-byte device buffer, dense64) finishes the blocks with long sequences
 // and marks the others (route[b] = 1: sequences 32..95 cover fewer than dense64 bytes); launch_compress_fast_ms(route) then
 // does exactly those.  route == nullptr: the kernel does every block.
-int launch_compress_fast(const BatchArgs& a, uint8_t* route, uint32_t dense64, void* stream);
-int launch_compress_fast_ms(const BatchArgs& a, const uint8_t* route, void* stream);
+// `queue`: one device uint32_t (the block queue of the CU-filling kernel, zeroed by the launch; nullptr = one workgroup per block),
+// n_cus: compute units of the device
+int launch_compress_fast(const BatchArgs& a, uint8_t* route, uint32_t dense64, uint32_t* queue, uint32_t n_cus, void* stream);
+int launch_compress_fast_ms(const BatchArgs& a, const uint8_t* route, uint32_t* queue, uint32_t n_cus, void* stream);
 void set_dbg_flags(uint32_t f);  // developer diagnostics
 void set_dbg_extra_lds(uint32_t bytes);
 // two-wave variant: `ws` = zeroed device workspace of compress_fast2_ws_bytes(grid) bytes

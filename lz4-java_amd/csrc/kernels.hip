@@ -31,6 +31,15 @@ void set_dbg_flags(uint32_t f) { g_dbg_flags = f; }
 // ------------------------------------------------------------------------------------------------
 // fast compress
 // ------------------------------------------------------------------------------------------------
+// Values loaded after a kernel's first store (every block but the first of a persistent wavefront) are fetched with vector
+// loads; readfirstlane puts the wave-uniform result back into scalar registers, which keeps the parser state scalar and every
+// access of the block in the {scalar base + lane offset} addressing form.
+template <class T> __device__ __forceinline__ T* uniform_ptr(T* q) {
+  const uint64_t v = (uint64_t)q;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return (T*)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ int32_t uniform_i32(int32_t v) { return (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)v); }
 // `route` (may be null): per-block routing byte of the adaptive two-pass scheme.  This kernel probes the density of each
 // block (lz4_fast_core.h, dense64); a block of short sequences is left unfinished with route[b] = 1 for compress_fast_ms_kernel.
 __global__ __launch_bounds__(64) void compress_fast_kernel(BatchArgs a, uint32_t dbg_flags, uint8_t* route, uint32_t dense64) {
@@ -68,14 +77,60 @@ __global__ __launch_bounds__(64) void compress_fast_kernel(BatchArgs a, uint32_t
   }
 }
 
+#ifndef LZ4HIP_WPC
+#define LZ4HIP_WPC 5
+#endif
+constexpr uint32_t WAVES_PER_CU = LZ4HIP_WPC;
+__global__ __launch_bounds__(64 * WAVES_PER_CU) void compress_fast_cu_kernel(BatchArgs a, uint32_t* next_block, uint8_t* route, uint32_t dense64) {
+  __shared__ __attribute__((aligned(16))) uint64_t tables[WAVES_PER_CU][4096];
+  uint64_t* table = tables[threadIdx.x >> 6];
+  for (;;) {
+    uint32_t b = 0;
+    if (__lane_id() == 0) b = atomicAdd(next_block, 1u);
+    b = __builtin_amdgcn_readfirstlane(b);
+    if (b >= a.n) return;
+  const int32_t n = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)a.src_len[b]);
+    const int32_t cap = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)a.dst_cap[b]);
+    uint32_t r = 0;
+    if (n >= 0 && (uint32_t)n <= 0x7E000000u && cap >= 0) {
+      const uint8_t* s = uniform_ptr(a.src + a.src_off[b]);
+      uint8_t* d = uniform_ptr(a.dst + a.dst_off[b]);
+      WaveDev w(table);
+      DirectOut<WaveDev> out(w, s, (uint32_t)n, d, (uint32_t)cap);
+      
+      bool bailed;
+      if (n < 65547) {
+        FastCore<WaveDev, true> c(w, out, s, (uint32_t)n);
+        c.dense64 = route ? dense64 : 0u;
+        r = c.run();
+        bailed = c.bailed;
+      } else {
+        FastCore<WaveDev, false> c(w, out, s, (uint32_t)n);
+        c.dense64 = route ? dense64 : 0u;
+        r = c.run();
+        bailed = c.bailed;
+      }
+      if (bailed) {
+        if (__lane_id() == 0) route[b] = 1;
+        continue;
+      }
+    }
+    if (__lane_id() == 0) {
+      a.out[b] = (int32_t)r;
+      if (route) route[b] = 0;
+    }
+  
+    WaveDev::sync();
+  }
+}
 // window-parallel core (lz4_fast_ms_core.h): every sequence of a 64-position window per step
 __device__ __forceinline__ void compress_fast_ms_block(const BatchArgs& a, uint32_t b, uint64_t* table) {
-  const int32_t n = a.src_len[b];
-  const int32_t cap = a.dst_cap[b];
+  const int32_t n = uniform_i32(a.src_len[b]);
+  const int32_t cap = uniform_i32(a.dst_cap[b]);
   uint32_t r = 0;
   if (n >= 0 && (uint32_t)n <= 0x7E000000u && cap >= 0) {
-    const uint8_t* s = a.src + a.src_off[b];
-    uint8_t* d = a.dst + a.dst_off[b];
+    const uint8_t* s = uniform_ptr(a.src + a.src_off[b]);
+    uint8_t* d = uniform_ptr(a.dst + a.dst_off[b]);
     WaveDev w(table);
     DirectOut<WaveDev> out(w, s, (uint32_t)n, d, (uint32_t)cap);
     if (n < 65547) {
@@ -86,7 +141,7 @@ __device__ __forceinline__ void compress_fast_ms_block(const BatchArgs& a, uint3
       r = c.run();
     }
   }
-  if (threadIdx.x == 0) a.out[b] = (int32_t)r;
+  if (__lane_id() == 0) a.out[b] = (int32_t)r;
 }
 // every block of the batch, one workgroup per block
 __global__ __launch_bounds__(64) void compress_fast_ms_kernel(BatchArgs a) {
@@ -108,10 +163,40 @@ __global__ __launch_bounds__(64) void compress_fast_ms_routed_kernel(BatchArgs a
     __builtin_amdgcn_s_barrier();  // (single-wave workgroup) the table is reused
   }
 }
-int launch_compress_fast_ms(const BatchArgs& a, const uint8_t* route, void* stream) {
+// CU-filling form (see compress_fast_cu_kernel): WAVES_PER_CU wavefronts per workgroup, each drawing groups of ROUTE_GROUP
+// blocks from the queue word and compressing the marked ones (route == nullptr: all of them)
+__global__ __launch_bounds__(64 * WAVES_PER_CU) void compress_fast_ms_cu_kernel(BatchArgs a, const uint8_t* route, uint32_t* next_group) {
+  __shared__ __attribute__((aligned(16))) uint64_t tables[WAVES_PER_CU][4096];
+  uint64_t* table = tables[threadIdx.x >> 6];
+  for (;;) {
+    uint32_t g = 0;
+    if (__lane_id() == 0) g = atomicAdd(next_group, 1u);
+    const uint32_t b0 = __builtin_amdgcn_readfirstlane(g) * ROUTE_GROUP;
+    if (b0 >= a.n) return;
+    uint32_t marks = 0x01010101u;
+    if (route) {
+      if (b0 + ROUTE_GROUP <= a.n) marks = *(const uint32_t*)(route + b0);  // (the route buffer is 4-byte aligned and padded)
+      else { marks = 0; for (uint32_t i = 0; b0 + i < a.n; i++) marks |= (uint32_t)route[b0 + i] << (8u * i); }
+      marks = __builtin_amdgcn_readfirstlane(marks);
+    }
+    for (uint32_t i = 0; i < ROUTE_GROUP && b0 + i < a.n; i++) {
+      if (!((marks >> (8u * i)) & 0xFFu)) continue;
+      compress_fast_ms_block(a, b0 + i, table);
+      WaveDev::sync();  // the table is reused
+    }
+  }
+}
+int launch_compress_fast_ms(const BatchArgs& a, const uint8_t* route, uint32_t* queue, uint32_t n_cus, void* stream) {
   if (a.n == 0) return 0;
-  if (route) hipLaunchKernelGGL(compress_fast_ms_routed_kernel, dim3((a.n + ROUTE_GROUP - 1) / ROUTE_GROUP), dim3(64), g_dbg_extra_lds, (hipStream_t)stream, a, route);
-  else hipLaunchKernelGGL(compress_fast_ms_kernel, dim3(a.n), dim3(64), g_dbg_extra_lds, (hipStream_t)stream, a);
+  if (g_dbg_extra_lds || !queue) {
+    if (route) hipLaunchKernelGGL(compress_fast_ms_routed_kernel, dim3((a.n + ROUTE_GROUP - 1) / ROUTE_GROUP), dim3(64), g_dbg_extra_lds, (hipStream_t)stream, a, route);
+    else hipLaunchKernelGGL(compress_fast_ms_kernel, dim3(a.n), dim3(64), g_dbg_extra_lds, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+  }
+  hipError_t e = hipMemsetAsync(queue, 0, sizeof(uint32_t), (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  const uint32_t groups = (a.n + ROUTE_GROUP - 1u) / ROUTE_GROUP, wgs = (groups + WAVES_PER_CU - 1u) / WAVES_PER_CU;
+  hipLaunchKernelGGL(compress_fast_ms_cu_kernel, dim3(wgs < n_cus ? wgs : n_cus), dim3(64 * WAVES_PER_CU), 0, (hipStream_t)stream, a, route, queue);
   return (int)hipGetLastError();
 }
 
@@ -293,7 +378,7 @@ uint32_t compress_fast2_grid(uint32_t n_blocks, uint32_t n_cus) {
 }
 size_t compress_fast2_ws_bytes(uint32_t grid) { return (size_t)grid * RING_WG_BYTES + 64u; }
 
-int launch_compress_fast(const BatchArgs& a, uint8_t* route, uint32_t dense64, void* stream) {
+int launch_compress_fast(const BatchArgs& a, uint8_t* route, uint32_t dense64, uint32_t* queue, uint32_t n_cus, void* stream) {
   if (a.n == 0) return 0;
   if (getenv("LZ4HIP_DEBUG")) {
     int nb = -1;
@@ -302,7 +387,14 @@ int launch_compress_fast(const BatchArgs& a, uint8_t* route, uint32_t dense64, v
     fprintf(stderr, "[lz4hip] compress_fast_kernel: occupancy API says %d workgroups/CU (err %d), extra LDS %u, sharedMemPerMultiprocessor %zu, maxSharedMemoryPerMultiProcessor %zu, sharedMemPerBlock %zu\n",
             nb, (int)e, g_dbg_extra_lds, (size_t)pr.sharedMemPerMultiprocessor, (size_t)pr.maxSharedMemoryPerMultiProcessor, (size_t)pr.sharedMemPerBlock);
   }
-  hipLaunchKernelGGL(compress_fast_kernel, dim3(a.n), dim3(64), g_dbg_extra_lds, (hipStream_t)stream, a, g_dbg_flags, route, dense64);
+  if (g_dbg_extra_lds || !queue) {
+    hipLaunchKernelGGL(compress_fast_kernel, dim3(a.n), dim3(64), g_dbg_extra_lds, (hipStream_t)stream, a, g_dbg_flags, route, dense64);
+    return (int)hipGetLastError();
+  }
+  hipError_t e = hipMemsetAsync(queue, 0, sizeof(uint32_t), (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  const uint32_t wgs = (a.n + WAVES_PER_CU - 1u) / WAVES_PER_CU;
+  hipLaunchKernelGGL(compress_fast_cu_kernel, dim3(wgs < n_cus ? wgs : n_cus), dim3(64 * WAVES_PER_CU), 0, (hipStream_t)stream, a, queue, route, dense64);
   return (int)hipGetLastError();
 }
 
