@@ -73,31 +73,44 @@ struct HcBuild {
     w.template lds_fill<true>(32768u, 0u);
     w.sync();
     const VU j = w.lane();
-    for (uint32_t p0 = 0; p0 <= last; p0 += 64u) {
-      const VU p = j + p0;
-      const VB valid = p <= last;
-      const VU idx = p + HC_BIAS;
-      const VU h = (w.ldu32(src, W::vmin(p, last)) * 2654435761u) >> 17;
-      const VU old = w.template lds_rd<true>(h, valid);
-      (void)w.template lds_max<true>(h, idx, valid);
-      w.sync();
-      const VU rb = w.template lds_rd<true>(h, valid);
-      VU prev = old;
-      uint64_t pend = w.ballot(valid & (rb != idx));  // a later lane of this step shares my bucket
-      while (pend) {
-        const int d = ctz64(pend);
-        const uint32_t hd = w.bcast(h, d);
-        const VB grp = valid & (h == hd);
-        const uint64_t gm = w.ballot(grp);
-        const VU64 lower = w.lanemask_lt() & VU64(gm);
-        const VB has = grp & (lower != VU64(0));
-        const VU srcl = VU(63u) - W::clz64(lower);
-        prev = W::select(has, w.template shfl_e<true>(idx, srcl), prev);
-        pend &= ~gm;
+    // The input words of a step do not depend on the table: they are requested one group of U steps ahead, so the only
+    // latency left in a step is the LDS round trip (one wavefront per CU runs here -- the 128 KB head table -- and nothing
+    // else would hide a global load).
+    constexpr uint32_t U = 4u;
+    VU xn[U];
+    for (uint32_t u = 0; u < U; u++) xn[u] = w.ldu32(src, W::vmin(j + u * 64u, last));
+    for (uint32_t g0 = 0; g0 <= last; g0 += 64u * U) {
+      VU x[U];
+      for (uint32_t u = 0; u < U; u++) x[u] = xn[u];
+      for (uint32_t u = 0; u < U; u++) xn[u] = w.ldu32(src, W::vmin(j + (g0 + 64u * U + u * 64u), last));
+      for (uint32_t u = 0; u < U; u++) {
+        const uint32_t p0 = g0 + u * 64u;
+        if (p0 > last) break;
+        const VU p = j + p0;
+        const VB valid = p <= last;
+        const VU idx = p + HC_BIAS;
+        const VU h = (x[u] * 2654435761u) >> 17;
+        const VU old = w.template lds_rd<true>(h, valid);
+        (void)w.template lds_max<true>(h, idx, valid);
+        w.sync();
+        const VU rb = w.template lds_rd<true>(h, valid);
+        VU prev = old;
+        uint64_t pend = w.ballot(valid & (rb != idx));  // a later lane of this step shares my bucket
+        while (pend) {
+          const int d = ctz64(pend);
+          const uint32_t hd = w.bcast(h, d);
+          const VB grp = valid & (h == hd);
+          const uint64_t gm = w.ballot(grp);
+          const VU64 lower = w.lanemask_lt() & VU64(gm);
+          const VB has = grp & (lower != VU64(0));
+          const VU srcl = VU(63u) - W::clz64(lower);
+          prev = W::select(has, w.template shfl_e<true>(idx, srcl), prev);
+          pend &= ~gm;
+        }
+        const VU dist = idx - prev;
+        w.st16(delta, p, W::select(dist > (uint32_t)HC_MAXD, VU(0u), dist), valid);
+        w.sync();
       }
-      const VU dist = idx - prev;
-      w.st16(delta, p, W::select(dist > (uint32_t)HC_MAXD, VU(0u), dist), valid);
-      w.sync();
     }
   }
 };
