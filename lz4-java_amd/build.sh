@@ -3,9 +3,9 @@
 set -euo pipefail
 here="$(cd "$(dirname "$0")" && pwd)"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-# -structurizecfg-skip-uniform-regions: the parsers branch on wave-uniform scalars almost everywhere; leaving those regions
-# unstructured saves the state variables / re-dispatch branches the structurizer adds (+3 % fast compress, +5 % on text)
-"$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -mllvm -structurizecfg-skip-uniform-regions=1 ${LZ4HIP_EXTRA_FLAGS:-} -fPIC -shared -fvisibility=hidden \
+# (-mllvm -structurizecfg-skip-uniform-regions=1 is worth +3 % on fast compress and MISCOMPILES the long-buffer xxhash kernels:
+# block checksums came out wrong in tests/test_gpu_streams.py -- do not use it)
+"$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 ${LZ4HIP_EXTRA_FLAGS:-} -fPIC -shared -fvisibility=hidden \
   -Wl,-rpath,/opt/rocm/lib -Wl,--exclude-libs,ALL \
   "$here/csrc/kernels.hip" "$here/csrc/api.cpp" -o "$here/liblz4hip.so"
 echo "built $here/liblz4hip.so"

@@ -3,6 +3,6 @@
 here="$(cd "$(dirname "$0")/.." && pwd)"
 name=$1; shift
 mkdir -p "$here/lz4-java_amd/variants"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -structurizecfg-skip-uniform-regions=1 "$@" -fPIC -shared -fvisibility=hidden -Wl,-rpath,/opt/rocm/lib -Wl,--exclude-libs,ALL \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 "$@" -fPIC -shared -fvisibility=hidden -Wl,-rpath,/opt/rocm/lib -Wl,--exclude-libs,ALL \
   "$here/lz4-java_amd/csrc/kernels.hip" "$here/lz4-java_amd/csrc/api.cpp" -o "$here/lz4-java_amd/variants/$name.so" 2>&1 | grep -v "warning\|^$" | head
 echo "built variants/$name.so"
