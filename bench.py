@@ -176,8 +176,8 @@ def main():
                        "blocks_per_gpu": n, "block_bytes": blk, "ratio": round(ratio, 4), "parallelism": "blocks sharded x%d" % world},
             "verified": ok,
             "compress_GBps": round(nbytes / t_c / 1e9, 3), "decompress_GBps": round(nbytes / t_d / 1e9, 3),
-            "roofline": {"kernel": "compress_fast_kernel", "bound": "hbm", "achieved": round(alg_c / t_c, 3), "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": round(alg_c / t_c / HBM_PEAK_GBPS, 5), "traffic": tr.get("compress_fast_kernel"),
+            "roofline": {"kernel": "compress_fast_cu_kernel", "bound": "hbm", "achieved": round(alg_c / t_c, 3), "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": round(alg_c / t_c / HBM_PEAK_GBPS, 5), "traffic": tr.get("compress_fast_cu_kernel"),
                          "algorithmic_bytes_per_launch": int(nbytes + csum), "avg_launch_ms": round(t_c * 1e3, 4)},
             "roofline_decode": {"kernel": "decode_kernel", "bound": "hbm", "achieved": round(alg_d / t_d, 3), "peak": HBM_PEAK_GBPS,
                                 "unit": "GB/s", "frac": round(alg_d / t_d / HBM_PEAK_GBPS, 5), "traffic": tr.get("decode_kernel"),

@@ -117,21 +117,19 @@ uint32_t cu_count() {
 // fast compress: single-wave kernel, or (default) the two-wave kernel with its zeroed ring workspace
 int launch_fast(const lz4hip::BatchArgs& a, hipStream_t st) {
   if (g_compress_waves != 2) {
-    // scratch: the route bytes of the adaptive scheme (padded to 4 bytes) + the two block-queue words of the CU-filling kernels
-    const size_t route_bytes = ((size_t)a.n + 7u) & ~(size_t)3u;
-    uint8_t* scratch = nullptr;
-    hipError_t e = hipMallocAsync((void**)&scratch, route_bytes + 2 * sizeof(uint32_t), st);
+    // scratch: three queue words + the routed-block list of the adaptive scheme
+    uint32_t* scratch = nullptr;
+    hipError_t e = hipMallocAsync((void**)&scratch, (3 + (size_t)a.n) * sizeof(uint32_t), st);
     if (e != hipSuccess) return (int)e;
-    uint32_t* queue = (uint32_t*)(scratch + route_bytes);
     const uint32_t cus = cu_count();
     int le;
     if (g_compress_core == 0) {
-      le = lz4hip::launch_compress_fast(a, nullptr, 0u, queue, cus, st);
+      le = lz4hip::launch_compress_fast(a, scratch, nullptr, 0u, cus, st);
     } else if (g_compress_core == 1) {
-      le = lz4hip::launch_compress_fast_ms(a, nullptr, queue + 1, cus, st);
+      le = lz4hip::launch_compress_fast_ms(a, scratch, nullptr, true, cus, st);
     } else {
-      le = lz4hip::launch_compress_fast(a, scratch, 64u * (uint32_t)g_compress_switch, queue, cus, st);
-      if (le == 0) le = lz4hip::launch_compress_fast_ms(a, scratch, queue + 1, cus, st);
+      le = lz4hip::launch_compress_fast(a, scratch, scratch + 3, 64u * (uint32_t)g_compress_switch, cus, st);
+      if (le == 0) le = lz4hip::launch_compress_fast_ms(a, scratch, scratch + 3, false, cus, st);
     }
     (void)hipFreeAsync(scratch, st);
     return le;

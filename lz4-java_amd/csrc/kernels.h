@@ -15,13 +15,13 @@ struct BatchArgs {
 // Fast compress, two cores (same bytes):
 //   launch_compress_fast     one sequence per step (lz4_fast_core.h): best when sequences are long
 //   launch_compress_fast_ms  every sequence of a 64-position window per step (lz4_fast_ms_core.h): best when they are short
-// Adaptive two-pass use: launch_compress_fast(route = n-byte device buffer, dense64) finishes the blocks with long sequences
-// and marks the others (route[b] = 1: sequences 32..95 cover fewer than dense64 bytes); launch_compress_fast_ms(route) then
-// does exactly those.  route == nullptr: the kernel does every block.
-// `queue`: one device uint32_t (the block queue of the CU-filling kernel, zeroed by the launch; nullptr = one workgroup per block),
-// n_cus: compute units of the device
-int launch_compress_fast(const BatchArgs& a, uint8_t* route, uint32_t dense64, uint32_t* queue, uint32_t n_cus, void* stream);
-int launch_compress_fast_ms(const BatchArgs& a, const uint8_t* route, uint32_t* queue, uint32_t n_cus, void* stream);
+// Both fill each CU with one workgroup of 5 wavefronts (5 x 32 KB tables = the CU's whole LDS) that draw blocks from a queue.
+// q = three device uint32_t (queue words), n_cus = compute units of the device.
+// Adaptive two-pass use: launch_compress_fast(q, routed = u32[n] device scratch, dense64) finishes the blocks with long sequences
+// and lists the others in routed[] (sequences 32..95 cover fewer than dense64 bytes); launch_compress_fast_ms(q, routed,
+// first = false) then does exactly those.  routed == nullptr: the kernel does every block (first = true zeroes q).
+int launch_compress_fast(const BatchArgs& a, uint32_t* q, uint32_t* routed, uint32_t dense64, uint32_t n_cus, void* stream);
+int launch_compress_fast_ms(const BatchArgs& a, uint32_t* q, const uint32_t* routed, bool first, uint32_t n_cus, void* stream);
 void set_dbg_flags(uint32_t f);  // developer diagnostics
 void set_dbg_extra_lds(uint32_t bytes);
 // two-wave variant: `ws` = zeroed device workspace of compress_fast2_ws_bytes(grid) bytes

@@ -40,9 +40,11 @@ template <class T> __device__ __forceinline__ T* uniform_ptr(T* q) {
   return (T*)(((uint64_t)hi << 32) | lo);
 }
 __device__ __forceinline__ int32_t uniform_i32(int32_t v) { return (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)v); }
-// `route` (may be null): per-block routing byte of the adaptive two-pass scheme.  This kernel probes the density of each
-// block (lz4_fast_core.h, dense64); a block of short sequences is left unfinished with route[b] = 1 for compress_fast_ms_kernel.
-__global__ __launch_bounds__(64) void compress_fast_kernel(BatchArgs a, uint32_t dbg_flags, uint8_t* route, uint32_t dense64) {
+// Adaptive two-pass scheme.  q = {next_block, n_routed, next_routed} (three queue words, zeroed by the first launch) and
+// `routed` (u32[n], may be null = no routing): the one-sequence kernels probe the density of each block (lz4_fast_core.h,
+// dense64); a block of short sequences is left unfinished and its index appended to routed[] for the window-parallel
+// kernel, which draws exactly those.
+__global__ __launch_bounds__(64) void compress_fast_kernel(BatchArgs a, uint32_t dbg_flags, uint32_t* q, uint32_t* routed, uint32_t dense64) {
   __shared__ __attribute__((aligned(16))) uint64_t table[4096];  // 32 KB: 8192 x u32 (byU16) or 4096 x u64 (byU32)
   const uint32_t b = blockIdx.x;
   const int32_t n = a.src_len[b];
@@ -57,23 +59,22 @@ __global__ __launch_bounds__(64) void compress_fast_kernel(BatchArgs a, uint32_t
     bool bailed;
     if (n < 65547) {
       FastCore<WaveDev, true> c(w, out, s, (uint32_t)n);
-      c.dense64 = route ? dense64 : 0u;
+      c.dense64 = routed ? dense64 : 0u;
       r = c.run();
       bailed = c.bailed;
     } else {
       FastCore<WaveDev, false> c(w, out, s, (uint32_t)n);
-      c.dense64 = route ? dense64 : 0u;
+      c.dense64 = routed ? dense64 : 0u;
       r = c.run();
       bailed = c.bailed;
     }
     if (bailed) {
-      if (threadIdx.x == 0) route[b] = 1;
+      if (threadIdx.x == 0) routed[atomicAdd(q + 1, 1u)] = b;
       return;
     }
   }
   if (threadIdx.x == 0) {
     a.out[b] = (int32_t)r;
-    if (route) route[b] = 0;
   }
 }
 
@@ -81,12 +82,12 @@ __global__ __launch_bounds__(64) void compress_fast_kernel(BatchArgs a, uint32_t
 #define LZ4HIP_WPC 5
 #endif
 constexpr uint32_t WAVES_PER_CU = LZ4HIP_WPC;
-__global__ __launch_bounds__(64 * WAVES_PER_CU) void compress_fast_cu_kernel(BatchArgs a, uint32_t* next_block, uint8_t* route, uint32_t dense64) {
+__global__ __launch_bounds__(64 * WAVES_PER_CU) void compress_fast_cu_kernel(BatchArgs a, uint32_t* q, uint32_t* routed, uint32_t dense64) {
   __shared__ __attribute__((aligned(16))) uint64_t tables[WAVES_PER_CU][4096];
   uint64_t* table = tables[threadIdx.x >> 6];
   for (;;) {
     uint32_t b = 0;
-    if (__lane_id() == 0) b = atomicAdd(next_block, 1u);
+    if (__lane_id() == 0) b = atomicAdd(q, 1u);
     b = __builtin_amdgcn_readfirstlane(b);
     if (b >= a.n) return;
   const int32_t n = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)a.src_len[b]);
@@ -101,24 +102,23 @@ __global__ __launch_bounds__(64 * WAVES_PER_CU) void compress_fast_cu_kernel(Bat
       bool bailed;
       if (n < 65547) {
         FastCore<WaveDev, true> c(w, out, s, (uint32_t)n);
-        c.dense64 = route ? dense64 : 0u;
+        c.dense64 = routed ? dense64 : 0u;
         r = c.run();
         bailed = c.bailed;
       } else {
         FastCore<WaveDev, false> c(w, out, s, (uint32_t)n);
-        c.dense64 = route ? dense64 : 0u;
+        c.dense64 = routed ? dense64 : 0u;
         r = c.run();
         bailed = c.bailed;
       }
       if (bailed) {
-        if (__lane_id() == 0) route[b] = 1;
+        if (__lane_id() == 0) routed[atomicAdd(q + 1, 1u)] = b;
         continue;
       }
     }
     if (__lane_id() == 0) {
       a.out[b] = (int32_t)r;
-      if (route) route[b] = 0;
-    }
+      }
   
     WaveDev::sync();
   }
@@ -148,55 +148,36 @@ __global__ __launch_bounds__(64) void compress_fast_ms_kernel(BatchArgs a) {
   __shared__ __attribute__((aligned(16))) uint64_t table[4096];
   compress_fast_ms_block(a, blockIdx.x, table);
 }
-// second pass of the adaptive scheme: only blocks with route[b] != 0.  One workgroup per ROUTE_GROUP blocks -- a workgroup that
-// finds nothing to do costs ~33 ns of dispatch, which at one per block was 2 % of the launch on a batch with no routed block
-constexpr uint32_t ROUTE_GROUP = 4;
-__global__ __launch_bounds__(64) void compress_fast_ms_routed_kernel(BatchArgs a, const uint8_t* route) {
-  __shared__ __attribute__((aligned(16))) uint64_t table[4096];
-  const uint32_t b0 = blockIdx.x * ROUTE_GROUP;
-  uint32_t marks = 0;
-  if (b0 + ROUTE_GROUP <= a.n) marks = *(const uint32_t*)(route + b0);  // (the route buffer is 4-byte aligned and padded)
-  else for (uint32_t i = 0; b0 + i < a.n; i++) marks |= (uint32_t)route[b0 + i] << (8u * i);
-  for (uint32_t i = 0; i < ROUTE_GROUP; i++) {
-    if (!((marks >> (8u * i)) & 0xFFu)) continue;
-    compress_fast_ms_block(a, b0 + i, table);
-    __builtin_amdgcn_s_barrier();  // (single-wave workgroup) the table is reused
-  }
-}
-// CU-filling form (see compress_fast_cu_kernel): WAVES_PER_CU wavefronts per workgroup, each drawing groups of ROUTE_GROUP
-// blocks from the queue word and compressing the marked ones (route == nullptr: all of them)
-__global__ __launch_bounds__(64 * WAVES_PER_CU) void compress_fast_ms_cu_kernel(BatchArgs a, const uint8_t* route, uint32_t* next_group) {
+// CU-filling form (see compress_fast_cu_kernel): WAVES_PER_CU wavefronts per workgroup drawing from q[2] either the blocks
+// listed in routed[0 .. q[1]) (second pass of the adaptive scheme; an empty list costs one queue draw per wavefront) or, with
+// routed == nullptr, every block of the batch
+__global__ __launch_bounds__(64 * WAVES_PER_CU) void compress_fast_ms_cu_kernel(BatchArgs a, uint32_t* q, const uint32_t* routed) {
   __shared__ __attribute__((aligned(16))) uint64_t tables[WAVES_PER_CU][4096];
   uint64_t* table = tables[threadIdx.x >> 6];
+  const uint32_t count = routed ? __builtin_amdgcn_readfirstlane(q[1]) : a.n;
   for (;;) {
-    uint32_t g = 0;
-    if (__lane_id() == 0) g = atomicAdd(next_group, 1u);
-    const uint32_t b0 = __builtin_amdgcn_readfirstlane(g) * ROUTE_GROUP;
-    if (b0 >= a.n) return;
-    uint32_t marks = 0x01010101u;
-    if (route) {
-      if (b0 + ROUTE_GROUP <= a.n) marks = *(const uint32_t*)(route + b0);  // (the route buffer is 4-byte aligned and padded)
-      else { marks = 0; for (uint32_t i = 0; b0 + i < a.n; i++) marks |= (uint32_t)route[b0 + i] << (8u * i); }
-      marks = __builtin_amdgcn_readfirstlane(marks);
-    }
-    for (uint32_t i = 0; i < ROUTE_GROUP && b0 + i < a.n; i++) {
-      if (!((marks >> (8u * i)) & 0xFFu)) continue;
-      compress_fast_ms_block(a, b0 + i, table);
-      WaveDev::sync();  // the table is reused
-    }
+    uint32_t i = 0;
+    if (__lane_id() == 0) i = atomicAdd(q + 2, 1u);
+    i = __builtin_amdgcn_readfirstlane(i);
+    if (i >= count) return;
+    const uint32_t b = routed ? __builtin_amdgcn_readfirstlane(routed[i]) : i;
+    compress_fast_ms_block(a, b, table);
+    WaveDev::sync();  // the table is reused
   }
 }
-int launch_compress_fast_ms(const BatchArgs& a, const uint8_t* route, uint32_t* queue, uint32_t n_cus, void* stream) {
+// `first` = this is the first launch that uses q (zero it)
+int launch_compress_fast_ms(const BatchArgs& a, uint32_t* q, const uint32_t* routed, bool first, uint32_t n_cus, void* stream) {
   if (a.n == 0) return 0;
-  if (g_dbg_extra_lds || !queue) {
-    if (route) hipLaunchKernelGGL(compress_fast_ms_routed_kernel, dim3((a.n + ROUTE_GROUP - 1) / ROUTE_GROUP), dim3(64), g_dbg_extra_lds, (hipStream_t)stream, a, route);
-    else hipLaunchKernelGGL(compress_fast_ms_kernel, dim3(a.n), dim3(64), g_dbg_extra_lds, (hipStream_t)stream, a);
+  if (g_dbg_extra_lds && !routed) {  // residency sweeps: one single-wave workgroup per block
+    hipLaunchKernelGGL(compress_fast_ms_kernel, dim3(a.n), dim3(64), g_dbg_extra_lds, (hipStream_t)stream, a);
     return (int)hipGetLastError();
   }
-  hipError_t e = hipMemsetAsync(queue, 0, sizeof(uint32_t), (hipStream_t)stream);
-  if (e != hipSuccess) return (int)e;
-  const uint32_t groups = (a.n + ROUTE_GROUP - 1u) / ROUTE_GROUP, wgs = (groups + WAVES_PER_CU - 1u) / WAVES_PER_CU;
-  hipLaunchKernelGGL(compress_fast_ms_cu_kernel, dim3(wgs < n_cus ? wgs : n_cus), dim3(64 * WAVES_PER_CU), 0, (hipStream_t)stream, a, route, queue);
+  if (first) {
+    hipError_t e = hipMemsetAsync(q, 0, 3 * sizeof(uint32_t), (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+  }
+  const uint32_t wgs = (a.n + WAVES_PER_CU - 1u) / WAVES_PER_CU;
+  hipLaunchKernelGGL(compress_fast_ms_cu_kernel, dim3(wgs < n_cus ? wgs : n_cus), dim3(64 * WAVES_PER_CU), 0, (hipStream_t)stream, a, q, routed);
   return (int)hipGetLastError();
 }
 
@@ -378,23 +359,16 @@ uint32_t compress_fast2_grid(uint32_t n_blocks, uint32_t n_cus) {
 }
 size_t compress_fast2_ws_bytes(uint32_t grid) { return (size_t)grid * RING_WG_BYTES + 64u; }
 
-int launch_compress_fast(const BatchArgs& a, uint8_t* route, uint32_t dense64, uint32_t* queue, uint32_t n_cus, void* stream) {
+int launch_compress_fast(const BatchArgs& a, uint32_t* q, uint32_t* routed, uint32_t dense64, uint32_t n_cus, void* stream) {
   if (a.n == 0) return 0;
-  if (getenv("LZ4HIP_DEBUG")) {
-    int nb = -1;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, compress_fast_kernel, 64, g_dbg_extra_lds);
-    hipDeviceProp_t pr; int dev = 0; (void)hipGetDevice(&dev); (void)hipGetDeviceProperties(&pr, dev);
-    fprintf(stderr, "[lz4hip] compress_fast_kernel: occupancy API says %d workgroups/CU (err %d), extra LDS %u, sharedMemPerMultiprocessor %zu, maxSharedMemoryPerMultiProcessor %zu, sharedMemPerBlock %zu\n",
-            nb, (int)e, g_dbg_extra_lds, (size_t)pr.sharedMemPerMultiprocessor, (size_t)pr.maxSharedMemoryPerMultiProcessor, (size_t)pr.sharedMemPerBlock);
-  }
-  if (g_dbg_extra_lds || !queue) {
-    hipLaunchKernelGGL(compress_fast_kernel, dim3(a.n), dim3(64), g_dbg_extra_lds, (hipStream_t)stream, a, g_dbg_flags, route, dense64);
+  hipError_t e = hipMemsetAsync(q, 0, 3 * sizeof(uint32_t), (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  if (g_dbg_extra_lds) {  // residency sweeps: one single-wave workgroup per block
+    hipLaunchKernelGGL(compress_fast_kernel, dim3(a.n), dim3(64), g_dbg_extra_lds, (hipStream_t)stream, a, g_dbg_flags, q, routed, dense64);
     return (int)hipGetLastError();
   }
-  hipError_t e = hipMemsetAsync(queue, 0, sizeof(uint32_t), (hipStream_t)stream);
-  if (e != hipSuccess) return (int)e;
   const uint32_t wgs = (a.n + WAVES_PER_CU - 1u) / WAVES_PER_CU;
-  hipLaunchKernelGGL(compress_fast_cu_kernel, dim3(wgs < n_cus ? wgs : n_cus), dim3(64 * WAVES_PER_CU), 0, (hipStream_t)stream, a, queue, route, dense64);
+  hipLaunchKernelGGL(compress_fast_cu_kernel, dim3(wgs < n_cus ? wgs : n_cus), dim3(64 * WAVES_PER_CU), 0, (hipStream_t)stream, a, q, routed, dense64);
   return (int)hipGetLastError();
 }
 

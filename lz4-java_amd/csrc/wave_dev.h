@@ -125,9 +125,9 @@ struct WaveDev {
     return v;
   }
   __device__ __forceinline__ static void st8(uint8_t* b, VU i, VU v, bool m) {
-    // compressed output is never read back by the kernel that writes it: non-temporal, so it does not push the source
-    // (candidate fetches are random re-reads of it) out of L2 -- +3.5 % on the bench workload
-    if (m) __builtin_nontemporal_store((uint8_t)v, &b[i]);
+    // (non-temporal byte stores here were +3.5 % on the bench workload -- the output no longer pushes the source out of L2 --
+    // but they reach memory as partial-line writes: WRITE_SIZE 2.1 -> 11.4 GB per launch, profiles/r01j; not worth it)
+    if (m) b[i] = (uint8_t)v;
   }
   __device__ __forceinline__ static void st16(uint16_t* b, VU i, VU v, bool m) {
     if (m) b[i] = (uint16_t)v;

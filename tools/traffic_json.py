@@ -7,7 +7,7 @@ vals = {}
 for db in glob.glob(os.path.join(d, "*", "pmc_results.db")):
     con = sqlite3.connect(db)
     for k, c, v in con.execute("select kernel_name, counter_name, avg(value) from counters_collection where kernel_name like '%lz4hip%' group by kernel_name, counter_name"):
-        key = "compress_fast_kernel" if "compress_fast_kernel" in k else ("decode_kernel" if "decode_kernel" in k else None)
+        key = "compress_fast_cu_kernel" if "compress_fast_cu_kernel" in k else ("decode_kernel" if "decode_kernel" in k else None)
         if key:
             vals.setdefault(key, {})[c] = v
 out = {"blocks_per_gpu": n, "block_bytes": blk, "source": tag,
