@@ -314,6 +314,10 @@ struct FastCore {
   static constexpr int HLOG = U16 ? 13 : 12;
   static constexpr int PSHIFT = U16 ? 16 : 32;
   static constexpr uint32_t MAXD = 65535u;
+#ifndef LZ4HIP_SPEC_LANES
+#define LZ4HIP_SPEC_LANES 16
+#endif
+  static constexpr uint32_t kSpecLanes = LZ4HIP_SPEC_LANES;  // lanes (x 8 bytes) of the speculative verify + extension compare
 
   W& w;
   Out& out;
@@ -501,8 +505,11 @@ struct FastCore {
       uint32_t mpos = se_pos(w.template bcast_e<U16>(e, (int)kk));
       bool hit_post = post && k0 == 1u;
       uint32_t maxback = (!have_hit || hit_post) ? 0u : ((hpos - anchor) < mpos ? (hpos - anchor) : mpos);
-      VU64 fa = w.ldu64(src, W::vmin(o8 + hpos, n - 8u));   // kept apart from fb: xor-ing here would wait for the loads
-      VU64 fb = w.ldu64_cand(src, W::vmin(o8 + mpos, n - 8u));
+      // (only the first kSpecLanes lanes take part -- 8 bytes each: the candidate side is a random re-read of the block and
+      // every further 128 bytes are one more cache line that mostly misses L2; longer matches take count_fwd's extra round trip)
+      const VB specl = j < kSpecLanes;
+      VU64 fa = w.ld64(src, W::vmin(o8 + hpos, n - 8u), specl);   // kept apart from fb: xor-ing here would wait for the loads
+      VU64 fb = w.ld64(src, W::vmin(o8 + mpos, n - 8u), specl);
       VU ba, bb;
       uint64_t bactm = maxback >= 64u ? ~0ull : ((1ull << maxback) - 1ull);
       {
@@ -557,8 +564,8 @@ struct FastCore {
           if (!had || hpos != hpos_old || mpos != mpos_old) {  // the speculation fetched the wrong candidate
             hit_post = post && k0 == 1u;
             maxback = hit_post ? 0u : ((hpos - anchor) < mpos ? (hpos - anchor) : mpos);
-            fa = w.ldu64(src, W::vmin(o8 + hpos, n - 8u));
-            fb = w.ldu64_cand(src, W::vmin(o8 + mpos, n - 8u));
+            fa = w.ld64(src, W::vmin(o8 + hpos, n - 8u), specl);
+            fb = w.ld64(src, W::vmin(o8 + mpos, n - 8u), specl);
             bactm = maxback >= 64u ? ~0ull : ((1ull << maxback) - 1ull);
             const VB bact = w.lanes(bactm);
             ba = w.ldu8(src, W::select(bact, (hpos - 1u) - j, VU(0u)));
@@ -587,12 +594,13 @@ struct FastCore {
       if (st) st->sequences++;
       uint32_t cnt;  // equal bytes from hpos on (>= 4)
       {
+        constexpr uint64_t specm = (1ull << kSpecLanes) - 1ull;
         const uint64_t fullm = w.ballot(o8 + (hpos + 8u) <= matchlimit);
         const VU64 xz = W::select(j == 0u, fx & VU64(0xFFFFFFFF00000000ull), fx);
-        const uint64_t dm = w.ballot(xz != VU64(0)) & fullm;
-        const uint64_t stop = dm | ~fullm;
+        const uint64_t dm = w.ballot(xz != VU64(0)) & fullm & specm;
+        const uint64_t stop = dm | (~fullm & specm);
         if (LZ4HIP_UNLIKELY(stop == 0)) {
-          cnt = 512u + count_fwd(hpos + 512u, mpos + 512u, matchlimit);
+          cnt = 8u * kSpecLanes + count_fwd(hpos + 8u * kSpecLanes, mpos + 8u * kSpecLanes, matchlimit);
         } else {
           const int f = ctz64(stop);
           cnt = 8u * (uint32_t)f;
