@@ -82,23 +82,31 @@ __global__ __launch_bounds__(64) void compress_fast_kernel(BatchArgs a, uint32_t
 #define LZ4HIP_WPC 5
 #endif
 constexpr uint32_t WAVES_PER_CU = LZ4HIP_WPC;
+// Residency: a wavefront needs its 32 KB table and nothing else, but LDS is allocated in 1280-byte granules, so a 32768-byte
+// workgroup occupies 33280 bytes and only FOUR fit a CU (measured: 1280 single-wave workgroups run in two rounds).  One
+// workgroup that owns all 163840 bytes of the CU holds FIVE tables exactly: WAVES_PER_CU wavefronts, each compressing its own
+// blocks, no barrier between them.  Blocks are handed out through the queue word q[0], so a wavefront that draws short blocks
+// simply draws more of them.
+// (The block body is written out here, not shared with compress_fast_kernel through a device function: behind a function
+// boundary the per-block loads lose their no-clobber marking, become vector loads, and the whole scalar parser state follows
+// them into vector registers -- 42 -> 83 VGPRs, -22 %.  Inside the loop every per-block value goes back to scalar registers
+// through readfirstlane for the same reason.)
 __global__ __launch_bounds__(64 * WAVES_PER_CU) void compress_fast_cu_kernel(BatchArgs a, uint32_t* q, uint32_t* routed, uint32_t dense64) {
-  __shared__ __attribute__((aligned(16))) uint64_t tables[WAVES_PER_CU][4096];
+  __shared__ __attribute__((aligned(16))) uint64_t tables[WAVES_PER_CU][4096];  // 160 KB: the whole LDS of the CU
   uint64_t* table = tables[threadIdx.x >> 6];
   for (;;) {
     uint32_t b = 0;
     if (__lane_id() == 0) b = atomicAdd(q, 1u);
     b = __builtin_amdgcn_readfirstlane(b);
     if (b >= a.n) return;
-  const int32_t n = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)a.src_len[b]);
-    const int32_t cap = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)a.dst_cap[b]);
+    const int32_t n = uniform_i32(a.src_len[b]);
+    const int32_t cap = uniform_i32(a.dst_cap[b]);
     uint32_t r = 0;
     if (n >= 0 && (uint32_t)n <= 0x7E000000u && cap >= 0) {
       const uint8_t* s = uniform_ptr(a.src + a.src_off[b]);
       uint8_t* d = uniform_ptr(a.dst + a.dst_off[b]);
       WaveDev w(table);
       DirectOut<WaveDev> out(w, s, (uint32_t)n, d, (uint32_t)cap);
-      
       bool bailed;
       if (n < 65547) {
         FastCore<WaveDev, true> c(w, out, s, (uint32_t)n);
@@ -116,11 +124,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_CU) void compress_fast_cu_kernel(Bat
         continue;
       }
     }
-    if (__lane_id() == 0) {
-      a.out[b] = (int32_t)r;
-      }
-  
-    WaveDev::sync();
+    if (__lane_id() == 0) a.out[b] = (int32_t)r;
+    WaveDev::sync();  // the table is reused
   }
 }
 // window-parallel core (lz4_fast_ms_core.h): every sequence of a 64-position window per step
