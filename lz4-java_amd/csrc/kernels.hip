@@ -37,7 +37,10 @@ void set_dbg_flags(uint32_t f) { g_dbg_flags = f; }
 template <class T> __device__ __forceinline__ T* uniform_ptr(T* q) {
   const uint64_t v = (uint64_t)q;
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-  return (T*)(((uint64_t)hi << 32) | lo);
+  // (the detour through address space 1 says "global memory": a pointer rebuilt from integers is otherwise a FLAT pointer --
+  // flat_load/flat_store with a 64-bit address per lane instead of global_load with the scalar base)
+  typedef __attribute__((address_space(1))) T* G;
+  return (T*)(G)(((uint64_t)hi << 32) | lo);
 }
 __device__ __forceinline__ int32_t uniform_i32(int32_t v) { return (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)v); }
 // Adaptive two-pass scheme.  q = {next_block, n_routed, next_routed} (three queue words, zeroed by the first launch) and
