@@ -460,8 +460,11 @@ struct FastCore {
   LZ4HIP_DEV uint32_t loop(bool post, uint32_t S, uint32_t r, uint32_t ip) {
     uint32_t probe_cd = 32u, probe_anchor = 0;  // (PROBE only) countdown to the next density-probe event
     uint32_t pf_end = PROBE ? 0u : (post ? ip : S) & ~(W::kPrefetchBytes - 1u);  // source prefetched up to here (LZ4HIP_PF_KB KB chunks, as far ahead)
+    // the next chunk is due once hpos + kPrefetchBytes > pf_end, i.e. hpos >= pf_trig (never again once pf_end >= n): ONE compare per step
+    uint32_t pf_trig = (n >= 16u && pf_end < n) ? (pf_end >= W::kPrefetchBytes ? pf_end - W::kPrefetchBytes + 1u : 0u) : 0xFFFFFFFFu;
     const VU j = w.lane();
     const VU o8 = j * 8u;
+    const VU o8s = W::vmin(o8, VU(8u * (kSpecLanes - 1u)));
     prepare_step(post, S, r, ip);
 
     for (;;) {
@@ -493,7 +496,7 @@ struct FastCore {
       uint32_t k0 = tmask ? (uint32_t)ctz64(tmask) : 64u;
       const uint32_t kinv = imask ? (uint32_t)ctz64(imask) : 64u;
       uint32_t ncommit = (k0 + 1u < kinv) ? k0 + 1u : kinv;
-      bool have_hit = k0 < kinv;
+      bool have_hit = ncommit == k0 + 1u;   // == (k0 < kinv), as a 32-bit equality (the 64-bit ctz results have no scalar "<")
       uint64_t inm = ncommit >= 64u ? ~0ull : ((1ull << ncommit) - 1ull);  // lanes that commit their insert
       LZ4HIP_PHASE(1, ncommit);          // t[1]: table read + ballots
       const VE old = w.template lds_max<U16>(h, newe, w.lanes(inm));
@@ -507,17 +510,23 @@ struct FastCore {
       uint32_t maxback = (!have_hit || hit_post) ? 0u : ((hpos - anchor) < mpos ? (hpos - anchor) : mpos);
       // (only the first kSpecLanes lanes take part -- 8 bytes each: the candidate side is a random re-read of the block and
       // every further 128 bytes are one more cache line that mostly misses L2; longer matches take count_fwd's extra round trip)
-      const VB specl = j < kSpecLanes;
-      VU64 fa = w.ld64(src, W::vmin(o8 + hpos, n - 8u), specl);   // kept apart from fb: xor-ing here would wait for the loads
-      VU64 fb = w.ld64(src, W::vmin(o8 + mpos, n - 8u), specl);
+      // (lanes past kSpecLanes repeat the last taking lane's address: same cache line, no exec-mask region around the loads)
+      VU64 fa = w.ldu64(src, W::vmin(o8s + hpos, n - 8u));   // kept apart from fb: xor-ing here would wait for the loads
+      VU64 fb = w.ldu64_cand(src, W::vmin(o8s + mpos, n - 8u));
       VU ba, bb;
       uint64_t bactm = maxback >= 64u ? ~0ull : ((1ull << maxback) - 1ull);
       {
         const VB bact = w.lanes(bactm);
-        ba = w.ldu8(src, W::select(bact, (hpos - 1u) - j, VU(0u)));
-        bb = w.ldu8(src, W::select(bact, (mpos - 1u) - j, VU(0u)));
+        // (opaque index: keeps the {scalar base + 32-bit lane offset} form; the optimiser otherwise folds the subtraction into a
+        // 64-bit address per lane)
+        ba = w.ldu8(src, W::opaque(W::select(bact, (hpos - 1u) - j, VU(0u))));
+        bb = w.ldu8(src, W::opaque(W::select(bact, (mpos - 1u) - j, VU(0u))));
       }
-      if (LZ4HIP_UNLIKELY(hpos + W::kPrefetchBytes > pf_end && pf_end < n && n >= 16u)) { w.prefetch4k(src, pf_end, n); pf_end += W::kPrefetchBytes; }
+      if (LZ4HIP_UNLIKELY(hpos >= pf_trig)) {
+        w.prefetch4k(src, pf_end, n);
+        pf_end += W::kPrefetchBytes;
+        pf_trig = pf_end < n ? pf_end - W::kPrefetchBytes + 1u : 0xFFFFFFFFu;
+      }
       LZ4HIP_PHASE(2, hpos);             // t[2]: commit issue + candidate-fetch issue
 
       // ---- [4] write out the previous sequence while those loads are in flight ----
@@ -564,8 +573,8 @@ struct FastCore {
           if (!had || hpos != hpos_old || mpos != mpos_old) {  // the speculation fetched the wrong candidate
             hit_post = post && k0 == 1u;
             maxback = hit_post ? 0u : ((hpos - anchor) < mpos ? (hpos - anchor) : mpos);
-            fa = w.ld64(src, W::vmin(o8 + hpos, n - 8u), specl);
-            fb = w.ld64(src, W::vmin(o8 + mpos, n - 8u), specl);
+            fa = w.ldu64(src, W::vmin(o8s + hpos, n - 8u));
+            fb = w.ldu64_cand(src, W::vmin(o8s + mpos, n - 8u));
             bactm = maxback >= 64u ? ~0ull : ((1ull << maxback) - 1ull);
             const VB bact = w.lanes(bactm);
             ba = w.ldu8(src, W::select(bact, (hpos - 1u) - j, VU(0u)));

@@ -93,6 +93,7 @@ struct WaveDev {
     for (int i = 0; i < LZ4HIP_PF_KB; i++) asm volatile("" ::"v"(v[i].x), "v"(v[i].y), "v"(v[i].z), "v"(v[i].w));
   }
   static constexpr uint32_t kPrefetchBytes = LZ4HIP_PF_KB * 1024u;
+  __device__ __forceinline__ static VU opaque(VU v) { asm("" : "+v"(v)); return v; }  // identity the optimiser cannot see through
   __device__ __forceinline__ static void consume(VU v) { asm volatile("" ::"v"(v)); }  // keeps a prefetch load alive
   __device__ __forceinline__ static VU vmin(VU a, VU b) { return a < b ? a : b; }
   __device__ __forceinline__ static VU vmax(VU a, VU b) { return a > b ? a : b; }

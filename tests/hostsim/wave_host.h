@@ -92,6 +92,7 @@ struct WaveHost {
   VU64 ldu64(const uint8_t* b, const VU& i) { return ld64(b, i, VB(true)); }
   VU64 ldu64_cand(const uint8_t* b, const VU& i) { return ld64(b, i, VB(true)); }
   static VU vmin(const VU& a, const VU& b) { VU r; for (int l = 0; l < 64; l++) r.v[l] = a.v[l] < b.v[l] ? a.v[l] : b.v[l]; return r; }
+  static VU opaque(const VU& v) { return v; }
   static void consume(const VU&) {}
   static void prefetch4k(const uint8_t*, uint32_t, uint32_t) {}
   static constexpr uint32_t kPrefetchBytes = 4096u;
