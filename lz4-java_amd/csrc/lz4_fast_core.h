@@ -587,7 +587,7 @@ struct FastCore {
 
       // ---- [6] verify the tentative hit (4 bytes) ----
       const VU64 fx = fa ^ fb;
-      const bool hit = have_hit && (uint32_t)w.bcast64(fx, 0) == 0u;
+      const bool hit = have_hit & ((uint32_t)w.bcast64(fx, 0) == 0u);   // (no short circuit: one branch, and the likely side falls through)
       if (st && have_hit && !hit) st->false_pos++;
       LZ4HIP_PHASE(5, (uint32_t)hit);    // t[5]: wait for the candidate bytes
       if (LZ4HIP_UNLIKELY(!hit)) {
