@@ -63,6 +63,27 @@ struct GroupDev {
     }
   }
 
+  // Split sequence copy for the pipelined interior loop (lz4_decode_core.h PIPE): a "simple" sequence -- literals and match
+  // each fit one step, the match does not overlap its own output -- is LOADED in one trip of the loop and STORED in the next,
+  // behind the next sequence's loads.  A wavefront's memory operations retire in order, so a wait for a load also waits for
+  // every older store; with the stores of sequence t issued after the loads of sequence t+1, no wait ever covers a store.
+  struct SeqRegs { Chunk<LB / 4> v, u; };
+  __device__ __forceinline__ static constexpr uint32_t step() { return LB * GL; }   // bytes one step covers
+  __device__ __forceinline__ static constexpr uint32_t slack() { return LB; }   // bytes a wild step may touch past the end
+  __device__ __forceinline__ void seq_load(SeqRegs& r, const uint8_t* s, uint32_t lit, const uint8_t* m, uint32_t len) const {
+    const uint32_t i = l * LB;
+    if (i < lit) __builtin_memcpy(&r.v, s + i, LB);
+    if (i < len) {
+      const vecLB t = __builtin_nontemporal_load((const vecLB*)(m + i));
+      __builtin_memcpy(&r.u, &t, LB);
+    }
+  }
+  __device__ __forceinline__ void seq_store(const SeqRegs& r, uint8_t* d, uint32_t lit, uint32_t len) const {
+    const uint32_t i = l * LB;
+    if (i < lit) store_out(d + i, r.v);
+    if (i < len) store_out(d + lit + i, r.u);
+  }
+
   // dst[op+i] = dst[op-offset+i] for i in [0,len), byte-forward (overlap replicates the pattern)
   __device__ __forceinline__ void copy_match(uint8_t* dst, uint32_t op, uint32_t offset, uint32_t len, bool wild) const {
     uint8_t* d = dst + op;

@@ -478,38 +478,49 @@ int launch_pack(const BatchArgs& a, uint64_t* poff, uint8_t* pack, void* stream)
 // ------------------------------------------------------------------------------------------------
 // decode
 // ------------------------------------------------------------------------------------------------
-template <int GL, bool SAFE>
+template <int GL, bool SAFE, bool PIPE>
 __global__ __launch_bounds__(256) void decode_kernel(BatchArgs a) {
   const uint32_t gid = (blockIdx.x * 256u + threadIdx.x) / GL;
   if (gid >= a.n) return;  // a whole group leaves together
   GroupDev<GL> g;
-  const int r = decode_block<GroupDev<GL>, SAFE>(g, a.src + a.src_off[gid], a.src_len[gid], a.dst + a.dst_off[gid], a.dst_cap[gid]);
+  const int r = decode_block<GroupDev<GL>, SAFE, PIPE>(g, a.src + a.src_off[gid], a.src_len[gid], a.dst + a.dst_off[gid], a.dst_cap[gid]);
   if (g.l == 0) a.out[gid] = r;
 }
 
 template <int GL>
-static int launch_decode_gl(const BatchArgs& a, bool safe, hipStream_t st) {
+static int launch_decode_gl(const BatchArgs& a, bool safe, bool pipe, hipStream_t st) {
   const uint32_t per_wg = 256u / GL;
   const uint32_t grid = (a.n + per_wg - 1u) / per_wg;
-  if (safe) hipLaunchKernelGGL((decode_kernel<GL, true>), dim3(grid), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((decode_kernel<GL, false>), dim3(grid), dim3(256), 0, st, a);
+  if (safe) {
+    if (pipe) hipLaunchKernelGGL((decode_kernel<GL, true, true>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((decode_kernel<GL, true, false>), dim3(grid), dim3(256), 0, st, a);
+  } else {
+    if (pipe) hipLaunchKernelGGL((decode_kernel<GL, false, true>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((decode_kernel<GL, false, false>), dim3(grid), dim3(256), 0, st, a);
+  }
   return (int)hipGetLastError();
 }
 
-int launch_decompress(const BatchArgs& a, bool safe, int lanes_per_block, void* stream) {
+int launch_decompress(const BatchArgs& a, bool safe, int lanes_per_block, int pipe, void* stream) {
   if (a.n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  // default: 8 lanes x 8 bytes per block (8 blocks per wavefront) while the batch cannot fill the GPU with 4-lane groups; from
-  // 32768 blocks on 4 lanes x 16 bytes (16 blocks per wavefront): a full GPU is issue-bound on short sequences (text: +13 %),
-  // and long-sequence data is bandwidth-bound either way (measured equal)
-  if (lanes_per_block == 0) lanes_per_block = a.n >= 32768u ? 4 : 8;
+  // Defaults by batch size (tools/decode_matrix.sh; App. F / text / 4 MiB blocks):
+  //   >= 32768 blocks: 4 lanes x 16 bytes per block (16 blocks per wavefront), plain loop -- the GPU is full, long-sequence data
+  //                    is bandwidth-bound (pipelined or not: 512 vs 519 GB/s) and short-sequence data issue-bound (text: the
+  //                    pipelined loop costs 25 % there);
+  //   >= 8192 blocks:  8 lanes, pipelined loop (App. F 301 -> 422 GB/s at 16384 blocks; text 77 -> 73);
+  //   fewer:           16 lanes, pipelined loop (App. F 90 -> 138 GB/s at 4096 blocks, 4096 x 4 MiB 131 -> 179, text 25 -> 27):
+  //                    every wavefront has to make progress on its own.
+  const bool auto_lanes = lanes_per_block == 0;
+  if (auto_lanes) lanes_per_block = a.n >= 32768u ? 4 : (a.n >= 8192u ? 8 : 16);
+  const bool p = pipe < 0 ? (a.n < 32768u && lanes_per_block >= 8) : pipe != 0;
   switch (lanes_per_block) {
-    case 4: return launch_decode_gl<4>(a, safe, st);
-    case 16: return launch_decode_gl<16>(a, safe, st);
-    case 32: return launch_decode_gl<32>(a, safe, st);
-    case 64: return launch_decode_gl<64>(a, safe, st);
+    case 4: return launch_decode_gl<4>(a, safe, p, st);
+    case 16: return launch_decode_gl<16>(a, safe, p, st);
+    case 32: return launch_decode_gl<32>(a, safe, p, st);
+    case 64: return launch_decode_gl<64>(a, safe, p, st);
     case 8:
-    default: return launch_decode_gl<8>(a, safe, st);
+    default: return launch_decode_gl<8>(a, safe, p, st);
   }
 }
 

@@ -39,7 +39,9 @@ namespace lz4hip {
 // !SAFE: LZ4_decompress_fast(src, dst, out_size) -> bytes consumed or negative; `src_size` is then
 //        the readable capacity of the source slot and is never exceeded (liblz4 itself trusts the
 //        stream blindly; results on valid streams are identical).
-template <class Grp, bool SAFE>
+// PIPE: pipelined interior loop (below).  Pays when a wavefront has to make progress on its own (few, large blocks);
+//       with the GPU full of blocks the plain loop is as fast.
+template <class Grp, bool SAFE, bool PIPE = false>
 LZ4HIP_DEV int decode_block(Grp& g, const uint8_t* src, int src_size, uint8_t* dst, int out_size) {
   int ip = 0, op = 0;
   const int iend = src_size, oend = out_size;  // iend: real end (SAFE) / read bound (!SAFE)
@@ -63,7 +65,83 @@ LZ4HIP_DEV int decode_block(Grp& g, const uint8_t* src, int src_size, uint8_t* d
     // sequence start, to the exact tier-1 code below, which re-decodes that sequence with all checks. ----
     // The 8 bytes fetched at the offset position also hold the NEXT sequence's token (and its first length byte), so the
     // steady state costs two dependent loads per sequence: {offset word + literals} and {match source}.
-    if (ip <= iend - 306 && op <= oend - 606) {
+    if (PIPE && ip <= iend - 306 && op <= oend - 606) {
+      // ---- the same loop, software-pipelined.  A wavefront's memory operations retire in order, so a wait for a load also
+      // waits for every OLDER store.  Here (a) the next sequence's offset word is requested as soon as this sequence's header
+      // is parsed, (b) a "simple" sequence (literals and match take one step each, match source entirely before the
+      // sequence's own output) is LOADED in one trip and STORED in the next, behind that trip's loads -- no wait ever covers
+      // a store, and both of a trip's waits are for loads issued a trip earlier.  Two register sets alternate (a copy would
+      // have to wait for the loads).  Anything not simple, or whose source reaches into bytes still waiting to be stored,
+      // flushes the pending stores first. ----
+      typename Grp::SeqRegs R0, R1;
+      bool have_p = false, p_in0 = false;  // a loaded-not-stored sequence exists; it sits in R0 / R1
+      uint32_t p_op = 0, p_lit = 0, p_ml = 0;
+      uint32_t t4 = g.ld32(src + ip);
+      uint64_t o8 = 0;
+      bool have_o8 = false;                // o8 already holds the offset word of the sequence at ip
+      auto trip = [&](typename Grp::SeqRegs& cur, typename Grp::SeqRegs& pnd, const bool cur_is0) -> bool {  // false: leave the loop
+        int lit = (int)((t4 >> 4) & 15u);
+        int ml = (int)(t4 & 15u);
+        int hdr = 1;
+        if (lit == 15) {
+          const uint32_t e = (t4 >> 8) & 255u;
+          if (e == 255u) return false;
+          lit += (int)e;
+          hdr = 2;
+        }
+        if (!have_o8) o8 = g.ld64(src + ip + hdr + lit);
+        const int off = (int)((uint32_t)o8 & 0xFFFFu);
+        int adv = hdr + lit + 2;
+        uint32_t nxt = (uint32_t)(o8 >> 16);
+        if (ml == 15) {
+          const uint32_t e = nxt & 255u;
+          if (e == 255u) { have_o8 = false; return false; }
+          ml += (int)e;
+          adv++;
+          nxt = (uint32_t)(o8 >> 24);
+        }
+        ml += 4;
+        if (off > op + lit) { have_o8 = false; return false; }  // invalid offset: the exact path produces liblz4's error code
+        const uint8_t* lit_src = src + ip + hdr;
+        {
+          // the next sequence's header is in nxt: if it can run in this loop, request its offset word now (the address the
+          // next trip computes from t4 = nxt; ip + adv <= iend - 306 leaves >= 306 readable bytes, the word ends <= 279 in)
+          have_o8 = false;
+          int lit2 = (int)((nxt >> 4) & 15u), hdr2 = 1;
+          bool ok2 = ip + adv <= iend - 306;
+          if (lit2 == 15) {
+            const uint32_t e2 = (nxt >> 8) & 255u;
+            if (e2 == 255u) ok2 = false;
+            lit2 += (int)e2;
+            hdr2 = 2;
+          }
+          if (ok2) { o8 = g.ld64(src + ip + adv + hdr2 + lit2); have_o8 = true; }
+        }
+        // simple: one step each, and the match source [op+lit-off, +ml+slack) ends before this sequence's own output;
+        // dep: the source reaches into the bytes the pending sequence has yet to store
+        const uint32_t ulit = (uint32_t)lit, uml = (uint32_t)ml, uoff = (uint32_t)off, sl = g.slack();
+        const bool simple = ulit <= g.step() && uml <= g.step() && uoff >= ulit + uml + sl;
+        const bool dep = have_p && uoff < ulit + uml + sl + p_lit + p_ml;
+        if (have_p && (!simple || dep)) { g.seq_store(pnd, dst + p_op, p_lit, p_ml); have_p = false; }
+        if (simple) {
+          g.seq_load(cur, lit_src, ulit, dst + op + lit - off, uml);
+          if (have_p) g.seq_store(pnd, dst + p_op, p_lit, p_ml);
+          have_p = true; p_in0 = cur_is0; p_op = (uint32_t)op; p_lit = ulit; p_ml = uml;
+          op += lit;
+        } else {
+          g.copy_lits_wide(dst + op, lit_src, ulit);
+          op += lit;
+          g.copy_match_wide(dst, (uint32_t)op, uoff, uml);
+        }
+        op += ml;
+        ip += adv;
+        t4 = nxt;
+        return ip <= iend - 306 && op <= oend - 606;
+      };
+      while (trip(R0, R1, true) && trip(R1, R0, false)) {}
+      if (have_p) g.seq_store(p_in0 ? R0 : R1, dst + p_op, p_lit, p_ml);  // the exact code below reads what is in memory
+    }
+    if (!PIPE && ip <= iend - 306 && op <= oend - 606) {
       uint32_t t4 = g.ld32(src + ip);  // {token, first literal-length byte, ...} of the sequence at ip
       do {
         int lit = (int)((t4 >> 4) & 15u);

@@ -68,6 +68,25 @@ struct GroupHost {
     }
   }
 
+  // split sequence copy of the pipelined interior loop (group_dev.h seq_load / seq_store), lock-step per call
+  struct SeqRegs { uint8_t v[64][16], u[64][16]; };
+  uint32_t step() const { return lb() * (uint32_t)GL; }
+  uint32_t lb() const { return 64u / GL < 4u ? 4u : 64u / GL; }
+  uint32_t slack() const { return lb(); }
+  void seq_load(SeqRegs& r, const uint8_t* s, uint32_t lit, const uint8_t* m, uint32_t len) {
+    const uint32_t LB = lb();
+    for (int l = 0; l < GL; l++) {
+      const uint32_t i = LB * l;
+      if (i < lit && rd_ok(s + i, LB)) memcpy(r.v[l], s + i, LB);
+      if (i < len && rd_ok(m + i, LB)) memcpy(r.u[l], m + i, LB);
+    }
+  }
+  void seq_store(const SeqRegs& r, uint8_t* d, uint32_t lit, uint32_t len) {
+    const uint32_t LB = lb();
+    for (int l = 0; l < GL; l++) { const uint32_t i = LB * l; if (i < lit && wr_ok(d + i, LB)) memcpy(d + i, r.v[l], LB); }
+    for (int l = 0; l < GL; l++) { const uint32_t i = LB * l; if (i < len && wr_ok(d + lit + i, LB)) memcpy(d + lit + i, r.u[l], LB); }
+  }
+
   void copy_match(uint8_t* dst, uint32_t op, uint32_t offset, uint32_t len, bool wild) {
     uint8_t* d = dst + op;
     const uint8_t* m = d - offset;
