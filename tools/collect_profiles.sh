@@ -5,7 +5,6 @@
 tag=$1
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-python bench.py 2>&1 | tail -1 > gpurun_out/${tag}_bench_line.json
 timeout 400 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$tag -o kt -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline > gpurun_out/prof_$tag.log 2>&1
 db=$(find gpurun_out/prof_$tag -name "*.db" | head -1)
 (echo "# profiles/${tag}_bench_kernel_trace.txt"
@@ -18,4 +17,6 @@ cp profiles/traffic.json gpurun_out/traffic_$tag.json
  echo "# command: tools/traffic_passes.sh (one rocprofv3 --kernel-trace --pmc <set> run per counter set; bench.py --steps 2 --warmup 1 --no-cpu-baseline)"
  for t in gpurun_out/traffic_$tag/*/; do db=$(find $t -name "*.db" | head -1); python tools/rocprof_summary.py $db lz4hip | grep -v "^$"; done) > gpurun_out/${tag}_traffic_pmc.txt
 rm -rf gpurun_out/prof_$tag gpurun_out/traffic_$tag
+# the bench line last: it quotes profiles/traffic.json, which the passes above have just rewritten
+python bench.py 2>&1 | tail -1 > gpurun_out/${tag}_bench_line.json
 cat gpurun_out/${tag}_bench_line.json
