@@ -45,10 +45,13 @@ for core in (0, 1, 2):
 amd.set_option("compress_core", 2)
 caps = [len(v) for v in inputs]
 src, so, sl, dst, do = pack(exp_full, caps)
-out = amd.LZ4HIPBatch.decompressSafe(src, so, sl, dst, do, caps)
-for i, (r, o) in enumerate(zip(out, do)):
-    if r != len(inputs[i]) or bytes(dst[o:o + r]) != inputs[i]:
-        print("MISMATCH decode_safe input", i); sys.exit(1)
+for lanes, pipe in ((0, -1), (4, 0), (4, 1), (8, 1), (16, 1), (64, 1), (64, 0)):   # every lane count x plain / pipelined interior loop
+    amd.set_option("decode_lanes", lanes); amd.set_option("decode_pipe", pipe)
+    out = amd.LZ4HIPBatch.decompressSafe(src, so, sl, dst, do, caps)
+    for i, (r, o) in enumerate(zip(out, do)):
+        if r != len(inputs[i]) or bytes(dst[o:o + r]) != inputs[i]:
+            print("MISMATCH decode_safe input", i, "lanes", lanes, "pipe", pipe); sys.exit(1)
+amd.set_option("decode_lanes", 0); amd.set_option("decode_pipe", -1)
 out = amd.LZ4HIPBatch.decompressFast(src, so, sl, dst, do, caps)
 for i, (r, o) in enumerate(zip(out, do)):
     if r != len(exp_full[i]) or bytes(dst[o:o + len(inputs[i])]) != inputs[i]:
@@ -63,4 +66,14 @@ for i, (r, o) in enumerate(zip(out, do)):
     if r != len(e) or bytes(dst[o:o + r]) != e:
         print("MISMATCH HC input", i, len(sub[i]), r, len(e)); sys.exit(1)
 print("HC level 9: %d inputs bit-exact" % len(sub), flush=True)
+sub = inputs[: max(1, n // 40)]
+caps = [ref.compress_bound(len(v)) for v in sub]
+src, so, sl, dst, do = pack(sub, caps)
+for level in (1, 3, 6, 10, 12):
+    out = amd.LZ4HIPBatch.compressHC(src, so, sl, dst, do, caps, level)
+    for i, (r, o) in enumerate(zip(out, do)):
+        e = ref.compress_hc(sub[i], level)
+        if r != len(e) or bytes(dst[o:o + r]) != e:
+            print("MISMATCH HC level", level, "input", i, len(sub[i]), r, len(e)); sys.exit(1)
+print("HC levels 1, 3, 6, 10, 12: %d inputs each bit-exact" % len(sub), flush=True)
 print("fuzz ok")
