@@ -65,6 +65,7 @@ struct DeviceGuard {  // callers (e.g. PyTorch) own the thread's current device:
 
 enum Op { OP_COMPRESS_FAST, OP_DECODE_SAFE, OP_DECODE_FAST, OP_COMPRESS_HC };
 int g_decode_lanes = 0;  // tuning knob (lz4hip_set_option "decode_lanes"); 0 = kernel default
+int g_decode_stage = -1; // tuning knob "decode_stage": 1 = LDS output staging in the plain loop
 int g_decode_pipe = -1;  // tuning knob "decode_pipe": 1/0 = pipelined interior loop on/off, -1 = kernel default
 // lz4hip_set_option "compress_core": 2 = adaptive two-pass (default), 1 = window-parallel core only (lz4_fast_ms_core.h),
 // 0 = one-sequence-per-step core only (lz4_fast_core.h); "compress_switch" = bytes per sequence below which a block counts
@@ -150,8 +151,8 @@ int launch_op(Op op, const lz4hip::BatchArgs& a, hipStream_t st) {
   int e = 0;
   switch (op) {
     case OP_COMPRESS_FAST: e = launch_fast(a, st); break;
-    case OP_DECODE_SAFE: e = lz4hip::launch_decompress(a, true, g_decode_lanes, g_decode_pipe, st); break;
-    case OP_DECODE_FAST: e = lz4hip::launch_decompress(a, false, g_decode_lanes, g_decode_pipe, st); break;
+    case OP_DECODE_SAFE: e = lz4hip::launch_decompress(a, true, g_decode_lanes, g_decode_pipe, g_decode_stage, st); break;
+    case OP_DECODE_FAST: e = lz4hip::launch_decompress(a, false, g_decode_lanes, g_decode_pipe, g_decode_stage, st); break;
     case OP_COMPRESS_HC: return fail(LZ4HIP_E_ARG, "internal: HC goes through dev_hc");
   }
   if (e != 0) return fail(LZ4HIP_E_HIP, "kernel launch", (hipError_t)e);
@@ -360,8 +361,8 @@ int host_shard(Op op, int level, int ord, const uint8_t* src, const uint64_t* sr
     int le = 0;
     switch (op) {
       case OP_COMPRESS_FAST: le = launch_fast(a, s.st); break;
-      case OP_DECODE_SAFE: le = lz4hip::launch_decompress(a, true, g_decode_lanes, g_decode_pipe, s.st); break;
-      case OP_DECODE_FAST: le = lz4hip::launch_decompress(a, false, g_decode_lanes, g_decode_pipe, s.st); break;
+      case OP_DECODE_SAFE: le = lz4hip::launch_decompress(a, true, g_decode_lanes, g_decode_pipe, g_decode_stage, s.st); break;
+      case OP_DECODE_FAST: le = lz4hip::launch_decompress(a, false, g_decode_lanes, g_decode_pipe, g_decode_stage, s.st); break;
       case OP_COMPRESS_HC: le = lz4hip::launch_compress_hc(a, level, s.d_ws.p, sb, s.st); break;
     }
     if (le) { rc = bad("kernel launch", (hipError_t)le); break; }
@@ -562,6 +563,11 @@ int lz4hip_device_count(void) {
 }
 
 int lz4hip_set_option(const char* name, int value) {
+  if (name && strcmp(name, "decode_stage") == 0) {
+    if (value < -1 || value > 1) return fail(LZ4HIP_E_ARG, "decode_stage must be -1, 0 or 1");
+    g_decode_stage = value;
+    return LZ4HIP_OK;
+  }
   if (name && strcmp(name, "decode_pipe") == 0) {
     if (value < -1 || value > 1) return fail(LZ4HIP_E_ARG, "decode_pipe must be -1, 0 or 1");
     g_decode_pipe = value;

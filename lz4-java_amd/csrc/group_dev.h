@@ -84,6 +84,68 @@ struct GroupDev {
     if (i < len) store_out(d + lit + i, r.u);
   }
 
+  // ---- output staging in LDS (lz4_decode_core.h STAGE): the interior loop's output goes to a per-block staging buffer and
+  // leaves it as whole 128-byte lines.  Why: with every block of a big batch in flight, the partially written line of each
+  // block is evicted from L2 between the small stores that fill it and reaches HBM several times (WRITE_SIZE 11.8 GB for
+  // 4.3 GB of output, profiles/r01n).  Staging holds the output bytes [fl, fl + kStage); everything below fl is in memory.
+  // Match sources are read from memory only, so the caller flushes everything first when a source reaches past fl. ----
+  static constexpr uint32_t kStage = 576u;   // >= 127 (open line) + what two sequences of the interior loop typically add + a step + slack
+  uint8_t* stg = nullptr;
+  uint32_t fl = 0;
+  __device__ __forceinline__ void st_begin(uint8_t* lds, uint32_t op) { stg = lds; fl = op; }
+  // whole lines below p (p = end of the valid staged bytes) go to memory; the open line moves to the front
+  __device__ __forceinline__ void st_flush_lines(uint8_t* dst, uint32_t p) {
+    const uint32_t target = p - (((uint32_t)(uintptr_t)dst + p) & 127u);   // last position <= p at a 128-byte address
+    if ((int32_t)(target - fl) <= 0) return;
+    const uint32_t nb = target - fl, rem = p - target;
+    for (uint32_t o = l * LB; o < nb; o += LB * GL) {   // (may carry up to LB-1 staged bytes past target: written again by the next flush)
+      Chunk<LB / 4> v;
+      __builtin_memcpy(&v, stg + o, LB);
+      store_out(dst + fl + o, v);
+    }
+    for (uint32_t o = l * LB; o < rem; o += LB * GL) {  // shift down by nb (forward, one instruction's loads before its stores)
+      Chunk<LB / 4> v;
+      __builtin_memcpy(&v, stg + nb + o, LB);
+      __builtin_memcpy(stg + o, &v, LB);
+    }
+    fl = target;
+  }
+  // everything below p goes to memory (up to LB-1 bytes past p are touched: output positions that are written again later)
+  __device__ __forceinline__ void st_flush_all(uint8_t* dst, uint32_t p) {
+    const uint32_t nb = p - fl;
+    for (uint32_t o = l * LB; o < nb; o += LB * GL) {
+      Chunk<LB / 4> v;
+      __builtin_memcpy(&v, stg + o, LB);
+      store_out(dst + fl + o, v);
+    }
+    fl = p;
+  }
+  __device__ __forceinline__ void st_lits(uint8_t* dst, uint32_t op, const uint8_t* s, uint32_t len) {
+    for (uint32_t base = 0; base < len; base += LB * GL) {
+      if (op + base - fl + LB * GL + LB > kStage) st_flush_lines(dst, op + base);
+      const uint32_t i = base + l * LB;
+      if (i < len) {
+        Chunk<LB / 4> v;
+        __builtin_memcpy(&v, s + i, LB);
+        __builtin_memcpy(stg + (op + i - fl), &v, LB);
+      }
+    }
+  }
+  // staged[op+i] = memory[op-offset+i]; the caller guarantees offset >= step() and (op - offset) + len + slack() <= fl
+  __device__ __forceinline__ void st_match(uint8_t* dst, uint32_t op, uint32_t offset, uint32_t len) {
+    const uint8_t* m = dst + op - offset;
+    for (uint32_t base = 0; base < len; base += LB * GL) {
+      if (op + base - fl + LB * GL + LB > kStage) st_flush_lines(dst, op + base);
+      const uint32_t i = base + l * LB;
+      if (i < len) {
+        Chunk<LB / 4> v;
+        const vecLB t = __builtin_nontemporal_load((const vecLB*)(m + i));
+        __builtin_memcpy(&v, &t, LB);
+        __builtin_memcpy(stg + (op + i - fl), &v, LB);
+      }
+    }
+  }
+
   // dst[op+i] = dst[op-offset+i] for i in [0,len), byte-forward (overlap replicates the pattern)
   __device__ __forceinline__ void copy_match(uint8_t* dst, uint32_t op, uint32_t offset, uint32_t len, bool wild) const {
     uint8_t* d = dst + op;

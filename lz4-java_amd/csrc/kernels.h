@@ -37,7 +37,8 @@ int launch_compress_hc(const BatchArgs& a, int level, void* ws, uint64_t span, v
 int launch_pack(const BatchArgs& a, uint64_t* poff, uint8_t* pack, void* stream);
 // lanes_per_block: lanes of a wavefront that share one block in the decoder (4..64); 0 = default
 // pipe: 1 = pipelined interior loop (lz4_decode_core.h PIPE), 0 = plain, -1 = default for the batch size
-int launch_decompress(const BatchArgs& a, bool safe, int lanes_per_block, int pipe, void* stream);
+// stage: 1 = the plain interior loop writes through LDS staging (whole-line output), 0 / -1 = off
+int launch_decompress(const BatchArgs& a, bool safe, int lanes_per_block, int pipe, int stage, void* stream);
 int launch_xxh32(const uint8_t* buf, const uint64_t* off, const int32_t* len, uint32_t seed, uint32_t* out, uint32_t n, void* stream);
 int launch_xxh64(const uint8_t* buf, const uint64_t* off, const int32_t* len, uint64_t seed, uint64_t* out, uint32_t n, void* stream);
 // streaming xxhash: `rec` = device record of xxh_stream_rec_bytes() bytes (the digest so far sits at xxh_stream_digest_offset());

@@ -478,49 +478,58 @@ int launch_pack(const BatchArgs& a, uint64_t* poff, uint8_t* pack, void* stream)
 // ------------------------------------------------------------------------------------------------
 // decode
 // ------------------------------------------------------------------------------------------------
-template <int GL, bool SAFE, bool PIPE>
+template <int GL, bool SAFE, bool PIPE, bool STAGE>
 __global__ __launch_bounds__(256) void decode_kernel(BatchArgs a) {
+  // STAGE: one staging buffer per block of the workgroup (group_dev.h st_*): 256/GL x 576 bytes
+  __shared__ __attribute__((aligned(16))) uint8_t stage_mem[STAGE ? (256 / GL) * GroupDev<GL>::kStage : 16];
   const uint32_t gid = (blockIdx.x * 256u + threadIdx.x) / GL;
   if (gid >= a.n) return;  // a whole group leaves together
   GroupDev<GL> g;
-  const int r = decode_block<GroupDev<GL>, SAFE, PIPE>(g, a.src + a.src_off[gid], a.src_len[gid], a.dst + a.dst_off[gid], a.dst_cap[gid]);
+  uint8_t* stage = STAGE ? stage_mem + (threadIdx.x / GL) * GroupDev<GL>::kStage : nullptr;
+  const int r = decode_block<GroupDev<GL>, SAFE, PIPE, STAGE>(g, a.src + a.src_off[gid], a.src_len[gid], a.dst + a.dst_off[gid], a.dst_cap[gid], stage);
   if (g.l == 0) a.out[gid] = r;
 }
 
 template <int GL>
-static int launch_decode_gl(const BatchArgs& a, bool safe, bool pipe, hipStream_t st) {
+static int launch_decode_gl(const BatchArgs& a, bool safe, bool pipe, bool stage, hipStream_t st) {
   const uint32_t per_wg = 256u / GL;
   const uint32_t grid = (a.n + per_wg - 1u) / per_wg;
-  if (safe) {
-    if (pipe) hipLaunchKernelGGL((decode_kernel<GL, true, true>), dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((decode_kernel<GL, true, false>), dim3(grid), dim3(256), 0, st, a);
+  if (stage) {   // (staging belongs to the plain loop)
+    if (safe) hipLaunchKernelGGL((decode_kernel<GL, true, false, true>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((decode_kernel<GL, false, false, true>), dim3(grid), dim3(256), 0, st, a);
+  } else if (safe) {
+    if (pipe) hipLaunchKernelGGL((decode_kernel<GL, true, true, false>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((decode_kernel<GL, true, false, false>), dim3(grid), dim3(256), 0, st, a);
   } else {
-    if (pipe) hipLaunchKernelGGL((decode_kernel<GL, false, true>), dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((decode_kernel<GL, false, false>), dim3(grid), dim3(256), 0, st, a);
+    if (pipe) hipLaunchKernelGGL((decode_kernel<GL, false, true, false>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((decode_kernel<GL, false, false, false>), dim3(grid), dim3(256), 0, st, a);
   }
   return (int)hipGetLastError();
 }
 
-int launch_decompress(const BatchArgs& a, bool safe, int lanes_per_block, int pipe, void* stream) {
+int launch_decompress(const BatchArgs& a, bool safe, int lanes_per_block, int pipe, int stage, void* stream) {
   if (a.n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   // Defaults by batch size (tools/decode_matrix.sh; App. F / text / 4 MiB blocks):
-  //   >= 32768 blocks: 4 lanes x 16 bytes per block (16 blocks per wavefront), plain loop -- the GPU is full, long-sequence data
-  //                    is bandwidth-bound (pipelined or not: 512 vs 519 GB/s) and short-sequence data issue-bound (text: the
-  //                    pipelined loop costs 25 % there);
+  //   >= 32768 blocks: 4 lanes x 16 bytes per block (16 blocks per wavefront), plain loop with output staging -- the GPU is
+  //                    full, long-sequence data is bandwidth-bound (pipelined or not: 512 vs 519 GB/s) and short-sequence data
+  //                    issue-bound (text: the pipelined loop costs 25 % there);
   //   >= 8192 blocks:  8 lanes, pipelined loop (App. F 301 -> 422 GB/s at 16384 blocks; text 77 -> 73);
   //   fewer:           16 lanes, pipelined loop (App. F 90 -> 138 GB/s at 4096 blocks, 4096 x 4 MiB 131 -> 179, text 25 -> 27):
   //                    every wavefront has to make progress on its own.
   const bool auto_lanes = lanes_per_block == 0;
   if (auto_lanes) lanes_per_block = a.n >= 32768u ? 4 : (a.n >= 8192u ? 8 : 16);
   const bool p = pipe < 0 ? (a.n < 32768u && lanes_per_block >= 8) : pipe != 0;
+  // staging (whole-line output through LDS) pays where the batch is bandwidth-bound: App. F 65536 blocks 487 -> 680 GB/s
+  // (text 106 -> 111); below that the pipelined loop wins (16384 blocks: 424 vs 289 staged vs 304 plain)
+  const bool sg = !p && (stage < 0 ? a.n >= 32768u : stage != 0);
   switch (lanes_per_block) {
-    case 4: return launch_decode_gl<4>(a, safe, p, st);
-    case 16: return launch_decode_gl<16>(a, safe, p, st);
-    case 32: return launch_decode_gl<32>(a, safe, p, st);
-    case 64: return launch_decode_gl<64>(a, safe, p, st);
+    case 4: return launch_decode_gl<4>(a, safe, p, sg, st);
+    case 16: return launch_decode_gl<16>(a, safe, p, sg, st);
+    case 32: return launch_decode_gl<32>(a, safe, p, sg, st);
+    case 64: return launch_decode_gl<64>(a, safe, p, sg, st);
     case 8:
-    default: return launch_decode_gl<8>(a, safe, p, st);
+    default: return launch_decode_gl<8>(a, safe, p, sg, st);
   }
 }
 

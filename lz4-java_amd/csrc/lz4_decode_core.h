@@ -41,8 +41,10 @@ namespace lz4hip {
 //        stream blindly; results on valid streams are identical).
 // PIPE: pipelined interior loop (below).  Pays when a wavefront has to make progress on its own (few, large blocks);
 //       with the GPU full of blocks the plain loop is as fast.
-template <class Grp, bool SAFE, bool PIPE = false>
-LZ4HIP_DEV int decode_block(Grp& g, const uint8_t* src, int src_size, uint8_t* dst, int out_size) {
+// STAGE: the interior loop writes through an LDS staging buffer (`stage`, Grp::kStage bytes for this block) and output leaves
+//        it as whole 128-byte lines (group_dev.h st_*).
+template <class Grp, bool SAFE, bool PIPE = false, bool STAGE = false>
+LZ4HIP_DEV int decode_block(Grp& g, const uint8_t* src, int src_size, uint8_t* dst, int out_size, uint8_t* stage = nullptr) {
   int ip = 0, op = 0;
   const int iend = src_size, oend = out_size;  // iend: real end (SAFE) / read bound (!SAFE)
   const int shortiend = iend - (SAFE ? 14 : 8) - 2;
@@ -141,7 +143,55 @@ LZ4HIP_DEV int decode_block(Grp& g, const uint8_t* src, int src_size, uint8_t* d
       while (trip(R0, R1, true) && trip(R1, R0, false)) {}
       if (have_p) g.seq_store(p_in0 ? R0 : R1, dst + p_op, p_lit, p_ml);  // the exact code below reads what is in memory
     }
-    if (!PIPE && ip <= iend - 306 && op <= oend - 606) {
+    if (STAGE && !PIPE && ip <= iend - 306 && op <= oend - 606) {
+      // ---- the plain loop below, writing through the staging buffer.  Match sources are read from memory only: a source that
+      // reaches past the flushed position (rare unless offsets are short) flushes everything first, and that match is then
+      // written straight to memory.  Whole lines are flushed every second sequence -- on a schedule, not when a block happens
+      // to have filled a line, so that the blocks sharing a wavefront flush in the same instructions. ----
+      g.st_begin(stage, (uint32_t)op);
+      uint32_t t4 = g.ld32(src + ip);
+      uint32_t it = 0;
+      do {
+        int lit = (int)((t4 >> 4) & 15u);
+        int ml = (int)(t4 & 15u);
+        int hdr = 1;
+        if (lit == 15) {
+          const uint32_t e = (t4 >> 8) & 255u;
+          if (e == 255u) break;
+          lit += (int)e;
+          hdr = 2;
+        }
+        const uint64_t o8 = g.ld64(src + ip + hdr + lit);
+        g.st_lits(dst, (uint32_t)op, src + ip + hdr, (uint32_t)lit);
+        const int off = (int)((uint32_t)o8 & 0xFFFFu);
+        int adv = hdr + lit + 2;
+        uint32_t nxt = (uint32_t)(o8 >> 16);
+        if (ml == 15) {
+          const uint32_t e = nxt & 255u;
+          if (e == 255u) break;  // (the staged literals lie beyond op: never flushed)
+          ml += (int)e;
+          adv++;
+          nxt = (uint32_t)(o8 >> 24);
+        }
+        ml += 4;
+        if (off > op + lit) break;
+        op += lit;
+        if ((uint32_t)(op - off) + (uint32_t)ml + g.slack() > g.fl) {
+          g.st_flush_all(dst, (uint32_t)op);
+          g.copy_match_wide(dst, (uint32_t)op, (uint32_t)off, (uint32_t)ml);
+          op += ml;
+          g.fl = (uint32_t)op;
+        } else {
+          g.st_match(dst, (uint32_t)op, (uint32_t)off, (uint32_t)ml);
+          op += ml;
+        }
+        ip += adv;
+        t4 = nxt;
+        if ((++it & 1u) == 0u) g.st_flush_lines(dst, (uint32_t)op);
+      } while (ip <= iend - 306 && op <= oend - 606);
+      g.st_flush_all(dst, (uint32_t)op);  // the exact code below reads and writes memory
+    }
+    if (!STAGE && !PIPE && ip <= iend - 306 && op <= oend - 606) {
       uint32_t t4 = g.ld32(src + ip);  // {token, first literal-length byte, ...} of the sequence at ip
       do {
         int lit = (int)((t4 >> 4) & 15u);

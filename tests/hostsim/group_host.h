@@ -87,6 +87,60 @@ struct GroupHost {
     for (int l = 0; l < GL; l++) { const uint32_t i = LB * l; if (i < len && wr_ok(d + lit + i, LB)) memcpy(d + lit + i, r.u[l], LB); }
   }
 
+  // output staging (group_dev.h st_*): same chunking, same flush rules; an index outside the staging buffer counts as oob
+  static constexpr uint32_t kStage = 576u;
+  uint8_t stg_buf[kStage + 64];
+  uint8_t* stg = nullptr;
+  uint32_t fl = 0;
+  bool st_ok(uint32_t idx, uint32_t k) { if (idx + k > kStage) { oob = true; return false; } return true; }
+  void st_begin(uint8_t*, uint32_t op) { stg = stg_buf; fl = op; memset(stg_buf, 0xEE, sizeof stg_buf); }
+  void st_flush_lines(uint8_t* dst, uint32_t p) {
+    const uint32_t LB = lb();
+    const uint32_t target = p - (((uint32_t)(uintptr_t)dst + p) & 127u);
+    if ((int32_t)(target - fl) <= 0) return;
+    const uint32_t nb = target - fl, rem = p - target;
+    for (uint32_t base = 0; base < nb; base += LB * GL)
+      for (int l = 0; l < GL; l++) { const uint32_t o = base + LB * l; if (o < nb && st_ok(o, LB) && wr_ok(dst + fl + o, LB)) memcpy(dst + fl + o, stg + o, LB); }
+    for (uint32_t base = 0; base < rem; base += LB * GL) {
+      uint8_t v[64][16]; bool act[64];
+      for (int l = 0; l < GL; l++) { const uint32_t o = base + LB * l; act[l] = o < rem && st_ok(nb + o, LB); if (act[l]) memcpy(v[l], stg + nb + o, LB); }
+      for (int l = 0; l < GL; l++) { const uint32_t o = base + LB * l; if (act[l]) memcpy(stg + o, v[l], LB); }
+    }
+    fl = target;
+  }
+  void st_flush_all(uint8_t* dst, uint32_t p) {
+    const uint32_t LB = lb();
+    const uint32_t nb = p - fl;
+    for (uint32_t base = 0; base < nb; base += LB * GL)
+      for (int l = 0; l < GL; l++) { const uint32_t o = base + LB * l; if (o < nb && st_ok(o, LB) && wr_ok(dst + fl + o, LB)) memcpy(dst + fl + o, stg + o, LB); }
+    fl = p;
+  }
+  void st_lits(uint8_t* dst, uint32_t op, const uint8_t* s, uint32_t len) {
+    const uint32_t LB = lb();
+    for (uint32_t base = 0; base < len; base += LB * GL) {
+      if (op + base - fl + LB * GL + LB > kStage) st_flush_lines(dst, op + base);
+      uint8_t v[64][16]; bool act[64];
+      for (int l = 0; l < GL; l++) { const uint32_t i = base + LB * l; act[l] = i < len && rd_ok(s + i, LB); if (act[l]) memcpy(v[l], s + i, LB); }
+      for (int l = 0; l < GL; l++) { const uint32_t i = base + LB * l; if (act[l] && st_ok(op + i - fl, LB)) memcpy(stg + (op + i - fl), v[l], LB); }
+    }
+  }
+  void st_match(uint8_t* dst, uint32_t op, uint32_t offset, uint32_t len) {
+    const uint32_t LB = lb();
+    const uint8_t* m = dst + op - offset;
+    for (uint32_t base = 0; base < len; base += LB * GL) {
+      if (op + base - fl + LB * GL + LB > kStage) st_flush_lines(dst, op + base);
+      uint8_t v[64][16]; bool act[64];
+      for (int l = 0; l < GL; l++) {
+        const uint32_t i = base + LB * l;
+        act[l] = i < len;
+        if (act[l] && (uint32_t)(op - offset + i) + LB > fl) { oob = true; act[l] = false; }   // the source must be flushed memory
+        if (act[l] && !rd_ok(m + i, LB)) act[l] = false;
+        if (act[l]) memcpy(v[l], m + i, LB);
+      }
+      for (int l = 0; l < GL; l++) { const uint32_t i = base + LB * l; if (act[l] && st_ok(op + i - fl, LB)) memcpy(stg + (op + i - fl), v[l], LB); }
+    }
+  }
+
   void copy_match(uint8_t* dst, uint32_t op, uint32_t offset, uint32_t len, bool wild) {
     uint8_t* d = dst + op;
     const uint8_t* m = d - offset;

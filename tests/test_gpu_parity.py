@@ -125,17 +125,20 @@ def test_decode_fuzz_bit_exact(amd, ref, O, corpus):
         elif mode == 5:
             c, cap = bytearray(rng.randbytes(rng.randrange(1, 40))), rng.randrange(0, 200)
         streams.append(bytes(c)); caps.append(cap)
-    for lanes, pipe in ((0, -1), (4, 0), (4, 1), (8, 1), (16, 0), (64, 0), (64, 1)):   # pipe: the pipelined interior loop on / off
+    # pipe: the pipelined interior loop; stage: output staging in LDS (plain loop only)
+    for lanes, pipe, stage in ((0, -1, -1), (4, 0, 0), (4, 1, 0), (8, 1, 0), (16, 0, 0), (64, 0, 0), (64, 1, 0), (4, 0, 1), (8, 0, 1), (32, 0, 1), (64, 0, 1)):
         amd.set_option("decode_lanes", lanes)
         amd.set_option("decode_pipe", pipe)
+        amd.set_option("decode_stage", stage)
         res = gpu_decode_safe_many(amd, streams, caps)
         for c, cap, (r, d) in zip(streams, caps, res):
             er, ed = ref.decompress_safe_raw(c, cap)
-            assert r == er, (lanes, pipe, len(c), cap, r, er, c[:24].hex())
+            assert r == er, (lanes, pipe, stage, len(c), cap, r, er, c[:24].hex())
             if er >= 0:
                 assert d[:er] == ed[:er]
     amd.set_option("decode_lanes", 0)
     amd.set_option("decode_pipe", -1)
+    amd.set_option("decode_stage", -1)
     # fast decoder: bounded-input semantics defined by the oracle port; equal to liblz4 on valid streams
     src, so, sl, dst, do = pack(streams, caps)
     out = amd.LZ4HIPBatch.decompressFast(src, so, sl, dst, do, caps)

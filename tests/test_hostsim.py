@@ -157,7 +157,7 @@ def test_decode_core_fuzz(sim, ref, O, corpus):
         elif mode == 5:
             c, cap = bytearray(rng.randbytes(rng.randrange(1, 40))), rng.randrange(0, 200)
         c = bytes(c)
-        gl = rng.choice([4, 8, 16, 32, 64]) | rng.choice([0, 0x100])   # bit 8: the pipelined interior loop
+        gl = rng.choice([4, 8, 16, 32, 64]) | rng.choice([0, 0x100, 0x200])   # bit 8: the pipelined interior loop, bit 9: output staging
         r2, d2 = ref.decompress_safe_raw(c, cap)
         r1, d1 = sim_decode(sim, c, cap, 1, gl)
         assert r1 == r2 and (r2 < 0 or d1[:r2] == d2[:r2]), ("safe", mode, gl, len(v), cap, r1, r2)
@@ -174,7 +174,7 @@ def test_decode_core_fuzz(sim, ref, O, corpus):
 def test_decode_core_malformed_vectors(sim, golden):
     for v in golden["malformed"]:
         vec = bytes.fromhex(v["hex"])
-        for gl in (4, 16, 64, 8 | 0x100, 64 | 0x100):
+        for gl in (4, 16, 64, 8 | 0x100, 64 | 0x100, 4 | 0x200, 16 | 0x200):
             r, d = sim_decode(sim, vec, v["safe_cap"], 1, gl)
             assert r == v["safe_ret"]
             if r >= 0:

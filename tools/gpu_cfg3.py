@@ -36,6 +36,8 @@ try:
     print("block 0 vs reference library: %s" % ("bit-exact" if got == ref.compress_fast(h) else "MISMATCH"), flush=True)
 except Exception as e:  # the reference library is test infrastructure; its absence only skips this check
     print("reference check skipped: %r" % (e,))
+if os.environ.get("DS"):
+    amd.set_option("decode_stage", int(os.environ["DS"]))
 if os.environ.get("DP"):
     amd.set_option("decode_pipe", int(os.environ["DP"]))
 for lanes in lanes_list:

@@ -45,17 +45,21 @@ for core in (0, 1, 2):
 amd.set_option("compress_core", 2)
 caps = [len(v) for v in inputs]
 src, so, sl, dst, do = pack(exp_full, caps)
-for lanes, pipe in ((0, -1), (4, 0), (4, 1), (8, 1), (16, 1), (64, 1), (64, 0)):   # every lane count x plain / pipelined interior loop
-    amd.set_option("decode_lanes", lanes); amd.set_option("decode_pipe", pipe)
+# every lane count x plain / pipelined / staged interior loop
+for lanes, pipe, stage in ((0, -1, -1), (4, 0, 0), (4, 1, 0), (8, 1, 0), (16, 1, 0), (64, 1, 0), (64, 0, 0), (4, 0, 1), (8, 0, 1), (16, 0, 1), (64, 0, 1)):
+    amd.set_option("decode_lanes", lanes); amd.set_option("decode_pipe", pipe); amd.set_option("decode_stage", stage)
     out = amd.LZ4HIPBatch.decompressSafe(src, so, sl, dst, do, caps)
     for i, (r, o) in enumerate(zip(out, do)):
         if r != len(inputs[i]) or bytes(dst[o:o + r]) != inputs[i]:
-            print("MISMATCH decode_safe input", i, "lanes", lanes, "pipe", pipe); sys.exit(1)
-amd.set_option("decode_lanes", 0); amd.set_option("decode_pipe", -1)
-out = amd.LZ4HIPBatch.decompressFast(src, so, sl, dst, do, caps)
-for i, (r, o) in enumerate(zip(out, do)):
-    if r != len(exp_full[i]) or bytes(dst[o:o + len(inputs[i])]) != inputs[i]:
-        print("MISMATCH decode_fast input", i, r, len(exp_full[i])); sys.exit(1)
+            print("MISMATCH decode_safe input", i, "lanes", lanes, "pipe", pipe, "stage", stage); sys.exit(1)
+amd.set_option("decode_lanes", 0); amd.set_option("decode_pipe", -1); amd.set_option("decode_stage", -1)
+for lanes, pipe, stage in ((0, -1, -1), (4, 0, 1), (8, 1, 0), (16, 0, 1)):
+    amd.set_option("decode_lanes", lanes); amd.set_option("decode_pipe", pipe); amd.set_option("decode_stage", stage)
+    out = amd.LZ4HIPBatch.decompressFast(src, so, sl, dst, do, caps)
+    for i, (r, o) in enumerate(zip(out, do)):
+        if r != len(exp_full[i]) or bytes(dst[o:o + len(inputs[i])]) != inputs[i]:
+            print("MISMATCH decode_fast input", i, r, len(exp_full[i]), "lanes", lanes, "pipe", pipe, "stage", stage); sys.exit(1)
+amd.set_option("decode_lanes", 0); amd.set_option("decode_pipe", -1); amd.set_option("decode_stage", -1)
 print("decode safe/fast: %d streams bit-exact" % n, flush=True)
 sub = inputs[: max(1, n // 8)]
 caps = [ref.compress_bound(len(v)) for v in sub]

@@ -41,6 +41,8 @@ if os.environ.get("CC"):
     amd.set_option("compress_core", int(os.environ["CC"]))
 if os.environ.get("CS"):
     amd.set_option("compress_switch", int(os.environ["CS"]))
+if os.environ.get("DS"):
+    amd.set_option("decode_stage", int(os.environ["DS"]))
 if os.environ.get("DP"):
     amd.set_option("decode_pipe", int(os.environ["DP"]))
 if os.environ.get("CW"):
