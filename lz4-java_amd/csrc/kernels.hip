@@ -511,18 +511,19 @@ int launch_decompress(const BatchArgs& a, bool safe, int lanes_per_block, int pi
   if (a.n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   // Defaults by batch size (tools/decode_matrix.sh; App. F / text / 4 MiB blocks):
-  //   >= 32768 blocks: 4 lanes x 16 bytes per block (16 blocks per wavefront), plain loop with output staging -- the GPU is
+  //   >= 40960 blocks: 4 lanes x 16 bytes per block (16 blocks per wavefront), plain loop with output staging -- the GPU is
   //                    full, long-sequence data is bandwidth-bound (pipelined or not: 512 vs 519 GB/s) and short-sequence data
   //                    issue-bound (text: the pipelined loop costs 25 % there);
   //   >= 8192 blocks:  8 lanes, pipelined loop (App. F 301 -> 422 GB/s at 16384 blocks; text 77 -> 73);
   //   fewer:           16 lanes, pipelined loop (App. F 90 -> 138 GB/s at 4096 blocks, 4096 x 4 MiB 131 -> 179, text 25 -> 27):
   //                    every wavefront has to make progress on its own.
   const bool auto_lanes = lanes_per_block == 0;
-  if (auto_lanes) lanes_per_block = a.n >= 32768u ? 4 : (a.n >= 8192u ? 8 : 16);
-  const bool p = pipe < 0 ? (a.n < 32768u && lanes_per_block >= 8) : pipe != 0;
+  if (auto_lanes) lanes_per_block = a.n >= 40960u ? 4 : (a.n >= 8192u ? 8 : 16);
+  const bool p = pipe < 0 ? (a.n < 40960u && lanes_per_block >= 8) : pipe != 0;
   // staging (whole-line output through LDS) pays where the batch is bandwidth-bound: App. F 65536 blocks 487 -> 680 GB/s
-  // (text 106 -> 111); below that the pipelined loop wins (16384 blocks: 424 vs 289 staged vs 304 plain)
-  const bool sg = !p && (stage < 0 ? a.n >= 32768u : stage != 0);
+  // (text 106 -> 111); below that the pipelined loop wins (16384 blocks: 424 vs 289 staged vs 304 plain; 32768: 545 vs 447;
+  // 49152: 508 vs 597)
+  const bool sg = !p && (stage < 0 ? a.n >= 40960u : stage != 0);
   switch (lanes_per_block) {
     case 4: return launch_decode_gl<4>(a, safe, p, sg, st);
     case 16: return launch_decode_gl<16>(a, safe, p, sg, st);
