@@ -61,7 +61,8 @@ int lz4hip_version(void);
  * block in the decoder (0 = default by batch size, 4/8/16/32/64); "decode_pipe" = 1 / 0 / -1 (default by batch size): the
  * software-pipelined interior loop of the decoder (faster when the batch is too small to fill the GPU); "decode_stage" =
  * 1 / 0 / -1 (default by batch size): the decoder's interior loop writes through an LDS staging buffer so that output
- * reaches memory as whole 128-byte lines (faster when the batch is bandwidth-bound); "compress_core" = 2 (default: adaptive two-pass -- blocks of
+ * reaches memory as whole 128-byte lines (faster when the batch is bandwidth-bound); "xxh_kernel" = 1 (default: batches of more than 512 buffers
+ * are hashed 16 buffers per wavefront through LDS, coalesced) or 0 (one thread per buffer); "compress_core" = 2 (default: adaptive two-pass -- blocks of
  * long sequences are finished by the one-sequence-per-step core, blocks of short sequences by the window-parallel core),
  * 1 (window-parallel core only) or 0 (one-sequence-per-step core only); "compress_switch" = routing threshold of the
  * adaptive scheme in bytes per sequence (default 20); "compress_waves" = 1 (default: one wavefront per block) or

@@ -563,6 +563,11 @@ int lz4hip_device_count(void) {
 }
 
 int lz4hip_set_option(const char* name, int value) {
+  if (name && strcmp(name, "xxh_kernel") == 0) {
+    if (value != 0 && value != 1) return fail(LZ4HIP_E_ARG, "xxh_kernel must be 0 or 1");
+    lz4hip::set_xxh_kernel(value);
+    return LZ4HIP_OK;
+  }
   if (name && strcmp(name, "decode_stage") == 0) {
     if (value < -1 || value > 1) return fail(LZ4HIP_E_ARG, "decode_stage must be -1, 0 or 1");
     g_decode_stage = value;

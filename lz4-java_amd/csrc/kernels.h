@@ -23,6 +23,7 @@ struct BatchArgs {
 int launch_compress_fast(const BatchArgs& a, uint32_t* q, uint32_t* routed, uint32_t dense64, uint32_t n_cus, void* stream);
 int launch_compress_fast_ms(const BatchArgs& a, uint32_t* q, const uint32_t* routed, bool first, uint32_t n_cus, void* stream);
 void set_dbg_flags(uint32_t f);  // developer diagnostics
+void set_xxh_kernel(int v);       // batches of more than 512 buffers: 1 = four buffers per wavefront (default), 0 = one thread per buffer
 void set_dbg_extra_lds(uint32_t bytes);
 // two-wave variant: `ws` = zeroed device workspace of compress_fast2_ws_bytes(grid) bytes
 uint32_t compress_fast2_grid(uint32_t n_blocks, uint32_t n_cus);

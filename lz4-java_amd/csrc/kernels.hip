@@ -27,6 +27,8 @@ uint32_t g_dbg_extra_lds = 0;  // developer diagnostics: extra dynamic LDS per w
 void set_dbg_extra_lds(uint32_t b) { g_dbg_extra_lds = b; }
 uint32_t g_dbg_flags = 0;  // developer diagnostics (lz4hip_set_option "dbg_flags"): bit 0 = skip emission (timing only)
 void set_dbg_flags(uint32_t f) { g_dbg_flags = f; }
+int g_xxh_kernel = 1;  // "xxh_kernel": 1 = 4 / 16 buffers per wavefront through LDS (coalesced), 0 = one thread per buffer
+void set_xxh_kernel(int v) { g_xxh_kernel = v; }
 
 // ------------------------------------------------------------------------------------------------
 // fast compress
@@ -606,6 +608,61 @@ template <> __device__ __forceinline__ uint64_t xxh_lane_get<uint64_t>(uint64_t 
   return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((uint32_t)v, l) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((uint32_t)(v >> 32), l) << 32);
 }
 
+// Many buffers, coalesced: 64/LPB buffers per wavefront, LPB lanes each.  The one-thread-per-buffer kernels read 16 bytes from
+// 64 different cache lines per load instruction; here every LPB-lane group streams its buffer through LDS with contiguous
+// 16*LPB-byte loads (chunks of 256*LPB bytes, the input multiply applied while staging) and lanes 0..3 of the group run the four
+// accumulator chains.  Measured on 1 Mi x 4 KiB (tools/xxh_cfg5.py): one thread per buffer 4.5 / 4.6 TB/s (XXH32 / XXH64);
+// LPB = 16: 5.2 / 4.5 (only 16 of 64 lanes carry a chain: XXH64's 64-bit multiplies make that the cost); LPB = 8: 6.1 / -;
+// LPB = 4 (all 64 lanes carry a chain, a buffer still reads 64 contiguous bytes per instruction): 6.2 / 6.2 TB/s.
+// (lz4hip_set_option "xxh_kernel": 0 selects the one-thread-per-buffer kernels.)
+template <class T, int LPB>
+__global__ __launch_bounds__(64) void xxh_multi_kernel(const uint8_t* buf, const uint64_t* off, const int32_t* len, T seed, T* out, uint32_t nbuf) {
+  constexpr uint32_t STRIPE = 4u * sizeof(T), CH = 256u * LPB, SPC = CH / STRIPE, NG = 64u / LPB;
+  __shared__ __attribute__((aligned(16))) uint32_t stage[NG][CH / 4u];  // 16 KB
+  const uint32_t lane = threadIdx.x, g = lane / LPB, gl = lane % LPB, k = lane & 3u;
+  const uint32_t b = blockIdx.x * NG + g;
+  const bool have = b < nbuf;
+  const int32_t l = have ? len[b] : 0;
+  const uint32_t n = l < 0 ? 0u : (uint32_t)l;
+  const uint8_t* p = buf + (have ? off[b] : 0ull);
+  const uint32_t nst = n / STRIPE;
+  const uint32_t lim = nst * STRIPE;
+  uint32_t nch = (nst + SPC - 1u) / SPC;
+#pragma unroll
+  for (int d = 32; d >= LPB; d >>= 1) nch = max(nch, (uint32_t)__shfl_xor((int)nch, d, 64));  // the wave runs the longest buffer's trip count
+  T v = XxhOps<T>::init(seed, k);
+  for (uint32_t c = 0; c < nch; c++) {
+    uint4 r[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const uint32_t o = c * CH + (uint32_t)i * (16u * LPB) + gl * 16u;
+      if (o + 16u <= lim) __builtin_memcpy(&r[i], p + o, 16);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      T w[16 / sizeof(T)];
+      __builtin_memcpy(w, &r[i], 16);
+#pragma unroll
+      for (uint32_t q = 0; q < 16 / sizeof(T); q++) w[q] = XxhOps<T>::premul(w[q]);
+      __builtin_memcpy(&stage[g][(uint32_t)i * (4u * LPB) + gl * 4u], w, 16);
+    }
+    __syncthreads();
+    const uint8_t* st = (const uint8_t*)stage[g] + k * sizeof(T);
+    const uint32_t done = c * SPC;
+    const uint32_t cnt = nst > done ? (nst - done < SPC ? nst - done : SPC) : 0u;
+#pragma unroll 8
+    for (uint32_t s = 0; s < cnt; s++) {
+      T x;
+      __builtin_memcpy(&x, st + s * STRIPE, sizeof(T));
+      v = XxhOps<T>::round_pre(v, x);
+    }
+    __syncthreads();
+  }
+  const int base = (int)(g * LPB);
+  const T v1 = __shfl(v, base, 64), v2 = __shfl(v, base + 1, 64), v3 = __shfl(v, base + 2, 64), v4 = __shfl(v, base + 3, 64);
+  if (gl == 0u && have) out[b] = XxhOps<T>::finish(v1, v2, v3, v4, seed, p + lim, n - lim, n);
+}
+
 __global__ __launch_bounds__(64) void xxh32_wave_kernel(const uint8_t* buf, const uint64_t* off, const int32_t* len, uint32_t seed, uint32_t* out) {
   __shared__ __attribute__((aligned(16))) uint32_t stage[2][1024];
   const uint32_t b = blockIdx.x, lane = threadIdx.x;
@@ -624,6 +681,7 @@ __global__ __launch_bounds__(64) void xxh32_wave_kernel(const uint8_t* buf, cons
 int launch_xxh32(const uint8_t* buf, const uint64_t* off, const int32_t* len, uint32_t seed, uint32_t* out, uint32_t n, void* stream) {
   if (n == 0) return 0;
   if (n <= 512u) hipLaunchKernelGGL(xxh32_wave_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, buf, off, len, seed, out);
+  else if (g_xxh_kernel != 0) hipLaunchKernelGGL((xxh_multi_kernel<uint32_t, 4>), dim3((n + 15u) / 16u), dim3(64), 0, (hipStream_t)stream, buf, off, len, seed, out, n);
   else hipLaunchKernelGGL(xxh32_kernel, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, buf, off, len, seed, out, n);
   return (int)hipGetLastError();
 }
@@ -700,6 +758,7 @@ size_t xxh_stream_digest_offset(bool is64) { return is64 ? offsetof(XxhRec<uint6
 int launch_xxh64(const uint8_t* buf, const uint64_t* off, const int32_t* len, uint64_t seed, uint64_t* out, uint32_t n, void* stream) {
   if (n == 0) return 0;
   if (n <= 512u) hipLaunchKernelGGL(xxh64_wave_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, buf, off, len, seed, out);
+  else if (g_xxh_kernel != 0) hipLaunchKernelGGL((xxh_multi_kernel<uint64_t, 4>), dim3((n + 15u) / 16u), dim3(64), 0, (hipStream_t)stream, buf, off, len, seed, out, n);
   else hipLaunchKernelGGL(xxh64_kernel, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, buf, off, len, seed, out, n);
   return (int)hipGetLastError();
 }
