@@ -90,12 +90,13 @@ struct HcBuild {
         const VB valid = p <= last;
         const VU idx = p + HC_BIAS;
         const VU h = (x[u] * 2654435761u) >> 17;
-        const VU old = w.template lds_rd<true>(h, valid);
-        (void)w.template lds_max<true>(h, idx, valid);
-        w.sync();
-        const VU rb = w.template lds_rd<true>(h, valid);
+        // ONE LDS round trip per step: the atomic max returns the bucket's value right before this lane's insert.  The lanes of
+        // an instruction execute in some order; if the lanes sharing a bucket happened to go in rising position order, every
+        // returned value already is the previous occurrence.  If not, the lane that went too late got back a position ABOVE its
+        // own -- that flags the bucket, and its group is put in order with ballots below.
+        const VU old = w.template lds_max<true>(h, idx, valid);
         VU prev = old;
-        uint64_t pend = w.ballot(valid & (rb != idx));  // a later lane of this step shares my bucket
+        uint64_t pend = w.ballot(valid & (old > idx));
         while (pend) {
           const int d = ctz64(pend);
           const uint32_t hd = w.bcast(h, d);
@@ -104,7 +105,10 @@ struct HcBuild {
           const VU64 lower = w.lanemask_lt() & VU64(gm);
           const VB has = grp & (lower != VU64(0));
           const VU srcl = VU(63u) - W::clz64(lower);
-          prev = W::select(has, w.template shfl_e<true>(idx, srcl), prev);
+          // the group's first lane takes what the bucket held before this step: the value the lane that executed first got back
+          const uint64_t fm = w.ballot(grp & (old < p0 + HC_BIAS));
+          const uint32_t before = w.bcast(old, ctz64(fm));
+          prev = W::select(has, w.template shfl_e<true>(idx, srcl), W::select(grp, VU(before), prev));
           pend &= ~gm;
         }
         const VU dist = idx - prev;
