@@ -187,7 +187,10 @@ LZ4HIP_DEV int decode_block(Grp& g, const uint8_t* src, int src_size, uint8_t* d
         }
         ip += adv;
         t4 = nxt;
-        if ((++it & 1u) == 0u) g.st_flush_lines(dst, (uint32_t)op);
+#ifndef LZ4HIP_STAGE_EVERY
+#define LZ4HIP_STAGE_EVERY 2
+#endif
+        if (++it % LZ4HIP_STAGE_EVERY == 0u) g.st_flush_lines(dst, (uint32_t)op);
       } while (ip <= iend - 306 && op <= oend - 606);
       g.st_flush_all(dst, (uint32_t)op);  // the exact code below reads and writes memory
     }
