@@ -1,11 +1,18 @@
 // kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the LZ4 block engine.
 //
-//   compress_fast_kernel : one wavefront (= one 64-thread workgroup) per block, 32 KB LDS table of
-//                          {position, fingerprint} entries, algorithm in lz4_fast_core.h.
-//                          Bound: LDS/L2 latency of the serial parse chain (roofline: HBM, 1+1/ratio B/B).
-//   decode_kernel<GL>    : GL lanes per block, 64/GL blocks per wavefront, no LDS, algorithm in
-//                          lz4_decode_core.h.  Bound: HBM (reads C, writes N per block).
-//   xxh32/xxh64_kernel   : one thread per buffer, 16/32-byte loads (xxh_core.h). Bound: HBM (1 B/B).
+//   compress_fast_cu_kernel / compress_fast_ms_cu_kernel
+//                        : one workgroup of 5 wavefronts per CU (5 x 32 KB tables of {position, fingerprint} entries = the CU's
+//                          whole LDS), every wavefront draws blocks from a queue; algorithms in lz4_fast_core.h (one sequence
+//                          per step) and lz4_fast_ms_core.h (every sequence of a 64-position window per step).
+//                          Bound: the serial parse chain of a wavefront x 5 chains per CU (roofline: HBM, 1+1/ratio B/B).
+//   decode_kernel<GL, SAFE, PIPE, STAGE>
+//                        : GL lanes per block, 64/GL blocks per wavefront, algorithm in lz4_decode_core.h; PIPE = software-
+//                          pipelined loop for small batches, STAGE = output through LDS as whole lines for large ones.
+//                          Bound: HBM (reads C, writes N per block; match sources are random lines).
+//   hc_build_kernel / hc_parse_kernel
+//                        : LZ4 HC levels 1..12 (lz4_hc_core.h): chain deltas through a 128 KB LDS head table, then the parse.
+//   xxh_multi_kernel<T,4>: 16 buffers per wavefront streamed through LDS, every lane an accumulator chain (xxh_core.h);
+//                          xxh*_wave_kernel / xxh_stream_kernel: one wavefront per long buffer / stream.  Bound: HBM (1 B/B).
 //   gen_blocks_kernel    : SURVEY.md App. F workload generator (setup only, never timed).
 // No MFMA anywhere: this is byte shuffling, not a contraction.
 #include <hip/hip_runtime.h>
