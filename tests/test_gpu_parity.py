@@ -197,6 +197,34 @@ def test_offsets_inside_bigger_buffers(amd, ref, corpus):
     assert bytes(out[7:7 + len(data)]) == data and out[:7] == b"\x22" * 7 and out[7 + len(data):] == b"\x22" * 13
 
 
+def test_decode_variants_at_odd_offsets(amd, ref, corpus):
+    """every decoder variant (plain / pipelined / staged interior loop x lane counts) with source and destination slots at odd
+    byte offsets (the staged loop flushes whole 128-byte lines by ADDRESS): decoded bytes exact, nothing outside the slot touched"""
+    rng = random.Random(5)
+    blocks = [corpus["book1[:200000]"][a:a + n] for a, n in ((0, 70000), (1234, 3000), (50000, 65536), (7, 1500), (99999, 40000))]
+    blocks += [rng.randbytes(700) * 40, bytes(30000), corpus["geo[:65536]"], corpus["pic[:65536]"][:33333]]
+    comp = [ref.compress_fast(b) for b in blocks]
+    src, so = bytearray(), []
+    for c in comp:
+        src += b"\x5A" * rng.choice([1, 3, 5, 7, 11])
+        so.append(len(src)); src += c
+    dst_off, pos = [], 0
+    for b in blocks:
+        pos += rng.choice([1, 3, 9, 13, 127, 129])
+        dst_off.append(pos); pos += len(b)
+    total = pos + 77
+    for lanes, pipe, stage in ((4, 0, 1), (8, 0, 1), (16, 0, 1), (64, 0, 1), (4, 0, 0), (8, 1, 0), (16, 1, 0)):
+        amd.set_option("decode_lanes", lanes); amd.set_option("decode_pipe", pipe); amd.set_option("decode_stage", stage)
+        dst = bytearray(b"\xC3" * total)
+        out = amd.LZ4HIPBatch.decompressSafe(bytes(src), so, [len(c) for c in comp], dst, dst_off, [len(b) for b in blocks])
+        assert list(out) == [len(b) for b in blocks], (lanes, pipe, stage)
+        expect = bytearray(b"\xC3" * total)
+        for o, b in zip(dst_off, blocks):
+            expect[o:o + len(b)] = b
+        assert dst == expect, (lanes, pipe, stage)
+    amd.set_option("decode_lanes", 0); amd.set_option("decode_pipe", -1); amd.set_option("decode_stage", -1)
+
+
 def test_device_batch_and_generator(amd, O, ref):
     """device-pointer entry points (what bench.py times) + the on-device workload generator"""
     import torch
