@@ -225,6 +225,48 @@ def test_decode_variants_at_odd_offsets(amd, ref, corpus):
     amd.set_option("decode_lanes", 0); amd.set_option("decode_pipe", -1); amd.set_option("decode_stage", -1)
 
 
+def test_concurrent_callers(amd, ref, corpus):
+    """instances are shared singletons and must be thread-safe (LZ4Compressor.java:25): 8 threads hammer the single-block and
+    batch entry points (ctypes releases the GIL across the calls) and every result must equal the reference's"""
+    import threading
+    f = amd.LZ4Factory.hipInstance()
+    xf = amd.XXHashFactory.hipInstance()
+    book = corpus["book1[:200000]"]
+    errors = []
+
+    def worker(t):
+        try:
+            rng = random.Random(100 + t)
+            for it in range(12):
+                a, n = rng.randrange(0, 100000), rng.choice([0, 1, 13, 500, 5000, 70000])
+                v = book[a:a + n]
+                c = f.fastCompressor().compress(v)
+                assert c == ref.compress_fast(v)
+                assert f.safeDecompressor().decompress(c, len(v)) == v
+                assert f.fastDecompressor().decompress(c, len(v)) == v
+                assert xf.hash32().hash(v, 0, len(v), t) == ref.xxh32(v, t)
+                if it % 4 == 0:
+                    blocks = [book[rng.randrange(0, 150000):][:rng.choice([100, 4000, 30000])] for _ in range(5)]
+                    caps = [ref.compress_bound(len(b)) for b in blocks]
+                    src = b"".join(blocks); so = [sum(map(len, blocks[:i])) for i in range(5)]
+                    do = [sum(caps[:i]) for i in range(5)]
+                    dst = bytearray(sum(caps))
+                    out = amd.LZ4HIPBatch.compress(src, so, [len(b) for b in blocks], dst, do, caps)
+                    for b, o, r in zip(blocks, do, out):
+                        assert bytes(dst[o:o + r]) == ref.compress_fast(b)
+                    h = f.highCompressor(9).compress(blocks[0])
+                    assert h == ref.compress_hc(blocks[0], 9)
+        except Exception as e:  # noqa: BLE001 -- reported on the main thread
+            errors.append((t, repr(e)))
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errors, errors
+
+
 def test_device_batch_and_generator(amd, O, ref):
     """device-pointer entry points (what bench.py times) + the on-device workload generator"""
     import torch
