@@ -14,6 +14,7 @@
 #pragma once
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <istream>
 #include <ostream>
 #include "lz4hip.hpp"
@@ -385,6 +386,9 @@ constexpr int MAGIC_LENGTH = 8, HEADER_LENGTH = MAGIC_LENGTH + 1 + 4 + 4 + 4;  /
 constexpr int COMPRESSION_LEVEL_BASE = 10, MIN_BLOCK_SIZE = 64, MAX_BLOCK_SIZE = 1 << (COMPRESSION_LEVEL_BASE + 0x0F);
 constexpr int COMPRESSION_METHOD_RAW = 0x10, COMPRESSION_METHOD_LZ4 = 0x20;
 constexpr uint32_t DEFAULT_SEED = 0x9747B28Cu, CHECK_MASK = 0x0FFFFFFFu;  // StreamingXXHash32.asChecksum keeps 28 bits
+// a caller-supplied java.util.zip.Checksum (the 5-argument constructor, LZ4BlockOutputStream.java:96-101): the value of one block,
+// i.e. reset(); update(block); (int) getValue().  Empty = the default XXH32 above, batched on the device.
+using Checksum = std::function<uint32_t(const uint8_t*, size_t)>;
 inline const uint8_t* magic() { static const uint8_t m[8] = {'L', 'Z', '4', 'B', 'l', 'o', 'c', 'k'}; return m; }
 inline int compressionLevel(int blockSize) {  // LZ4BlockOutputStream.java:57-69
   if (blockSize < MIN_BLOCK_SIZE) throw std::invalid_argument("blockSize must be >= " + std::to_string(MIN_BLOCK_SIZE) + ", got " + std::to_string(blockSize));
@@ -397,9 +401,10 @@ inline int compressionLevel(int blockSize) {  // LZ4BlockOutputStream.java:57-69
 
 class LZ4BlockOutputStream {
  public:
-  LZ4BlockOutputStream(std::ostream& out, int blockSize = 1 << 16, BatchEngine engine = BatchEngine(), bool syncFlush = false, size_t batchBlocks = 256)
+  LZ4BlockOutputStream(std::ostream& out, int blockSize = 1 << 16, BatchEngine engine = BatchEngine(), bool syncFlush = false, size_t batchBlocks = 256,
+                       blockstream::Checksum checksum = blockstream::Checksum())
       : out_(out), e_(engine), blockSize_(blockSize), level_(blockstream::compressionLevel(blockSize)), syncFlush_(syncFlush),
-        batch_(batchBlocks ? batchBlocks : 1) {}
+        batch_(batchBlocks ? batchBlocks : 1), checksum_(std::move(checksum)) {}
   ~LZ4BlockOutputStream() { try { close(); } catch (...) {} }
   void write(const uint8_t* p, size_t n) {
     if (finished_) throw IllegalStateException("This stream is already closed");
@@ -428,7 +433,13 @@ class LZ4BlockOutputStream {
     const detail::Compressed c = detail::compressBlocks(e_, data, blockSize_);
     std::vector<uint64_t> so(c.lens.size());
     for (size_t i = 0; i < so.size(); i++) so[i] = i * (size_t)blockSize_;
-    const std::vector<uint32_t> checks = e_.xxh32(data.data(), so, c.lens, blockstream::DEFAULT_SEED);
+    std::vector<uint32_t> checks;
+    if (!checksum_) {
+      checks = e_.xxh32(data.data(), so, c.lens, blockstream::DEFAULT_SEED);
+      for (auto& v : checks) v &= blockstream::CHECK_MASK;
+    } else {
+      for (size_t i = 0; i < so.size(); i++) checks.push_back(checksum_(data.data() + so[i], (size_t)c.lens[i]));
+    }
     bytes o;
     for (size_t i = 0; i < c.lens.size(); i++) {
       const bool raw = c.sizes[i] >= c.lens[i];
@@ -438,7 +449,7 @@ class LZ4BlockOutputStream {
       o.push_back((uint8_t)((raw ? blockstream::COMPRESSION_METHOD_RAW : blockstream::COMPRESSION_METHOD_LZ4) | level_));
       detail::putLE32(o, (uint32_t)clen);
       detail::putLE32(o, (uint32_t)c.lens[i]);
-      detail::putLE32(o, checks[i] & blockstream::CHECK_MASK);
+      detail::putLE32(o, checks[i]);
       o.insert(o.end(), payload, payload + clen);
     }
     out_.write((const char*)o.data(), (std::streamsize)o.size());
@@ -448,14 +459,16 @@ class LZ4BlockOutputStream {
   int blockSize_, level_;
   bool syncFlush_;
   size_t batch_;
+  blockstream::Checksum checksum_;
   bytes buf_;
   bool finished_ = false;
 };
 
 class LZ4BlockInputStream {
  public:
-  explicit LZ4BlockInputStream(std::istream& in, bool stopOnEmptyBlock = true, BatchEngine engine = BatchEngine(), size_t batchBlocks = 256)
-      : in_(in), e_(engine), stopOnEmpty_(stopOnEmptyBlock), batch_(batchBlocks ? batchBlocks : 1) {}
+  explicit LZ4BlockInputStream(std::istream& in, bool stopOnEmptyBlock = true, BatchEngine engine = BatchEngine(), size_t batchBlocks = 256,
+                               blockstream::Checksum checksum = blockstream::Checksum())
+      : in_(in), e_(engine), stopOnEmpty_(stopOnEmptyBlock), batch_(batchBlocks ? batchBlocks : 1), checksum_(std::move(checksum)) {}
   size_t read(uint8_t* p, size_t n) {
     if (n == 0 || !fill()) return 0;
     const size_t k = std::min(n, ready_.size());
@@ -532,8 +545,14 @@ class LZ4BlockInputStream {
         std::vector<uint64_t> offs(bad);
         std::vector<int32_t> lens(bad);
         for (size_t i = 0; i < bad; i++) { offs[i] = all.size(); lens[i] = (int32_t)raw[i].size(); all.insert(all.end(), raw[i].begin(), raw[i].end()); }
-        const std::vector<uint32_t> h = e_.xxh32(all.data(), offs, lens, blockstream::DEFAULT_SEED);
-        for (size_t i = 0; i < bad; i++) if ((h[i] & blockstream::CHECK_MASK) != blocks[i].check) { bad = i; badExc = CORRUPTED; break; }
+        std::vector<uint32_t> h;
+        if (!checksum_) {
+          h = e_.xxh32(all.data(), offs, lens, blockstream::DEFAULT_SEED);
+          for (auto& v : h) v &= blockstream::CHECK_MASK;
+        } else {
+          for (size_t i = 0; i < bad; i++) h.push_back(checksum_(raw[i].data(), raw[i].size()));
+        }
+        for (size_t i = 0; i < bad; i++) if (h[i] != blocks[i].check) { bad = i; badExc = CORRUPTED; break; }
       }
       for (size_t i = 0; i < bad; i++) ready_.insert(ready_.end(), raw[i].begin(), raw[i].end());
       if (!badExc.empty()) { pending_ = badExc; pendingEof_ = false; return; }
@@ -558,6 +577,7 @@ class LZ4BlockInputStream {
   BatchEngine e_;
   bool stopOnEmpty_;
   size_t batch_;
+  blockstream::Checksum checksum_;
   std::deque<uint8_t> ready_;
   std::string pending_;
   bool pendingEof_ = false, finished_ = false;

@@ -508,11 +508,26 @@ def _compressionLevel(blockSize):  # LZ4BlockOutputStream.java:57-69
     return max(0, level - COMPRESSION_LEVEL_BASE)
 
 
-class LZ4BlockOutputStream(io.RawIOBase):
-    """Twin of lz4/LZ4BlockOutputStream.java with the default checksum (XXH32, seed 0x9747b28c, 28 bits)."""
+def _user_checks(checksum, pieces):
+    """per-block values of a caller-supplied java.util.zip.Checksum-like object (reset / update / getValue), as the reference
+    computes them: `checksum.reset(); checksum.update(block); (int) checksum.getValue()` (LZ4BlockOutputStream.java:207-209)"""
+    out = []
+    for piece in pieces:
+        checksum.reset()
+        checksum.update(piece, 0, len(piece))
+        out.append(checksum.getValue() & 0xFFFFFFFF)
+    return out
 
-    def __init__(self, out, blockSize=1 << 16, engine=None, syncFlush=False, batchBlocks=256):
+
+class LZ4BlockOutputStream(io.RawIOBase):
+    """Twin of lz4/LZ4BlockOutputStream.java.  checksum=None is the reference's default (XXH32, seed 0x9747b28c, 28 bits:
+    LZ4BlockOutputStream.java:125), computed for all blocks of a batch in one launch; any object with reset() / update(buf, off,
+    len) / getValue() -- the java.util.zip.Checksum contract of the 5-argument constructor (:96-101), e.g. an Adler32 or CRC32
+    adapter -- is used per block on the host, as the reference does."""
+
+    def __init__(self, out, blockSize=1 << 16, engine=None, syncFlush=False, batchBlocks=256, checksum=None):
         super().__init__()
+        self.checksum = checksum
         self.out = out
         self.blockSize = blockSize
         self.compressionLevel = _compressionLevel(blockSize)
@@ -546,7 +561,10 @@ class LZ4BlockOutputStream(io.RawIOBase):
         data = bytes(self.buffer[:nbytes])
         del self.buffer[:nbytes]
         dst, bound, lens, sizes = _compress_batch(self.engine, data, self.blockSize)
-        checks = self.engine.xxh32(data, [i * self.blockSize for i in range(len(lens))], lens, DEFAULT_SEED)
+        if self.checksum is None:
+            checks = [c & _CHECK_MASK for c in self.engine.xxh32(data, [i * self.blockSize for i in range(len(lens))], lens, DEFAULT_SEED)]
+        else:
+            checks = _user_checks(self.checksum, [data[i * self.blockSize: i * self.blockSize + n] for i, n in enumerate(lens)])
         outb = bytearray()
         for i, (raw_len, clen, check) in enumerate(zip(lens, sizes, checks)):
             if clen >= raw_len:
@@ -557,7 +575,7 @@ class LZ4BlockOutputStream(io.RawIOBase):
                 payload = dst[i * bound: i * bound + clen]
             outb += BLOCK_MAGIC
             outb.append(method | self.compressionLevel)
-            outb += _U32.pack(clen) + _U32.pack(raw_len) + _U32.pack(check & _CHECK_MASK)
+            outb += _U32.pack(clen) + _U32.pack(raw_len) + _U32.pack(check)
             outb += payload
         self.out.write(bytes(outb))
 
@@ -593,8 +611,9 @@ class LZ4BlockInputStream(io.RawIOBase):
 
     CORRUPTED = "Stream is corrupted"
 
-    def __init__(self, inp, stopOnEmptyBlock=True, engine=None, batchBlocks=256):
+    def __init__(self, inp, stopOnEmptyBlock=True, engine=None, batchBlocks=256, checksum=None):
         super().__init__()
+        self.checksum = checksum   # None: the default XXH32 (batched); else a Checksum-like object (LZ4BlockInputStream.java:71-76)
         self.r = _Reader(inp)
         self.engine = engine or HIPEngine()
         self.stopOnEmptyBlock = stopOnEmptyBlock
@@ -675,9 +694,12 @@ class LZ4BlockInputStream(io.RawIOBase):
                 for i in range(bad):
                     offs.append(o)
                     o += len(raw[i])
-                hashes = self.engine.xxh32(allb, offs, [len(raw[i]) for i in range(bad)], DEFAULT_SEED)
+                if self.checksum is None:
+                    hashes = [h & _CHECK_MASK for h in self.engine.xxh32(allb, offs, [len(raw[i]) for i in range(bad)], DEFAULT_SEED)]
+                else:
+                    hashes = _user_checks(self.checksum, raw[:bad])
                 for i in range(bad):
-                    if (hashes[i] & _CHECK_MASK) != blocks[i][3]:
+                    if hashes[i] != blocks[i][3]:
                         bad, bad_exc = i, IOException(self.CORRUPTED)
                         break
             for i in range(bad):

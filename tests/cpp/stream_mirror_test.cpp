@@ -119,6 +119,18 @@ int main(int argc, char** argv) {
       const std::vector<bytes> h = LZ4CompressorWithLength(BatchEngine{9}).compressMany({bufs[2]});
       CHECK(LZ4DecompressorWithLength().decompressMany(h)[0] == bufs[2] && h[0].size() <= c[2].size());
     }
+    // ---- block stream with a caller-supplied checksum (the 5-argument constructor): a plain byte sum stands in for Adler32 / CRC32 ----
+    {
+      const blockstream::Checksum sum = [](const uint8_t* p, size_t n) { uint32_t v = 1; for (size_t i = 0; i < n; i++) v = v * 31u + p[i]; return v; };
+      std::ostringstream os;
+      { LZ4BlockOutputStream w(os, 1 << 14, BatchEngine(), false, 3, sum); w.write(data.data(), 100000); w.close(); }
+      const std::string st = os.str();
+      std::istringstream is(st);
+      LZ4BlockInputStream r(is, true, BatchEngine(), 5, sum);
+      CHECK(r.readAll() == bytes(data.begin(), data.begin() + 100000));
+      std::istringstream is2(st);
+      CHECK(thrown([&] { LZ4BlockInputStream r2(is2); r2.readAll(); }) == "Stream is corrupted");   // the default checksum rejects it
+    }
     // ---- streaming xxhash (XXHashFactory.java:186-203 self-test shape): any split == the one-shot hash; reset(); closed state ----
     {
       auto& xf = xxhash::XXHashFactory::hipInstance();

@@ -361,6 +361,34 @@ def case_block_stream(S, engine, port, data):
         assert i == len(dd)
         for bb in (1, 7):
             assert S.LZ4BlockInputStream(io.BytesIO(st), engine=engine, batchBlocks=bb).read() == dd
+    # caller-supplied Checksum (LZ4BlockStreamingTest.java: Adler32 / CRC32 besides the default): stored per block, verified on read
+    import zlib
+
+    class ZChecksum:  # java.util.zip.Adler32 / CRC32 contract over zlib
+        def __init__(self, fn, init):
+            self.fn, self.init, self.v = fn, init, init
+
+        def reset(self):
+            self.v = self.init
+
+        def update(self, buf, off, n):
+            self.v = self.fn(bytes(buf[off:off + n]), self.v)
+
+        def getValue(self):
+            return self.v & 0xFFFFFFFF
+    for fn, init in ((zlib.adler32, 1), (zlib.crc32, 0)):
+        sink = io.BytesIO()
+        w = S.LZ4BlockOutputStream(sink, 1 << 14, engine=engine, batchBlocks=3, checksum=ZChecksum(fn, init))
+        w.write(d[:100000]); w.close()
+        st = sink.getvalue()
+        olen, check = struct.unpack_from("<iI", st, 13)
+        assert olen == 1 << 14 and check == fn(d[:1 << 14], init) & 0xFFFFFFFF
+        assert S.LZ4BlockInputStream(io.BytesIO(st), engine=engine, checksum=ZChecksum(fn, init)).read() == d[:100000]
+        try:  # the default checksum does not accept it
+            S.LZ4BlockInputStream(io.BytesIO(st), engine=engine).read()
+            assert False, "a stream written with another checksum must be rejected"
+        except S.IOException as e:
+            assert str(e) == "Stream is corrupted"
     # syncFlush cuts a block at flush(); concatenated streams need stopOnEmptyBlock=False
     st = block_stream_bytes(S, d[:100000], engine, 1 << 16, chunk=30000, syncFlush=True, flush_at=0)
     assert struct.unpack_from("<i", st, 13)[0] == 30000

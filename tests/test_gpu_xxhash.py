@@ -136,3 +136,23 @@ def test_streaming_device_updates_and_long_xxh64(amd, ref):
     assert f.hash64().hash(data, 3, 8192, 99) == ref.xxh64(data[3:3 + 8192], 99)
     got = amd.LZ4HIPBatch.xxh64(data, [0, 1, 100], [len(data), 70000, 8191], 5)
     assert list(got) == [ref.xxh64(data, 5), ref.xxh64(data[1:70001], 5), ref.xxh64(data[100:100 + 8191], 5)]
+
+
+def test_streaming_more_than_4GiB(amd):
+    """XXHash32Test.java:144-165 / XXHash64Test test4GB: a stream longer than 2^32 bytes (the 32-bit length wraps inside XXH32;
+    the state keeps 64 bits).  17 x 256 MiB device-resident updates, checked against the python xxhash package's streaming state."""
+    import torch
+    xxhash = pytest.importorskip("xxhash")
+    chunk = 256 << 20
+    t = torch.randint(0, 256, (chunk,), dtype=torch.uint8, device="cuda:0")
+    host = t.cpu().numpy().tobytes()
+    f = amd.XXHashFactory.hipInstance()
+    e32, e64 = xxhash.xxh32(seed=0x9747b28c), xxhash.xxh64(seed=0x9747b28c)
+    with f.newStreamingHash32(0x9747b28c) as h32, f.newStreamingHash64(0x9747b28c) as h64:
+        for i in range(17):
+            h32.update_device(t.data_ptr(), chunk)
+            h64.update_device(t.data_ptr(), chunk)
+            e32.update(host); e64.update(host)
+            if i in (0, 15, 16):   # below, at and past 2^32 bytes
+                assert h32.getValue() == e32.intdigest(), i
+                assert h64.getValue() == e64.intdigest(), i
