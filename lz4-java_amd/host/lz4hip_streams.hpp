@@ -233,6 +233,15 @@ class LZ4FrameInputStream {
     while (fill()) { all.insert(all.end(), ready_.begin(), ready_.end()); ready_.clear(); }
     return all;
   }
+  // InputStream.skip / available: at most what is decoded and waiting (one batch of blocks); mark/reset are not supported
+  int64_t skip(int64_t n) {
+    if (n <= 0 || !fill()) return 0;
+    const size_t k = std::min((size_t)n, ready_.size());
+    ready_.erase(ready_.begin(), ready_.begin() + (std::ptrdiff_t)k);
+    return (int64_t)k;
+  }
+  size_t available() const { return ready_.size(); }
+  static bool markSupported() { return false; }
   int64_t getExpectedContentSize() { if (!headerRead_) fill(); return expectedContentSize_; }
   bool isExpectedContentSizeDefined() { return getExpectedContentSize() >= 0; }
 
@@ -481,6 +490,15 @@ class LZ4BlockInputStream {
     while (fill()) { all.insert(all.end(), ready_.begin(), ready_.end()); ready_.clear(); }
     return all;
   }
+  // InputStream.skip / available: at most what is decoded and waiting (one batch of blocks); mark/reset are not supported
+  int64_t skip(int64_t n) {
+    if (n <= 0 || !fill()) return 0;
+    const size_t k = std::min((size_t)n, ready_.size());
+    ready_.erase(ready_.begin(), ready_.begin() + (std::ptrdiff_t)k);
+    return (int64_t)k;
+  }
+  size_t available() const { return ready_.size(); }
+  static bool markSupported() { return false; }
 
  private:
   static constexpr const char* CORRUPTED = "Stream is corrupted";

@@ -475,6 +475,25 @@ class LZ4FrameInputStream(io.RawIOBase):
         b[: len(data)] = data
         return len(data)
 
+    def skip(self, n):  # LZ4FrameInputStream.java:361-379: at most what is decoded and waiting (here: up to one batch of blocks)
+        if n <= 0 or not self._fill():
+            return 0
+        k = min(n, len(self.ready))
+        del self.ready[:k]
+        return k
+
+    def available(self):  # :382-384
+        return len(self.ready)
+
+    def markSupported(self):  # :402-404
+        return False
+
+    def mark(self, readlimit):  # :392-394
+        raise NotImplementedError("mark not supported")
+
+    def reset(self):  # :397-399
+        raise NotImplementedError("reset not supported")
+
     def getExpectedContentSize(self):  # :375-383
         if not self.firstFrameHeaderRead:
             self._fill()
@@ -742,6 +761,27 @@ class LZ4BlockInputStream(io.RawIOBase):
         data = self.read(len(b))
         b[: len(data)] = data
         return len(data)
+
+    def skip(self, n):  # LZ4BlockInputStream.java:176-189: at most what is decoded and waiting (here: up to one batch of blocks)
+        if n <= 0 or self.finished and not self.ready:
+            return 0
+        if not self._fill():
+            return 0
+        k = min(n, len(self.ready))
+        del self.ready[:k]
+        return k
+
+    def available(self):  # :134-136
+        return len(self.ready)
+
+    def markSupported(self):  # :288-290
+        return False
+
+    def mark(self, readlimit):  # :294-296: unsupported, silently
+        pass
+
+    def reset(self):  # :300-302
+        raise IOException("mark/reset not supported")
 
 
 # =================================================================================================

@@ -127,7 +127,9 @@ int main(int argc, char** argv) {
       const std::string st = os.str();
       std::istringstream is(st);
       LZ4BlockInputStream r(is, true, BatchEngine(), 5, sum);
-      CHECK(r.readAll() == bytes(data.begin(), data.begin() + 100000));
+      CHECK(r.available() == 0 && r.skip(0) == 0 && !r.markSupported());
+      CHECK(r.skip(12345) == 12345);
+      CHECK(r.readAll() == bytes(data.begin() + 12345, data.begin() + 100000) && r.skip(5) == 0);
       std::istringstream is2(st);
       CHECK(thrown([&] { LZ4BlockInputStream r2(is2); r2.readAll(); }) == "Stream is corrupted");   // the default checksum rejects it
     }

@@ -188,6 +188,24 @@ def case_frame_flush_and_bytewise(S, engine, port, data):
     small = data[:150000]
     fr = frame_bytes(S, small, engine, S.BLOCKSIZE.SIZE_64KB, (B.BLOCK_INDEPENDENCE,), chunk=50000, flush_at=0)
     _, _, _, _, blocks, _, _ = parse_frame(fr)
+    # skip / available / mark on the frame reader (LZ4FrameInputStream.java:361-404)
+    rd = S.LZ4FrameInputStream(io.BytesIO(fr), engine=engine, batchBlocks=1)
+    assert rd.available() == 0 and rd.skip(0) == 0 and not rd.markSupported()
+    k = rd.skip(1234)
+    assert k == 1234 and rd.available() == 50000 - 1234 and rd.read(10) == small[1234:1244]
+    tot = 1244
+    while True:
+        k = rd.skip(1 << 20)
+        if k == 0:
+            break
+        tot += k
+    assert tot == len(small)
+    for op in (lambda: rd.mark(1), rd.reset):
+        try:
+            op()
+            assert False
+        except NotImplementedError:
+            pass
     # flush() after the first 50000 bytes cuts a short block there (LZ4FrameOutputStream.java:279-286)
     assert [len(b) if r else len(port.decompress_safe(b, 65536)) for r, b, _ in blocks] == [50000, 65536, 150000 - 50000 - 65536]
     rd = S.LZ4FrameInputStream(io.BytesIO(fr), engine=engine, batchBlocks=2)
@@ -389,6 +407,27 @@ def case_block_stream(S, engine, port, data):
             assert False, "a stream written with another checksum must be rejected"
         except S.IOException as e:
             assert str(e) == "Stream is corrupted"
+    # skip / available / mark (LZ4BlockStreamingTest.java skip cases; LZ4BlockInputStream.java:134-136, :176-189, :288-302)
+    st = block_stream_bytes(S, d[:200000], engine, 1 << 14)
+    rd = S.LZ4BlockInputStream(io.BytesIO(st), engine=engine, batchBlocks=2)
+    assert rd.available() == 0 and rd.skip(0) == 0 and rd.skip(-5) == 0 and not rd.markSupported()
+    got, pos = bytearray(), 0
+    while True:
+        k = rd.skip(1000)
+        if k == 0:
+            break
+        assert 0 < k <= 1000
+        pos += k
+        piece = rd.read(777)
+        assert piece == d[pos:pos + len(piece)] and rd.available() >= 0
+        pos += len(piece)
+    assert pos == 200000 and rd.read(10) == b"" and rd.skip(10) == 0
+    rd.mark(5)
+    try:
+        rd.reset()
+        assert False
+    except S.IOException as e:
+        assert str(e) == "mark/reset not supported"
     # syncFlush cuts a block at flush(); concatenated streams need stopOnEmptyBlock=False
     st = block_stream_bytes(S, d[:100000], engine, 1 << 16, chunk=30000, syncFlush=True, flush_at=0)
     assert struct.unpack_from("<i", st, 13)[0] == 30000
