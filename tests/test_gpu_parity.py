@@ -197,6 +197,23 @@ def test_offsets_inside_bigger_buffers(amd, ref, corpus):
     assert bytes(out[7:7 + len(data)]) == data and out[:7] == b"\x22" * 7 and out[7 + len(data):] == b"\x22" * 13
 
 
+def test_issue12_regression_blob_gpu(amd, ref):
+    """LZ4Test.testRoundtripIssue12 (LZ4Test.java:487-541), bytes [9:]: every HIP compressor's output equals the reference
+    library's and decodes back through both HIP decompressors"""
+    import os
+    data = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "issue12.bin"), "rb").read()[9:]
+    f = amd.LZ4Factory.hipInstance()
+    for core in (0, 1, 2):
+        amd.set_option("compress_core", core)
+        c = f.fastCompressor().compress(data)
+        assert c == ref.compress_fast(data), core
+        assert f.safeDecompressor().decompress(c, len(data)) == data and f.fastDecompressor().decompress(c, len(data)) == data
+    amd.set_option("compress_core", 2)
+    for level in (1, 9, 12, 17):
+        h = f.highCompressor(level).compress(data)
+        assert h == ref.compress_hc(data, min(level, 12)) and f.safeDecompressor().decompress(h, len(data)) == data
+
+
 def test_decode_variants_at_odd_offsets(amd, ref, corpus):
     """every decoder variant (plain / pipelined / staged interior loop x lane counts) with source and destination slots at odd
     byte offsets (the staged loop flushes whole 128-byte lines by ADDRESS): decoded bytes exact, nothing outside the slot touched"""

@@ -48,6 +48,19 @@ def sim_decode(sim, c, cap, safe, gl, src_size=None):
     return r, bytes(out[:cap])
 
 
+def test_cores_on_issue12_blob(sim, ref):
+    """LZ4Test.testRoundtripIssue12 (LZ4Test.java:487-541), bytes [9:], through both compress cores and the decoder"""
+    import os
+    data = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "issue12.bin"), "rb").read()[9:]
+    want = ref.compress_fast(data)
+    for ms in (False, True):
+        r, b, _ = sim_compress(sim, data, ref.compress_bound(len(data)), ms=ms)
+        assert b == want, ms
+    for gl in (4, 64, 8 | 0x100, 4 | 0x200):
+        r, d = sim_decode(sim, want, len(data), 1, gl)
+        assert r == len(data) and d == data
+
+
 def test_compress_core_golden(sim, ref, corpus):
     slow = 0
     for name, v in corpus.items():

@@ -105,3 +105,15 @@ def test_port_equals_reference_decode_fuzz(port, ref, O, corpus):
         if mode == 0:
             assert port.decompress_fast_raw(c, cap) == ref.decompress_fast_raw(c, cap)
     assert accepted > 500
+
+
+def test_issue12_regression_blob(port, ref):
+    """LZ4Test.testRoundtripIssue12 (LZ4Test.java:487-541): the input that broke an early lz4-java; bytes [9:] as there.
+    The restatement must agree with the reference library on it (fast, HC 9, HC 12) and every stream must decode back."""
+    data = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "issue12.bin"), "rb").read()[9:]
+    assert len(data) == 1510
+    c = port.compress_fast(data)
+    assert c == ref.compress_fast(data) and port.decompress_safe(c, len(data)) == data
+    for level in (1, 9, 12):
+        h = port.compress_hc(data, level)
+        assert h == ref.compress_hc(data, level) and ref.decompress_safe(h, len(data)) == data
