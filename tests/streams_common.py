@@ -167,6 +167,25 @@ def case_frame_layout_and_roundtrip(S, engine, port, data):
             assert got == data
 
 
+def case_frame_size_sweep(S, engine, data):
+    """LZ4FrameIOStreamTest.java:72-90: sizes 0, 1, 1K, 1K+1, 64K, 128K, 1M (+ two ragged ones) x every optional-field
+    combination round-trip; the lz4 CLI, when there, decodes every frame and its own output is read back"""
+    B = S.FLG.Bits
+    combos = [tuple(b for b, on in zip((B.BLOCK_CHECKSUM, B.CONTENT_CHECKSUM, B.CONTENT_SIZE), (k & 1, k & 2, k & 4)) if on) for k in range(8)]
+    for size in (0, 1, 1024, 1025, 65536, 131072, 1 << 20, 77777, 300001):
+        d = (data * (size // len(data) + 1))[:size]
+        for k, extra in enumerate(combos):
+            bits = (B.BLOCK_INDEPENDENCE,) + extra
+            known = size if B.CONTENT_SIZE in bits else -1
+            fr = frame_bytes(S, d, engine, S.BLOCKSIZE.SIZE_64KB if k % 2 else S.BLOCKSIZE.SIZE_256KB, bits, known, chunk=40000, batchBlocks=4)
+            rd = S.LZ4FrameInputStream(io.BytesIO(fr), engine=engine, batchBlocks=3)
+            assert rd.read() == d, (size, k)
+            if LZ4_CLI and k in (0, 7) and size in (0, 1, 1025, 131072):
+                assert cli(["-d"], fr) == d, (size, k)
+        if LZ4_CLI and size in (0, 1, 1025, 131072):
+            assert S.LZ4FrameInputStream(io.BytesIO(cli(["-1"], d)), engine=engine).read() == d, size
+
+
 def case_frame_known_header_bytes(S, engine):
     # known descriptor checksums: FLG 0x60 / BD 0x70 -> HC 0x73 (what `lz4 --no-frame-crc` writes), BD 0x40 -> 0x82;
     # XXH32("", 0) = 0x02CC5D05 is the content checksum of an empty frame

@@ -28,6 +28,10 @@ def test_frame_layout_and_roundtrip(S, engine, port, data):
     sc.case_frame_layout_and_roundtrip(S, engine, port, data)
 
 
+def test_frame_size_sweep(S, engine, data):
+    sc.case_frame_size_sweep(S, engine, data)
+
+
 def test_frame_known_header_bytes(S, engine):
     sc.case_frame_known_header_bytes(S, engine)
 
