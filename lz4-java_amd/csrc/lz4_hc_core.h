@@ -177,6 +177,9 @@ struct HcSearch {
       attempts--;
       const int mp = (int)(mi - HC_BIAS);
       int ml = 0;
+      // the link to the next node depends on mi alone: requested here, together with the candidate's bytes, so a hop that
+      // fails its compare (most of them) costs one memory round trip, not two
+      const uint32_t dist_next = chain(mi);
       if (hc_rd16(src + ilow + longest - 1) == hc_rd16(src + mp - look_back + longest - 1)) {
         if (hc_rd32(src + mp) == pattern) {
           int back = 0;
@@ -205,7 +208,6 @@ struct HcSearch {
           }
         }
       }
-      const uint32_t dist_next = chain(mi);
       if (pattern_analysis && dist_next == 1u && chain_pos == 0u) {
         const uint32_t cand = mi - 1u;
         if (repeat == 0) {
@@ -247,7 +249,7 @@ struct HcSearch {
           }
         }
       }
-      mi -= chain(mi + chain_pos);
+      mi -= chain_pos == 0u ? dist_next : chain(mi + chain_pos);
     }
     return longest;
   }
