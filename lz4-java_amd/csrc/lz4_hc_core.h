@@ -180,8 +180,9 @@ struct HcSearch {
       // the link to the next node depends on mi alone: requested here, together with the candidate's bytes, so a hop that
       // fails its compare (most of them) costs one memory round trip, not two
       const uint32_t dist_next = chain(mi);
+      const uint32_t c32 = hc_rd32(src + mp);   // (likewise: not behind the 2-byte pre-check)
       if (hc_rd16(src + ilow + longest - 1) == hc_rd16(src + mp - look_back + longest - 1)) {
-        if (hc_rd32(src + mp) == pattern) {
+        if (c32 == pattern) {
           int back = 0;
           if (look_back) {
             const int mn = -((ip - ilow) < mp ? (ip - ilow) : mp);
