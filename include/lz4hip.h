@@ -61,13 +61,11 @@ int lz4hip_version(void);
  * block in the decoder (0 = default by batch size, 4/8/16/32/64); "decode_pipe" = 1 / 0 / -1 (default by batch size): the
  * software-pipelined interior loop of the decoder (faster when the batch is too small to fill the GPU); "decode_stage" =
  * 1 / 0 / -1 (default by batch size): the decoder's interior loop writes through an LDS staging buffer so that output
- * reaches memory as whole 128-byte lines (faster when the batch is bandwidth-bound); "xxh_kernel" = 1 (default: batches of more than 512 buffers
- * are hashed 16 buffers per wavefront through LDS, coalesced) or 0 (one thread per buffer); "compress_core" = 2 (default: adaptive two-pass -- blocks of
- * long sequences are finished by the one-sequence-per-step core, blocks of short sequences by the window-parallel core),
- * 1 (window-parallel core only) or 0 (one-sequence-per-step core only); "compress_switch" = routing threshold of the
- * adaptive scheme in bytes per sequence (default 20); "compress_waves" = 1 (default: one wavefront per block) or
- * 2 (experimental: a match-finder wavefront plus an emitter wavefront per block; same bytes, measured
- * slower so far -- see DESIGN.md).                                                                  */
+ * reaches memory as whole 128-byte lines (faster when the batch is bandwidth-bound); "compress_core" = 4 (default: adaptive two-pass -- blocks of long
+ * sequences are finished by the lean core (lz4_fast_v2_core.h), blocks of short sequences by the window-parallel core), 3 (lean
+ * core only), 2 (adaptive over the round-1 one-sequence-per-step core), 1 (window-parallel core only) or 0 (one-sequence-per-step
+ * core only); "compress_switch" = routing threshold of the adaptive schemes in bytes per sequence (default 20).  The knobs are
+ * process-wide atomics read once per launch; every setting produces the same bytes.                                       */
 int lz4hip_set_option(const char* name, int value);
 
 /* == LZ4_compressBound (LZ4JNI.c:237): n + n/255 + 16, 0 if n < 0 or n > 0x7E000000            */
@@ -160,13 +158,16 @@ void lz4hip_xxh_stream_free(lz4hip_xxh_stream* st);                      /* XXH3
 int lz4hip_gen_blocks_dev(uint8_t* dst, uint64_t stride, int32_t block_len, uint64_t seed, uint64_t first_idx,
                           uint32_t litmax, uint32_t win, uint32_t n_blocks, int device, void* stream);
 
+#ifdef LZ4HIP_DEV_TOOLS
 /* ---- developer diagnostics (not part of the reference API) --------------------------------------
  * lz4hip_compress_fast_batch_dev with per-phase shader-clock accounting: prof[b*12 .. b*12+11] =
  * {steps, collision steps, fingerprint false positives, sequences, cycles of phases 0..7} of block b
- * (phases are documented in csrc/lz4_fast_core.h).  Output bytes are identical to the product kernel. */
+ * (phases are documented in csrc/lz4_fast_core.h).  Output bytes are identical to the product kernel.
+ * Only in developer builds of the library (tools/build_variant.sh dev -DLZ4HIP_DEV_TOOLS); the release library does not export it. */
 int lz4hip_dbg_compress_fast_profile_dev(const uint8_t* src, const uint64_t* src_off, const int32_t* src_len,
                                          uint8_t* dst, const uint64_t* dst_off, const int32_t* dst_cap,
                                          int32_t* out_len, uint32_t n_blocks, uint64_t* prof, int device, void* stream);
+#endif
 
 #if defined(__GNUC__)
 #pragma GCC visibility pop

@@ -69,7 +69,6 @@ C_ABI = {
     "lz4hip_xxh32_stream_digest": (C.c_int, [C.c_void_p, _u32p]),
     "lz4hip_xxh64_stream_digest": (C.c_int, [C.c_void_p, _u64p]),
     "lz4hip_xxh_stream_free": (None, [C.c_void_p]),
-    "lz4hip_dbg_compress_fast_profile_dev": (C.c_int, [C.c_void_p] * 7 + [C.c_uint32, C.c_void_p, C.c_int, C.c_void_p]),
     "lz4hip_gen_blocks_dev": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
                                         C.c_uint32, C.c_int, C.c_void_p]),
 }
@@ -107,6 +106,9 @@ def lib():
             f = getattr(l, name)
             f.restype = res
             f.argtypes = args
+        if hasattr(l, "lz4hip_dbg_compress_fast_profile_dev"):   # developer builds only (-DLZ4HIP_DEV_TOOLS)
+            l.lz4hip_dbg_compress_fast_profile_dev.restype = C.c_int
+            l.lz4hip_dbg_compress_fast_profile_dev.argtypes = [C.c_void_p] * 7 + [C.c_uint32, C.c_void_p, C.c_int, C.c_void_p]
         _lib = l
     return _lib
 

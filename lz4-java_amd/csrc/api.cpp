@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <limits.h>
+#include <atomic>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -64,15 +65,17 @@ struct DeviceGuard {  // callers (e.g. PyTorch) own the thread's current device:
 };
 
 enum Op { OP_COMPRESS_FAST, OP_DECODE_SAFE, OP_DECODE_FAST, OP_COMPRESS_HC };
-int g_decode_lanes = 0;  // tuning knob (lz4hip_set_option "decode_lanes"); 0 = kernel default
-int g_decode_stage = -1; // tuning knob "decode_stage": 1 = LDS output staging in the plain loop
-int g_decode_pipe = -1;  // tuning knob "decode_pipe": 1/0 = pipelined interior loop on/off, -1 = kernel default
-// lz4hip_set_option "compress_core": 2 = adaptive two-pass (default), 1 = window-parallel core only (lz4_fast_ms_core.h),
-// 0 = one-sequence-per-step core only (lz4_fast_core.h); "compress_switch" = bytes per sequence below which a block counts
-// as dense and goes to the window-parallel core (probe: sequences 32..95 of the block)
-int g_compress_core = 2;
-int g_compress_switch = 20;
-int g_compress_waves = 1; // 1 = single-wave kernel (default, fastest so far), 2 = match-finder wave + emitter wave per block
+// tuning knobs (lz4hip_set_option): atomics, so that a caller changing one while other threads launch is a race on the VALUE chosen,
+// never undefined behaviour; every launch reads each knob once
+std::atomic<int> g_decode_lanes{0};   // "decode_lanes"; 0 = kernel default
+std::atomic<int> g_decode_stage{-1};  // "decode_stage": 1 = LDS output staging in the plain loop
+std::atomic<int> g_decode_pipe{-1};   // "decode_pipe": 1/0 = pipelined interior loop on/off, -1 = kernel default
+// lz4hip_set_option "compress_core": 4 = adaptive two-pass, lean core + window-parallel core (default); 3 = lean core only
+// (lz4_fast_v2_core.h); 2 = adaptive, one-sequence-per-step core + window-parallel core; 1 = window-parallel core only
+// (lz4_fast_ms_core.h); 0 = one-sequence-per-step core only (lz4_fast_core.h).  "compress_switch" = bytes per sequence below
+// which a block counts as dense and goes to the window-parallel core (probe: sequences 32..95 of the block)
+std::atomic<int> g_compress_core{4};
+std::atomic<int> g_compress_switch{20};
 
 // liblz4's level handling: < 1 -> 9, > 12 -> 12; 10..12 are the optimal parser (lz4-java levels 10..17)
 int hc_level(int level, int* out) {
@@ -116,34 +119,30 @@ uint32_t cu_count() {
   return (uint32_t)cache[dev];
 }
 
-// fast compress: single-wave kernel, or (default) the two-wave kernel with its zeroed ring workspace
+// fast compress: the cores of kernels.h, selected by "compress_core"
 int launch_fast(const lz4hip::BatchArgs& a, hipStream_t st) {
-  if (g_compress_waves != 2) {
-    // scratch: three queue words + the routed-block list of the adaptive scheme
-    uint32_t* scratch = nullptr;
-    hipError_t e = hipMallocAsync((void**)&scratch, (3 + (size_t)a.n) * sizeof(uint32_t), st);
-    if (e != hipSuccess) return (int)e;
-    const uint32_t cus = cu_count();
-    int le;
-    if (g_compress_core == 0) {
-      le = lz4hip::launch_compress_fast(a, scratch, nullptr, 0u, cus, st);
-    } else if (g_compress_core == 1) {
-      le = lz4hip::launch_compress_fast_ms(a, scratch, nullptr, true, cus, st);
-    } else {
-      le = lz4hip::launch_compress_fast(a, scratch, scratch + 3, 64u * (uint32_t)g_compress_switch, cus, st);
-      if (le == 0) le = lz4hip::launch_compress_fast_ms(a, scratch, scratch + 3, false, cus, st);
-    }
-    (void)hipFreeAsync(scratch, st);
-    return le;
-  }
-  const uint32_t grid = lz4hip::compress_fast2_grid(a.n, cu_count());
-  const size_t bytes = lz4hip::compress_fast2_ws_bytes(grid);
-  uint8_t* ws = nullptr;
-  hipError_t e = hipMallocAsync((void**)&ws, bytes, st);
+  // scratch: three queue words + the routed-block list of the adaptive scheme
+  uint32_t* scratch = nullptr;
+  hipError_t e = hipMallocAsync((void**)&scratch, (3 + (size_t)a.n) * sizeof(uint32_t), st);
   if (e != hipSuccess) return (int)e;
-  if ((e = hipMemsetAsync(ws, 0, bytes, st)) != hipSuccess) { (void)hipFreeAsync(ws, st); return (int)e; }
-  const int le = lz4hip::launch_compress_fast2(a, ws, grid, st);
-  (void)hipFreeAsync(ws, st);
+  const uint32_t cus = cu_count();
+  const int core = g_compress_core.load(std::memory_order_relaxed);
+  const uint32_t dense64 = 64u * (uint32_t)g_compress_switch.load(std::memory_order_relaxed);
+  int le;
+  switch (core) {
+    case 0: le = lz4hip::launch_compress_fast(a, scratch, nullptr, 0u, cus, st); break;
+    case 1: le = lz4hip::launch_compress_fast_ms(a, scratch, nullptr, true, cus, st); break;
+    case 2:
+      le = lz4hip::launch_compress_fast(a, scratch, scratch + 3, dense64, cus, st);
+      if (le == 0) le = lz4hip::launch_compress_fast_ms(a, scratch, scratch + 3, false, cus, st);
+      break;
+    case 3: le = lz4hip::launch_compress_fast_v2(a, scratch, nullptr, 0u, cus, st); break;
+    default:
+      le = lz4hip::launch_compress_fast_v2(a, scratch, scratch + 3, dense64, cus, st);
+      if (le == 0) le = lz4hip::launch_compress_fast_ms(a, scratch, scratch + 3, false, cus, st);
+      break;
+  }
+  (void)hipFreeAsync(scratch, st);
   return le;
 }
 
@@ -563,11 +562,6 @@ int lz4hip_device_count(void) {
 }
 
 int lz4hip_set_option(const char* name, int value) {
-  if (name && strcmp(name, "xxh_kernel") == 0) {
-    if (value != 0 && value != 1) return fail(LZ4HIP_E_ARG, "xxh_kernel must be 0 or 1");
-    lz4hip::set_xxh_kernel(value);
-    return LZ4HIP_OK;
-  }
   if (name && strcmp(name, "decode_stage") == 0) {
     if (value < -1 || value > 1) return fail(LZ4HIP_E_ARG, "decode_stage must be -1, 0 or 1");
     g_decode_stage = value;
@@ -583,21 +577,14 @@ int lz4hip_set_option(const char* name, int value) {
     g_decode_lanes = value;
     return LZ4HIP_OK;
   }
-  if (name && strcmp(name, "dbg_extra_lds") == 0) { lz4hip::set_dbg_extra_lds((uint32_t)value); return LZ4HIP_OK; }
-  if (name && strcmp(name, "dbg_flags") == 0) { lz4hip::set_dbg_flags((uint32_t)value); return LZ4HIP_OK; }
   if (name && strcmp(name, "compress_core") == 0) {
-    if (value < 0 || value > 2) return fail(LZ4HIP_E_ARG, "compress_core must be 0, 1 or 2");
+    if (value < 0 || value > 4) return fail(LZ4HIP_E_ARG, "compress_core must be 0..4");
     g_compress_core = value;
     return LZ4HIP_OK;
   }
   if (name && strcmp(name, "compress_switch") == 0) {
     if (value < 0 || value > 1024) return fail(LZ4HIP_E_ARG, "compress_switch must be 0..1024");
     g_compress_switch = value;
-    return LZ4HIP_OK;
-  }
-  if (name && strcmp(name, "compress_waves") == 0) {
-    if (value != 1 && value != 2) return fail(LZ4HIP_E_ARG, "compress_waves must be 1 or 2");
-    g_compress_waves = value;
     return LZ4HIP_OK;
   }
   return fail(LZ4HIP_E_ARG, "unknown option");
@@ -676,6 +663,7 @@ int lz4hip_xxh64_batch_dev(const uint8_t* buf, const uint64_t* off, const int32_
   return e ? fail(LZ4HIP_E_HIP, "kernel launch", (hipError_t)e) : LZ4HIP_OK;
 }
 
+#ifdef LZ4HIP_DEV_TOOLS
 // developer diagnostics (see include/lz4hip.h)
 int lz4hip_dbg_compress_fast_profile_dev(const uint8_t* src, const uint64_t* src_off, const int32_t* src_len, uint8_t* dst,
                                          const uint64_t* dst_off, const int32_t* dst_cap, int32_t* out_len, uint32_t n, uint64_t* prof,
@@ -688,9 +676,10 @@ int lz4hip_dbg_compress_fast_profile_dev(const uint8_t* src, const uint64_t* src
   if (ordinal(device, &ord)) return fail(LZ4HIP_E_ARG, "bad device index");
   DeviceGuard g(ord);
   lz4hip::BatchArgs a{src, src_off, src_len, dst, dst_off, dst_cap, out_len, n};
-  int e = lz4hip::launch_compress_fast_prof(a, prof, g_compress_core >= 1, stream);
+  int e = lz4hip::launch_compress_fast_prof(a, prof, g_compress_core.load() == 2 ? 1 : (g_compress_core.load() == 4 ? 3 : g_compress_core.load()), stream);
   return e ? fail(LZ4HIP_E_HIP, "kernel launch", (hipError_t)e) : LZ4HIP_OK;
 }
+#endif  // LZ4HIP_DEV_TOOLS
 
 // ---- single-block convenience ----
 int lz4hip_compress_fast(const uint8_t* src, int src_len, uint8_t* dst, int dst_cap) { return single(OP_COMPRESS_FAST, src, src_len, dst, dst_cap); }

@@ -12,24 +12,21 @@ struct BatchArgs {
   int32_t* out; uint32_t n;
 };
 
-// Fast compress, two cores (same bytes):
-//   launch_compress_fast     one sequence per step (lz4_fast_core.h): best when sequences are long
-//   launch_compress_fast_ms  every sequence of a 64-position window per step (lz4_fast_ms_core.h): best when they are short
-// Both fill each CU with one workgroup of 5 wavefronts (5 x 32 KB tables = the CU's whole LDS) that draw blocks from a queue.
+// Fast compress, three cores (same bytes):
+//   launch_compress_fast_v2  lean finder loop, sequences parked in lanes and written 64 at a time (lz4_fast_v2_core.h): the default
+//   launch_compress_fast     one sequence per step, written as found (lz4_fast_core.h)
+//   launch_compress_fast_ms  every sequence of a 64-position window per step (lz4_fast_ms_core.h): best when sequences are short
+// All fill each CU with one workgroup of 5 wavefronts (5 x 32 KB tables = the CU's whole LDS) that draw blocks from a queue.
 // q = three device uint32_t (queue words), n_cus = compute units of the device.
-// Adaptive two-pass use: launch_compress_fast(q, routed = u32[n] device scratch, dense64) finishes the blocks with long sequences
-// and lists the others in routed[] (sequences 32..95 cover fewer than dense64 bytes); launch_compress_fast_ms(q, routed,
+// Adaptive two-pass use: launch_compress_fast{,_v2}(q, routed = u32[n] device scratch, dense64) finishes the blocks with long
+// sequences and lists the others in routed[] (sequences 32..95 cover fewer than dense64 bytes); launch_compress_fast_ms(q, routed,
 // first = false) then does exactly those.  routed == nullptr: the kernel does every block (first = true zeroes q).
+int launch_compress_fast_v2(const BatchArgs& a, uint32_t* q, uint32_t* routed, uint32_t dense64, uint32_t n_cus, void* stream);
 int launch_compress_fast(const BatchArgs& a, uint32_t* q, uint32_t* routed, uint32_t dense64, uint32_t n_cus, void* stream);
 int launch_compress_fast_ms(const BatchArgs& a, uint32_t* q, const uint32_t* routed, bool first, uint32_t n_cus, void* stream);
-void set_dbg_flags(uint32_t f);  // developer diagnostics
-void set_xxh_kernel(int v);       // batches of more than 512 buffers: 1 = four buffers per wavefront (default), 0 = one thread per buffer
-void set_dbg_extra_lds(uint32_t bytes);
-// two-wave variant: `ws` = zeroed device workspace of compress_fast2_ws_bytes(grid) bytes
-uint32_t compress_fast2_grid(uint32_t n_blocks, uint32_t n_cus);
-size_t compress_fast2_ws_bytes(uint32_t grid);
-int launch_compress_fast2(const BatchArgs& a, uint8_t* ws, uint32_t grid, void* stream);
-int launch_compress_fast_prof(const BatchArgs& a, uint64_t* prof, bool ms, void* stream);  // developer diagnostics
+#ifdef LZ4HIP_DEV_TOOLS
+int launch_compress_fast_prof(const BatchArgs& a, uint64_t* prof, int core, void* stream);  // developer build only (tools/build_variant.sh dev -DLZ4HIP_DEV_TOOLS)
+#endif
 // HC levels 1..12: `ws` = device workspace of hc_ws_bytes(span, n, level) bytes, span = max(src_off+src_len) (launch_hc_span)
 int launch_hc_span(const uint64_t* src_off, const int32_t* src_len, uint32_t n, uint64_t* out_dev, void* stream);
 size_t hc_ws_bytes(uint64_t span, uint32_t n_blocks, int level);

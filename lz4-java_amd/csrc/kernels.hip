@@ -1,9 +1,10 @@
 // kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the LZ4 block engine.
 //
-//   compress_fast_cu_kernel / compress_fast_ms_cu_kernel
+//   compress_fast_v2_cu_kernel / compress_fast_cu_kernel / compress_fast_ms_cu_kernel
 //                        : one workgroup of 5 wavefronts per CU (5 x 32 KB tables of {position, fingerprint} entries = the CU's
-//                          whole LDS), every wavefront draws blocks from a queue; algorithms in lz4_fast_core.h (one sequence
-//                          per step) and lz4_fast_ms_core.h (every sequence of a 64-position window per step).
+//                          whole LDS), every wavefront draws blocks from a queue; algorithms in lz4_fast_v2_core.h (lean finder
+//                          loop + sequences parked in lanes, written 64 at a time; the default), lz4_fast_core.h (one sequence
+//                          per step, written as found) and lz4_fast_ms_core.h (every sequence of a 64-position window per step).
 //                          Bound: the serial parse chain of a wavefront x 5 chains per CU (roofline: HBM, 1+1/ratio B/B).
 //   decode_kernel<GL, SAFE, PIPE, STAGE>
 //                        : GL lanes per block, 64/GL blocks per wavefront, algorithm in lz4_decode_core.h; PIPE = software-
@@ -24,18 +25,13 @@
 #include "group_dev.h"
 #include "lz4_fast_core.h"
 #include "lz4_fast_ms_core.h"
+#include "lz4_fast_v2_core.h"
 #include "lz4_decode_core.h"
 #include "lz4_hc_core.h"
 #include "xxh_core.h"
 
 namespace lz4hip {
 
-uint32_t g_dbg_extra_lds = 0;  // developer diagnostics: extra dynamic LDS per workgroup (lowers residency, for scaling studies)
-void set_dbg_extra_lds(uint32_t b) { g_dbg_extra_lds = b; }
-uint32_t g_dbg_flags = 0;  // developer diagnostics (lz4hip_set_option "dbg_flags"): bit 0 = skip emission (timing only)
-void set_dbg_flags(uint32_t f) { g_dbg_flags = f; }
-int g_xxh_kernel = 1;  // "xxh_kernel": 1 = 4 / 16 buffers per wavefront through LDS (coalesced), 0 = one thread per buffer
-void set_xxh_kernel(int v) { g_xxh_kernel = v; }
 
 // ------------------------------------------------------------------------------------------------
 // fast compress
@@ -56,40 +52,6 @@ __device__ __forceinline__ int32_t uniform_i32(int32_t v) { return (int32_t)__bu
 // `routed` (u32[n], may be null = no routing): the one-sequence kernels probe the density of each block (lz4_fast_core.h,
 // dense64); a block of short sequences is left unfinished and its index appended to routed[] for the window-parallel
 // kernel, which draws exactly those.
-__global__ __launch_bounds__(64) void compress_fast_kernel(BatchArgs a, uint32_t dbg_flags, uint32_t* q, uint32_t* routed, uint32_t dense64) {
-  __shared__ __attribute__((aligned(16))) uint64_t table[4096];  // 32 KB: 8192 x u32 (byU16) or 4096 x u64 (byU32)
-  const uint32_t b = blockIdx.x;
-  const int32_t n = a.src_len[b];
-  const int32_t cap = a.dst_cap[b];
-  uint32_t r = 0;
-  if (n >= 0 && (uint32_t)n <= 0x7E000000u && cap >= 0) {
-    const uint8_t* s = a.src + a.src_off[b];
-    uint8_t* d = a.dst + a.dst_off[b];
-    WaveDev w(table);
-    DirectOut<WaveDev> out(w, s, (uint32_t)n, d, (uint32_t)cap);
-    (void)dbg_flags;
-    bool bailed;
-    if (n < 65547) {
-      FastCore<WaveDev, true> c(w, out, s, (uint32_t)n);
-      c.dense64 = routed ? dense64 : 0u;
-      r = c.run();
-      bailed = c.bailed;
-    } else {
-      FastCore<WaveDev, false> c(w, out, s, (uint32_t)n);
-      c.dense64 = routed ? dense64 : 0u;
-      r = c.run();
-      bailed = c.bailed;
-    }
-    if (bailed) {
-      if (threadIdx.x == 0) routed[atomicAdd(q + 1, 1u)] = b;
-      return;
-    }
-  }
-  if (threadIdx.x == 0) {
-    a.out[b] = (int32_t)r;
-  }
-}
-
 #ifndef LZ4HIP_WPC
 #define LZ4HIP_WPC 5
 #endif
@@ -99,7 +61,7 @@ constexpr uint32_t WAVES_PER_CU = LZ4HIP_WPC;
 // workgroup that owns all 163840 bytes of the CU holds FIVE tables exactly: WAVES_PER_CU wavefronts, each compressing its own
 // blocks, no barrier between them.  Blocks are handed out through the queue word q[0], so a wavefront that draws short blocks
 // simply draws more of them.
-// (The block body is written out here, not shared with compress_fast_kernel through a device function: behind a function
+// (The block body is written out in the kernel, not shared through a device function: behind a function
 // boundary the per-block loads lose their no-clobber marking, become vector loads, and the whole scalar parser state follows
 // them into vector registers -- 42 -> 83 VGPRs, -22 %.  Inside the loop every per-block value goes back to scalar registers
 // through readfirstlane for the same reason.)
@@ -140,6 +102,52 @@ __global__ __launch_bounds__(64 * WAVES_PER_CU) void compress_fast_cu_kernel(Bat
     WaveDev::sync();  // the table is reused
   }
 }
+
+// lean core (lz4_fast_v2_core.h): minimal finder loop + sequences parked in lanes and written 64 at a time; same CU-filling
+// shape and the same routing contract as compress_fast_cu_kernel (routed == nullptr: every block is finished here)
+__global__ __launch_bounds__(64 * WAVES_PER_CU) void compress_fast_v2_cu_kernel(BatchArgs a, uint32_t* q, uint32_t* routed, uint32_t dense64) {
+  __shared__ __attribute__((aligned(16))) uint64_t tables[WAVES_PER_CU][4096];
+  uint64_t* table = tables[threadIdx.x >> 6];
+  for (;;) {
+    uint32_t b = 0;
+    if (__lane_id() == 0) b = atomicAdd(q, 1u);
+    b = __builtin_amdgcn_readfirstlane(b);
+    if (b >= a.n) return;
+    const int32_t n = uniform_i32(a.src_len[b]);
+    const int32_t cap = uniform_i32(a.dst_cap[b]);
+    uint32_t r = 0;
+    if (n >= 0 && (uint32_t)n <= 0x7E000000u && cap >= 0) {
+      const uint8_t* s = uniform_ptr(a.src + a.src_off[b]);
+      uint8_t* d = uniform_ptr(a.dst + a.dst_off[b]);
+      WaveDev w(table);
+      ParkOut<WaveDev> out(w, s, (uint32_t)n, d, (uint32_t)cap);
+      out.dense64 = routed ? dense64 : 0u;
+      if (n < 65547) {
+        FastV2<WaveDev> c(w, out, s, (uint32_t)n);
+        r = c.run();
+      } else {
+        FastCore<WaveDev, false, ParkOut<WaveDev>> c(w, out, s, (uint32_t)n);
+        r = c.run();
+      }
+      if (out.bail) {
+        if (__lane_id() == 0) routed[atomicAdd(q + 1, 1u)] = b;
+        WaveDev::sync();
+        continue;
+      }
+    }
+    if (__lane_id() == 0) a.out[b] = (int32_t)r;
+    WaveDev::sync();  // the table is reused
+  }
+}
+int launch_compress_fast_v2(const BatchArgs& a, uint32_t* q, uint32_t* routed, uint32_t dense64, uint32_t n_cus, void* stream) {
+  if (a.n == 0) return 0;
+  hipError_t e = hipMemsetAsync(q, 0, 3 * sizeof(uint32_t), (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  const uint32_t wgs = (a.n + WAVES_PER_CU - 1u) / WAVES_PER_CU;
+  hipLaunchKernelGGL(compress_fast_v2_cu_kernel, dim3(wgs < n_cus ? wgs : n_cus), dim3(64 * WAVES_PER_CU), 0, (hipStream_t)stream, a, q, routed, dense64);
+  return (int)hipGetLastError();
+}
+
 // window-parallel core (lz4_fast_ms_core.h): every sequence of a 64-position window per step
 __device__ __forceinline__ void compress_fast_ms_block(const BatchArgs& a, uint32_t b, uint64_t* table) {
   const int32_t n = uniform_i32(a.src_len[b]);
@@ -159,11 +167,6 @@ __device__ __forceinline__ void compress_fast_ms_block(const BatchArgs& a, uint3
     }
   }
   if (__lane_id() == 0) a.out[b] = (int32_t)r;
-}
-// every block of the batch, one workgroup per block
-__global__ __launch_bounds__(64) void compress_fast_ms_kernel(BatchArgs a) {
-  __shared__ __attribute__((aligned(16))) uint64_t table[4096];
-  compress_fast_ms_block(a, blockIdx.x, table);
 }
 // CU-filling form (see compress_fast_cu_kernel): WAVES_PER_CU wavefronts per workgroup drawing from q[2] either the blocks
 // listed in routed[0 .. q[1]) (second pass of the adaptive scheme; an empty list costs one queue draw per wavefront) or, with
@@ -185,10 +188,6 @@ __global__ __launch_bounds__(64 * WAVES_PER_CU) void compress_fast_ms_cu_kernel(
 // `first` = this is the first launch that uses q (zero it)
 int launch_compress_fast_ms(const BatchArgs& a, uint32_t* q, const uint32_t* routed, bool first, uint32_t n_cus, void* stream) {
   if (a.n == 0) return 0;
-  if (g_dbg_extra_lds && !routed) {  // residency sweeps: one single-wave workgroup per block
-    hipLaunchKernelGGL(compress_fast_ms_kernel, dim3(a.n), dim3(64), g_dbg_extra_lds, (hipStream_t)stream, a);
-    return (int)hipGetLastError();
-  }
   if (first) {
     hipError_t e = hipMemsetAsync(q, 0, 3 * sizeof(uint32_t), (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
@@ -198,9 +197,10 @@ int launch_compress_fast_ms(const BatchArgs& a, uint32_t* q, const uint32_t* rou
   return (int)hipGetLastError();
 }
 
+#ifdef LZ4HIP_DEV_TOOLS
 // developer diagnostics: same algorithm with per-phase shader-clock accumulation; prof[b*12 + i] =
 // {steps, slow_steps, false_pos, sequences, t[0..7]} of block b
-template <bool MS>
+template <int MS>   // 0 = lz4_fast_core.h, 1 = lz4_fast_ms_core.h, 3 = lz4_fast_v2_core.h
 __global__ __launch_bounds__(64) void compress_fast_prof_kernel(BatchArgs a, uint64_t* prof) {
   __shared__ __attribute__((aligned(16))) uint64_t table[4096];
   const uint32_t b = blockIdx.x;
@@ -213,7 +213,11 @@ __global__ __launch_bounds__(64) void compress_fast_prof_kernel(BatchArgs a, uin
     uint8_t* d = a.dst + a.dst_off[b];
     WaveDev w(table);
     DirectOut<WaveDev> out(w, s, (uint32_t)n, d, (uint32_t)cap);
-    if constexpr (MS) {
+    if constexpr (MS == 3) {
+      ParkOut<WaveDev> po(w, s, (uint32_t)n, d, (uint32_t)cap);
+      if (n < 65547) { FastV2<WaveDev> c(w, po, s, (uint32_t)n, &st); r = c.run(); }
+      else { FastCore<WaveDev, false, ParkOut<WaveDev>> c(w, po, s, (uint32_t)n, &st); r = c.run(); }
+    } else if constexpr (MS == 1) {
       if (n < 65547) { FastCoreMS<WaveDev, true> c(w, out, s, (uint32_t)n, &st); r = c.run(); }
       else { FastCoreMS<WaveDev, false> c(w, out, s, (uint32_t)n, &st); r = c.run(); }
     } else {
@@ -228,162 +232,19 @@ __global__ __launch_bounds__(64) void compress_fast_prof_kernel(BatchArgs a, uin
     for (int i = 0; i < 8; i++) p[4 + i] = st.t[i];
   }
 }
-int launch_compress_fast_prof(const BatchArgs& a, uint64_t* prof, bool ms, void* stream) {
+int launch_compress_fast_prof(const BatchArgs& a, uint64_t* prof, int core, void* stream) {
   if (a.n == 0) return 0;
-  if (ms) hipLaunchKernelGGL(compress_fast_prof_kernel<true>, dim3(a.n), dim3(64), 0, (hipStream_t)stream, a, prof);
-  else hipLaunchKernelGGL(compress_fast_prof_kernel<false>, dim3(a.n), dim3(64), 0, (hipStream_t)stream, a, prof);
+  if (core == 3) hipLaunchKernelGGL(compress_fast_prof_kernel<3>, dim3(a.n), dim3(64), 0, (hipStream_t)stream, a, prof);
+  else if (core >= 1) hipLaunchKernelGGL(compress_fast_prof_kernel<1>, dim3(a.n), dim3(64), 0, (hipStream_t)stream, a, prof);
+  else hipLaunchKernelGGL(compress_fast_prof_kernel<0>, dim3(a.n), dim3(64), 0, (hipStream_t)stream, a, prof);
   return (int)hipGetLastError();
 }
-
-// ------------------------------------------------------------------------------------------------
-// fast compress, two wavefronts per block: wave 0 finds matches (FastCore + QueueOut), wave 1 drains the
-// descriptor ring and writes the LZ4 stream (DirectOut).  Emission (about a third of the single-wave
-// instruction stream, plus its scalar state) leaves the match finder's serial path and runs on another
-// SIMD of the same CU.  Persistent workgroups pull block indices from a global counter.
-//
-// Ring: single producer / single consumer, both on the same CU (same vector L1, so plain stores/loads are
-// mutually visible without cache maintenance).  Each 16-byte descriptor is written by ONE dwordx4 store and
-// carries a 16-bit lap tag in its last word; the consumer polls that word -- no release/acquire fence, hence
-// no s_waitcnt vmcnt(0) on the match finder's critical path.  `tail` (consumer progress, for back-pressure)
-// is published every 64 pops.
-// ------------------------------------------------------------------------------------------------
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-constexpr uint32_t RING_ENTRIES = 256;
-constexpr uint32_t RING_WG_BYTES = RING_ENTRIES * 16u + 64u;
-
-struct RingProducer {
-  u32x4* ring;
-  volatile uint32_t* tail;
-  uint32_t head = 0, tail_seen = 0;
-  __device__ __forceinline__ void push(const SeqDesc& d) {
-    while (head - tail_seen >= RING_ENTRIES) {  // ring full (rare): wait for the drain side
-      tail_seen = *tail;
-      if (head - tail_seen >= RING_ENTRIES) __builtin_amdgcn_s_sleep(8);
-    }
-    const uint32_t lap = (head / RING_ENTRIES + 1u) & 0xFFFFu;
-    if (__lane_id() == 0) {
-      // two 8-byte relaxed stores, payload first, then the granule that carries the lap tag.  (A `volatile` store would make
-      // the compiler append s_waitcnt vmcnt(0) -- a full memory round trip on the match finder's critical path.)
-      uint64_t* slot = (uint64_t*)&ring[head % RING_ENTRIES];
-      __hip_atomic_store(slot, (uint64_t)d.anchor | ((uint64_t)d.lit << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      __hip_atomic_store(slot + 1, (uint64_t)d.mc | ((uint64_t)((d.offset & 0xFFFFu) | (lap << 16)) << 32), __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    head++;
-  }
-};
-
-struct RingConsumer {
-  const u32x4* ring;
-  volatile uint32_t* tail;
-  uint32_t pos = 0;
-  // lane i looks at slot pos+i; returns how many consecutive descriptors (from lane 0) are ready and their words
-  __device__ __forceinline__ uint32_t peek(uint32_t& w0, uint32_t& w1, uint32_t& w2, uint32_t& w3) {
-    const uint32_t idx = pos + __lane_id();
-    const uint32_t lap = (idx / RING_ENTRIES + 1u) & 0xFFFFu;
-    uint64_t* p = (uint64_t*)&ring[idx % RING_ENTRIES];
-    const uint64_t g1 = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // {mc, offset | tag << 16}
-    w2 = (uint32_t)g1;
-    w3 = (uint32_t)(g1 >> 32);
-    const uint64_t ready = __ballot((w3 >> 16) == lap);
-    const uint32_t cnt = ready == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~ready);
-    // payload granule: stored BEFORE the tag granule by the producer (same wave, same cache line), loaded after it here
-    const uint64_t g0 = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    w0 = (uint32_t)g0;
-    w1 = (uint32_t)(g0 >> 32);
-    return cnt;
-  }
-  __device__ __forceinline__ void advance(uint32_t k) {
-    const uint32_t before = pos;
-    pos += k;
-    if (((before ^ pos) & ~63u) && __lane_id() == 0) *tail = pos;
-  }
-};
-
-__global__ __launch_bounds__(128) void compress_fast2_kernel(BatchArgs a, uint8_t* ws, uint32_t* next_block, uint32_t dbg_flags) {
-  __shared__ __attribute__((aligned(16))) uint64_t table[4096];
-  uint8_t* my = ws + (size_t)blockIdx.x * RING_WG_BYTES;
-  u32x4* ring = (u32x4*)my;
-  volatile uint32_t* tail = (volatile uint32_t*)(my + RING_ENTRIES * 16u);
-  if (threadIdx.x < 64) {
-    // ---- wave 0: match finder ----
-    RingProducer q{ring, tail};
-    QueueOut<WaveDev, RingProducer> qo(q);
-    WaveDev w(table);
-    for (;;) {
-      uint32_t b = 0;
-      if (__lane_id() == 0) b = atomicAdd(next_block, 1u);
-      b = __builtin_amdgcn_readfirstlane(b);
-      if (b >= a.n) { q.push(SeqDesc{0u, SEQ_KIND_STOP, 0u, 0u}); return; }
-      q.push(SeqDesc{b, SEQ_KIND_BEGIN, 0u, 0u});
-      const int32_t n = a.src_len[b];
-      if (n < 0 || (uint32_t)n > 0x7E000000u || a.dst_cap[b] < 0) { q.push(SeqDesc{0u, SEQ_KIND_LAST | SEQ_NOCHECK, 0u, 0u}); continue; }
-      const uint8_t* s = a.src + a.src_off[b];
-      if (n < 65547) { FastCore<WaveDev, true, QueueOut<WaveDev, RingProducer>> c(w, qo, s, (uint32_t)n); c.run(); }
-      else { FastCore<WaveDev, false, QueueOut<WaveDev, RingProducer>> c(w, qo, s, (uint32_t)n); c.run(); }
-    }
-  } else {
-    // ---- wave 1: drains descriptors in batches, writes the stream ----
-    RingConsumer q{ring, tail};
-    WaveDev w(nullptr);
-    uint32_t b = 0;
-    bool ok = false;
-    DirectOut<WaveDev> out(w, a.src, 0u, a.dst, 0u);
-    BatchEmitter<WaveDev> be(out);
-    for (;;) {
-      uint32_t w0, w1, w2, w3;
-      const uint32_t cnt = q.peek(w0, w1, w2, w3);
-      if (cnt == 0u) { __builtin_amdgcn_s_sleep(4); continue; }
-      const uint64_t ctrl = __ballot(__lane_id() < cnt && (w1 & SEQ_KIND_MASK) != SEQ_KIND_SEQ);
-      const uint32_t nseq = ctrl ? (uint32_t)__builtin_ctzll(ctrl) : cnt;
-      if (nseq) {
-        if (ok && !(dbg_flags & 1u)) ok = be.emit_batch(w0, w1, w2, w3 & 0xFFFFu, nseq);
-        q.advance(nseq);
-        continue;
-      }
-      const uint32_t kind = __builtin_amdgcn_readfirstlane(w1) & SEQ_KIND_MASK;
-      const uint32_t arg = __builtin_amdgcn_readfirstlane(w0);
-      q.advance(1u);
-      if (kind == SEQ_KIND_BEGIN) {
-        b = arg;
-        const int32_t n = a.src_len[b], cap = a.dst_cap[b];
-        ok = n >= 0 && (uint32_t)n <= 0x7E000000u && cap >= 0;
-        out.src = a.src + a.src_off[b];
-        out.dst = a.dst + a.dst_off[b];
-        out.n = ok ? (uint32_t)n : 0u;
-        out.cap = ok ? (uint32_t)cap : 0u;
-        out.limited = out.cap < out.n + out.n / 255u + 16u;
-        out.op = 0;
-      } else if (kind == SEQ_KIND_LAST) {
-        const uint32_t r = ok ? out.emit_last(arg) : 0u;
-        if (__lane_id() == 0) a.out[b] = (int32_t)r;
-      } else {
-        return;
-      }
-    }
-  }
-}
-
-int launch_compress_fast2(const BatchArgs& a, uint8_t* ws, uint32_t grid, void* stream) {
-  if (a.n == 0) return 0;
-  uint32_t* counter = (uint32_t*)(ws + (size_t)grid * RING_WG_BYTES);
-  hipLaunchKernelGGL(compress_fast2_kernel, dim3(grid), dim3(128), 0, (hipStream_t)stream, a, ws, counter, g_dbg_flags);
-  return (int)hipGetLastError();
-}
-uint32_t compress_fast2_grid(uint32_t n_blocks, uint32_t n_cus) {
-  const uint32_t resident = n_cus * 5u;  // 32 KB LDS per workgroup -> 5 per CU
-  return n_blocks < resident ? n_blocks : resident;
-}
-size_t compress_fast2_ws_bytes(uint32_t grid) { return (size_t)grid * RING_WG_BYTES + 64u; }
+#endif  // LZ4HIP_DEV_TOOLS
 
 int launch_compress_fast(const BatchArgs& a, uint32_t* q, uint32_t* routed, uint32_t dense64, uint32_t n_cus, void* stream) {
   if (a.n == 0) return 0;
   hipError_t e = hipMemsetAsync(q, 0, 3 * sizeof(uint32_t), (hipStream_t)stream);
   if (e != hipSuccess) return (int)e;
-  if (g_dbg_extra_lds) {  // residency sweeps: one single-wave workgroup per block
-    hipLaunchKernelGGL(compress_fast_kernel, dim3(a.n), dim3(64), g_dbg_extra_lds, (hipStream_t)stream, a, g_dbg_flags, q, routed, dense64);
-    return (int)hipGetLastError();
-  }
   const uint32_t wgs = (a.n + WAVES_PER_CU - 1u) / WAVES_PER_CU;
   hipLaunchKernelGGL(compress_fast_cu_kernel, dim3(wgs < n_cus ? wgs : n_cus), dim3(64 * WAVES_PER_CU), 0, (hipStream_t)stream, a, q, routed, dense64);
   return (int)hipGetLastError();
@@ -546,18 +407,6 @@ int launch_decompress(const BatchArgs& a, bool safe, int lanes_per_block, int pi
 // ------------------------------------------------------------------------------------------------
 // xxhash
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void xxh32_kernel(const uint8_t* buf, const uint64_t* off, const int32_t* len, uint32_t seed, uint32_t* out, uint32_t n) {
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  if (i >= n) return;
-  const int32_t l = len[i];
-  out[i] = xxh32_one(buf + off[i], l < 0 ? 0u : (uint32_t)l, seed);
-}
-__global__ __launch_bounds__(256) void xxh64_kernel(const uint8_t* buf, const uint64_t* off, const int32_t* len, uint64_t seed, uint64_t* out, uint32_t n) {
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  if (i >= n) return;
-  const int32_t l = len[i];
-  out[i] = xxh64_one(buf + off[i], l < 0 ? 0u : (uint32_t)l, seed);
-}
 // XXH32 is a serial chain per buffer (the round is not associative), so one thread per buffer is the right shape for many
 // buffers -- but a lone thread walking a LONG buffer pays a full memory round trip per 64 bytes (0.16 GB/s).  With few buffers
 // each gets a wavefront instead: all 64 lanes stream the buffer through LDS in 4 KB chunks (double-buffered, coalesced 1 KB
@@ -688,8 +537,7 @@ __global__ __launch_bounds__(64) void xxh32_wave_kernel(const uint8_t* buf, cons
 int launch_xxh32(const uint8_t* buf, const uint64_t* off, const int32_t* len, uint32_t seed, uint32_t* out, uint32_t n, void* stream) {
   if (n == 0) return 0;
   if (n <= 512u) hipLaunchKernelGGL(xxh32_wave_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, buf, off, len, seed, out);
-  else if (g_xxh_kernel != 0) hipLaunchKernelGGL((xxh_multi_kernel<uint32_t, 4>), dim3((n + 15u) / 16u), dim3(64), 0, (hipStream_t)stream, buf, off, len, seed, out, n);
-  else hipLaunchKernelGGL(xxh32_kernel, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, buf, off, len, seed, out, n);
+  else hipLaunchKernelGGL((xxh_multi_kernel<uint32_t, 4>), dim3((n + 15u) / 16u), dim3(64), 0, (hipStream_t)stream, buf, off, len, seed, out, n);
   return (int)hipGetLastError();
 }
 __global__ __launch_bounds__(64) void xxh64_wave_kernel(const uint8_t* buf, const uint64_t* off, const int32_t* len, uint64_t seed, uint64_t* out) {
@@ -765,8 +613,7 @@ size_t xxh_stream_digest_offset(bool is64) { return is64 ? offsetof(XxhRec<uint6
 int launch_xxh64(const uint8_t* buf, const uint64_t* off, const int32_t* len, uint64_t seed, uint64_t* out, uint32_t n, void* stream) {
   if (n == 0) return 0;
   if (n <= 512u) hipLaunchKernelGGL(xxh64_wave_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, buf, off, len, seed, out);
-  else if (g_xxh_kernel != 0) hipLaunchKernelGGL((xxh_multi_kernel<uint64_t, 4>), dim3((n + 15u) / 16u), dim3(64), 0, (hipStream_t)stream, buf, off, len, seed, out, n);
-  else hipLaunchKernelGGL(xxh64_kernel, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, buf, off, len, seed, out, n);
+  else hipLaunchKernelGGL((xxh_multi_kernel<uint64_t, 4>), dim3((n + 15u) / 16u), dim3(64), 0, (hipStream_t)stream, buf, off, len, seed, out, n);
   return (int)hipGetLastError();
 }
 

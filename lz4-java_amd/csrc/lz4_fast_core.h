@@ -60,9 +60,10 @@ struct FastStats {  // optional counters (host simulator / profiling kernel); th
 // ---------------------------------------------------------------------------------------------------
 // Output policies.  The match finder (FastCore) hands every sequence to an `Out`:
 //   DirectOut  writes the LZ4 stream itself; a sequence found in step t is written in step t+1, after step
-//              t+1 has issued its candidate loads, so the stores overlap that latency (single-wave kernel);
-//   QueueOut   pushes 16-byte descriptors to a queue that a second wavefront drains with a DirectOut
-//              (two-wave kernel: emission leaves the match finder's serial instruction stream entirely).
+//              t+1 has issued its candidate loads, so the stores overlap that latency;
+//   ParkOut    (lz4_fast_v2_core.h) parks {match start, length, offset} one lane per sequence and writes 64 at a time.
+// (A third policy, descriptors pushed to a ring drained by a second wavefront, measured 8 % slower than DirectOut in round 1
+// and was removed.)
 // ---------------------------------------------------------------------------------------------------
 template <class W>
 struct DirectOut {
@@ -201,108 +202,14 @@ struct DirectOut {
     pend.regs = regs;
     pend_b0 = b0;
   }
-  // immediate emission of one sequence whose literals are in memory (used by the drain side of the two-wave kernel)
-  LZ4HIP_DEV bool seq_now(uint32_t lit, uint32_t mc, uint32_t offset, uint32_t anchor, bool check_lits) {
-    seq(lit, mc, offset, anchor, check_lits, false, VU(0u));
-    return emit_pending();
-  }
   LZ4HIP_DEV uint32_t last(uint32_t anchor) {
     if (!emit_pending()) return 0;
     return emit_last(anchor);
   }
 };
 
-// one queue entry (16 bytes): kind in the top bits of `lit`
-struct SeqDesc {
-  uint32_t anchor, lit, mc, offset;
-};
-constexpr uint32_t SEQ_KIND_SEQ = 0u, SEQ_KIND_LAST = 1u << 30, SEQ_KIND_BEGIN = 2u << 30, SEQ_KIND_STOP = 3u << 30;
-constexpr uint32_t SEQ_KIND_MASK = 3u << 30, SEQ_NOCHECK = 1u << 29, SEQ_LIT_MASK = (1u << 29) - 1u;
-
-// drains one block's descriptors (everything up to and including its LAST entry); returns the compressed size or 0
-template <class W>
-LZ4HIP_DEV uint32_t drain_block(DirectOut<W>& out, const SeqDesc* d, size_t count) {
-  bool ok = true;
-  for (size_t i = 0; i < count; i++) {
-    const uint32_t kind = d[i].lit & SEQ_KIND_MASK;
-    if (kind == SEQ_KIND_LAST) return ok ? out.emit_last(d[i].anchor) : 0u;
-    if (ok) ok = out.seq_now(d[i].lit & SEQ_LIT_MASK, d[i].mc, d[i].offset, d[i].anchor, !(d[i].lit & SEQ_NOCHECK));
-  }
-  return 0u;
-}
-
-// Batched drain (emitter wavefront of the two-wave kernel): up to 64 sequence descriptors at once, ONE LANE
-// PER SEQUENCE for everything that is per-sequence (sizes, output offsets by a wave prefix sum, capacity
-// checks, token / length / offset bytes: five scattered store instructions for the whole batch), then the
-// literal runs are copied sequence by sequence with all lanes.
-template <class W>
-struct BatchEmitter {
-  using VU = typename W::VU;
-  using VU64 = typename W::VU64;
-  using VB = typename W::VB;
-  DirectOut<W>& out;
-  LZ4HIP_DEV explicit BatchEmitter(DirectOut<W>& o) : out(o) {}
-
-  // lanes 0..m-1 hold one SEQ descriptor each (litw = lit | SEQ_NOCHECK flag); returns false on output overflow
-  LZ4HIP_DEV bool emit_batch(VU anchor, VU litw, VU mc, VU offset, uint32_t m) {
-    W& w = out.w;
-    const VU j = w.lane();
-    const VB act = j < m;
-    const VU lit = litw & SEQ_LIT_MASK;
-    const VU nlx = W::select(lit >= 15u, W::div255(lit - 15u) + 1u, VU(0u));
-    const VU nmx = W::select(mc >= 15u, W::div255(mc - 15u) + 1u, VU(0u));
-    const VU size = W::select(act, nlx + lit + nmx + 3u, VU(0u));
-    const VU o = w.excl_scan(size) + out.op;  // where each sequence starts
-    const uint32_t end = w.bcast(o + size, (int)(m - 1u));
-    if (out.limited) {
-      // liblz4's two per-sequence checks, with o = position of the token (op in liblz4 is o+1 at check 1)
-      const VB c1 = ((litw & SEQ_NOCHECK) == 0u) & (W::u64(o) + W::u64(lit) + W::u64(W::div255(lit)) + VU64(1u + 8u) > VU64((uint64_t)out.cap));
-      const VB c2 = W::u64(o) + W::u64(nlx) + W::u64(lit) + W::u64(W::div255(mc + 240u)) + VU64(1u + 2u + 6u) > VU64((uint64_t)out.cap);
-      if (w.ballot(act & (c1 | c2))) return false;
-    }
-    const VU tok = (W::vmin(lit, VU(15u)) << 4) | W::vmin(mc, VU(15u));
-    w.st8(out.dst, o, tok, act);
-    w.st8(out.dst, o + 1u, lit - 15u, act & (nlx == 1u));
-    const VU oo = o + nlx + lit + 1u;
-    w.st8(out.dst, oo, offset & 0xFFu, act);
-    w.st8(out.dst, oo + 1u, offset >> 8, act);
-    w.st8(out.dst, oo + 2u, mc - 15u, act & (nmx == 1u));
-    uint64_t longs = w.ballot(act & ((nlx > 1u) | (nmx > 1u)));  // length runs of more than one byte (rare)
-    while (longs) {
-      const int k = ctz64(longs);
-      longs &= longs - 1u;
-      const uint32_t l = w.bcast(lit, k), c = w.bcast(mc, k), ok_ = w.bcast(o, k), nl = w.bcast(nlx, k), nm = w.bcast(nmx, k);
-      if (nl > 1u) out.put_ext_at(ok_ + 1u, l, nl);
-      if (nm > 1u) out.put_ext_at(ok_ + 1u + nl + l + 2u, c, nm);
-    }
-    const VU ld = o + nlx + 1u;  // where each literal run goes
-    for (uint32_t k = 0; k < m; k++) {
-      const uint32_t l = w.bcast(lit, (int)k);
-      if (l == 0u) continue;
-      const uint32_t a = w.bcast(anchor, (int)k), d = w.bcast(ld, (int)k);
-      if (l <= 64u) w.st8(out.dst, j + d, w.ld8(out.src, j + a, j < l), j < l);
-      else w.copy(out.dst, d, out.src, a, l);
-    }
-    out.op = end;
-    return true;
-  }
-};
-
-template <class W, class Q>
-struct QueueOut {
-  using VU = typename W::VU;
-  static constexpr bool kUsesWindowRegs = false;
-  Q& q;
-  LZ4HIP_DEV explicit QueueOut(Q& q_) : q(q_) {}
-  LZ4HIP_DEV bool overlap_point() { return true; }
-  LZ4HIP_DEV void seq(uint32_t lit, uint32_t mc, uint32_t offset, uint32_t anchor, bool check_lits, bool, VU) {
-    q.push(SeqDesc{anchor, lit | (check_lits ? 0u : SEQ_NOCHECK), mc, offset});
-  }
-  LZ4HIP_DEV uint32_t last(uint32_t anchor) {
-    q.push(SeqDesc{anchor, SEQ_KIND_LAST, 0u, 0u});
-    return 1u;  // the drain side computes the real size
-  }
-};
+// flag / mask of a packed literal length (lz4_fast_ms_core.h): bit 29 = liblz4's _next_match path (no literal-capacity check)
+constexpr uint32_t SEQ_NOCHECK = 1u << 29, SEQ_LIT_MASK = (1u << 29) - 1u;
 
 template <class W, bool U16, class Out = DirectOut<W>>
 struct FastCore {
@@ -330,7 +237,7 @@ struct FastCore {
   // short sequences -- the window-parallel core (lz4_fast_ms_core.h) is the faster one for it; loop() then stops with
   // `bailed` set and the caller leaves the block to that core.
   uint32_t dense64 = 0;
-  bool bailed = false, probe_done = false;
+  bool bailed = false, probe_done = false, one_done = false;
   uint32_t p_S = 0, p_ip = 0;
 
   LZ4HIP_DEV FastCore(W& w_, Out& out_, const uint8_t* s, uint32_t n_, FastStats* st_ = nullptr)
@@ -445,19 +352,23 @@ struct FastCore {
     }
     w.template lds_fill<U16>(1u << HLOG, (E)fp0);
     w.sync();
-    if (dense64 == 0u) return loop<false>(false, 1u, 0u, 0u);
+    if (dense64 == 0u) return loop<0>(false, 1u, 0u, 0u);
     // density probe: a second copy of the loop counts the first 96 sequences, so the main loop stays untouched
-    const uint32_t res = loop<true>(false, 1u, 0u, 0u);
+    const uint32_t res = loop<1>(false, 1u, 0u, 0u);
     if (!probe_done) return res;   // the block ended (or ran out of output) before the probe did
     if (bailed) return 0u;
-    return loop<false>(true, p_S, 0u, p_ip);
+    return loop<0>(true, p_S, 0u, p_ip);
   }
 
   // the step loop from a given parser state (also entered mid-block by lz4_fast_ms_core.h when it hands a block over):
   //   post: step kind: false = run probes only; true = {insert ip-2, probe ip, run from ip+1}
   //   S, r: run start, index of the first run probe of this step;  ip: post-match position (== anchor) when post
-  template <bool PROBE>
+  //   MODE: 0 = to the end of the block; 1 = density probe (see dense64); 2 = ONE sequence: returns 0 with `one_done` set and
+  //         p_ip = the post-match position once a sequence has been handed to `out` (lz4_fast_v2_core.h uses this loop as the
+  //         exact path for the steps its lean loop does not handle), or the block's result if the block ended first
+  template <int MODE>
   LZ4HIP_DEV uint32_t loop(bool post, uint32_t S, uint32_t r, uint32_t ip) {
+    constexpr bool PROBE = MODE == 1, ONE = MODE == 2;
     uint32_t probe_cd = 32u, probe_anchor = 0;  // (PROBE only) countdown to the next density-probe event
     uint32_t pf_end = PROBE ? 0u : (post ? ip : S) & ~(W::kPrefetchBytes - 1u);  // source prefetched up to here (LZ4HIP_PF_KB KB chunks, as far ahead)
     // the next chunk is due once hpos + kPrefetchBytes > pf_end, i.e. hpos >= pf_trig (never again once pf_end >= n): ONE compare per step
@@ -622,7 +533,7 @@ struct FastCore {
       const VU b0 = x32 & 0xFFu;         // literal bytes of this step (before the slots are re-prepared)
       const bool was_post = post;
       const bool done = ip_new >= mfl1;
-      if (!done) {                        // request the next step's window NOW; the rest of the bookkeeping overlaps it
+      if (!done && !ONE) {                // request the next step's window NOW; the rest of the bookkeeping overlaps it
         post = true;
         S = ip_new + 1u;
         r = 0;
@@ -649,6 +560,11 @@ struct FastCore {
       anchor = ip_new;
       LZ4HIP_PHASE(6, ip_new);           // t[6]: match length + catch-up + bookkeeping
       if (done) return out.last(anchor);
+      if constexpr (ONE) {
+        one_done = true;
+        p_ip = ip_new;
+        return 0u;
+      }
       if constexpr (PROBE) {
         if (--probe_cd == 0u) {
           if (probe_anchor == 0u) { probe_anchor = anchor; probe_cd = 64u; }

@@ -1,0 +1,314 @@
+// lz4_fast_v2_core.h -- the lean fast-compress core: a minimal match-finder chain + batched emission.
+//
+// Same contract as lz4_fast_core.h: byte-identical to LZ4_compress_default of liblz4 1.9.3
+// (/root/reference/src/jni/net_jpountz_lz4_LZ4JNI.c:75; algorithm: SURVEY.md App. A).
+//
+// Why a second core: one wavefront per block is a SERIAL chain (table state depends on the parse), a CU holds five of
+// them (32 KB tables), so throughput = 1 / (dependent instructions + memory round trips of one step).  lz4_fast_core.h
+// spends ~200 instructions per sequence, a third of them writing the previous sequence.  Here
+//   * the match finder keeps only what the chain needs.  Its loop handles the common step -- a post-match step
+//     {insert ip-2, probe ip, probe ip+1 ..} whose first tentative lane verifies, matches < 256 bytes, no bucket
+//     collision inside the step, far from the block end -- in ~70 instructions: catch-up compares the window registers
+//     against ONE contiguous byte load of the candidate side, the forward compare is 64 lanes x 4 bytes;
+//   * every other step (collision, false positive, miss-run beyond 63 probes, long match, block head and tail) is
+//     UNDONE (the committed lanes write their old buckets back) and replayed by the exact generic step of
+//     lz4_fast_core.h (FastCore::loop<2>, one sequence), so there is one definition of the hard cases;
+//   * sequences are not written when found: {match start, match length, offset} are parked one LANE per sequence
+//     (v_writelane) and every 64 sequences one vector pass sizes them (DPP prefix sum), checks liblz4's capacity
+//     conditions, copies all literal runs (lane per sequence, dword pieces) and stores tokens / length bytes / offsets --
+//     ~5 instructions per sequence instead of ~60, and nothing of it sits between two steps of the chain.
+#pragma once
+#include "lz4_fast_core.h"
+
+#ifndef LZ4HIP_V2_PROBE
+#define LZ4HIP_V2_PROBE 0   /* profiling kernel: 0 = all phases, k + 1 = only the interval that ends at phase point k */
+#endif
+
+namespace lz4hip {
+
+LZ4HIP_DEV int ctz32(uint32_t x) { return __builtin_ctz(x); }
+LZ4HIP_DEV int clz64(uint64_t x) { return __builtin_clzll(x); }
+
+// Output policy: sequences parked in lanes, written 64 at a time.
+template <class W>
+struct ParkOut {
+  using VU = typename W::VU;
+  using VU64 = typename W::VU64;
+  using VB = typename W::VB;
+  static constexpr bool kUsesWindowRegs = false;
+  static constexpr uint32_t kNoCheck = 1u << 16;  // flag in p_off: liblz4's _next_match path (no literal-capacity check)
+
+  W& w;
+  const uint8_t* src;
+  uint32_t n;
+  uint8_t* dst;
+  uint32_t cap;
+  bool limited;
+  uint32_t op = 0;
+  VU p_ms, p_ml, p_off;   // lane s: match start, match length, offset (| kNoCheck) of parked sequence s
+  uint32_t cnt = 0;       // parked sequences
+  uint32_t prev_end = 0;  // input position after the last written sequence (= anchor of parked sequence 0)
+  bool ok = true;         // false: the output does not fit (liblz4 returns 0)
+  // density probe of the adaptive scheme (0 = off): sequences 32..95 of the block cover fewer than dense64 input bytes -> `bail`
+  // (the block is made of short sequences: the window-parallel core of lz4_fast_ms_core.h is the faster one and redoes it)
+  uint32_t dense64 = 0, flushes = 0, mark = 0;
+  bool bail = false;
+
+  LZ4HIP_DEV ParkOut(W& w_, const uint8_t* s, uint32_t n_, uint8_t* d, uint32_t cap_) : w(w_), src(s), n(n_), dst(d), cap(cap_) {
+    limited = cap < n + n / 255u + 16u;
+    p_ms = VU(0u); p_ml = VU(0u); p_off = VU(0u);
+  }
+
+  LZ4HIP_DEV static uint32_t ext_count(uint32_t len) { return len >= 15u ? (len - 15u) / 255u + 1u : 0u; }
+  // writes `c` bytes of the 255-run encoding of (len-15) at dst[o..): 255,...,255,rem
+  LZ4HIP_DEV void put_ext(uint32_t o, uint32_t len, uint32_t c) {
+    const uint32_t rem = (len - 15u) - 255u * (c - 1u);
+    for (uint32_t base = 0; base < c; base += 64u) {
+      VU i = w.lane() + base;
+      w.st8(dst, i + o, W::select(i == c - 1u, VU(rem), VU(255u)), i < c);
+    }
+  }
+
+  LZ4HIP_DEV void park(uint32_t ms, uint32_t ml, uint32_t offx) {
+    p_ms = W::writelane(p_ms, ms, cnt);
+    p_ml = W::writelane(p_ml, ml, cnt);
+    p_off = W::writelane(p_off, offx, cnt);
+    if (++cnt == 64u) flush();
+  }
+
+  // writes the parked sequences
+  LZ4HIP_DEV void flush() {
+    if (cnt == 0u) return;
+    const uint32_t m = cnt;
+    cnt = 0u;
+    if (!ok) return;
+    const VU j = w.lane();
+    const VB act = j < m;
+    const VU endv = p_ms + p_ml;                                       // input position after each sequence
+    const VU anchor = W::select(j == 0u, VU(prev_end), W::shfl_up1(endv));
+    const VU lit = p_ms - anchor;
+    const VU mc = p_ml - 4u;
+    const VU offset = p_off & 0xFFFFu;
+    const VU nlx = W::select(lit >= 15u, W::div255(lit - 15u) + 1u, VU(0u));
+    const VU nmx = W::select(mc >= 15u, W::div255(mc - 15u) + 1u, VU(0u));
+    const VU size = W::select(act, nlx + lit + nmx + 3u, VU(0u));
+    const VU o = w.excl_scan(size) + op;                               // where each sequence's token goes
+    const uint32_t end = w.bcast(o + size, (int)(m - 1u));
+    prev_end = w.bcast(endv, (int)(m - 1u));
+    if (dense64 != 0u && flushes < 2u && m == 64u) {
+      const uint32_t e31 = w.bcast(endv, 31);
+      if (flushes == 0u) mark = e31;
+      else if (e31 - mark < dense64) { bail = true; return; }
+      flushes++;
+    }
+    if (limited) {
+      // liblz4's two per-sequence checks (o = position of the token)
+      const VB c1 = ((p_off & kNoCheck) == 0u) & (W::u64(o) + W::u64(lit) + W::u64(W::div255(lit)) + VU64(1u + 8u) > VU64((uint64_t)cap));
+      const VB c2 = W::u64(o) + W::u64(nlx) + W::u64(lit) + W::u64(W::div255(mc + 240u)) + VU64(1u + 2u + 6u) > VU64((uint64_t)cap);
+      if (w.ballot(act & (c1 | c2))) { ok = false; return; }
+    }
+    // literal runs: lane per sequence, whole dwords then the 0..3 byte tail
+    const VU ld = o + nlx + 1u;
+    // (all loads of a 16-byte group are requested before its stores: one memory round trip per group, not one per dword)
+    uint32_t i = 0;
+    for (; i < 48u; i += 16u) {
+      if (!w.ballot(act & (VU(i + 4u) <= lit))) break;
+      VU t[4];
+      VB mk[4];
+#pragma unroll
+      for (uint32_t k = 0; k < 4u; k++) { mk[k] = act & (VU(i + 4u * k + 4u) <= lit); t[k] = w.ld32(src, anchor + (i + 4u * k), mk[k]); }
+#pragma unroll
+      for (uint32_t k = 0; k < 4u; k++) w.st32(dst, ld + (i + 4u * k), t[k], mk[k]);
+    }
+    for (;; i += 4u) {                                                 // literal runs beyond 48 bytes
+      const VB mk = act & (VU(i + 4u) <= lit);
+      if (!w.ballot(mk)) break;
+      w.st32(dst, ld + i, w.ld32(src, anchor + i, mk), mk);
+    }
+    {
+      const VU t0 = lit & ~3u;
+      VU tb[3];
+      VB mk[3];
+#pragma unroll
+      for (uint32_t k = 0; k < 3u; k++) { mk[k] = act & (t0 + k < lit); tb[k] = w.ld8(src, anchor + t0 + k, mk[k]); }
+#pragma unroll
+      for (uint32_t k = 0; k < 3u; k++) w.st8(dst, ld + t0 + k, tb[k], mk[k]);
+    }
+    const VU tok = (W::vmin(lit, VU(15u)) << 4) | W::vmin(mc, VU(15u));
+    w.st8(dst, o, tok, act);
+    w.st8(dst, o + 1u, lit - 15u, act & (nlx == 1u));
+    const VU oo = ld + lit;
+    w.st8(dst, oo, offset & 0xFFu, act);
+    w.st8(dst, oo + 1u, offset >> 8, act);
+    w.st8(dst, oo + 2u, mc - 15u, act & (nmx == 1u));
+    uint64_t longs = w.ballot(act & ((nlx > 1u) | (nmx > 1u)));  // length runs of more than one byte (rare)
+    while (longs) {
+      const int k = ctz64(longs);
+      longs &= longs - 1u;
+      const uint32_t l = w.bcast(lit, k), c = w.bcast(mc, k), ok_ = w.bcast(o, k), nl = w.bcast(nlx, k), nm = w.bcast(nmx, k);
+      if (nl > 1u) put_ext(ok_ + 1u, l, nl);
+      if (nm > 1u) put_ext(ok_ + 1u + nl + l + 2u, c, nm);
+    }
+    op = end;
+  }
+
+  // last literals: token + run + raw bytes; returns total size or 0
+  LZ4HIP_DEV uint32_t emit_last(uint32_t anchor) {
+    const uint32_t last = n - anchor;
+    if (limited && (uint64_t)op + last + 1u + (last + 255u - 15u) / 255u > cap) return 0;
+    const uint32_t nlx = ext_count(last);
+    w.st8(dst, VU(op), VU((last < 15u ? last : 15u) << 4), w.lane() == 0u);
+    if (nlx) put_ext(op + 1u, last, nlx);
+    w.copy(dst, op + 1u + nlx, src, anchor, last);
+    return op + 1u + nlx + last;
+  }
+
+  // ---- the Out interface of FastCore ----
+  LZ4HIP_DEV bool overlap_point() { return ok; }
+  LZ4HIP_DEV void seq(uint32_t lit, uint32_t mc, uint32_t offset, uint32_t anchor, bool check_lits, bool, VU) {
+    park(anchor + lit, mc + 4u, offset | (check_lits ? 0u : kNoCheck));
+  }
+  LZ4HIP_DEV uint32_t last(uint32_t anchor) {
+    flush();
+    if (!ok) return 0u;
+    return emit_last(anchor);
+  }
+};
+
+// byU16 blocks (n < 65547).
+// Measured dead end, kept as a note (round 2, profiles/r02_compress_notes.txt): the block's recent 40 KB in a ring of 156 VGPRs the
+// compiler does not allocate (amdgpu_num_vgpr + VGPR-indexing mode with a wave-uniform slot index), so that the window, the row at
+// the hit and the row at the candidate are register reads + ds_bpermute rotations instead of global loads.  Bit-exact on the GPU,
+// memory waits fell from 66 % to 42 % of the wave's cycles -- but a step grew from 110 to 200 instructions, a wavefront issues one
+// instruction per ~4.4 cycles whatever its dependencies, and a mode switch (s_set_gpr_idx_on/off) costs ~80 cycles that overlap
+// with nothing: 49.5 .. 55.3 GB/s against 59.9 without the ring.
+template <class W>
+struct FastV2 {
+  using VU = typename W::VU;
+  using VB = typename W::VB;
+  using Gen = FastCore<W, true, ParkOut<W>>;
+  static constexpr uint32_t kFwdBytes = 256u;                       // forward compare of the lean step: 64 lanes x 4 bytes
+  static constexpr uint32_t kTail = 12u + 64u + kFwdBytes + 16u;    // the lean loop stays this far from the block end
+
+  W& w;
+  ParkOut<W>& out;
+  const uint8_t* src;
+  uint32_t n;
+  FastStats* st;
+
+  LZ4HIP_DEV FastV2(W& w_, ParkOut<W>& out_, const uint8_t* s, uint32_t n_, FastStats* st_ = nullptr) : w(w_), out(out_), src(s), n(n_), st(st_) {}
+
+  LZ4HIP_DEV uint32_t run() {
+    if (n < 13u) return out.last(0u);
+    {
+      const uint32_t x0 = w.sld32(src, 0);
+      w.template lds_fill<true>(1u << 13, (((x0 * 2654435761u) >> 3) & 0xFFFFu));  // every bucket: {pos 0, fp(bytes at 0)}
+      w.sync();
+    }
+    Gen gen(w, out, src, n, st);
+    // the head of the block is a plain run from position 1: exact path, one sequence
+    uint32_t r = gen.template loop<2>(false, 1u, 0u, 0u);
+    while (gen.one_done && !out.bail) {
+      gen.one_done = false;
+      const uint32_t ip = lean(gen.p_ip);
+      gen.anchor = ip;
+      r = gen.template loop<2>(true, ip + 1u, 0u, ip);
+    }
+    return r;
+  }
+
+  // The lean loop.  Enters and leaves in the post-match state at `ip` (== anchor; table committed up to the previous step);
+  // returns the position at which the exact path has to take the next sequence.
+  LZ4HIP_DEV uint32_t lean(uint32_t ip) {
+    if (n < kTail + 8u) return ip;
+    const uint32_t lim = n - kTail;
+    const VU j = w.lane();
+    const VU cj = W::select(j == 0u, VU(0xFFFFFFFEu), j - 1u);   // lane 0: ip-2 (insert only), lane 1: ip, lane l: ip + l - 1
+    const VU j4 = j * 4u;
+    uint32_t pf_end = ip & ~(W::kPrefetchBytes - 1u);
+    uint64_t l_steps = 0, l_slow = 0, l_seq = 0, l_t[6] = {0, 0, 0, 0, 0, 0}, tk_keep = 0;   // (profiling kernel: registers, added to *st at the end)
+    VU prev_fa = VU(0u);
+    uint32_t prev_hpos = 0x80000000u;   // (no row yet: ip - prev_hpos is huge)
+    while (ip <= lim && !out.bail) {
+      if (st) l_steps++;
+      uint64_t tk = (st && LZ4HIP_V2_PROBE == 0) ? w.tick(ip) : tk_keep;
+      // profiling kernel only.  LZ4HIP_V2_PROBE = k + 1 measures ONLY the interval that ends at phase point k (one pair of clock
+      // reads per step: the reads themselves cost ~40 cycles each and wait for LDS, so all phases at once distort each other)
+#define LZ4HIP_PHASE2(i, dep) do { if (st) { if (LZ4HIP_V2_PROBE == 0) { const uint64_t t_ = w.tick(dep); l_t[i] += t_ - tk; tk = t_; } \
+        else if (LZ4HIP_V2_PROBE == (i) + 2 || (LZ4HIP_V2_PROBE == 1 && (i) == 5)) { tk_keep = tk = w.tick(dep); } \
+        else if (LZ4HIP_V2_PROBE == (i) + 1) { l_t[i] += w.tick(dep) - tk; } } } while (0)
+      const VU pos = cj + ip;
+#ifndef LZ4HIP_V2_WIN_FROM_ROW
+#define LZ4HIP_V2_WIN_FROM_ROW 1   /* the next window is taken out of the 256 bytes the forward compare fetched at the hit (two lane permutes) */
+#endif
+      VU x32;
+      if (LZ4HIP_V2_WIN_FROM_ROW && LZ4HIP_LIKELY(ip - prev_hpos <= 189u)) {   // bytes [ip - 2, ip + 66) lie inside prev_fa = row at prev_hpos
+        const VU o = cj + (ip - prev_hpos);
+        const VU d = o >> 2;
+        x32 = W::alignbyte(W::shfl(prev_fa, d + 1u), W::shfl(prev_fa, d), o & 3u);
+      } else {
+        x32 = w.ldu32(src, pos);
+      }
+      const VU prod = x32 * 2654435761u;
+      const VU h = prod >> 19;
+      const VU fp = (prod >> 3) & 0xFFFFu;
+      LZ4HIP_PHASE2(0, w.bcast(h, 0));     // t[0]: window load + hash
+      const VU e = w.template lds_rdu<true>(h);
+      const VU newe = (pos << 16) | fp;
+      const uint64_t tmask = w.ballot((e & 0xFFFFu) == fp) & ~1ull;
+      if (LZ4HIP_UNLIKELY(tmask == 0)) break;                    // no tentative hit in 63 probes (nothing committed yet)
+      const uint32_t k0 = (uint32_t)ctz64(tmask);
+      LZ4HIP_PHASE2(1, k0);                 // t[1]: table read + ballot
+      const uint64_t inm = (2ull << k0) - 1ull;                  // lanes 0..k0 commit
+      const VU old = w.template lds_max<true>(h, newe, w.lanes(inm));
+      const uint32_t hpos = ip + k0 - 1u;
+      const uint32_t mpos = w.bcast(e, (int)k0) >> 16;
+      // candidate fetch: forward 64 x 4 bytes from both positions; backward: lane l (1..k0-1) holds src[ip+l-1] in its
+      // window word and needs src[mpos-k0+l] -- one contiguous byte load
+      // (32 or 16 lanes instead of 64 -- fewer candidate lines per fetch -- measured no different: 59.2 / 59.2 / 59.1 GB/s)
+      const VU fa = w.ldu32(src, j4 + hpos);
+      const VU fb = w.ldu32(src, j4 + mpos);
+      const VU bidx = j + (mpos - k0);
+      const VB bval = j + mpos >= VU(k0);
+      const VU bb = w.ldu8(src, W::select(bval, bidx, VU(0u)));
+      if (LZ4HIP_UNLIKELY(hpos + W::kPrefetchBytes > pf_end)) {
+        if (pf_end < n) w.prefetch4k(src, pf_end, n);
+        pf_end += W::kPrefetchBytes;
+      }
+      LZ4HIP_PHASE2(2, mpos);               // t[2]: commit + fetch issue
+      const uint64_t det = w.ballot(old != e) & inm;
+      LZ4HIP_PHASE2(3, (uint32_t)det);      // t[3]: atomic result
+      const VU fx = fa ^ fb;
+      const uint64_t dm = w.ballot(fx != 0u);
+      uint32_t cnt = 0;
+      if (LZ4HIP_LIKELY(dm != 0)) {
+        const int f = ctz64(dm);
+        cnt = 4u * (uint32_t)f + ((uint32_t)ctz32(w.bcast(fx, f)) >> 3);
+      }
+      LZ4HIP_PHASE2(4, cnt);                // t[4]: candidate fetch wait + forward count
+      if (LZ4HIP_UNLIKELY(det != 0 || cnt < 4u)) {               // collision, false positive or a match of >= 256 bytes: undo, exact path
+        if (st) l_slow++;
+        w.template lds_wr<true>(h, e, w.lanes(inm));
+        w.sync();
+        break;
+      }
+      w.sync();
+      if (st) l_seq++;
+      // catch-up: equal bytes below the hit, down to lane 1 (= anchor) and position 0 of the candidate side
+      const uint64_t eqm = w.ballot(bval & ((x32 & 0xFFu) == bb));
+      const uint64_t range = ((1ull << k0) - 1ull) & ~1ull;      // lanes 1..k0-1
+      const uint64_t ne = (~eqm & range) | 1ull;
+      const uint32_t back = k0 - 1u - (63u - (uint32_t)clz64(ne));
+      out.park(hpos - back, cnt + back, (hpos - mpos) | (k0 == 1u ? ParkOut<W>::kNoCheck : 0u));
+      ip = hpos + cnt;
+      prev_fa = fa;
+      prev_hpos = hpos;
+      LZ4HIP_PHASE2(5, ip);                 // t[5]: catch-up + park (+ flush every 64 sequences)
+    }
+#undef LZ4HIP_PHASE2
+    if (st) { st->steps += l_steps; st->slow_steps += l_slow; st->sequences += l_seq; for (int i = 0; i < 6; i++) st->t[i] += l_t[i]; }
+    return ip;
+  }
+};
+
+}  // namespace lz4hip

@@ -130,6 +130,21 @@ struct WaveDev {
     // but they reach memory as partial-line writes: WRITE_SIZE 2.1 -> 11.4 GB per launch, profiles/r01j; not worth it)
     if (m) b[i] = (uint8_t)v;
   }
+  __device__ __forceinline__ static void st32(uint8_t* b, VU i, VU v, bool m) {
+    if (m) __builtin_memcpy(b + i, &v, 4);
+  }
+  // lane `l` of v replaced by the scalar s, both wave-uniform: ONE v_writelane_b32 (set_lane's compare + select is two VALU
+  // instructions and needs the lane index in a VGPR)
+  __device__ __forceinline__ static VU writelane(VU v, uint32_t s, uint32_t l) {
+    // (gfx9 VALU instructions read ONE SGPR over the constant bus: the lane select goes through M0)
+    asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(s), "s"(l) : "m0");
+    return v;
+  }
+  __device__ __forceinline__ static VU shfl_down1(VU v) {   // lane l <- lane l+1 (lane 63: unspecified)
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false);   // wave_shl:1
+  }
+  // bytes [sh, sh+4) of the 8-byte little-endian value {hi, lo}, sh = 0..3 (per lane)
+  __device__ __forceinline__ static VU alignbyte(VU hi, VU lo, VU sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
   __device__ __forceinline__ static void st16(uint16_t* b, VU i, VU v, bool m) {
     if (m) b[i] = (uint16_t)v;
   }

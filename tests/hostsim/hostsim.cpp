@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include "../../lz4-java_amd/csrc/lz4_fast_core.h"
 #include "../../lz4-java_amd/csrc/lz4_fast_ms_core.h"
+#include "../../lz4-java_amd/csrc/lz4_fast_v2_core.h"
 #include "wave_host.h"
 #include "../../lz4-java_amd/csrc/lz4_decode_core.h"
 #include "group_host.h"
@@ -51,6 +52,41 @@ int sim_compress_fast_probe(const uint8_t* src, int n, uint8_t* dst, int cap, ui
   return bailed ? -2 : (int)r;
 }
 
+// lean core + parked/batched emission (lz4_fast_v2_core.h); blocks >= 65547 bytes: the generic loop over the same output policy
+int sim_compress_fast_v2(const uint8_t* src, int n, uint8_t* dst, int cap, uint64_t* stats4, uint64_t rng_seed) {
+  if (n < 0 || (uint32_t)n > 0x7E000000u || cap < 0) return 0;
+  hostsim::WaveHost w;
+  if (rng_seed) w.rng = rng_seed;
+  w.bounds(src, (size_t)n, dst, (size_t)cap);
+  lz4hip::FastStats st = {0, 0, 0, 0};
+  uint32_t r;
+  lz4hip::ParkOut<hostsim::WaveHost> out(w, src, (uint32_t)n, dst, (uint32_t)cap);
+  if (n < 65547) {
+    lz4hip::FastV2<hostsim::WaveHost> c(w, out, src, (uint32_t)n, &st);
+    r = c.run();
+  } else {
+    lz4hip::FastCore<hostsim::WaveHost, false, lz4hip::ParkOut<hostsim::WaveHost>> c(w, out, src, (uint32_t)n, &st);
+    r = c.run();
+  }
+  if (stats4) { stats4[0] = st.steps; stats4[1] = st.slow_steps; stats4[2] = st.false_pos; stats4[3] = st.sequences; }
+  if (w.oob) return -1000;
+  return (int)r;
+}
+
+// lean core with the density probe of the adaptive scheme: -2 = left to the window-parallel core
+int sim_compress_fast_v2_probe(const uint8_t* src, int n, uint8_t* dst, int cap, uint32_t dense64) {
+  if (n < 0 || (uint32_t)n > 0x7E000000u || cap < 0) return 0;
+  hostsim::WaveHost w;
+  w.bounds(src, (size_t)n, dst, (size_t)cap);
+  lz4hip::ParkOut<hostsim::WaveHost> out(w, src, (uint32_t)n, dst, (uint32_t)cap);
+  out.dense64 = dense64;
+  uint32_t r;
+  if (n < 65547) { lz4hip::FastV2<hostsim::WaveHost> c(w, out, src, (uint32_t)n); r = c.run(); }
+  else { lz4hip::FastCore<hostsim::WaveHost, false, lz4hip::ParkOut<hostsim::WaveHost>> c(w, out, src, (uint32_t)n); r = c.run(); }
+  if (w.oob) return -1000;
+  return out.bail ? -2 : (int)r;
+}
+
 // window-parallel core (lz4_fast_ms_core.h): every sequence of a 64-position window per step
 int sim_compress_fast_ms(const uint8_t* src, int n, uint8_t* dst, int cap, uint64_t* stats4, uint64_t rng_seed) {
   if (n < 0 || (uint32_t)n > 0x7E000000u || cap < 0) return 0;
@@ -87,47 +123,6 @@ int sim_decompress(const uint8_t* src, int src_size, uint8_t* dst, int out_size,
   else r = safe ? lz4hip::decode_block<hostsim::GroupHost, true>(g, src, src_size, dst, out_size)
                 : lz4hip::decode_block<hostsim::GroupHost, false>(g, src, src_size, dst, out_size);
   if (g.oob) return -1000000;
-  return r;
-}
-
-// two-wave variant: the match finder pushes descriptors to a queue, a separate pass drains it through DirectOut
-// (on the GPU the two halves run concurrently in two wavefronts of one workgroup)
-struct VecQueue {
-  std::vector<lz4hip::SeqDesc> v;
-  void push(const lz4hip::SeqDesc& d) { v.push_back(d); }
-};
-int sim_compress_fast_queue(const uint8_t* src, int n, uint8_t* dst, int cap, uint64_t rng_seed) {
-  if (n < 0 || (uint32_t)n > 0x7E000000u || cap < 0) return 0;
-  hostsim::WaveHost w;
-  if (rng_seed) w.rng = rng_seed;
-  w.bounds(src, (size_t)n, dst, (size_t)cap);
-  VecQueue q;
-  lz4hip::QueueOut<hostsim::WaveHost, VecQueue> qo(q);
-  if (n < 65547) { lz4hip::FastCore<hostsim::WaveHost, true, lz4hip::QueueOut<hostsim::WaveHost, VecQueue>> c(w, qo, src, (uint32_t)n); c.run(); }
-  else { lz4hip::FastCore<hostsim::WaveHost, false, lz4hip::QueueOut<hostsim::WaveHost, VecQueue>> c(w, qo, src, (uint32_t)n); c.run(); }
-  hostsim::WaveHost w2;
-  w2.bounds(src, (size_t)n, dst, (size_t)cap);
-  lz4hip::DirectOut<hostsim::WaveHost> out(w2, src, (uint32_t)n, dst, (uint32_t)cap);
-  // drain in batches of up to `batch` SEQ descriptors (BatchEmitter), as the emitter wavefront does
-  int r = 0;
-  {
-    lz4hip::BatchEmitter<hostsim::WaveHost> be(out);
-    bool ok = true;
-    size_t i = 0;
-    uint64_t bs = rng_seed ? rng_seed : 12345;
-    while (i < q.v.size()) {
-      if ((q.v[i].lit & lz4hip::SEQ_KIND_MASK) == lz4hip::SEQ_KIND_LAST) { r = ok ? (int)out.emit_last(q.v[i].anchor) : 0; break; }
-      bs = bs * 6364136223846793005ull + 1442695040888963407ull;
-      size_t want = 1 + (size_t)((bs >> 33) % 64), m = 0;
-      hostsim::WaveHost::VU va, vl, vm, vo;
-      while (m < want && i + m < q.v.size() && (q.v[i + m].lit & lz4hip::SEQ_KIND_MASK) == lz4hip::SEQ_KIND_SEQ) {
-        va.v[m] = q.v[i + m].anchor; vl.v[m] = q.v[i + m].lit; vm.v[m] = q.v[i + m].mc; vo.v[m] = q.v[i + m].offset; m++;
-      }
-      if (ok) ok = be.emit_batch(va, vl, vm, vo, (uint32_t)m);
-      i += m;
-    }
-  }
-  if (w.oob || w2.oob) return -1000;
   return r;
 }
 

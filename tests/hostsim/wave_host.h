@@ -109,6 +109,14 @@ struct WaveHost {
   void st8(uint8_t* b, const VU& i, const VU& v, const VB& m) {
     for (int l = 0; l < 64; l++) if (m.v[l] && out_ok(b + i.v[l], 1)) b[i.v[l]] = (uint8_t)v.v[l];
   }
+  void st32(uint8_t* b, const VU& i, const VU& v, const VB& m) {
+    for (int l = 0; l < 64; l++) if (m.v[l] && out_ok(b + i.v[l], 4)) memcpy(b + i.v[l], &v.v[l], 4);
+  }
+  static VU writelane(const VU& v, uint32_t s, uint32_t l) { VU r = v; r.v[l & 63u] = s; return r; }
+  static VU shfl_down1(const VU& v) { VU r; for (int l = 0; l < 63; l++) r.v[l] = v.v[l + 1]; r.v[63] = 0xDEADBEEFu; return r; }
+  static VU alignbyte(const VU& hi, const VU& lo, const VU& sh) {
+    VU r; for (int l = 0; l < 64; l++) r.v[l] = (uint32_t)((((uint64_t)hi.v[l] << 32) | lo.v[l]) >> (8u * (sh.v[l] & 3u))); return r;
+  }
   void st16(uint16_t* b, const VU& i, const VU& v, const VB& m) {
     for (int l = 0; l < 64; l++) if (m.v[l]) b[i.v[l]] = (uint16_t)v.v[l];
   }

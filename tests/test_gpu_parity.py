@@ -203,12 +203,12 @@ def test_issue12_regression_blob_gpu(amd, ref):
     import os
     data = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "issue12.bin"), "rb").read()[9:]
     f = amd.LZ4Factory.hipInstance()
-    for core in (0, 1, 2):
+    for core in (0, 1, 2, 3, 4):
         amd.set_option("compress_core", core)
         c = f.fastCompressor().compress(data)
         assert c == ref.compress_fast(data), core
         assert f.safeDecompressor().decompress(c, len(data)) == data and f.fastDecompressor().decompress(c, len(data)) == data
-    amd.set_option("compress_core", 2)
+    amd.set_option("compress_core", 4)
     for level in (1, 9, 12, 17):
         h = f.highCompressor(level).compress(data)
         assert h == ref.compress_hc(data, min(level, 12)) and f.safeDecompressor().decompress(h, len(data)) == data
@@ -371,30 +371,11 @@ def test_cpp_host_mirror_runs():
     assert subprocess.call([exe]) == 0
 
 
-def test_two_wave_compress_kernel_same_bytes(amd, ref, O, corpus):
-    """compress_waves=2 (match-finder wavefront + emitter wavefront, descriptor ring) must produce the same bytes"""
-    import random as _r
-    rng = _r.Random(303)
-    blocks, caps = [], []
-    for v in list(corpus.values()) + rnd_inputs(O, corpus, 91, 600):
-        full = ref.compress_bound(len(v))
-        er, _ = ref.compress_fast_raw(v, full)
-        for cap in (full, max(0, er + rng.choice([-1, 0, 1, -7, 9]))):
-            blocks.append(v); caps.append(cap)
-    amd.set_option("compress_waves", 2)
-    try:
-        res = gpu_compress_many(amd, blocks, caps)
-    finally:
-        amd.set_option("compress_waves", 1)
-    for v, cap, (r, c) in zip(blocks, caps, res):
-        er, eb = ref.compress_fast_raw(v, cap)
-        assert r == er and (er <= 0 or c == eb), (len(v), cap, r, er)
-
-
-@pytest.mark.parametrize("core,switch", [(0, 20), (1, 20), (2, 0), (2, 1024)])
+@pytest.mark.parametrize("core,switch", [(0, 20), (1, 20), (2, 0), (2, 20), (2, 1024), (3, 20), (4, 0), (4, 1024)])
 def test_compress_core_variants_same_bytes(amd, ref, O, corpus, core, switch):
-    """compress_core 0 (one sequence per step only), 1 (window-parallel only) and 2 (adaptive two-pass) with extreme routing
-    thresholds produce the same bytes as the default (2, threshold 20 bytes per sequence)"""
+    """compress_core 0 (one sequence per step, written as found), 1 (window-parallel only), 3 (lean core only), 2 and 4 (adaptive
+    two-pass over core 0 / the lean core) with extreme routing thresholds produce the same bytes as the default (4, threshold 20
+    bytes per sequence)"""
     import random as _r
     rng = _r.Random(304)
     blocks, caps = [], []
@@ -408,7 +389,7 @@ def test_compress_core_variants_same_bytes(amd, ref, O, corpus, core, switch):
     try:
         res = gpu_compress_many(amd, blocks, caps)
     finally:
-        amd.set_option("compress_core", 2)
+        amd.set_option("compress_core", 4)
         amd.set_option("compress_switch", 20)
     for v, cap, (r, c) in zip(blocks, caps, res):
         er, eb = ref.compress_fast_raw(v, cap)

@@ -29,17 +29,14 @@ def test_batch_random_vs_oracle(amd, ref):
         n = rng.choice([0, 1, 3, 4, 5, 15, 16, 17, 31, 32, 33, 63, 64, 100, 4096, rng.randrange(0, 20000)])
         o = rng.randrange(0, len(buf) - n + 1)
         off.append(o); ln.append(n)
-    for kern in (1, 0):   # 16 buffers per wavefront through LDS (default) / one thread per buffer
-        amd.set_option("xxh_kernel", kern)
-        for seed in (0, 0x9747b28c, rng.getrandbits(32)):
-            got = amd.LZ4HIPBatch.xxh32(buf, off, ln, seed)
-            for o, n, g in zip(off, ln, got):
-                assert g == ref.xxh32(buf[o:o + n], seed), (kern, o, n)
-        for seed in (0, 0x9747b28c, rng.getrandbits(64)):
-            got = amd.LZ4HIPBatch.xxh64(buf, off, ln, seed)
-            for o, n, g in zip(off, ln, got):
-                assert g == ref.xxh64(buf[o:o + n], seed), (kern, o, n)
-    amd.set_option("xxh_kernel", 1)
+    for seed in (0, 0x9747b28c, rng.getrandbits(32)):
+        got = amd.LZ4HIPBatch.xxh32(buf, off, ln, seed)
+        for o, n, g in zip(off, ln, got):
+            assert g == ref.xxh32(buf[o:o + n], seed), (o, n)
+    for seed in (0, 0x9747b28c, rng.getrandbits(64)):
+        got = amd.LZ4HIPBatch.xxh64(buf, off, ln, seed)
+        for o, n, g in zip(off, ln, got):
+            assert g == ref.xxh64(buf[o:o + n], seed), (o, n)
 
 
 def test_cfg5_shape_device(amd, O, ref):

@@ -19,7 +19,7 @@ def sim():
     d = os.path.join(ROOT, "tests", "hostsim")
     so = os.path.join(d, "libhostsim.so")
     srcs = [os.path.join(d, f) for f in ("hostsim.cpp", "wave_host.h", "group_host.h")] + \
-           [os.path.join(ROOT, "lz4-java_amd", "csrc", f) for f in ("lz4_fast_core.h", "lz4_fast_ms_core.h", "lz4_decode_core.h", "lz4_hc_core.h")]
+           [os.path.join(ROOT, "lz4-java_amd", "csrc", f) for f in ("lz4_fast_core.h", "lz4_fast_ms_core.h", "lz4_fast_v2_core.h", "lz4_decode_core.h", "lz4_hc_core.h")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, os.path.join(d, "hostsim.cpp")])
     l = C.CDLL(so)
@@ -27,6 +27,8 @@ def sim():
     l.sim_compress_fast.argtypes = [C.c_char_p, C.c_int, _u8p, C.c_int, C.POINTER(C.c_uint64), C.c_uint64]
     l.sim_compress_fast_ms.restype = C.c_int
     l.sim_compress_fast_ms.argtypes = [C.c_char_p, C.c_int, _u8p, C.c_int, C.POINTER(C.c_uint64), C.c_uint64]
+    l.sim_compress_fast_v2.restype = C.c_int
+    l.sim_compress_fast_v2.argtypes = [C.c_char_p, C.c_int, _u8p, C.c_int, C.POINTER(C.c_uint64), C.c_uint64]
     l.sim_compress_fast_probe.restype = C.c_int
     l.sim_compress_fast_probe.argtypes = [C.c_char_p, C.c_int, _u8p, C.c_int, C.c_uint32]
     l.sim_decompress.restype = C.c_int
@@ -34,10 +36,11 @@ def sim():
     return l
 
 
-def sim_compress(sim, v, cap, seed=0, ms=False):
+def sim_compress(sim, v, cap, seed=0, ms=False, v2=False):
     out = (C.c_uint8 * max(cap, 1))()
     st = (C.c_uint64 * 4)()
-    r = (sim.sim_compress_fast_ms if ms else sim.sim_compress_fast)(bytes(v), len(v), out, cap, st, seed)
+    f = sim.sim_compress_fast_v2 if v2 else (sim.sim_compress_fast_ms if ms else sim.sim_compress_fast)
+    r = f(bytes(v), len(v), out, cap, st, seed)
     return r, bytes(out[:max(r, 0)]), list(st)
 
 
@@ -104,6 +107,54 @@ def test_compress_ms_core_fuzz(sim, ref, O, corpus):
             a = ref.compress_fast_raw(v, cap)
             r, b, _ = sim_compress(sim, v, cap, seed=rng.getrandbits(63) | 1, ms=True)
             assert r == a[0] and (r <= 0 or b == a[1]), (len(v), cap, r, a[0])
+
+
+def test_compress_v2_core_golden(sim, ref, corpus):
+    """lean core (lz4_fast_v2_core.h): minimal finder loop, exact generic step for everything else, sequences parked in lanes and
+    written 64 at a time"""
+    slow = steps = seqs = 0
+    for name, v in corpus.items():
+        cap = ref.compress_bound(len(v))
+        r, b, st = sim_compress(sim, v, cap, v2=True)
+        assert b == ref.compress_fast(v), name
+        steps += st[0]; slow += st[1]; seqs += st[3]
+    assert slow > 0           # the undo + exact-path replay was exercised
+    assert seqs > steps // 2  # and most sequences come from the lean loop
+
+
+def test_compress_v2_core_fuzz(sim, ref, O, corpus):
+    rng = random.Random(5)
+    for v in rnd_inputs(O, corpus, 23, 500):
+        full = ref.compress_bound(len(v))
+        er, _ = ref.compress_fast_raw(v, full)
+        for cap in (full, max(0, er + rng.choice([-1, 0, 1, 2, -5, 5, -20, 20])), rng.randrange(0, full + 1)):
+            a = ref.compress_fast_raw(v, cap)
+            seed = rng.getrandbits(63) | 1
+            r, b, _ = sim_compress(sim, v, cap, seed=seed, v2=True)
+            assert r == a[0] and (r <= 0 or b == a[1]), (len(v), cap, r, a[0], seed & 2)
+
+
+def test_v2_density_probe_routes_blocks(sim, ref, O, corpus):
+    """the lean core leaves a block to the window-parallel core exactly when its sequences 32..95 cover fewer than dense64
+    bytes (decided when 128 sequences are parked); otherwise it finishes it with the usual bytes"""
+    sim.sim_compress_fast_v2_probe.restype = C.c_int
+    sim.sim_compress_fast_v2_probe.argtypes = [C.c_char_p, C.c_int, _u8p, C.c_int, C.c_uint32]
+    routed = kept = 0
+    for name, v in list(corpus.items()) + [("rnd%d" % i, x) for i, x in enumerate(rnd_inputs(O, corpus, 25, 120))]:
+        cap = ref.compress_bound(len(v))
+        want = ref.compress_fast(v)
+        ends = lz4_sequence_ends(want)
+        for dense64 in (64 * 8, 64 * 20, 64 * 40):
+            out = (C.c_uint8 * max(cap, 1))()
+            r = sim.sim_compress_fast_v2_probe(bytes(v), len(v), out, cap, dense64)
+            dense = len(ends) >= 128 and ends[95] - ends[31] < dense64
+            if dense:
+                assert r == -2, (name, dense64, r)
+                routed += 1
+            else:
+                assert r == len(want) and bytes(out[:r]) == want, (name, dense64, r)
+                kept += 1
+    assert routed > 0 and kept > 0
 
 
 def lz4_sequence_ends(c):
@@ -260,17 +311,3 @@ def test_hc_core_optimal_parser(sim, ref, golden, corpus, O):
             assert sim_hc(sim, v, lvl, ref.compress_bound(n))[1] == ref.compress_hc(v, lvl), (period, lvl)
 
 
-def test_compress_queue_variant(sim, ref, O, corpus):
-    """match finder -> descriptor queue -> drain (the two-wave kernel's split) gives the same bytes"""
-    sim.sim_compress_fast_queue.restype = C.c_int
-    sim.sim_compress_fast_queue.argtypes = [C.c_char_p, C.c_int, _u8p, C.c_int, C.c_uint64]
-    rng = random.Random(77)
-    cases = list(corpus.values()) + rnd_inputs(O, corpus, 81, 300)
-    for v in cases:
-        full = ref.compress_bound(len(v))
-        er, _ = ref.compress_fast_raw(v, full)
-        for cap in (full, max(0, er + rng.choice([-1, 0, 1, -7, 9])), rng.randrange(0, full + 1)):
-            out = (C.c_uint8 * max(cap, 1))()
-            r = sim.sim_compress_fast_queue(bytes(v), len(v), out, cap, rng.getrandbits(63) | 1)
-            a = ref.compress_fast_raw(v, cap)
-            assert r == a[0] and (r <= 0 or bytes(out[:r]) == a[1]), (len(v), cap, r, a[0])

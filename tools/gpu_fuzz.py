@@ -25,7 +25,7 @@ def pack(blocks, caps):
         so.append(p); sl.append(len(b)); do.append(q); p += len(b); q += c
     return src, so, sl, bytearray(max(q, 1)), do
 
-for core in (0, 1, 2):
+for core in (0, 1, 2, 3, 4):
     amd.set_option("compress_core", core)
     caps = [ref.compress_bound(len(v)) for v in inputs]
     src, so, sl, dst, do = pack(inputs, caps)
@@ -42,7 +42,7 @@ for core in (0, 1, 2):
         if r != er or (er > 0 and bytes(dst[o:o + r]) != eb[:er]):
             print("MISMATCH tight core", core, "input", i, "len", len(inputs[i]), "cap", caps[i], r, er); sys.exit(1)
     print("core %d: %d inputs bit-exact (full and tight capacities)" % (core, n), flush=True)
-amd.set_option("compress_core", 2)
+amd.set_option("compress_core", 4)
 caps = [len(v) for v in inputs]
 src, so, sl, dst, do = pack(exp_full, caps)
 # every lane count x plain / pipelined / staged interior loop

@@ -33,10 +33,6 @@ back = torch.zeros(n * blk, dtype=torch.uint8, device=dev)
 dlen = torch.zeros(n, dtype=torch.int32, device=dev)
 if lanes:
     amd.set_option("decode_lanes", lanes)
-if os.environ.get("XLDS"):
-    amd.set_option("dbg_extra_lds", int(os.environ["XLDS"]))
-if os.environ.get("DBG"):
-    amd.set_option("dbg_flags", int(os.environ["DBG"]))
 if os.environ.get("CC"):
     amd.set_option("compress_core", int(os.environ["CC"]))
 if os.environ.get("CS"):
@@ -45,8 +41,6 @@ if os.environ.get("DS"):
     amd.set_option("decode_stage", int(os.environ["DS"]))
 if os.environ.get("DP"):
     amd.set_option("decode_pipe", int(os.environ["DP"]))
-if os.environ.get("CW"):
-    amd.set_option("compress_waves", int(os.environ["CW"]))
 for _ in range(reps):
     a, b, c = (torch.cuda.Event(enable_timing=True) for _ in range(3))
     a.record(); amd.DeviceBatch.compress_fast(src, so, sl, comp, co, cc, clen); b.record()

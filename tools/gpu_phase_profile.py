@@ -11,6 +11,8 @@ dev = torch.device("cuda:0"); blk = 65536; cap = amd.maxCompressedLength(blk)
 if os.environ.get("CC"):
     amd.set_option("compress_core", int(os.environ["CC"]))
 ms = os.environ.get("CC", "1") == "1"
+v2 = os.environ.get("CC", "1") == "3"
+names_v2 = ["window+hash", "table+ballot", "commit+fetch issue", "atomic result", "fetch wait+count", "catch-up+park(+flush)", "-", "-"]
 names_ms = ["window+hash", "bucket+fp ballot", "cand fetch issue", "emit prev window", "wait cand+verdict", "chain walk", "commit+collision", "handover+prepare"]
 names = ["window+hash", "table+ballot", "issue commit/fetch", "emit prev", "atomic/collision", "wait candidate", "extend+bookkeep", "-"]
 for data in kinds:
@@ -31,5 +33,5 @@ for data in kinds:
     print("== %s: %d blocks, kernel %.2f ms; per block: steps %.0f collision-steps %.0f false-pos %.1f sequences %.0f" % (data, n, a.elapsed_time(b2), p[0], p[1], p[2], p[3]))
     tot = sum(p[4:12])
     for i in range(8):
-        print("   %-20s %8.0f cycles/step  %5.1f%%" % ((names_ms if ms else names)[i], p[4 + i] / steps, 100 * p[4 + i] / tot))
+        print("   %-20s %8.0f cycles/step  %5.1f%%" % ((names_v2 if v2 else names_ms if ms else names)[i], p[4 + i] / steps, 100 * p[4 + i] / tot))
     print("   %-20s %8.0f cycles/step" % ("total", tot / steps))
