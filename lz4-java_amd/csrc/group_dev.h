@@ -112,6 +112,7 @@ struct GroupDev {
   }
   // everything below p goes to memory (up to LB-1 bytes past p are touched: output positions that are written again later)
   __device__ __forceinline__ void st_flush_all(uint8_t* dst, uint32_t p) {
+    if ((int32_t)(p - fl) <= 0) return;   // (st_lits may have flushed lines past p: a sequence that then leaves the loop has nothing left to flush)
     const uint32_t nb = p - fl;
     for (uint32_t o = l * LB; o < nb; o += LB * GL) {
       Chunk<LB / 4> v;

@@ -110,6 +110,7 @@ struct GroupHost {
   }
   void st_flush_all(uint8_t* dst, uint32_t p) {
     const uint32_t LB = lb();
+    if ((int32_t)(p - fl) <= 0) return;   // (st_lits may have flushed lines past p: a sequence that then leaves the loop has nothing left to flush)
     const uint32_t nb = p - fl;
     for (uint32_t base = 0; base < nb; base += LB * GL)
       for (int l = 0; l < GL; l++) { const uint32_t o = base + LB * l; if (o < nb && st_ok(o, LB) && wr_ok(dst + fl + o, LB)) memcpy(dst + fl + o, stg + o, LB); }

@@ -235,6 +235,46 @@ def test_decode_core_fuzz(sim, ref, O, corpus):
             assert ref.decompress_fast_raw(c, cap)[0] == r4
 
 
+def _lz4_seq(lit, ml, off, rng):
+    """one LZ4 sequence: `lit` random literals, then a match of `ml` >= 4 bytes at distance `off` (hand-assembled)"""
+    def ext(v):
+        out = bytearray()
+        while v >= 255:
+            out.append(255); v -= 255
+        out.append(v)
+        return bytes(out)
+    tok = (min(lit, 15) << 4) | min(ml - 4, 15)
+    s = bytes([tok]) + (ext(lit - 15) if lit >= 15 else b"") + rng.randbytes(lit) + bytes([off & 255, off >> 8])
+    return s + (ext(ml - 4 - 15) if ml - 4 >= 15 else b"")
+
+
+def test_staged_decoder_flush_past_position(sim, ref):
+    """round-1 advisor finding: in the staged interior loop st_lits may flush whole lines PAST the sequence start; a sequence
+    that then leaves the loop (match length >= 274: second extension byte) made st_flush_all run with fl > op -- a 4 GiB
+    out-of-slot copy.  Valid blocks: a few short sequences, then literals 65..269 + a match of >= 274 bytes, at every
+    destination alignment the staging cares about."""
+    rng = random.Random(1234)
+    for trial in range(400):
+        c = bytearray()
+        n = 0
+        for _ in range(rng.randrange(2, 13)):
+            lit, ml = rng.randrange(1, 60), rng.randrange(4, 100)
+            c += _lz4_seq(lit, ml, rng.randrange(1, n + lit + 1), rng); n += lit + ml
+        lit, ml = rng.randrange(65, 270), rng.randrange(274, 900)
+        c += _lz4_seq(lit, ml, rng.randrange(1, n + lit + 1), rng); n += lit + ml
+        for _ in range(rng.randrange(8, 40)):     # enough tail for the interior loop to be entered at all (>= 606 bytes from the end)
+            lit, ml = rng.randrange(1, 60), rng.randrange(4, 100)
+            c += _lz4_seq(lit, ml, rng.randrange(1, n + lit + 1), rng); n += lit + ml
+        last = rng.randrange(5, 40)
+        c += bytes([last << 4 if last < 15 else 0xF0]) + (bytes([last - 15]) if last >= 15 else b"") + rng.randbytes(last); n += last
+        c = bytes(c)
+        want_r, want = ref.decompress_safe_raw(c, n)
+        assert want_r == n
+        for gl in (4 | 0x200, 8 | 0x200, 16 | 0x200, 64 | 0x200):
+            r, d = sim_decode(sim, c, n, 1, gl)
+            assert r == n and d == want, (trial, gl, r)
+
+
 def test_decode_core_malformed_vectors(sim, golden):
     for v in golden["malformed"]:
         vec = bytes.fromhex(v["hex"])
