@@ -1,24 +1,33 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json metric: uncompressed GB/s (compress + decompress) per GPU, 64 KiB blocks.
 
-Workload (BASELINE.json configs[1]): 65536 x 64 KiB synthetic blocks per GPU
+Headline workload (BASELINE.json configs[1]): 65536 x 64 KiB synthetic blocks per GPU
 (App. F generator, seed 0x4C5A3447, litmax 38, win 65535, fast ratio ~2.00), generated ON the device
 so nothing crosses PCIe.  One "step" = LZ4 fast-compress every block of the rank's shard, gather the
 compressed sizes, LZ4 safe-decompress every block (the LZ4Factory fastCompressor() +
 safeDecompressor() hot path of the reference, one block per call there, one launch per batch here).
-Multi-GPU (`--gpus N`, one process per GPU under torch.distributed.run): blocks are independent, so
-each rank owns a contiguous range of block indices (weak scaling: 65536 blocks per GPU) and the only
-collective is the all-gather of the int32 compressed sizes over RCCL.
+
+Multi-GPU: `--gpus N` runs N ranks, one process per GPU.  Under torch.distributed.run (WORLD_SIZE set) the
+script is a rank; started plainly with N > 1 it re-executes itself under `python -m torch.distributed.run
+--nproc-per-node N` (127.0.0.1).  Blocks are independent, so each rank owns a contiguous range of block
+indices (weak scaling: 65536 blocks per GPU) and the only collective is the all-gather of the int32
+compressed sizes over RCCL.  `n_gpus` in the line is the number of ranks that actually joined the nccl
+group; a run that asked for N and got fewer fails.
 
 Prints ONE JSON line on rank 0.  `value` = uncompressed bytes that went through compress+decompress
-on all ranks / wall time (max over ranks) -- inputs resident in HBM.  `roofline` describes the
-dominant kernel (compress); `roofline_decode` the decoder; `cpu_baseline` is the reference's own
-liblz4 1.9.3 (oracle/_ref) timed on this box's host cores on a bounded sample of the same blocks.
+on all ranks / wall time (max over ranks) -- inputs resident in HBM.  `roofline` describes the dominant
+kernel (fast compress); `roofline_decode` the decoder; `cpu_baseline` is the reference's own liblz4 1.9.3
+(oracle/_ref) timed on this box's host cores on a bounded sample of the same blocks.  `configs` carries the
+other BASELINE.json workloads, each timed outside the headline region with its own roofline and cpu_baseline:
+decompress_fast on the headline blocks, configs[2] (safe decode of 4 MiB blocks), configs[3] (HC level 9 of
+1 MiB blocks), configs[4] (XXH32 / XXH64 of 4 KiB buffers).
 """
 import argparse
+import hashlib
 import importlib
 import json
 import os
+import socket
 import subprocess
 import sys
 import time
@@ -27,6 +36,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def kernel_source_hash():
+    """sha256 over the kernel sources: profiles/traffic.json records the hash it was measured at, so a traffic figure that
+    predates a kernel change is reported as stale instead of silently quoted"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "lz4-java_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def measured_traffic(n_blocks, block):
@@ -43,26 +64,43 @@ def measured_traffic(n_blocks, block):
     return None
 
 
-def cpu_baseline(n_blocks, block, litmax, win):
-    """oracle leg: the reference liblz4 (kind "reference") or the C port, all host cores, bounded sample"""
+def cpu_bench(args, env=None):
+    """runs oracle/cpu_bench (the reference's liblz4 through dlopen, or the C port) and returns its JSON line"""
     from oracle import oracle as O
     O.build_port()
     odir = os.path.join(ROOT, "oracle")
     exe = os.path.join(odir, "cpu_bench")
     if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(os.path.join(odir, "cpu_bench.c")):
         subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-o", exe, os.path.join(odir, "cpu_bench.c"), "-ldl", "-lpthread"])
-    cores = os.cpu_count() or 1
     port_so = os.path.join(odir, "liblz4oracle.so")
     ref = O.ref_path()
     kind, lib = ("reference", ref) if ref else ("port", port_so)
-    sample = min(n_blocks, 512 * cores)
-    out = subprocess.check_output([exe, kind, lib, port_so, str(sample), str(block), str(cores), "3", "0", str(litmax), str(win)])
+    e = dict(os.environ)
+    e.update(env or {})
+    out = subprocess.check_output([exe, kind, lib, port_so] + [str(a) for a in args], env=e)
     r = json.loads(out.decode().strip().splitlines()[-1])
-    return {"value": round(r["roundtrip_GBps"], 3), "unit": "GB/s", "cores": cores, "kind": kind,
-            "sample": "%d x %d B blocks (same generator/seed), %d threads, best of 3; LZ4_compress_default + LZ4_decompress_safe; no JVM/JNI overhead"
-                      % (sample, block, cores),
-            "compress_GBps": round(r["compress_GBps"], 3), "decompress_safe_GBps": round(r["decompress_safe_GBps"], 3),
-            "decompress_fast_GBps": round(r["decompress_fast_GBps"], 3), "lib": os.path.relpath(lib, ROOT) if lib.startswith(ROOT) else lib}
+    r["_kind"], r["_lib"] = kind, (os.path.relpath(lib, ROOT) if lib.startswith(ROOT) else lib)
+    return r
+
+
+def cpu_entry(fn):
+    try:
+        return fn()
+    except Exception as e:  # a baseline is a reported extra, never a reason to lose the GPU line
+        return {"value": None, "unit": "GB/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
+
+
+def relaunch(n):
+    """`bench.py --gpus N` started without a launcher: become N ranks under torch.distributed.run"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -76,7 +114,11 @@ def main():
     ap.add_argument("--win", type=int, default=65535)
     ap.add_argument("--decode-lanes", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the configs[2..4] / decompress_fast sub-objects")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch(args.gpus)
 
     import torch
     import torch.distributed as dist
@@ -88,32 +130,79 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
+    if torch.cuda.device_count() < (local_rank + 1):
+        raise SystemExit("bench.py: rank %d has no GPU (%d visible)" % (rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    joined = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        one = torch.ones(1, dtype=torch.int32, device=dev)
+        dist.all_reduce(one)                      # every rank that joined the RCCL group adds itself
+        joined = int(one.item())
+        if joined != args.gpus:
+            raise SystemExit("bench.py: %d rank(s) joined the nccl group, %d were asked for" % (joined, args.gpus))
     if args.decode_lanes:
         amd.set_option("decode_lanes", args.decode_lanes)
 
+    i64, i32, u8 = torch.int64, torch.int32, torch.uint8
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if world > 1:
+            tt = torch.tensor([x], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item())
+        return x
+
+    def all_ok(ok):
+        if world > 1:
+            okt = torch.tensor([1 if ok else 0], device=dev)
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            return bool(okt.item())
+        return ok
+
+    def timed(fn, reps, warm=1):
+        """reps launches of fn between barriers: (wall seconds per launch, max over ranks; HIP-event seconds per launch on this rank)"""
+        for _ in range(warm):
+            fn()
+        barrier()
+        a, b = ev(), ev()
+        t0 = time.perf_counter()
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        barrier()
+        return max_over_ranks((time.perf_counter() - t0) / reps), a.elapsed_time(b) / reps * 1e-3
+
+    def batch(n, blk, cap):
+        return dict(so=torch.arange(n, dtype=i64, device=dev) * blk, sl=torch.full((n,), blk, dtype=i32, device=dev),
+                    co=torch.arange(n, dtype=i64, device=dev) * cap, cc=torch.full((n,), cap, dtype=i32, device=dev),
+                    clen=torch.zeros(n, dtype=i32, device=dev), dlen=torch.zeros(n, dtype=i32, device=dev))
+
+    # ------------------------------------------------------------------------------------------------------------------
+    # headline: configs[1]
+    # ------------------------------------------------------------------------------------------------------------------
     n, blk = args.blocks, args.block_size
     cap = amd.maxCompressedLength(blk)
-    i64, i32, u8 = torch.int64, torch.int32, torch.uint8
     src = torch.empty(n * blk, dtype=u8, device=dev)
     comp = torch.empty(n * cap, dtype=u8, device=dev)
     back = torch.zeros(n * blk, dtype=u8, device=dev)
-    so = torch.arange(n, dtype=i64, device=dev) * blk
-    sl = torch.full((n,), blk, dtype=i32, device=dev)
-    co = torch.arange(n, dtype=i64, device=dev) * cap
-    cc = torch.full((n,), cap, dtype=i32, device=dev)
-    clen = torch.zeros(n, dtype=i32, device=dev)
-    dlen = torch.zeros(n, dtype=i32, device=dev)
+    B = batch(n, blk, cap)
+    so, sl, co, cc, clen, dlen = B["so"], B["sl"], B["co"], B["cc"], B["clen"], B["dlen"]
     assert shard.block_range(n * world, world, rank) == (rank * n, (rank + 1) * n)
     # rank r owns block indices [r*n, (r+1)*n): contiguous ranges, no data exchange (SURVEY.md 8e)
     amd.DeviceBatch.gen_blocks(src, blk, blk, n, first_idx=rank * n, litmax=args.litmax, win=args.win)
     torch.cuda.synchronize()
-
-    ev = lambda: torch.cuda.Event(enable_timing=True)
 
     def step(events=None):
         if events:
@@ -129,11 +218,6 @@ def main():
         if events:
             events[3].record()
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     for _ in range(args.warmup):
         step()
     barrier()
@@ -142,32 +226,125 @@ def main():
     for k in range(args.steps):
         step(evs[k])
     barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = max_over_ranks(time.perf_counter() - t0)
 
     # ---- checks (outside the timed region): the work was real ----
     ok = bool(torch.equal(back, src)) and bool((clen > 0).all()) and bool(torch.equal(dlen, sl))
     csum = int(clen.sum().item())
     t_c = sum(e[0].elapsed_time(e[1]) for e in evs) / args.steps * 1e-3   # s per compress launch (HIP events on the launch stream)
     t_d = sum(e[2].elapsed_time(e[3]) for e in evs) / args.steps * 1e-3
-    if world > 1:
-        okt = torch.tensor([1 if ok else 0], device=dev)
-        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
-        ok = bool(okt.item())
+    ok = all_ok(ok)
+    nbytes = float(n) * blk
+
+    def roof(kernel, alg_bytes, secs, traffic=None):
+        return {"kernel": kernel, "bound": "hbm", "achieved": round(alg_bytes / secs / 1e9, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(alg_bytes / secs / 1e9 / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(secs * 1e3, 4)}
+
+    extra = {}
+    cores = os.cpu_count() or 1
+    want_cpu = world == 1 and rank == 0 and not args.no_cpu_baseline
+    if not args.no_extra_configs:
+        # ---- decompress_fast on the headline blocks (LZ4FastDecompressor: LZ4JNI.c:169) ----
+        back.zero_()
+        wall, tk = timed(lambda: amd.DeviceBatch.decompress_fast(comp, co, cc, back, so, sl, dlen), 3)
+        okf = all_ok(bool(torch.equal(back, src)) and bool(torch.equal(dlen, clen)))
+        extra["decompress_fast"] = {"workload": "the headline blocks, LZ4_decompress_fast", "value": round(world * nbytes / wall / 1e9, 3), "unit": "GB/s",
+                                    "verified": okf, "roofline": roof("decode_kernel<SAFE=false>", nbytes + csum, tk)}
+        ok = ok and okf
+        del comp, back
+        torch.cuda.empty_cache()
+
+        # ---- configs[2]: safe decode of 4 MiB blocks (gen_block(4 MiB, win 4096): fast ratio ~2.1) ----
+        n3, b3 = 4096, 4 << 20
+        cap3 = amd.maxCompressedLength(b3)
+        s3 = torch.empty(n3 * b3, dtype=u8, device=dev)
+        amd.DeviceBatch.gen_blocks(s3, b3, b3, n3, first_idx=(1 << 24) + rank * n3, litmax=args.litmax, win=4096)
+        c3 = torch.empty(n3 * cap3, dtype=u8, device=dev)
+        B3 = batch(n3, b3, cap3)
+        amd.DeviceBatch.compress_fast(s3, B3["so"], B3["sl"], c3, B3["co"], B3["cc"], B3["clen"])   # setup (bit-exactness of these bytes: tests/)
+        torch.cuda.synchronize()
+        cs3 = int(B3["clen"].sum().item())
+        bk3 = torch.zeros(n3 * b3, dtype=u8, device=dev)
+        wall, tk = timed(lambda: amd.DeviceBatch.decompress_safe(c3, B3["co"], B3["clen"], bk3, B3["so"], B3["sl"], B3["dlen"]), 2)
+        ok3 = all_ok(bool(torch.equal(bk3, s3)))
+        extra["configs2_decode_4MiB"] = {"workload": "%d x 4 MiB blocks per GPU (BASELINE configs[2]: 16384 blocks in all), App.F win 4096, "
+                                                     "LZ4_decompress_safe of fast-compressed blocks, ratio %.3f" % (n3, n3 * b3 / cs3),
+                                         "value": round(world * float(n3) * b3 / wall / 1e9, 3), "unit": "GB/s", "verified": ok3,
+                                         "roofline": roof("decode_kernel", float(n3) * b3 + cs3, tk)}
+        ok = ok and ok3
+        if want_cpu:
+            def f3():
+                r = cpu_bench([min(256, 2 * cores), b3, cores, 2, 1 << 24, args.litmax, 4096])
+                return {"value": round(r["decompress_safe_GBps"], 3), "unit": "GB/s", "cores": cores, "kind": r["_kind"],
+                        "sample": "%d x 4 MiB blocks (same generator), %d threads, best of 2, LZ4_decompress_safe" % (r["n_blocks"], cores)}
+            extra["configs2_decode_4MiB"]["cpu_baseline"] = cpu_entry(f3)
+        del s3, c3, bk3, B3
+        torch.cuda.empty_cache()
+
+        # ---- configs[3]: LZ4 HC level 9 of 1 MiB blocks ----
+        n4, b4 = 4096, 1 << 20
+        cap4 = amd.maxCompressedLength(b4)
+        s4 = torch.empty(n4 * b4, dtype=u8, device=dev)
+        amd.DeviceBatch.gen_blocks(s4, b4, b4, n4, first_idx=(2 << 24) + rank * n4, litmax=args.litmax, win=4096)
+        c4 = torch.empty(n4 * cap4, dtype=u8, device=dev)
+        B4 = batch(n4, b4, cap4)
+        wall, tk = timed(lambda: amd.DeviceBatch.compress_hc(s4, B4["so"], B4["sl"], c4, B4["co"], B4["cc"], B4["clen"], 9), 2)
+        cs4 = int(B4["clen"].sum().item())
+        bk4 = torch.zeros(n4 * b4, dtype=u8, device=dev)
+        amd.DeviceBatch.decompress_safe(c4, B4["co"], B4["clen"], bk4, B4["so"], B4["sl"], B4["dlen"])
+        ok4 = all_ok(bool(torch.equal(bk4, s4)) and bool((B4["clen"] > 0).all()))
+        extra["configs3_hc9_1MiB"] = {"workload": "%d x 1 MiB blocks per GPU, App.F win 4096, LZ4_compress_HC level 9, ratio %.3f" % (n4, n4 * b4 / cs4),
+                                      "value": round(world * float(n4) * b4 / wall / 1e9, 3), "unit": "GB/s", "verified": ok4,
+                                      # build + parse: reads N, writes + re-reads the u16 chain deltas (4 N), writes C
+                                      "roofline": roof("hc_build_kernel + hc_parse_kernel", float(n4) * b4 * 5 + cs4, tk)}
+        ok = ok and ok4
+        if want_cpu:
+            def f4():
+                r = cpu_bench([min(512, 2 * cores), b4, cores, 1, 2 << 24, args.litmax, 4096], {"LZ4_HC_LEVEL": "9"})
+                return {"value": round(r["compress_GBps"], 3), "unit": "GB/s", "cores": cores, "kind": r["_kind"],
+                        "sample": "%d x 1 MiB blocks (same generator), %d threads, one pass, LZ4_compress_HC level 9" % (r["n_blocks"], cores)}
+            extra["configs3_hc9_1MiB"]["cpu_baseline"] = cpu_entry(f4)
+        del c4, bk4, B4
+        torch.cuda.empty_cache()
+
+        # ---- configs[4]: XXH32 / XXH64 of 4 KiB buffers (the 4 GiB of configs[3]'s input as 1 Mi slices) ----
+        n5, b5 = 1 << 20, 4096
+        off5 = torch.arange(n5, dtype=i64, device=dev) * b5
+        len5 = torch.full((n5,), b5, dtype=i32, device=dev)
+        h32 = torch.zeros(n5, dtype=torch.int32, device=dev)
+        h64 = torch.zeros(n5, dtype=torch.int64, device=dev)
+        w32, t32 = timed(lambda: amd.DeviceBatch.xxh32(s4, off5, len5, 0x9747b28c, h32), 5)
+        w64, t64 = timed(lambda: amd.DeviceBatch.xxh64(s4, off5, len5, 0x9747b28c, h64), 5)
+        ok5 = True
+        try:   # a sample against python-xxhash where it is installed (the full check against the reference library: tests/)
+            import xxhash
+            host = s4[:64 * b5].cpu().numpy().tobytes()
+            a32, a64 = h32[:64].cpu().tolist(), h64[:64].cpu().tolist()
+            ok5 = all((a32[i] & 0xFFFFFFFF) == xxhash.xxh32_intdigest(host[i * b5:(i + 1) * b5], 0x9747b28c) and
+                      (a64[i] & 0xFFFFFFFFFFFFFFFF) == xxhash.xxh64_intdigest(host[i * b5:(i + 1) * b5], 0x9747b28c) for i in range(64))
+        except ImportError:
+            pass
+        ok5 = all_ok(ok5)
+        extra["configs4_xxhash_4KiB"] = {"workload": "%d x 4 KiB buffers per GPU, seed 0x9747b28c" % n5, "unit": "GB/s", "verified": ok5,
+                                         "xxh32": {"value": round(world * float(n5) * b5 / w32 / 1e9, 3), "roofline": roof("xxh_multi_kernel<u32,4>", float(n5) * (b5 + 4), t32)},
+                                         "xxh64": {"value": round(world * float(n5) * b5 / w64 / 1e9, 3), "roofline": roof("xxh_multi_kernel<u64,4>", float(n5) * (b5 + 8), t64)}}
+        ok = ok and ok5
+        if want_cpu:
+            def f5():
+                r = cpu_bench([min(n5, 4096 * cores), b5, cores, 3, 0, args.litmax, 4096], {"XXH_MODE": "1"})
+                return {"xxh32_GBps": round(r["xxh32_GBps"], 3), "xxh64_GBps": round(r["xxh64_GBps"], 3), "unit": "GB/s", "cores": cores, "kind": r["_kind"],
+                        "sample": "%d x 4 KiB buffers, %d threads, best of 3, XXH32 / XXH64 one-shot" % (r["n_blocks"], cores)}
+            extra["configs4_xxhash_4KiB"]["cpu_baseline"] = cpu_entry(f5)
+        del s4
 
     if rank == 0:
-        nbytes = float(n) * blk
         ratio = nbytes / csum
         value = world * nbytes * args.steps / dt / 1e9
         tr = measured_traffic(n, blk) or {}
-        alg_c = (nbytes + csum) / 1e9   # compress: reads N, writes C  (1 + 1/ratio B/B)
-        alg_d = (csum + nbytes) / 1e9   # decompress: reads C, writes N
         out = {
             "metric": "uncompressed GB/s (compress + decompress) per GPU, 64 KiB blocks",
-            "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 3), "unit": "GB/s", "n_gpus": joined, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%d x %d B blocks per GPU, SURVEY App.F gen_block(seed 0x4C5A3447, litmax %d, win %d); "
@@ -176,20 +353,25 @@ def main():
                        "blocks_per_gpu": n, "block_bytes": blk, "ratio": round(ratio, 4), "parallelism": "blocks sharded x%d" % world},
             "verified": ok,
             "compress_GBps": round(nbytes / t_c / 1e9, 3), "decompress_GBps": round(nbytes / t_d / 1e9, 3),
-            "roofline": {"kernel": "compress_fast_cu_kernel", "bound": "hbm", "achieved": round(alg_c / t_c, 3), "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": round(alg_c / t_c / HBM_PEAK_GBPS, 5), "traffic": tr.get("compress_fast_cu_kernel"),
-                         "algorithmic_bytes_per_launch": int(nbytes + csum), "avg_launch_ms": round(t_c * 1e3, 4)},
-            "roofline_decode": {"kernel": "decode_kernel", "bound": "hbm", "achieved": round(alg_d / t_d, 3), "peak": HBM_PEAK_GBPS,
-                                "unit": "GB/s", "frac": round(alg_d / t_d / HBM_PEAK_GBPS, 5), "traffic": tr.get("decode_kernel"),
-                                "algorithmic_bytes_per_launch": int(nbytes + csum), "avg_launch_ms": round(t_d * 1e3, 4)},
+            # compress: reads N, writes C (1 + 1/ratio B/B); decompress: reads C, writes N
+            "roofline": roof("compress_fast_v2_cu_kernel", nbytes + csum, t_c, tr.get("compress_fast_v2_cu_kernel")),
+            "roofline_decode": roof("decode_kernel", nbytes + csum, t_d, tr.get("decode_kernel")),
         }
         if tr:
             out["traffic_source"] = tr.get("source")
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline(n, blk, args.litmax, args.win)
-            except Exception as e:  # the baseline is a reported extra, never a reason to lose the GPU line
-                out["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
+            out["traffic_stale"] = tr.get("kernel_source_hash") != kernel_source_hash()   # true: kernels changed since the PMC passes
+        if extra:
+            out["configs"] = extra
+        if want_cpu:
+            def f1():
+                sample = min(n, 64 * cores)
+                r = cpu_bench([sample, blk, cores, 3, 0, args.litmax, args.win])
+                return {"value": round(r["roundtrip_GBps"], 3), "unit": "GB/s", "cores": cores, "kind": r["_kind"],
+                        "sample": "%d x %d B blocks (same generator/seed), %d threads, best of 3; LZ4_compress_default + LZ4_decompress_safe; no JVM/JNI overhead"
+                                  % (sample, blk, cores),
+                        "compress_GBps": round(r["compress_GBps"], 3), "decompress_safe_GBps": round(r["decompress_safe_GBps"], 3),
+                        "decompress_fast_GBps": round(r["decompress_fast_GBps"], 3), "lib": r["_lib"]}
+            out["cpu_baseline"] = cpu_entry(f1)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

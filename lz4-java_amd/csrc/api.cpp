@@ -70,9 +70,7 @@ enum Op { OP_COMPRESS_FAST, OP_DECODE_SAFE, OP_DECODE_FAST, OP_COMPRESS_HC };
 std::atomic<int> g_decode_lanes{0};   // "decode_lanes"; 0 = kernel default
 std::atomic<int> g_decode_stage{-1};  // "decode_stage": 1 = LDS output staging in the plain loop
 std::atomic<int> g_decode_pipe{-1};   // "decode_pipe": 1/0 = pipelined interior loop on/off, -1 = kernel default
-std::atomic<int> g_decode_two_pass{-1};   // "decode_two_pass": 1/0 = two-pass decoder (lz4_decode2_dev.h) on/off, -1 = by batch size
-std::atomic<int> g_decode_near_pct{0};    // "decode_near_pct": share of near matches (%) from which a block stays with the one-pass kernel
-std::atomic<uint32_t> g_d2_chunks_wanted[64];   // per device: arena chunks the last two-pass batch asked for (sizes the next arena)
+
 // lz4hip_set_option "compress_core": 4 = adaptive two-pass, lean core + window-parallel core (default); 3 = lean core only
 // (lz4_fast_v2_core.h); 2 = adaptive, one-sequence-per-step core + window-parallel core; 1 = window-parallel core only
 // (lz4_fast_ms_core.h); 0 = one-sequence-per-step core only (lz4_fast_core.h).  "compress_switch" = bytes per sequence below
@@ -149,37 +147,8 @@ int launch_fast(const lz4hip::BatchArgs& a, hipStream_t st) {
   return le;
 }
 
-// decode: one-pass kernels for small batches, the two-pass decoder from TWO_PASS_MIN blocks on.  The arena of the two-pass decoder
-// is sized from what the previous batch on this device asked for (read back asynchronously; first call: 4 chunks = 2044 sequences
-// per block); blocks that do not fit fall back to the one-pass kernel inside the same launch sequence, so a wrong guess costs
-// speed, never correctness, and nothing here waits for the device.
-constexpr uint32_t TWO_PASS_MIN = 4096;
 int launch_decode(const lz4hip::BatchArgs& a, bool safe, hipStream_t st) {
-  const int lanes = g_decode_lanes.load(), pipe = g_decode_pipe.load(), stage = g_decode_stage.load(), tp = g_decode_two_pass.load();
-  if (!(tp > 0 || (tp < 0 && a.n >= TWO_PASS_MIN))) return lz4hip::launch_decompress(a, safe, lanes, pipe, stage, st);
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  static uint32_t* h_want[64];   // pinned words the cursor of each launch is copied to
-  static std::mutex mu;
-  {
-    std::lock_guard<std::mutex> lk(mu);
-    if (!h_want[dev] && hipHostMalloc((void**)&h_want[dev], 64) == hipSuccess) *h_want[dev] = 0;
-  }
-  uint64_t chunks = (uint64_t)a.n * 4u + 64u;
-  if (h_want[dev]) {
-    const uint32_t seen = *(volatile uint32_t*)h_want[dev];
-    if (seen > g_d2_chunks_wanted[dev].load()) g_d2_chunks_wanted[dev].store(seen);
-  }
-  const uint64_t wanted = (uint64_t)g_d2_chunks_wanted[dev].load() * 9u / 8u + 64u;
-  if (wanted > chunks) chunks = wanted;
-  if (chunks > (3u << 20)) chunks = 3u << 20;   // 24 GB of descriptors at most
-  void* ws = nullptr;
-  hipError_t e = hipMallocAsync(&ws, lz4hip::decode2_ws_bytes(a.n, (uint32_t)chunks), st);
-  if (e != hipSuccess) return lz4hip::launch_decompress(a, safe, lanes, pipe, stage, st);
-  const int le = lz4hip::launch_decompress2(a, safe, ws, (uint32_t)chunks, (uint32_t)g_decode_near_pct.load(), lanes, pipe, stage, st);
-  if (h_want[dev]) (void)hipMemcpyAsync(h_want[dev], ws, 4, hipMemcpyDeviceToHost, st);
-  (void)hipFreeAsync(ws, st);
-  return le;
+  return lz4hip::launch_decompress(a, safe, g_decode_lanes.load(), g_decode_pipe.load(), g_decode_stage.load(), st);
 }
 
 int launch_op(Op op, const lz4hip::BatchArgs& a, hipStream_t st) {
@@ -606,16 +575,6 @@ int lz4hip_set_option(const char* name, int value) {
   if (name && strcmp(name, "decode_pipe") == 0) {
     if (value < -1 || value > 1) return fail(LZ4HIP_E_ARG, "decode_pipe must be -1, 0 or 1");
     g_decode_pipe = value;
-    return LZ4HIP_OK;
-  }
-  if (name && strcmp(name, "decode_two_pass") == 0) {
-    if (value < -1 || value > 1) return fail(LZ4HIP_E_ARG, "decode_two_pass must be -1, 0 or 1");
-    g_decode_two_pass = value;
-    return LZ4HIP_OK;
-  }
-  if (name && strcmp(name, "decode_near_pct") == 0) {
-    if (value < 0 || value > 100) return fail(LZ4HIP_E_ARG, "decode_near_pct must be 0..100");
-    g_decode_near_pct = value;
     return LZ4HIP_OK;
   }
   if (name && strcmp(name, "decode_lanes") == 0) {

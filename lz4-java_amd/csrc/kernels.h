@@ -37,12 +37,6 @@ int launch_pack(const BatchArgs& a, uint64_t* poff, uint8_t* pack, void* stream)
 // pipe: 1 = pipelined interior loop (lz4_decode_core.h PIPE), 0 = plain, -1 = default for the batch size
 // stage: 1 = the plain interior loop writes through LDS staging (whole-line output), 0 / -1 = off
 int launch_decompress(const BatchArgs& a, bool safe, int lanes_per_block, int pipe, int stage, void* stream);
-// two-pass decoder for big batches (lz4_decode2_dev.h): token walk of every block into sequence descriptors, then one workgroup per
-// block with the block's output window in LDS.  ws = decode2_ws_bytes(n, cap_chunks) bytes of device memory (word 0 reports the
-// arena chunks the batch wanted); blocks that do not fit the arena, or whose share of near matches reaches near_pct % (0 = off),
-// are decoded by the one-pass kernel with the given lanes / pipe / stage settings.
-size_t decode2_ws_bytes(uint32_t n, uint32_t cap_chunks);
-int launch_decompress2(const BatchArgs& a, bool safe, void* ws, uint32_t cap_chunks, uint32_t near_pct, int lanes_per_block, int pipe, int stage, void* stream);
 int launch_xxh32(const uint8_t* buf, const uint64_t* off, const int32_t* len, uint32_t seed, uint32_t* out, uint32_t n, void* stream);
 int launch_xxh64(const uint8_t* buf, const uint64_t* off, const int32_t* len, uint64_t seed, uint64_t* out, uint32_t n, void* stream);
 // streaming xxhash: `rec` = device record of xxh_stream_rec_bytes() bytes (the digest so far sits at xxh_stream_digest_offset());

@@ -27,7 +27,6 @@
 #include "lz4_fast_ms_core.h"
 #include "lz4_fast_v2_core.h"
 #include "lz4_decode_core.h"
-#include "lz4_decode2_dev.h"
 #include "lz4_hc_core.h"
 #include "xxh_core.h"
 
@@ -349,14 +348,12 @@ int launch_pack(const BatchArgs& a, uint64_t* poff, uint8_t* pack, void* stream)
 // ------------------------------------------------------------------------------------------------
 // decode
 // ------------------------------------------------------------------------------------------------
-// route != nullptr: only the blocks pass 1 of the two-pass decoder flagged (lz4_decode2_dev.h Blk2::flags) are decoded here
 template <int GL, bool SAFE, bool PIPE, bool STAGE>
-__global__ __launch_bounds__(256) void decode_kernel(BatchArgs a, const Blk2* route) {
+__global__ __launch_bounds__(256) void decode_kernel(BatchArgs a) {
   // STAGE: one staging buffer per block of the workgroup (group_dev.h st_*): 256/GL x 576 bytes
   __shared__ __attribute__((aligned(16))) uint8_t stage_mem[STAGE ? (256 / GL) * GroupDev<GL>::kStage : 16];
   const uint32_t gid = (blockIdx.x * 256u + threadIdx.x) / GL;
   if (gid >= a.n) return;  // a whole group leaves together
-  if (route && route[gid].flags == 0u) return;
   GroupDev<GL> g;
   uint8_t* stage = STAGE ? stage_mem + (threadIdx.x / GL) * GroupDev<GL>::kStage : nullptr;
   const int r = decode_block<GroupDev<GL>, SAFE, PIPE, STAGE>(g, a.src + a.src_off[gid], a.src_len[gid], a.dst + a.dst_off[gid], a.dst_cap[gid], stage);
@@ -364,27 +361,23 @@ __global__ __launch_bounds__(256) void decode_kernel(BatchArgs a, const Blk2* ro
 }
 
 template <int GL>
-static int launch_decode_gl(const BatchArgs& a, bool safe, bool pipe, bool stage, hipStream_t st, const Blk2* route) {
+static int launch_decode_gl(const BatchArgs& a, bool safe, bool pipe, bool stage, hipStream_t st) {
   const uint32_t per_wg = 256u / GL;
   const uint32_t grid = (a.n + per_wg - 1u) / per_wg;
   if (stage) {   // (staging belongs to the plain loop)
-    if (safe) hipLaunchKernelGGL((decode_kernel<GL, true, false, true>), dim3(grid), dim3(256), 0, st, a, route);
-    else hipLaunchKernelGGL((decode_kernel<GL, false, false, true>), dim3(grid), dim3(256), 0, st, a, route);
+    if (safe) hipLaunchKernelGGL((decode_kernel<GL, true, false, true>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((decode_kernel<GL, false, false, true>), dim3(grid), dim3(256), 0, st, a);
   } else if (safe) {
-    if (pipe) hipLaunchKernelGGL((decode_kernel<GL, true, true, false>), dim3(grid), dim3(256), 0, st, a, route);
-    else hipLaunchKernelGGL((decode_kernel<GL, true, false, false>), dim3(grid), dim3(256), 0, st, a, route);
+    if (pipe) hipLaunchKernelGGL((decode_kernel<GL, true, true, false>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((decode_kernel<GL, true, false, false>), dim3(grid), dim3(256), 0, st, a);
   } else {
-    if (pipe) hipLaunchKernelGGL((decode_kernel<GL, false, true, false>), dim3(grid), dim3(256), 0, st, a, route);
-    else hipLaunchKernelGGL((decode_kernel<GL, false, false, false>), dim3(grid), dim3(256), 0, st, a, route);
+    if (pipe) hipLaunchKernelGGL((decode_kernel<GL, false, true, false>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((decode_kernel<GL, false, false, false>), dim3(grid), dim3(256), 0, st, a);
   }
   return (int)hipGetLastError();
 }
 
-static int launch_decompress_routed(const BatchArgs& a, bool safe, int lanes_per_block, int pipe, int stage, void* stream, const Blk2* route);
 int launch_decompress(const BatchArgs& a, bool safe, int lanes_per_block, int pipe, int stage, void* stream) {
-  return launch_decompress_routed(a, safe, lanes_per_block, pipe, stage, stream, nullptr);
-}
-static int launch_decompress_routed(const BatchArgs& a, bool safe, int lanes_per_block, int pipe, int stage, void* stream, const Blk2* route) {
   if (a.n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   // Defaults by batch size (tools/decode_matrix.sh; App. F / text / 4 MiB blocks):
@@ -402,34 +395,13 @@ static int launch_decompress_routed(const BatchArgs& a, bool safe, int lanes_per
   // 49152: 508 vs 597)
   const bool sg = !p && (stage < 0 ? a.n >= 40960u : stage != 0);
   switch (lanes_per_block) {
-    case 4: return launch_decode_gl<4>(a, safe, p, sg, st, route);
-    case 16: return launch_decode_gl<16>(a, safe, p, sg, st, route);
-    case 32: return launch_decode_gl<32>(a, safe, p, sg, st, route);
-    case 64: return launch_decode_gl<64>(a, safe, p, sg, st, route);
+    case 4: return launch_decode_gl<4>(a, safe, p, sg, st);
+    case 16: return launch_decode_gl<16>(a, safe, p, sg, st);
+    case 32: return launch_decode_gl<32>(a, safe, p, sg, st);
+    case 64: return launch_decode_gl<64>(a, safe, p, sg, st);
     case 8:
-    default: return launch_decode_gl<8>(a, safe, p, sg, st, route);
+    default: return launch_decode_gl<8>(a, safe, p, sg, st);
   }
-}
-
-// two-pass decoder (lz4_decode2_dev.h): ws = decode2_ws_bytes(n, cap_chunks) bytes of device workspace
-size_t decode2_ws_bytes(uint32_t n, uint32_t cap_chunks) {
-  return 256u + (((size_t)n * sizeof(Blk2) + 255u) & ~(size_t)255u) + (size_t)cap_chunks * D2_CHUNK * sizeof(uint4);
-}
-int launch_decompress2(const BatchArgs& a, bool safe, void* ws, uint32_t cap_chunks, uint32_t near_pct, int lanes_per_block, int pipe, int stage, void* stream) {
-  if (a.n == 0) return 0;
-  hipStream_t st = (hipStream_t)stream;
-  uint32_t* cursor = (uint32_t*)ws;                      // [0]: chunks handed out by pass 1 (may exceed cap_chunks: what the batch wanted)
-  Blk2* meta = (Blk2*)((uint8_t*)ws + 256u);
-  uint4* arena = (uint4*)((uint8_t*)ws + 256u + (((size_t)a.n * sizeof(Blk2) + 255u) & ~(size_t)255u));
-  hipError_t e = hipMemsetAsync(cursor, 0, 4, st);
-  if (e != hipSuccess) return (int)e;
-  const uint32_t pgrid = (a.n + 63u) / 64u;              // 4 lanes per block, 64 blocks per 256-thread workgroup
-  if (safe) hipLaunchKernelGGL((decode2_parse_kernel<4, true>), dim3(pgrid), dim3(256), 0, st, a, meta, arena, cursor, cap_chunks, near_pct);
-  else hipLaunchKernelGGL((decode2_parse_kernel<4, false>), dim3(pgrid), dim3(256), 0, st, a, meta, arena, cursor, cap_chunks, near_pct);
-  hipLaunchKernelGGL(decode2_copy_kernel, dim3(a.n), dim3(D2_NT), 0, st, a, (const Blk2*)meta, (const uint4*)arena);
-  if ((e = hipGetLastError()) != hipSuccess) return (int)e;
-  // the blocks pass 1 left alone (arena full, dependency-heavy): one-pass kernel, every other group leaves at once
-  return launch_decompress_routed(a, safe, lanes_per_block, pipe, stage, stream, meta);
 }
 
 // ------------------------------------------------------------------------------------------------

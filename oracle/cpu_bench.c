@@ -10,7 +10,9 @@
  *
  *   cpu_bench <reference|port> <lib.so> <liblz4oracle.so> <n_blocks> <block_size> <threads> <reps> <first_idx> <litmax> <win>
  * prints one JSON line.  With LZ4_HC_LEVEL=<1..9> in the environment the compress leg is LZ4_compress_HC at that level
- * (LZ4JNI.c:122; row a4) instead of LZ4_compress_default ("reference" kind only).
+ * (LZ4JNI.c:122; row a4) instead of LZ4_compress_default ("reference" kind only).  With XXH_MODE=1 the buffers are hashed
+ * instead: XXH32 and XXH64 (seed 0x9747b28c) of every block (src/jni/net_jpountz_xxhash_XXHashJNI.c:54,164; row a6), and the
+ * line reports xxh32_GBps / xxh64_GBps.
  */
 #define _GNU_SOURCE
 #include <dlfcn.h>
@@ -38,7 +40,11 @@ static gen_fn gen;
 static int n_blocks, block_size, n_threads, bound;
 static uint64_t first_idx; static uint32_t litmax, win;
 static uint8_t *src, *comp, *back; static int* clen;
-static int phase;  /* 0 gen, 1 compress, 2 dsafe, 3 dfast */
+typedef uint32_t (*xxh32_fn)(const void*, size_t, uint32_t);
+typedef uint64_t (*xxh64_fn)(const void*, size_t, uint64_t);
+static xxh32_fn x32; static xxh64_fn x64;
+static uint64_t* hsum;
+static int phase;  /* 0 gen, 1 compress, 2 dsafe, 3 dfast, 4 xxh32, 5 xxh64 */
 static volatile int bad = 0;
 
 static double now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
@@ -56,6 +62,8 @@ static void* worker(void* arg) {
               clen[i] = r; if (r <= 0) bad = 1; break;
       case 2: r = is_ref ? r_ds((const char*)c, (char*)d, clen[i], block_size) : p_ds(c, clen[i], d, block_size); if (r != block_size) bad = 1; break;
       case 3: r = is_ref ? r_df((const char*)c, (char*)d, block_size) : p_df(c, d, block_size); if (r != clen[i]) bad = 1; break;
+      case 4: hsum[t] += x32(s, (size_t)block_size, 0x9747b28cu); break;
+      case 5: hsum[t] += x64(s, (size_t)block_size, 0x9747b28cull); break;
     }
   }
   return NULL;
@@ -93,6 +101,21 @@ int main(int argc, char** argv) {
     if (!p_c || !p_ds || !p_df) { fprintf(stderr, "missing lz4o_* symbols\n"); return 4; }
   }
   bound = block_size + block_size / 255 + 16;
+  if (getenv("XXH_MODE")) {
+    x32 = (xxh32_fn)dlsym(lib, is_ref ? "XXH32" : "lz4o_xxh32_raw"); x64 = (xxh64_fn)dlsym(lib, is_ref ? "XXH64" : "lz4o_xxh64_raw");
+    if (!x32 || !x64) { fprintf(stderr, "missing XXH32/XXH64 symbols\n"); return 4; }
+    src = malloc((size_t)n_blocks * block_size); hsum = calloc(256, sizeof(uint64_t));
+    if (!src || !hsum) { fprintf(stderr, "malloc\n"); return 5; }
+    run_phase(0);
+    double b32 = 1e30, b64 = 1e30;
+    run_phase(4);
+    for (int r = 0; r < reps; r++) { double t = run_phase(4); if (t < b32) b32 = t; t = run_phase(5); if (t < b64) b64 = t; }
+    uint64_t chk = 0; for (int i = 0; i < 256; i++) chk += hsum[i];
+    double bytes = (double)n_blocks * block_size;
+    printf("{\"kind\": \"%s\", \"threads\": %d, \"n_blocks\": %d, \"block_size\": %d, \"check\": %llu, \"xxh32_GBps\": %.4f, \"xxh64_GBps\": %.4f}\n",
+           argv[1], n_threads, n_blocks, block_size, (unsigned long long)chk, bytes / b32 / 1e9, bytes / b64 / 1e9);
+    return 0;
+  }
   src = malloc((size_t)n_blocks * block_size); comp = malloc((size_t)n_blocks * bound); back = malloc((size_t)n_blocks * block_size);
   clen = malloc(sizeof(int) * n_blocks);
   if (!src || !comp || !back || !clen) { fprintf(stderr, "malloc\n"); return 5; }

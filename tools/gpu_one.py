@@ -39,10 +39,6 @@ if os.environ.get("CS"):
     amd.set_option("compress_switch", int(os.environ["CS"]))
 if os.environ.get("DS"):
     amd.set_option("decode_stage", int(os.environ["DS"]))
-if os.environ.get("DT"):
-    amd.set_option("decode_two_pass", int(os.environ["DT"]))
-if os.environ.get("DN"):
-    amd.set_option("decode_near_pct", int(os.environ["DN"]))
 if os.environ.get("DP"):
     amd.set_option("decode_pipe", int(os.environ["DP"]))
 for _ in range(reps):
