@@ -84,8 +84,19 @@ int lz4hip_compress_hc_batch(const uint8_t* src, const uint64_t* src_off, const 
 int lz4hip_decompress_safe_batch(const uint8_t* src, const uint64_t* src_off, const int32_t* src_len,
                                  uint8_t* dst, const uint64_t* dst_off, const int32_t* dst_cap,
                                  int32_t* out_len, uint32_t n_blocks);
-/* src_cap[i] bounds how far block i may be read (the Java array/buffer length past srcOff):
- * unlike liblz4's LZ4_decompress_fast this implementation never reads beyond it.                */
+/* FAST DECODER CONTRACT.  src_cap[i] bounds how far block i may be read (the Java array/buffer length past srcOff):
+ * unlike liblz4's LZ4_decompress_fast (which trusts the stream and reads wherever it points) this implementation never reads
+ * beyond src_cap[i] bytes of the source slot and never before the destination slot.
+ *   - valid stream whose decoded size is dst_len[i]: out_consumed[i] = the compressed length, dst = the decoded bytes --
+ *     identical to LZ4_decompress_fast (LZ4JNI.c:169);
+ *   - anything else (truncated / corrupted / random bytes, wrong dst_len): liblz4's own decode loop with ONE change -- a read
+ *     that would leave the source slot, or an offset that would reach before the destination, is the error at that point:
+ *     out_consumed[i] = -(input position) - 1.  Streams liblz4 happens to accept while reading garbage past the slot are
+ *     therefore rejected here; streams liblz4 rejects are rejected with the same code when the rejection does not depend on
+ *     bytes outside the slot.
+ * The behaviour is pinned by 600 vectors in tests/golden/fast_decode_contract.json (generated from oracle/lz4_oracle.c
+ * lz4o_decompress_fast_bounded; its valid cases are cross-checked against the reference library) and tested on the CPU
+ * (tests/test_oracle.py) and on the GPU (tests/test_gpu_scale.py).                                                        */
 int lz4hip_decompress_fast_batch(const uint8_t* src, const uint64_t* src_off, const int32_t* src_cap,
                                  uint8_t* dst, const uint64_t* dst_off, const int32_t* dst_len,
                                  int32_t* out_consumed, uint32_t n_blocks);

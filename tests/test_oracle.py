@@ -117,3 +117,17 @@ def test_issue12_regression_blob(port, ref):
     for level in (1, 9, 12):
         h = port.compress_hc(data, level)
         assert h == ref.compress_hc(data, level) and ref.decompress_safe(h, len(data)) == data
+
+
+def test_fast_decoder_contract_vectors(O):
+    """tests/golden/fast_decode_contract.json (the bounded fast decoder's pinned behaviour, include/lz4hip.h): the C restatement
+    reproduces every vector"""
+    import hashlib, json, os
+    from conftest import GOLD
+    cases = json.load(open(os.path.join(GOLD, "fast_decode_contract.json")))["cases"]
+    assert len(cases) >= 600
+    for e in cases:
+        r, d = O.decompress_fast_bounded(bytes.fromhex(e["hex"]), e["src_cap"], e["dst_len"])
+        assert r == e["ret"]
+        if r >= 0:
+            assert hashlib.sha256(d[:e["dst_len"]]).hexdigest() == e["sha256"]
