@@ -17,15 +17,22 @@
 #include "lz4hip.h"
 
 static jclass OutOfMemoryError;
+static jclass RuntimeException;
 
 JNIEXPORT void JNICALL Java_net_jpountz_lz4_LZ4HIPJNI_init(JNIEnv* env, jclass cls) {
   (void)cls;
   jclass local = (*env)->FindClass(env, "java/lang/OutOfMemoryError");
   OutOfMemoryError = (jclass)(*env)->NewGlobalRef(env, local);
+  local = (*env)->FindClass(env, "java/lang/RuntimeException");
+  RuntimeException = (jclass)(*env)->NewGlobalRef(env, local);
   (void)lz4hip_init(NULL, 0); /* a failure surfaces on the first codec call as a library error */
 }
 
 static void throw_OOM(JNIEnv* env) { (*env)->ThrowNew(env, OutOfMemoryError, "Out of memory"); }
+/* a liblz4hip failure (no device, HIP error, bad handle) in an entry point whose Java signature has no error channel: the
+ * reference's XXHashJNI cannot fail there; returning hash 0 or a stale digest silently would let a checksum comparison pass or
+ * fail wrongly, so the caller gets an unchecked exception carrying lz4hip_last_error() */
+static void throw_lib(JNIEnv* env) { (*env)->ThrowNew(env, RuntimeException, lz4hip_last_error()); }
 
 /* A (array | direct buffer, offset, length) argument made addressable for the native call. */
 typedef struct {
@@ -167,6 +174,7 @@ static int hash_region(JNIEnv* env, jbyteArray arr, jobject buf, jint off, jint 
   if (is64) rc = lz4hip_xxh64(in.p, len, seed, out);
   else { uint32_t h = 0; rc = lz4hip_xxh32(in.p, len, (uint32_t)seed, &h); *out = h; }
   region_out(env, NULL, 0, 0, &in);
+  if (rc != 0) throw_lib(env);
   return rc;
 }
 
@@ -221,16 +229,17 @@ static jlong stream_init(JNIEnv* env, int is64, uint64_t seed) {
 static void stream_update(JNIEnv* env, jlong state, jbyteArray src, jint off, jint len) {
   region_t in;   /* staged copy: the GC lock is not held across the launch */
   if (region_in(env, src, NULL, off, len, 1, &in) != 0) { throw_OOM(env); return; }
-  (void)lz4hip_xxh_stream_update((lz4hip_xxh_stream*)(intptr_t)state, in.p, len);
+  const int rc = lz4hip_xxh_stream_update((lz4hip_xxh_stream*)(intptr_t)state, in.p, len);
   region_out(env, NULL, 0, 0, &in);
+  if (rc != 0) throw_lib(env);
 }
 JNIEXPORT jlong JNICALL Java_net_jpountz_xxhash_XXHashHIPJNI_XXH32_1init(JNIEnv* env, jclass cls, jint seed) { (void)cls; return stream_init(env, 0, (uint32_t)seed); }
 JNIEXPORT jlong JNICALL Java_net_jpountz_xxhash_XXHashHIPJNI_XXH64_1init(JNIEnv* env, jclass cls, jlong seed) { (void)cls; return stream_init(env, 1, (uint64_t)seed); }
 JNIEXPORT void JNICALL Java_net_jpountz_xxhash_XXHashHIPJNI_XXH32_1reset(JNIEnv* env, jclass cls, jlong state, jint seed) {
-  (void)env; (void)cls; (void)lz4hip_xxh_stream_reset((lz4hip_xxh_stream*)(intptr_t)state, (uint32_t)seed);
+  (void)cls; if (lz4hip_xxh_stream_reset((lz4hip_xxh_stream*)(intptr_t)state, (uint32_t)seed) != 0) throw_lib(env);
 }
 JNIEXPORT void JNICALL Java_net_jpountz_xxhash_XXHashHIPJNI_XXH64_1reset(JNIEnv* env, jclass cls, jlong state, jlong seed) {
-  (void)env; (void)cls; (void)lz4hip_xxh_stream_reset((lz4hip_xxh_stream*)(intptr_t)state, (uint64_t)seed);
+  (void)cls; if (lz4hip_xxh_stream_reset((lz4hip_xxh_stream*)(intptr_t)state, (uint64_t)seed) != 0) throw_lib(env);
 }
 JNIEXPORT void JNICALL Java_net_jpountz_xxhash_XXHashHIPJNI_XXH32_1update(JNIEnv* env, jclass cls, jlong state, jbyteArray src, jint off, jint len) {
   (void)cls; stream_update(env, state, src, off, len);
@@ -239,10 +248,10 @@ JNIEXPORT void JNICALL Java_net_jpountz_xxhash_XXHashHIPJNI_XXH64_1update(JNIEnv
   (void)cls; stream_update(env, state, src, off, len);
 }
 JNIEXPORT jint JNICALL Java_net_jpountz_xxhash_XXHashHIPJNI_XXH32_1digest(JNIEnv* env, jclass cls, jlong state) {
-  (void)env; (void)cls; uint32_t h = 0; (void)lz4hip_xxh32_stream_digest((lz4hip_xxh_stream*)(intptr_t)state, &h); return (jint)h;
+  (void)cls; uint32_t h = 0; if (lz4hip_xxh32_stream_digest((lz4hip_xxh_stream*)(intptr_t)state, &h) != 0) throw_lib(env); return (jint)h;
 }
 JNIEXPORT jlong JNICALL Java_net_jpountz_xxhash_XXHashHIPJNI_XXH64_1digest(JNIEnv* env, jclass cls, jlong state) {
-  (void)env; (void)cls; uint64_t h = 0; (void)lz4hip_xxh64_stream_digest((lz4hip_xxh_stream*)(intptr_t)state, &h); return (jlong)h;
+  (void)cls; uint64_t h = 0; if (lz4hip_xxh64_stream_digest((lz4hip_xxh_stream*)(intptr_t)state, &h) != 0) throw_lib(env); return (jlong)h;
 }
 JNIEXPORT void JNICALL Java_net_jpountz_xxhash_XXHashHIPJNI_XXH_1free(JNIEnv* env, jclass cls, jlong state) {
   (void)env; (void)cls; lz4hip_xxh_stream_free((lz4hip_xxh_stream*)(intptr_t)state);

@@ -132,3 +132,17 @@ def test_java_natives_match_jni_shim():
         assert os.path.exists(os.path.join(xx, cls + ".java")), cls
     for cls in ("StreamingXXHash32HIP", "StreamingXXHash64HIP"):
         assert "static class Factory implements" in open(os.path.join(xx, cls + ".java")).read()
+
+
+def test_jni_shim_executes_against_fake_jnienv_without_device():
+    """the JNI shim RUNS (no JVM needed): tests/jni_stub/fake_jni.c is a JNIEnv function table over malloc'd arrays, linked with
+    the shim and liblz4hip.so.  Without a device every compute entry point must fail loudly -- library error code from the codec
+    calls, RuntimeException from the hash calls -- with no staging buffer leaked and no array left pinned.  (The full scenario
+    list, incl. the reference's leak path LZ4JNI.c:59-73, runs on the GPU: tests/test_gpu_jni.py.)"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a device is present: covered by tests/test_gpu_jni.py")
+    d = os.path.join(ROOT, "tests", "jni_stub")
+    subprocess.check_call(["bash", os.path.join(d, "build.sh")])
+    out = subprocess.check_output([os.path.join(d, "fake_jni"), "--no-gpu"]).decode()
+    assert "checks ok" in out, out
