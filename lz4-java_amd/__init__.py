@@ -51,6 +51,8 @@ C_ABI = {
     "lz4hip_xxh64_batch": (C.c_int, [C.c_void_p, _u64p, _i32p, C.c_uint64, _u64p, C.c_uint32]),
     "lz4hip_compress_fast_batch_dev": (C.c_int, [C.c_void_p] * 7 + [C.c_uint32, C.c_int, C.c_void_p]),
     "lz4hip_compress_hc_batch_dev": (C.c_int, [C.c_void_p] * 7 + [C.c_uint32, C.c_int, C.c_int, C.c_void_p]),
+    "lz4hip_hc_workspace_bytes": (C.c_size_t, [C.c_uint64, C.c_uint32, C.c_int]),
+    "lz4hip_compress_hc_batch_dev_ws": (C.c_int, [C.c_void_p] * 7 + [C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t]),
     "lz4hip_decompress_safe_batch_dev": (C.c_int, [C.c_void_p] * 7 + [C.c_uint32, C.c_int, C.c_void_p]),
     "lz4hip_decompress_fast_batch_dev": (C.c_int, [C.c_void_p] * 7 + [C.c_uint32, C.c_int, C.c_void_p]),
     "lz4hip_xxh32_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]),
@@ -507,18 +509,26 @@ class LZ4HIPBatch:
     slot dst[dstOff[i]:+dstCap[i]]."""
 
     @staticmethod
-    def _call(fn, src, srcOff, srcLen, dst, dstOff, dstCap):
-        n = len(srcOff)
-        if hasattr(srcOff, "dtype"):   # numpy offsets/lengths: vectorised range checks (SafeUtils.checkRange per block)
+    def _check_ranges(buf, off, length):
+        """SafeUtils.checkRange for every block: 0 <= off and off + len <= len(buf) (for decompressFast `length` is the readable
+        capacity of the slot -- it bounds what the engine may read, so it must lie inside the buffer like any other range)"""
+        n = len(off)
+        if hasattr(off, "dtype") or hasattr(length, "dtype"):
             import numpy as np
-            so, sl, do, dc = (np.asarray(x, dtype=np.int64) for x in (srcOff, srcLen, dstOff, dstCap))
-            if n and ((sl < 0).any() or (dc < 0).any() or (so < 0).any() or (do < 0).any()
-                      or (fn != "lz4hip_decompress_fast_batch" and ((so + sl) > len(src)).any()) or ((do + dc) > len(dst)).any()):
+            o, l = np.asarray(off, dtype=np.int64), np.asarray(length, dtype=np.int64)
+            if n and ((l < 0).any() or (o < 0).any() or ((o + l) > len(buf)).any()):
                 raise IndexError("block range outside its buffer")
         else:
             for i in range(n):
-                _check_range(src, srcOff[i], srcLen[i]) if fn != "lz4hip_decompress_fast_batch" else None
-                _check_range(dst, dstOff[i], dstCap[i])
+                _check_range(buf, off[i], length[i])
+
+    @classmethod
+    def _call(cls, fn, src, srcOff, srcLen, dst, dstOff, dstCap):
+        n = len(srcOff)
+        if not (len(srcLen) == len(dstOff) == len(dstCap) == n):
+            raise ValueError("per-block arrays differ in length")
+        cls._check_ranges(src, srcOff, srcLen)
+        cls._check_ranges(dst, dstOff, dstCap)
         sp, sk = _ro_ptr(src)
         dp, dk = _rw_ptr(dst)
         out = (C.c_int32 * max(n, 1))()
@@ -536,9 +546,10 @@ class LZ4HIPBatch:
     @classmethod
     def compressHC(cls, src, srcOff, srcLen, dst, dstOff, dstCap, level=9):
         n = len(srcOff)
-        for i in range(n):
-            _check_range(src, srcOff[i], srcLen[i])
-            _check_range(dst, dstOff[i], dstCap[i])
+        if not (len(srcLen) == len(dstOff) == len(dstCap) == n):
+            raise ValueError("per-block arrays differ in length")
+        cls._check_ranges(src, srcOff, srcLen)
+        cls._check_ranges(dst, dstOff, dstCap)
         sp, sk = _ro_ptr(src)
         dp, dk = _rw_ptr(dst)
         out = (C.c_int32 * max(n, 1))()
@@ -554,17 +565,23 @@ class LZ4HIPBatch:
     def decompressFast(cls, src, srcOff, srcCap, dst, dstOff, dstLen):
         return cls._call("lz4hip_decompress_fast_batch", src, srcOff, srcCap, dst, dstOff, dstLen)
 
-    @staticmethod
-    def xxh32(buf, off, length, seed=0):
+    @classmethod
+    def xxh32(cls, buf, off, length, seed=0):
         n = len(off)
+        if len(length) != n:
+            raise ValueError("per-buffer arrays differ in length")
+        cls._check_ranges(buf, off, length)
         p, k = _ro_ptr(buf)
         out = (C.c_uint32 * max(n, 1))()
         _chk(lib().lz4hip_xxh32_batch(p, _arr(C.c_uint64, off), _arr(C.c_int32, length), seed & 0xFFFFFFFF, out, n))
         return list(out[:n])
 
-    @staticmethod
-    def xxh64(buf, off, length, seed=0):
+    @classmethod
+    def xxh64(cls, buf, off, length, seed=0):
         n = len(off)
+        if len(length) != n:
+            raise ValueError("per-buffer arrays differ in length")
+        cls._check_ranges(buf, off, length)
         p, k = _ro_ptr(buf)
         out = (C.c_uint64 * max(n, 1))()
         _chk(lib().lz4hip_xxh64_batch(p, _arr(C.c_uint64, off), _arr(C.c_int32, length), seed & 0xFFFFFFFFFFFFFFFF, out, n))
@@ -596,6 +613,21 @@ class DeviceBatch:
 
     @classmethod
     def compress_hc(cls, src, src_off, src_len, dst, dst_off, dst_cap, out, level=9):
+        """asynchronous: the workspace is a torch tensor sized from the source tensor (an upper bound of the batch's source span);
+        the caching allocator keeps it alive until the stream has used it"""
+        import torch
+        dev, st = cls._stream_dev(src)
+        span = src.numel()
+        nb = lib().lz4hip_hc_workspace_bytes(span, src_off.numel(), level)
+        ws = torch.empty(max(nb, 1), dtype=torch.uint8, device=src.device)
+        _chk(lib().lz4hip_compress_hc_batch_dev_ws(src.data_ptr(), src_off.data_ptr(), src_len.data_ptr(), dst.data_ptr(),
+                                                   dst_off.data_ptr(), dst_cap.data_ptr(), out.data_ptr(), src_off.numel(), level, dev, st,
+                                                   span, ws.data_ptr(), nb))
+        ws.record_stream(torch.cuda.current_stream(src.device))
+
+    @classmethod
+    def compress_hc_sync(cls, src, src_off, src_len, dst, dst_off, dst_cap, out, level=9):
+        """the entry that sizes its own workspace (synchronises the stream once)"""
         dev, st = cls._stream_dev(src)
         _chk(lib().lz4hip_compress_hc_batch_dev(src.data_ptr(), src_off.data_ptr(), src_len.data_ptr(), dst.data_ptr(),
                                                 dst_off.data_ptr(), dst_cap.data_ptr(), out.data_ptr(), src_off.numel(), level, dev, st))

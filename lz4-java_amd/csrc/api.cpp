@@ -8,6 +8,7 @@
 #include <string.h>
 #include <limits.h>
 #include <atomic>
+#include <condition_variable>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -86,17 +87,21 @@ int hc_level(int level, int* out) {
   return LZ4HIP_OK;
 }
 
-// HC on device pointers: sizes the u16 workspace (one stream synchronisation), runs build + parse
+// HC on device pointers.  The chain-delta workspace is indexed by source offset, so its size depends on the batch's source span
+// (max of src_off + src_len), which lives in device memory: this entry learns it with ONE synchronisation of the caller's stream
+// (stated in lz4hip.h); lz4hip_compress_hc_batch_dev_ws takes span and workspace from the caller and never synchronises.
 int dev_hc(const lz4hip::BatchArgs& a, int level, hipStream_t st) {
   uint64_t* d_span = nullptr;
   uint64_t span = 0;
   HIPCHK(hipMallocAsync((void**)&d_span, 8, st));
-  HIPCHK(hipMemsetAsync(d_span, 0, 8, st));
-  int e = lz4hip::launch_hc_span(a.src_off, a.src_len, a.n, d_span, st);
+  hipError_t he = hipMemsetAsync(d_span, 0, 8, st);
+  int e = 0;
+  if (he == hipSuccess) e = lz4hip::launch_hc_span(a.src_off, a.src_len, a.n, d_span, st);
+  if (he == hipSuccess && e == 0) he = hipMemcpyAsync(&span, d_span, 8, hipMemcpyDeviceToHost, st);
+  if (he == hipSuccess && e == 0) he = hipStreamSynchronize(st);
+  (void)hipFreeAsync(d_span, st);   // (on every path: round 1 leaked it when a call above failed)
   if (e) return fail(LZ4HIP_E_HIP, "kernel launch", (hipError_t)e);
-  HIPCHK(hipMemcpyAsync(&span, d_span, 8, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
-  HIPCHK(hipFreeAsync(d_span, st));
+  if (he != hipSuccess) return fail(LZ4HIP_E_HIP, "HC span query", he);
   void* ws = nullptr;
   if (hipMallocAsync(&ws, lz4hip::hc_ws_bytes(span, a.n, level), st) != hipSuccess) return fail(LZ4HIP_E_NOMEM, "HC workspace allocation failed");
   e = lz4hip::launch_compress_hc(a, level, ws, span, st);
@@ -179,24 +184,6 @@ int dev_batch(Op op, const uint8_t* src, const uint64_t* src_off, const int32_t*
 }
 
 // ---- host-pointer path ---------------------------------------------------------------------------
-struct Span { uint64_t lo, hi; };
-Span span_of(const uint64_t* off, const int32_t* len, uint32_t b0, uint32_t b1) {
-  Span s{UINT64_MAX, 0};
-  for (uint32_t i = b0; i < b1; i++) {
-    const uint64_t l = len[i] > 0 ? (uint64_t)len[i] : 0;
-    if (off[i] < s.lo) s.lo = off[i];
-    if (off[i] + l > s.hi) s.hi = off[i] + l;
-  }
-  if (s.lo == UINT64_MAX) s.lo = s.hi = 0;
-  return s;
-}
-
-struct DevBuf {
-  void* p = nullptr;
-  ~DevBuf() { if (p) (void)hipFree(p); }
-  hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
-};
-
 // ---- staging of the host-pointer batch API --------------------------------------------------------------------------
 // A host batch is cut into chunks of <= CHUNK_SRC source bytes.  Each chunk is packed into a PINNED staging buffer (user
 // memory is pageable: hipMemcpyAsync from it would be staged by the runtime at a fraction of the link rate), copied to the
@@ -239,18 +226,18 @@ struct ChunkSlot {
   ChunkSlot() { h_src.pinned = h_dst.pinned = h_meta.pinned = true; }
 };
 
-struct DevCtx {
-  std::mutex mu;   // one host batch at a time per device
-  bool ready = false;
+// One host batch in flight uses a SlotPair (two buffer sets that alternate).  Pairs are pooled per device: a caller takes a free
+// pair (or creates one, up to MAX_PAIRS; beyond that it waits for one), works WITHOUT any lock held -- N callers make progress on N
+// pairs, each on its own streams -- and hands the pair back.  (Round 1 held one per-device mutex for the whole batch: every
+// concurrent caller of the host API ran one at a time.)
+struct SlotPair {
   ChunkSlot slot[2];
   hipError_t init() {
-    if (ready) return hipSuccess;
     for (auto& s : slot) {
       hipError_t e;
       if ((e = hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking)) != hipSuccess) return e;
       if ((e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming)) != hipSuccess) return e;
     }
-    ready = true;
     return hipSuccess;
   }
   void release() {
@@ -260,7 +247,46 @@ struct DevCtx {
       s.st = nullptr; s.done = nullptr;
       for (GrowBuf* g : {&s.h_src, &s.h_dst, &s.h_meta, &s.d_src, &s.d_dst, &s.d_meta, &s.d_ws, &s.d_pack, &s.d_poff}) g->release();
     }
-    ready = false;
+  }
+  // keeps the staging of the first pairs (the steady state of big batches), drops big staging of the pairs beyond (bursts of callers)
+  void trim(size_t keep) {
+    for (auto& s : slot)
+      for (GrowBuf* g : {&s.h_src, &s.h_dst, &s.d_src, &s.d_dst, &s.d_ws, &s.d_pack})
+        if (g->cap > keep) g->release();
+  }
+};
+struct DevCtx {
+  static constexpr size_t MAX_PAIRS = 16, KEEP_PAIRS = 2;
+  std::mutex mu;                 // guards the pool only (never held while a batch runs)
+  std::condition_variable cv;
+  std::vector<SlotPair*> all, idle;
+  SlotPair* acquire(hipError_t* err) {
+    std::unique_lock<std::mutex> lk(mu);
+    for (;;) {
+      if (!idle.empty()) { SlotPair* p = idle.back(); idle.pop_back(); return p; }
+      if (all.size() < MAX_PAIRS) {
+        SlotPair* p = new (std::nothrow) SlotPair();
+        if (!p) { *err = hipErrorOutOfMemory; return nullptr; }
+        all.push_back(p);
+        lk.unlock();
+        if ((*err = p->init()) != hipSuccess) { lk.lock(); p->release(); all.erase(std::find(all.begin(), all.end(), p)); delete p; return nullptr; }
+        return p;
+      }
+      cv.wait(lk);
+    }
+  }
+  void give_back(SlotPair* p) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      if (std::find(all.begin(), all.end(), p) - all.begin() >= (ptrdiff_t)KEEP_PAIRS) p->trim(8u << 20);
+      idle.push_back(p);
+    }
+    cv.notify_one();
+  }
+  void release() {   // lz4hip_shutdown: nothing is in flight
+    std::lock_guard<std::mutex> lk(mu);
+    for (SlotPair* p : all) { p->release(); delete p; }
+    all.clear(); idle.clear();
   }
 };
 DevCtx g_ctx[64];
@@ -292,8 +318,9 @@ int host_shard(Op op, int level, int ord, const uint8_t* src, const uint64_t* sr
   hipError_t e;
   if ((e = hipSetDevice(ord)) != hipSuccess) return bad("hipSetDevice", e);
   DevCtx& cx = g_ctx[ord];
-  std::lock_guard<std::mutex> lk(cx.mu);
-  if ((e = cx.init()) != hipSuccess) return bad("stream/event creation", e);
+  SlotPair* pair = cx.acquire(&e);
+  if (!pair) return bad("stream/event creation", e);
+  struct Return { DevCtx& c; SlotPair* p; ~Return() { c.give_back(p); } } give_back_on_exit{cx, pair};
   auto slen_of = [&](uint32_t i) -> size_t { return src_len[i] > 0 ? (size_t)src_len[i] : 0; };
   auto dcap_of = [&](uint32_t i) -> size_t { return dst_cap[i] > 0 ? (size_t)dst_cap[i] : 0; };
 
@@ -327,7 +354,7 @@ int host_shard(Op op, int level, int ord, const uint8_t* src, const uint64_t* sr
   uint32_t i = b0;
   int k = 0;
   while (i < b1 && rc == LZ4HIP_OK) {
-    ChunkSlot& s = cx.slot[k];
+    ChunkSlot& s = pair->slot[k];
     if ((rc = finish(s)) != LZ4HIP_OK) break;   // the chunk that used this buffer set two rounds ago
     // the next chunk: blocks [i, j)
     uint32_t j = i;
@@ -385,7 +412,7 @@ int host_shard(Op op, int level, int ord, const uint8_t* src, const uint64_t* sr
   }
   // drain (also after an error: nothing may stay in flight on the cached buffers)
   for (int t = 0; t < 2; t++) {
-    ChunkSlot& s = cx.slot[(k + t) & 1];
+    ChunkSlot& s = pair->slot[(k + t) & 1];
     if (rc == LZ4HIP_OK) rc = finish(s);
     else { (void)hipStreamSynchronize(s.st); s.i0 = s.i1 = 0; }
   }
@@ -422,39 +449,166 @@ int host_batch(Op op, const uint8_t* src, const uint64_t* src_off, const int32_t
   return LZ4HIP_OK;
 }
 
+// hashes of one device's share [b0, b1) of a host batch: the same pinned, double-buffered staging as host_shard (chunks of
+// <= CHUNK_SRC bytes packed by several host threads while the previous chunk is on the GPU), from the same pool of buffer pairs
+template <class T>
+int xxh_shard(bool is64, int ord, const uint8_t* buf, const uint64_t* off, const int32_t* len, uint64_t seed, T* out, uint32_t b0, uint32_t b1, std::string* err) {
+  auto bad = [&](const char* what, hipError_t e) {
+    char m[512];
+    snprintf(m, sizeof m, "%s: %s", what, hipGetErrorString(e));
+    *err = m;
+    return e == hipErrorOutOfMemory ? (int)LZ4HIP_E_NOMEM : (int)LZ4HIP_E_HIP;
+  };
+  if (b1 == b0) return LZ4HIP_OK;
+  hipError_t e;
+  if ((e = hipSetDevice(ord)) != hipSuccess) return bad("hipSetDevice", e);
+  DevCtx& cx = g_ctx[ord];
+  SlotPair* pair = cx.acquire(&e);
+  if (!pair) return bad("stream/event creation", e);
+  struct Return { DevCtx& c; SlotPair* p; ~Return() { c.give_back(p); } } give_back_on_exit{cx, pair};
+  auto len_of = [&](uint32_t i) -> size_t { return len[i] > 0 ? (size_t)len[i] : 0; };
+  auto finish = [&](ChunkSlot& s) -> int {
+    if (s.i1 == s.i0) return LZ4HIP_OK;
+    if ((e = hipEventSynchronize(s.done)) != hipSuccess) return bad("hipEventSynchronize", e);
+    const uint32_t nb = s.i1 - s.i0;
+    memcpy(out + s.i0, (const uint8_t*)s.h_meta.p + (size_t)nb * 12u, (size_t)nb * sizeof(T));
+    s.i0 = s.i1 = 0;
+    return LZ4HIP_OK;
+  };
+  int rc = LZ4HIP_OK;
+  uint32_t i = b0;
+  int k = 0;
+  while (i < b1 && rc == LZ4HIP_OK) {
+    ChunkSlot& s = pair->slot[k];
+    if ((rc = finish(s)) != LZ4HIP_OK) break;
+    uint32_t j = i;
+    size_t sb = 0;
+    while (j < b1 && j - i < CHUNK_BLOCKS) {
+      const size_t a = (len_of(j) + 15u) & ~(size_t)15u;
+      if (j > i && sb + a > CHUNK_SRC) break;
+      sb += a; j++;
+    }
+    const uint32_t nb = j - i;
+    s.so.resize(nb);
+    { size_t so = 0; for (uint32_t t = 0; t < nb; t++) { s.so[t] = so; so += (len_of(i + t) + 15u) & ~(size_t)15u; } }
+    const size_t meta = (size_t)nb * (12u + sizeof(T));   // off[nb] u64 | len[nb] i32 | hash[nb]
+    if ((e = s.h_src.reserve(sb + 64)) != hipSuccess || (e = s.h_meta.reserve(meta)) != hipSuccess || (e = s.d_src.reserve(sb + 64)) != hipSuccess ||
+        (e = s.d_meta.reserve(meta)) != hipSuccess) { rc = bad("staging allocation", e); break; }
+    uint8_t* hs = (uint8_t*)s.h_src.p;
+    { const uint32_t base = i;
+      par_blocks(i, j, sb, [=, &s](uint32_t t) { if (len[t] > 0) memcpy(hs + s.so[t - base], buf + off[t], (size_t)len[t]); }); }
+    uint8_t* hm = (uint8_t*)s.h_meta.p;
+    memcpy(hm, s.so.data(), (size_t)nb * 8u);
+    memcpy(hm + (size_t)nb * 8u, len + i, (size_t)nb * 4u);
+    uint8_t* dm = (uint8_t*)s.d_meta.p;
+    if (sb && (e = hipMemcpyAsync(s.d_src.p, hs, sb, hipMemcpyHostToDevice, s.st)) != hipSuccess) { rc = bad("H2D src", e); break; }
+    if ((e = hipMemcpyAsync(dm, hm, (size_t)nb * 12u, hipMemcpyHostToDevice, s.st)) != hipSuccess) { rc = bad("H2D meta", e); break; }
+    const int le = is64 ? lz4hip::launch_xxh64((const uint8_t*)s.d_src.p, (const uint64_t*)dm, (const int32_t*)(dm + (size_t)nb * 8u), seed, (uint64_t*)(dm + (size_t)nb * 12u), nb, s.st)
+                        : lz4hip::launch_xxh32((const uint8_t*)s.d_src.p, (const uint64_t*)dm, (const int32_t*)(dm + (size_t)nb * 8u), (uint32_t)seed, (uint32_t*)(dm + (size_t)nb * 12u), nb, s.st);
+    if (le) { rc = bad("kernel launch", (hipError_t)le); break; }
+    if ((e = hipMemcpyAsync(hm + (size_t)nb * 12u, dm + (size_t)nb * 12u, (size_t)nb * sizeof(T), hipMemcpyDeviceToHost, s.st)) != hipSuccess) { rc = bad("D2H hashes", e); break; }
+    if ((e = hipEventRecord(s.done, s.st)) != hipSuccess) { rc = bad("hipEventRecord", e); break; }
+    s.i0 = i; s.i1 = j;
+    i = j;
+    k ^= 1;
+  }
+  for (int t = 0; t < 2; t++) {
+    ChunkSlot& s = pair->slot[(k + t) & 1];
+    if (rc == LZ4HIP_OK) rc = finish(s);
+    else { (void)hipStreamSynchronize(s.st); s.i0 = s.i1 = 0; }
+  }
+  return rc;
+}
+
 template <class T>
 int host_xxh(bool is64, const uint8_t* buf, const uint64_t* off, const int32_t* len, uint64_t seed, T* out, uint32_t n) {
   int rc = ensure_init();
   if (rc) return fail(rc, "no HIP device: liblz4hip has no CPU fallback");
   if (n == 0) return LZ4HIP_OK;
   if (!buf || !off || !len || !out) return fail(LZ4HIP_E_ARG, "null pointer argument");
-  int ord;
-  if (ordinal(0, &ord)) return fail(LZ4HIP_E_NO_DEVICE, "no device");
-  DeviceGuard g(ord);
-  const Span s = span_of(off, len, 0, n);
-  std::vector<uint64_t> o(n);
-  for (uint32_t i = 0; i < n; i++) o[i] = off[i] - s.lo;
-  DevBuf db, dof, dl, dout;
-  const size_t blen = (size_t)(s.hi - s.lo);
-  if (db.alloc(blen + 32) != hipSuccess || dof.alloc(n * 8) != hipSuccess || dl.alloc(n * 4) != hipSuccess || dout.alloc(n * sizeof(T)) != hipSuccess)
-    return fail(LZ4HIP_E_NOMEM, "hipMalloc failed");
-  if (blen) HIPCHK(hipMemcpy(db.p, buf + s.lo, blen, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(dof.p, o.data(), n * 8, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(dl.p, len, n * 4, hipMemcpyHostToDevice));
-  int e = is64 ? lz4hip::launch_xxh64((const uint8_t*)db.p, (const uint64_t*)dof.p, (const int32_t*)dl.p, seed, (uint64_t*)dout.p, n, nullptr)
-               : lz4hip::launch_xxh32((const uint8_t*)db.p, (const uint64_t*)dof.p, (const int32_t*)dl.p, (uint32_t)seed, (uint32_t*)dout.p, n, nullptr);
-  if (e) return fail(LZ4HIP_E_HIP, "kernel launch", (hipError_t)e);
-  HIPCHK(hipMemcpy(out, dout.p, n * sizeof(T), hipMemcpyDeviceToHost));
+  std::vector<int> devs;
+  { std::lock_guard<std::mutex> lk(g_mu); devs = g_devs; }
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  // contiguous ranges per device, like the LZ4 batches; small batches stay on one device
+  const uint32_t D = (uint32_t)std::min<size_t>(devs.size(), std::max<uint32_t>(1u, n / 1024u));
+  std::vector<int> rcs(D, 0);
+  std::vector<std::string> errs(D);
+  if (D == 1) {
+    rcs[0] = xxh_shard<T>(is64, devs[0], buf, off, len, seed, out, 0, n, &errs[0]);
+  } else {
+    std::vector<std::thread> th;
+    for (uint32_t d = 0; d < D; d++) {
+      const uint32_t b0 = (uint32_t)((uint64_t)n * d / D), b1 = (uint32_t)((uint64_t)n * (d + 1) / D);
+      th.emplace_back([&, d, b0, b1] { rcs[d] = xxh_shard<T>(is64, devs[d], buf, off, len, seed, out, b0, b1, &errs[d]); });
+    }
+    for (auto& t : th) t.join();
+  }
+  if (prev >= 0) (void)hipSetDevice(prev);
+  for (uint32_t d = 0; d < D; d++)
+    if (rcs[d]) return fail(rcs[d], errs[d].c_str());
   return LZ4HIP_OK;
 }
 
-int single(Op op, const uint8_t* src, int src_len, uint8_t* dst, int dst_cap) {
-  const uint64_t zero = 0;
-  int32_t sl = src_len, dc = dst_cap, out = 0;
-  uint8_t dummy = 0;
-  int rc = host_batch(op, src ? src : &dummy, &zero, &sl, dst ? dst : &dummy, &zero, &dc, &out, 1);
-  if (rc) return LZ4HIP_LIB_ERROR(rc);
-  return out;
+// ---- single-block calls: coalesced ---------------------------------------------------------------------------------------
+// The reference's API shape is one block per call from many threads (LZ4Compressor.compress, LZ4Compressor.java:59,82).  A GPU
+// launch per block would serialise those threads on launch + PCIe latency, so concurrent single-block calls of the same kind are
+// combined: a caller queues its request; whoever finds no batch in progress becomes the leader, takes EVERYTHING queued so far and
+// runs it as one host batch; requests that arrive meanwhile form the next batch (led by one of their own callers).  A lone caller
+// pays no waiting window; N concurrent callers share one launch.
+struct Req {
+  const uint8_t* src; int32_t len; uint8_t* dst; int32_t cap;
+  int32_t out = 0; int rc = 0; bool done = false; std::string err;
+};
+struct Combiner {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<Req*> q;
+  bool leader = false;
+};
+Combiner g_comb[4][13];   // [op][HC level]
+
+void run_combined(Op op, int level, std::vector<Req*>& batch) {
+  static uint8_t dummy_in = 0, dummy_out = 0;
+  const uint32_t n = (uint32_t)batch.size();
+  const uint8_t* sbase = nullptr; uint8_t* dbase = nullptr;
+  for (Req* r : batch) {
+    if (!r->src) r->src = &dummy_in;
+    if (!r->dst) r->dst = &dummy_out;
+    if (!sbase || r->src < sbase) sbase = r->src;
+    if (!dbase || r->dst < dbase) dbase = r->dst;
+  }
+  std::vector<uint64_t> so(n), dof(n);
+  std::vector<int32_t> sl(n), dc(n), out(n, 0);
+  for (uint32_t i = 0; i < n; i++) { so[i] = (uint64_t)(batch[i]->src - sbase); dof[i] = (uint64_t)(batch[i]->dst - dbase); sl[i] = batch[i]->len; dc[i] = batch[i]->cap; }
+  const int rc = host_batch(op, sbase, so.data(), sl.data(), dbase, dof.data(), dc.data(), out.data(), n, level);
+  for (uint32_t i = 0; i < n; i++) { batch[i]->rc = rc; batch[i]->out = out[i]; if (rc) batch[i]->err = g_err; }
+}
+
+int single(Op op, const uint8_t* src, int src_len, uint8_t* dst, int dst_cap, int level = 0) {
+  Req r{src, src_len, dst, dst_cap};
+  Combiner& c = g_comb[(int)op][level < 0 || level > 12 ? 0 : level];
+  {
+    std::unique_lock<std::mutex> lk(c.mu);
+    c.q.push_back(&r);
+    while (!r.done) {
+      if (!c.leader) {
+        c.leader = true;
+        std::vector<Req*> batch;
+        batch.swap(c.q);          // (contains r: only a leader takes requests out of the queue)
+        lk.unlock();
+        run_combined(op, level, batch);
+        lk.lock();
+        for (Req* x : batch) x->done = true;
+        c.leader = false;
+        c.cv.notify_all();
+      } else {
+        c.cv.wait(lk);
+      }
+    }
+  }
+  if (r.rc) { g_err = r.err; return LZ4HIP_LIB_ERROR(r.rc); }
+  return r.out;
 }
 
 }  // namespace
@@ -468,7 +622,12 @@ struct lz4hip_xxh_stream {
   size_t stage_cap = 0;
   uint64_t seed;
   bool pending_reset = true;   // the record is (re)initialised by the next launch
-  hipStream_t last = nullptr;  // stream of the last launch (digest waits for it)
+  // ordering of launches on different streams: every launch records `ev`; the next launch's stream waits for it on the device, the
+  // digest and the reuse of the staging buffer wait for it on the host.  (`launched` and not "last stream != NULL": the null stream
+  // is a stream too -- a host update() followed by update_dev() on a non-blocking stream raced on the record in round 1.)
+  hipEvent_t ev = nullptr;
+  hipStream_t last = nullptr;
+  bool launched = false;
   std::mutex mu;               // the reference's methods are `synchronized`
 };
 namespace {
@@ -494,13 +653,16 @@ int xxh_stream_create(bool is64, uint64_t seed, lz4hip_xxh_stream** out) {
 }
 // absorbs a DEVICE buffer (len may be 0: only applies a pending reset)
 int xxh_stream_launch(lz4hip_xxh_stream* st, const uint8_t* dbuf, uint32_t len, hipStream_t stream) {
-  if (st->last != stream && st->last) HIPCHK(hipStreamSynchronize(st->last));  // updates of one stream are ordered
+  if (!st->ev) HIPCHK(hipEventCreateWithFlags(&st->ev, hipEventDisableTiming));
+  if (st->launched && st->last != stream) HIPCHK(hipStreamWaitEvent(stream, st->ev, 0));   // updates of one hash are ordered
   const int reset = st->pending_reset ? 1 : 0;
   int e = st->is64 ? lz4hip::launch_xxh64_stream(st->rec, dbuf, len, reset, st->seed, stream)
                    : lz4hip::launch_xxh32_stream(st->rec, dbuf, len, reset, (uint32_t)st->seed, stream);
   if (e) return fail(LZ4HIP_E_HIP, "kernel launch", (hipError_t)e);
   st->pending_reset = false;
   st->last = stream;
+  st->launched = true;
+  HIPCHK(hipEventRecord(st->ev, stream));
   return LZ4HIP_OK;
 }
 template <class T>
@@ -512,7 +674,7 @@ int xxh_stream_digest(lz4hip_xxh_stream* st, bool is64, T* out) {
     int rc = xxh_stream_launch(st, (const uint8_t*)st->rec, 0, nullptr);
     if (rc) return rc;
   }
-  if (st->last) HIPCHK(hipStreamSynchronize(st->last));
+  if (st->launched) HIPCHK(hipEventSynchronize(st->ev));
   HIPCHK(hipMemcpy(out, (const uint8_t*)st->rec + lz4hip::xxh_stream_digest_offset(is64), sizeof(T), hipMemcpyDeviceToHost));
   return LZ4HIP_OK;
 }
@@ -553,8 +715,7 @@ void lz4hip_shutdown(void) {
   (void)hipGetDevice(&prev);
   for (int ord : g_devs) {
     if (ord < 0 || ord >= 64) continue;
-    std::lock_guard<std::mutex> lc(g_ctx[ord].mu);
-    if (g_ctx[ord].ready && hipSetDevice(ord) == hipSuccess) g_ctx[ord].release();
+    if (hipSetDevice(ord) == hipSuccess) g_ctx[ord].release();
   }
   if (prev >= 0) (void)hipSetDevice(prev);
   g_devs.clear();
@@ -639,6 +800,29 @@ int lz4hip_decompress_fast_batch_dev(const uint8_t* src, const uint64_t* src_off
                                      const uint64_t* dst_off, const int32_t* dst_len, int32_t* out_consumed, uint32_t n, int device, void* stream) {
   return dev_batch(OP_DECODE_FAST, src, src_off, src_cap, dst, dst_off, dst_len, out_consumed, n, device, stream);
 }
+size_t lz4hip_hc_workspace_bytes(uint64_t src_span, uint32_t n_blocks, int level) {
+  int lv;
+  if (hc_level(level, &lv)) return 0;
+  return lz4hip::hc_ws_bytes(src_span, n_blocks, lv);
+}
+int lz4hip_compress_hc_batch_dev_ws(const uint8_t* src, const uint64_t* src_off, const int32_t* src_len, uint8_t* dst, const uint64_t* dst_off,
+                                    const int32_t* dst_cap, int32_t* out_len, uint32_t n, int level, int device, void* stream,
+                                    uint64_t src_span, void* ws, size_t ws_bytes) {
+  int lv;
+  if (hc_level(level, &lv)) return LZ4HIP_E_UNSUPPORTED;
+  int rc = ensure_init();
+  if (rc) return fail(rc, "no HIP device: liblz4hip has no CPU fallback");
+  if (n == 0) return LZ4HIP_OK;
+  if (!src || !src_off || !src_len || !dst || !dst_off || !dst_cap || !out_len || !ws) return fail(LZ4HIP_E_ARG, "null pointer argument");
+  if (ws_bytes < lz4hip::hc_ws_bytes(src_span, n, lv)) return fail(LZ4HIP_E_ARG, "HC workspace too small for the source span");
+  int ord;
+  if (ordinal(device, &ord)) return fail(LZ4HIP_E_ARG, "bad device index");
+  DeviceGuard g(ord);
+  if (!g.ok) return fail(LZ4HIP_E_HIP, "hipSetDevice failed");
+  lz4hip::BatchArgs a{src, src_off, src_len, dst, dst_off, dst_cap, out_len, n};
+  const int e = lz4hip::launch_compress_hc(a, lv, ws, src_span, (hipStream_t)stream);
+  return e ? fail(LZ4HIP_E_HIP, "kernel launch", (hipError_t)e) : LZ4HIP_OK;
+}
 int lz4hip_compress_hc_batch_dev(const uint8_t* src, const uint64_t* src_off, const int32_t* src_len, uint8_t* dst,
                                  const uint64_t* dst_off, const int32_t* dst_cap, int32_t* out_len, uint32_t n, int level, int device, void* stream) {
   int lv;
@@ -691,12 +875,7 @@ int lz4hip_compress_fast(const uint8_t* src, int src_len, uint8_t* dst, int dst_
 int lz4hip_compress_hc(const uint8_t* src, int src_len, uint8_t* dst, int dst_cap, int level) {
   int lv;
   if (hc_level(level, &lv)) return LZ4HIP_LIB_ERROR(LZ4HIP_E_UNSUPPORTED);
-  const uint64_t zero = 0;
-  int32_t sl = src_len, dc = dst_cap, out = 0;
-  uint8_t dummy = 0;
-  int rc = host_batch(OP_COMPRESS_HC, src ? src : &dummy, &zero, &sl, dst ? dst : &dummy, &zero, &dc, &out, 1, lv);
-  if (rc) return LZ4HIP_LIB_ERROR(rc);
-  return out;
+  return single(OP_COMPRESS_HC, src, src_len, dst, dst_cap, lv);
 }
 int lz4hip_decompress_safe(const uint8_t* src, int src_len, uint8_t* dst, int dst_cap) { return single(OP_DECODE_SAFE, src, src_len, dst, dst_cap); }
 int lz4hip_decompress_fast(const uint8_t* src, int src_cap, uint8_t* dst, int dst_len) { return single(OP_DECODE_FAST, src, src_cap, dst, dst_len); }
@@ -732,7 +911,7 @@ int lz4hip_xxh_stream_update(lz4hip_xxh_stream* st, const uint8_t* buf, int len)
   while (done < (size_t)len) {
     const size_t part = std::min((size_t)len - done, XXH_STAGE_MAX);
     if (st->stage_cap < part) {
-      if (st->last) HIPCHK(hipStreamSynchronize(st->last));
+      if (st->launched) HIPCHK(hipEventSynchronize(st->ev));
       if (st->stage) (void)hipFree(st->stage);
       st->stage = nullptr;
       st->stage_cap = 0;
@@ -741,7 +920,7 @@ int lz4hip_xxh_stream_update(lz4hip_xxh_stream* st, const uint8_t* buf, int len)
       if (hipMalloc(&st->stage, cap) != hipSuccess) return fail(LZ4HIP_E_NOMEM, "hipMalloc failed");
       st->stage_cap = cap;
     }
-    if (st->last) HIPCHK(hipStreamSynchronize(st->last));  // the staging buffer is reused
+    if (st->launched) HIPCHK(hipEventSynchronize(st->ev));  // the staging buffer is reused
     HIPCHK(hipMemcpy(st->stage, buf + done, part, hipMemcpyHostToDevice));
     int rc = xxh_stream_launch(st, (const uint8_t*)st->stage, (uint32_t)part, nullptr);
     if (rc) return rc;
@@ -763,7 +942,8 @@ void lz4hip_xxh_stream_free(lz4hip_xxh_stream* st) {
   {
     std::lock_guard<std::mutex> lk(st->mu);
     DeviceGuard g(st->ord);
-    if (st->last) (void)hipStreamSynchronize(st->last);
+    if (st->launched) (void)hipEventSynchronize(st->ev);
+    if (st->ev) (void)hipEventDestroy(st->ev);
     if (st->rec) (void)hipFree(st->rec);
     if (st->stage) (void)hipFree(st->stage);
   }

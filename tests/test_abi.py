@@ -146,3 +146,28 @@ def test_jni_shim_executes_against_fake_jnienv_without_device():
     subprocess.check_call(["bash", os.path.join(d, "build.sh")])
     out = subprocess.check_output([os.path.join(d, "fake_jni"), "--no-gpu"]).decode()
     assert "checks ok" in out, out
+
+
+def test_batch_entry_points_validate_ranges_before_touching_memory(amd):
+    """round-1 advisor finding: LZ4HIPBatch.decompressFast / xxh32 / xxh64 handed unchecked offsets to the library, which memcpy's
+    from them.  Every batch entry checks 0 <= off and off + len <= len(buffer) for every block (lists and numpy arrays) first."""
+    import numpy as np
+    src, dst = bytes(100), bytearray(200)
+    B = amd.LZ4HIPBatch
+    bad = [([90], [20]), ([-1], [4]), ([0], [-4]), ([101], [0 + 1])]
+    for fn in (B.compress, B.decompressSafe, B.decompressFast, B.compressHC):
+        for so, sl in bad:
+            with pytest.raises((IndexError, ValueError)):
+                fn(src, so, sl, dst, [0], [50])
+            with pytest.raises((IndexError, ValueError)):
+                fn(src, np.array(so, dtype=np.int64), np.array(sl, dtype=np.int32), dst, np.array([0], dtype=np.int64), np.array([50], dtype=np.int32))
+        with pytest.raises((IndexError, ValueError)):
+            fn(src, [0], [10], dst, [190], [20])          # destination slot outside dst
+        with pytest.raises(ValueError):
+            fn(src, [0, 1], [10], dst, [0], [50])         # ragged descriptor arrays
+    for fn in (B.xxh32, B.xxh64):
+        for so, sl in bad:
+            with pytest.raises((IndexError, ValueError)):
+                fn(src, so, sl)
+            with pytest.raises((IndexError, ValueError)):
+                fn(src, np.array(so, dtype=np.int64), np.array(sl, dtype=np.int32))

@@ -243,7 +243,7 @@ def test_decode_variants_at_odd_offsets(amd, ref, corpus):
 
 
 def test_concurrent_callers(amd, ref, corpus):
-    """instances are shared singletons and must be thread-safe (LZ4Compressor.java:25): 8 threads hammer the single-block and
+    """instances are shared singletons and must be thread-safe (LZ4Compressor.java:25): 32 threads hammer the single-block and
     batch entry points (ctypes releases the GIL across the calls) and every result must equal the reference's"""
     import threading
     f = amd.LZ4Factory.hipInstance()
@@ -276,12 +276,51 @@ def test_concurrent_callers(amd, ref, corpus):
         except Exception as e:  # noqa: BLE001 -- reported on the main thread
             errors.append((t, repr(e)))
 
-    ths = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(32)]
     for th in ths:
         th.start()
     for th in ths:
         th.join()
     assert not errors, errors
+
+
+def test_single_block_calls_of_many_threads_coalesce(amd, ref, O):
+    """re-entrant, no global lock in the steady state.  The reference's API shape is one block per call from many
+    threads; liblz4hip combines concurrent single-block calls into shared launches (api.cpp `single`), so 32 caller threads must
+    get through well over 4x the calls per second of one thread -- and every result is still the reference's."""
+    import ctypes as C
+    import threading
+    import time
+    l = amd.lib()
+    blocks = [O.gen_block(65536, 7000 + i) for i in range(32)]
+    want = [ref.compress_fast(b) for b in blocks]
+    cap = ref.compress_bound(65536)
+
+    def run(nthreads, calls):
+        errs, done = [], [0] * nthreads
+
+        def worker(t):
+            src = blocks[t]
+            dst = (C.c_uint8 * cap)()
+            for _ in range(calls):
+                r = l.lz4hip_compress_fast(src, len(src), dst, cap)
+                if r != len(want[t]) or bytes(dst[:r]) != want[t]:
+                    errs.append((t, r))
+                    return
+                done[t] += 1
+        ths = [threading.Thread(target=worker, args=(t,)) for t in range(nthreads)]
+        t0 = time.perf_counter()
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        dt = time.perf_counter() - t0
+        assert not errs, errs[:3]
+        return sum(done) / dt
+    run(4, 5)                      # warm-up: staging buffers, streams
+    one = run(1, 60)
+    many = run(32, 60)
+    assert many >= 4.0 * one, (one, many)
 
 
 def test_device_batch_and_generator(amd, O, ref):
