@@ -5,16 +5,26 @@
 tag=$1
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 400 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$tag -o kt -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline > gpurun_out/prof_$tag.log 2>&1
+# headline launches only (--no-extra-configs): the per-kernel averages of this trace are the ones bench.py's HIP events must agree with
+timeout 400 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$tag -o kt -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extra-configs > gpurun_out/prof_$tag.log 2>&1
 db=$(find gpurun_out/prof_$tag -name "*.db" | head -1)
 (echo "# profiles/${tag}_bench_kernel_trace.txt"
- echo "# command: rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline   (1x MI355X; summary by tools/rocprof_summary.py)"
- python tools/rocprof_summary.py $db) > gpurun_out/${tag}_bench_kernel_trace.txt
+ echo "# command: rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extra-configs   (1x MI355X; summary by tools/rocprof_summary.py)"
+ python tools/rocprof_summary.py $db
+ echo "# the line that run printed:"
+ tail -1 gpurun_out/prof_$tag.log) > gpurun_out/${tag}_bench_kernel_trace.txt
+# the whole default command (all configs): one trace
+rm -rf gpurun_out/prof_$tag
+timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$tag -o kt -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline > gpurun_out/prof_$tag.log 2>&1
+db=$(find gpurun_out/prof_$tag -name "*.db" | head -1)
+(echo "# profiles/${tag}_bench_all_configs_kernel_trace.txt"
+ echo "# command: rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline   (all configs; 1x MI355X)"
+ python tools/rocprof_summary.py $db lz4hip) > gpurun_out/${tag}_bench_all_configs_kernel_trace.txt
 tools/traffic_passes.sh gpurun_out/traffic_$tag 2 > /dev/null
 python tools/traffic_json.py gpurun_out/traffic_$tag 65536 65536 "profiles/${tag}_traffic_pmc.txt (tools/traffic_passes.sh: separate rocprofv3 --pmc passes of bench.py, 1x MI355X)"
 cp profiles/traffic.json gpurun_out/traffic_$tag.json
 (echo "# profiles/${tag}_traffic_pmc.txt"
- echo "# command: tools/traffic_passes.sh (one rocprofv3 --kernel-trace --pmc <set> run per counter set; bench.py --steps 2 --warmup 1 --no-cpu-baseline)"
+ echo "# command: tools/traffic_passes.sh (one rocprofv3 --kernel-trace --pmc <set> run per counter set; bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra-configs)"
  for t in gpurun_out/traffic_$tag/*/; do db=$(find $t -name "*.db" | head -1); python tools/rocprof_summary.py $db lz4hip | grep -v "^$"; done) > gpurun_out/${tag}_traffic_pmc.txt
 rm -rf gpurun_out/prof_$tag gpurun_out/traffic_$tag
 # the bench line last: it quotes profiles/traffic.json, which the passes above have just rewritten
