@@ -66,3 +66,23 @@ def test_block_range_balance():
             assert all(r[k][1] == r[k + 1][0] for k in range(w - 1))
             sizes = [b - a for a, b in r]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_bench_relaunch_command(monkeypatch):
+    """`bench.py --gpus N` without WORLD_SIZE re-executes itself under torch.distributed.run with N ranks on 127.0.0.1 (round 1's
+    flag was parsed and ignored); with WORLD_SIZE set it is a rank and must not relaunch"""
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+    monkeypatch.setattr(bench.subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    with pytest.raises(SystemExit) as e:
+        bench.relaunch(4)
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    assert seen["env"].get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
