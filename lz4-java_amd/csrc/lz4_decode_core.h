@@ -60,6 +60,7 @@ LZ4HIP_DEV int decode_block(Grp& g, const uint8_t* src, int src_size, uint8_t* d
   if (SAFE && src_size == 0) return -1;
 
   if (oend - op >= 64) {
+  interior:
     // ---- tier 1, interior fast loop.  While the block is far from both buffer ends (ip <= iend-306, op <= oend-606)
     // and the sequence is "simple" -- literal and match lengths need at most ONE extension byte (<= 269 / <= 273),
     // offset <= op -- every check of liblz4's fast loop provably passes (a sequence consumes <= 274 and produces
@@ -301,6 +302,10 @@ LZ4HIP_DEV int decode_block(Grp& g, const uint8_t* src, int src_size, uint8_t* d
       if (ip + 4 <= iend) { w4 = g.ld32(src + ip); } else { LZ4HIP_NEED_IN(1); w4 = g.ld8(src + ip); }
       g.copy_match(dst, (uint32_t)op, (uint32_t)offset, (uint32_t)length, true);
       op += length;
+      // The interior loop left on a sequence it does not handle (a length run of two or more bytes, ...); that sequence has now
+      // been decoded with every check: back to the interior loop while the block is still far from both ends.  (Round 1 entered
+      // it once per block: data with an occasional long match or literal run fell off the fast path for the rest of the block.)
+      if (ip <= iend - 306 && op <= oend - 606) goto interior;
     }
   }
 
