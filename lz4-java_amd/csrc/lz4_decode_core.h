@@ -33,6 +33,9 @@
 #endif
 #endif
 
+#ifndef LZ4HIP_DECODE_REENTER
+#define LZ4HIP_DECODE_REENTER 1   // 0: the interior loop is entered once per block (round 1 behaviour; developer A/B builds)
+#endif
 namespace lz4hip {
 
 // SAFE: LZ4_decompress_safe(src, dst, src_size, out_size) -> decoded size or negative.
@@ -305,7 +308,7 @@ LZ4HIP_DEV int decode_block(Grp& g, const uint8_t* src, int src_size, uint8_t* d
       // The interior loop left on a sequence it does not handle (a length run of two or more bytes, ...); that sequence has now
       // been decoded with every check: back to the interior loop while the block is still far from both ends.  (Round 1 entered
       // it once per block: data with an occasional long match or literal run fell off the fast path for the rest of the block.)
-      if (ip <= iend - 306 && op <= oend - 606) goto interior;
+      if (LZ4HIP_DECODE_REENTER && ip <= iend - 306 && op <= oend - 606) goto interior;
     }
   }
 
