@@ -64,6 +64,14 @@ def measured_traffic(n_blocks, block):
     return None
 
 
+def kernel_traffic(tr, world, *names):
+    """HBM bytes per launch of the named kernels (summed) from the same PMC passes; None unless every one was measured, at N = 1"""
+    k = (tr or {}).get("kernels") or {}
+    if world != 1 or not names or any(n not in k for n in names):
+        return None
+    return int(sum(k[n] for n in names))
+
+
 def cpu_bench(args, env=None):
     """runs oracle/cpu_bench (the reference's liblz4 through dlopen, or the C port) and returns its JSON line"""
     from oracle import oracle as O
@@ -242,6 +250,7 @@ def main():
                 "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(secs * 1e3, 4)}
 
     extra = {}
+    tr = measured_traffic(n, blk) or {}
     cores = os.cpu_count() or 1
     want_cpu = world == 1 and rank == 0 and not args.no_cpu_baseline
     if not args.no_extra_configs:
@@ -250,7 +259,8 @@ def main():
         wall, tk = timed(lambda: amd.DeviceBatch.decompress_fast(comp, co, cc, back, so, sl, dlen), 3)
         okf = all_ok(bool(torch.equal(back, src)) and bool(torch.equal(dlen, clen)))
         extra["decompress_fast"] = {"workload": "the headline blocks, LZ4_decompress_fast", "value": round(world * nbytes / wall / 1e9, 3), "unit": "GB/s",
-                                    "verified": okf, "roofline": roof("decode_kernel<SAFE=false>", nbytes + csum, tk)}
+                                    "verified": okf, "roofline": roof("decode_kernel<4, false, false, true>", nbytes + csum, tk,
+                                                                              kernel_traffic(tr, world, "decode_kernel<4, false, false, true>") if n >= 40960 else None)}
         ok = ok and okf
         del comp, back
         torch.cuda.empty_cache()
@@ -277,7 +287,8 @@ def main():
         extra["configs2_decode_4MiB"] = {"workload": "%d x 4 MiB blocks per GPU in one launch (BASELINE configs[2]: 16384 blocks in all, sharded over the ranks), "
                                                      "App.F win 4096, LZ4_decompress_safe of fast-compressed blocks, ratio %.3f" % (n3, n3 * b3 / cs3),
                                          "value": round(world * float(n3) * b3 / wall / 1e9, 3), "unit": "GB/s", "verified": ok3,
-                                         "roofline": roof("decode_kernel", float(n3) * b3 + cs3, tk)}
+                                         "roofline": roof("decode_kernel<8, true, true, false>", float(n3) * b3 + cs3, tk,
+                                                          kernel_traffic(tr, world, "decode_kernel<8, true, true, false>") if 8192 <= n3 < 40960 else None)}
         ok = ok and ok3
         if want_cpu:
             def f3():
@@ -303,7 +314,8 @@ def main():
         extra["configs3_hc9_1MiB"] = {"workload": "%d x 1 MiB blocks per GPU, App.F win 4096, LZ4_compress_HC level 9, ratio %.3f" % (n4, n4 * b4 / cs4),
                                       "value": round(world * float(n4) * b4 / wall / 1e9, 3), "unit": "GB/s", "verified": ok4,
                                       # build + parse: reads N, writes + re-reads the u16 chain deltas (4 N), writes C
-                                      "roofline": roof("hc_build_kernel + hc_parse_kernel", float(n4) * b4 * 5 + cs4, tk)}
+                                      "roofline": roof("hc_build_kernel + hc_parse_kernel", float(n4) * b4 * 5 + cs4, tk,
+                                                       kernel_traffic(tr, world, "hc_build_kernel", "hc_parse_kernel"))}
         ok = ok and ok4
         if want_cpu:
             def f4():
@@ -333,8 +345,8 @@ def main():
             pass
         ok5 = all_ok(ok5)
         extra["configs4_xxhash_4KiB"] = {"workload": "%d x 4 KiB buffers per GPU, seed 0x9747b28c" % n5, "unit": "GB/s", "verified": ok5,
-                                         "xxh32": {"value": round(world * float(n5) * b5 / w32 / 1e9, 3), "roofline": roof("xxh_multi_kernel<u32,4>", float(n5) * (b5 + 4), t32)},
-                                         "xxh64": {"value": round(world * float(n5) * b5 / w64 / 1e9, 3), "roofline": roof("xxh_multi_kernel<u64,4>", float(n5) * (b5 + 8), t64)}}
+                                         "xxh32": {"value": round(world * float(n5) * b5 / w32 / 1e9, 3), "roofline": roof("xxh_multi_kernel<unsigned int, 4>", float(n5) * (b5 + 4), t32, kernel_traffic(tr, world, "xxh_multi_kernel<unsigned int, 4>"))},
+                                         "xxh64": {"value": round(world * float(n5) * b5 / w64 / 1e9, 3), "roofline": roof("xxh_multi_kernel<unsigned long, 4>", float(n5) * (b5 + 8), t64, kernel_traffic(tr, world, "xxh_multi_kernel<unsigned long, 4>"))}}
         ok = ok and ok5
         if want_cpu:
             def f5():
@@ -347,7 +359,6 @@ def main():
     if rank == 0:
         ratio = nbytes / csum
         value = world * nbytes * args.steps / dt / 1e9
-        tr = measured_traffic(n, blk) or {}
         out = {
             "metric": "uncompressed GB/s (compress + decompress) per GPU, 64 KiB blocks",
             "value": round(value, 3), "unit": "GB/s", "n_gpus": joined, "steps": args.steps, "warmup": args.warmup,

@@ -24,7 +24,7 @@ tools/traffic_passes.sh gpurun_out/traffic_$tag 2 > /dev/null
 python tools/traffic_json.py gpurun_out/traffic_$tag 65536 65536 "profiles/${tag}_traffic_pmc.txt (tools/traffic_passes.sh: separate rocprofv3 --pmc passes of bench.py, 1x MI355X)"
 cp profiles/traffic.json gpurun_out/traffic_$tag.json
 (echo "# profiles/${tag}_traffic_pmc.txt"
- echo "# command: tools/traffic_passes.sh (one rocprofv3 --kernel-trace --pmc <set> run per counter set; bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra-configs)"
+ echo "# command: tools/traffic_passes.sh (one rocprofv3 --kernel-trace --pmc <set> run per counter set; bench.py --steps 2 --warmup 1 --no-cpu-baseline, all configs)"
  for t in gpurun_out/traffic_$tag/*/; do db=$(find $t -name "*.db" | head -1); python tools/rocprof_summary.py $db lz4hip | grep -v "^$"; done) > gpurun_out/${tag}_traffic_pmc.txt
 rm -rf gpurun_out/prof_$tag gpurun_out/traffic_$tag
 # the bench line last: it quotes profiles/traffic.json, which the passes above have just rewritten

@@ -4,9 +4,16 @@ usage: traffic_json.py <passes dir> <blocks_per_gpu> <block_bytes> <source tag>"
 import glob, hashlib, json, os, sqlite3, sys
 d, n, blk, tag = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
 vals = {}
+full = {}   # every lz4hip kernel by its full (template) name: "decode_kernel<8, true, true, false>", ...
+def norm(k):
+    k = k.split("(")[0].replace("void ", "").replace("lz4hip::", "").strip()
+    return k
 for db in glob.glob(os.path.join(d, "*", "pmc_results.db")):
     con = sqlite3.connect(db)
     for k, c, v in con.execute("select kernel_name, counter_name, avg(value) from counters_collection where kernel_name like '%lz4hip%' group by kernel_name, counter_name"):
+        full.setdefault(norm(k), {})[c] = v
+        if "decode_kernel" in k and "decode_kernel<4, true, false, true>" not in k:
+            continue   # the legacy "decode_kernel" key below is the headline launch (65536 x 64 KiB: 4 lanes, safe, staged) only
         key = None
         for name in ("compress_fast_v2_cu_kernel", "compress_fast_cu_kernel", "compress_fast_ms_cu_kernel", "decode_kernel", "hc_parse_kernel", "hc_build_kernel", "xxh_multi_kernel"):
             if name in k:
@@ -31,5 +38,10 @@ out = {"blocks_per_gpu": n, "block_bytes": blk, "source": tag, "kernel_source_ha
 for key, c in vals.items():
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         out[key] = int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
+# cross-check of the doubling rule: read bytes from the request-size counters of the same passes (128/64/32-byte requests)
+out["kernels_read_bytes_by_request_size"] = {
+    k: int(128 * c["TCC_EA0_RDREQ_128B_sum"] + 64 * c["TCC_EA0_RDREQ_64B_sum"] + 32 * c["TCC_EA0_RDREQ_32B_sum"])
+    for k, c in full.items() if all(x in c for x in ("TCC_EA0_RDREQ_128B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_32B_sum"))}
+out["kernels"] = {k: int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024) for k, c in full.items() if "FETCH_SIZE" in c and "WRITE_SIZE" in c}
 json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json"), "w"), indent=1, sort_keys=True)
-print(json.dumps({k: out[k] for k in out if k.endswith("kernel")}))
+print(json.dumps(out["kernels"]))
