@@ -5,6 +5,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef LZ4HIP_NT_MATCH
+#define LZ4HIP_NT_MATCH 0   // 1: non-temporal loads for match sources (developer A/B builds; round 1 default)
+#endif
+#if LZ4HIP_NT_MATCH
+#define LZ4HIP_MATCH_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define LZ4HIP_MATCH_LOAD(p) (*(p))
+#endif
 namespace lz4hip {
 
 template <int GL>
@@ -52,9 +60,10 @@ struct GroupDev {
       const uint8_t* m = d - offset;
       for (uint32_t i = l * LB; i < len; i += LB * GL) {
         Chunk<LB / 4> v;
-        // match sources are (for far offsets) random lines that will not be touched again soon: a non-temporal load
-        // keeps them from displacing the streams in L2 (+3..8 % measured)
-        const vecLB t = __builtin_nontemporal_load((const vecLB*)(m + i));
+        // (round 1 loaded match sources non-temporally -- random lines that would displace the streams in L2, +3..8 % then.
+        // With output staging and whole-line stores in place that reversed: plain loads are +6 % on App. F blocks, +4 % on 4 MiB
+        // blocks and +20..50 % on text, where a line is the source of several matches; LZ4HIP_NT_MATCH keeps the A/B)
+        const vecLB t = LZ4HIP_MATCH_LOAD((const vecLB*)(m + i));
         __builtin_memcpy(&v, &t, LB);
         store_out(d + i, v);
       }
@@ -74,7 +83,7 @@ struct GroupDev {
     const uint32_t i = l * LB;
     if (i < lit) __builtin_memcpy(&r.v, s + i, LB);
     if (i < len) {
-      const vecLB t = __builtin_nontemporal_load((const vecLB*)(m + i));
+      const vecLB t = LZ4HIP_MATCH_LOAD((const vecLB*)(m + i));
       __builtin_memcpy(&r.u, &t, LB);
     }
   }
@@ -140,7 +149,7 @@ struct GroupDev {
       const uint32_t i = base + l * LB;
       if (i < len) {
         Chunk<LB / 4> v;
-        const vecLB t = __builtin_nontemporal_load((const vecLB*)(m + i));
+        const vecLB t = LZ4HIP_MATCH_LOAD((const vecLB*)(m + i));
         __builtin_memcpy(&v, &t, LB);
         __builtin_memcpy(stg + (op + i - fl), &v, LB);
       }
