@@ -56,6 +56,9 @@ __device__ __forceinline__ int32_t uniform_i32(int32_t v) { return (int32_t)__bu
 #define LZ4HIP_WPC 5
 #endif
 constexpr uint32_t WAVES_PER_CU = LZ4HIP_WPC;
+#ifndef LZ4HIP_TABLE_U64
+#define LZ4HIP_TABLE_U64 4096   // 32 KB per wavefront (developer probe builds: 2048 with LZ4HIP_PROBE_HLOG=12)
+#endif
 // Residency: a wavefront needs its 32 KB table and nothing else, but LDS is allocated in 1280-byte granules, so a 32768-byte
 // workgroup occupies 33280 bytes and only FOUR fit a CU (measured: 1280 single-wave workgroups run in two rounds).  One
 // workgroup that owns all 163840 bytes of the CU holds FIVE tables exactly: WAVES_PER_CU wavefronts, each compressing its own
@@ -66,7 +69,7 @@ constexpr uint32_t WAVES_PER_CU = LZ4HIP_WPC;
 // them into vector registers -- 42 -> 83 VGPRs, -22 %.  Inside the loop every per-block value goes back to scalar registers
 // through readfirstlane for the same reason.)
 __global__ __launch_bounds__(64 * WAVES_PER_CU) void compress_fast_cu_kernel(BatchArgs a, uint32_t* q, uint32_t* routed, uint32_t dense64) {
-  __shared__ __attribute__((aligned(16))) uint64_t tables[WAVES_PER_CU][4096];  // 160 KB: the whole LDS of the CU
+  __shared__ __attribute__((aligned(16))) uint64_t tables[WAVES_PER_CU][LZ4HIP_TABLE_U64];  // 160 KB: the whole LDS of the CU
   uint64_t* table = tables[threadIdx.x >> 6];
   for (;;) {
     uint32_t b = 0;
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_CU) void compress_fast_cu_kernel(Bat
 // lean core (lz4_fast_v2_core.h): minimal finder loop + sequences parked in lanes and written 64 at a time; same CU-filling
 // shape and the same routing contract as compress_fast_cu_kernel (routed == nullptr: every block is finished here)
 __global__ __launch_bounds__(64 * WAVES_PER_CU) void compress_fast_v2_cu_kernel(BatchArgs a, uint32_t* q, uint32_t* routed, uint32_t dense64) {
-  __shared__ __attribute__((aligned(16))) uint64_t tables[WAVES_PER_CU][4096];
+  __shared__ __attribute__((aligned(16))) uint64_t tables[WAVES_PER_CU][LZ4HIP_TABLE_U64];
   uint64_t* table = tables[threadIdx.x >> 6];
   for (;;) {
     uint32_t b = 0;
@@ -172,7 +175,7 @@ __device__ __forceinline__ void compress_fast_ms_block(const BatchArgs& a, uint3
 // listed in routed[0 .. q[1]) (second pass of the adaptive scheme; an empty list costs one queue draw per wavefront) or, with
 // routed == nullptr, every block of the batch
 __global__ __launch_bounds__(64 * WAVES_PER_CU) void compress_fast_ms_cu_kernel(BatchArgs a, uint32_t* q, const uint32_t* routed) {
-  __shared__ __attribute__((aligned(16))) uint64_t tables[WAVES_PER_CU][4096];
+  __shared__ __attribute__((aligned(16))) uint64_t tables[WAVES_PER_CU][LZ4HIP_TABLE_U64];
   uint64_t* table = tables[threadIdx.x >> 6];
   const uint32_t count = routed ? __builtin_amdgcn_readfirstlane(q[1]) : a.n;
   for (;;) {

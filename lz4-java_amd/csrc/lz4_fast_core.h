@@ -27,6 +27,11 @@
 // Rule: per-lane values have type W::VU / VU64 / VB; control flow branches only on wave-uniform
 // scalars (ballots, broadcasts).
 #pragma once
+// developer probe builds only: a byU16 table of 2^LZ4HIP_PROBE_HLOG entries (13 = liblz4's; anything else is NOT bit-exact and
+// exists to measure residency: 12 -> 16 KB tables, ten wavefronts per CU)
+#ifndef LZ4HIP_PROBE_HLOG
+#define LZ4HIP_PROBE_HLOG 13
+#endif
 #include <stdint.h>
 #include <stddef.h>
 
@@ -218,7 +223,7 @@ struct FastCore {
   using VB = typename W::VB;
   using E = typename W::template Entry<U16>::S;   // scalar table entry (uint32_t / uint64_t)
   using VE = typename W::template Entry<U16>::V;  // per-lane table entry
-  static constexpr int HLOG = U16 ? 13 : 12;
+  static constexpr int HLOG = U16 ? LZ4HIP_PROBE_HLOG : 12;
   static constexpr int PSHIFT = U16 ? 16 : 32;
   static constexpr uint32_t MAXD = 65535u;
 #ifndef LZ4HIP_SPEC_LANES

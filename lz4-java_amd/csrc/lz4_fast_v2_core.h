@@ -202,7 +202,7 @@ struct FastV2 {
     if (n < 13u) return out.last(0u);
     {
       const uint32_t x0 = w.sld32(src, 0);
-      w.template lds_fill<true>(1u << 13, (((x0 * 2654435761u) >> 3) & 0xFFFFu));  // every bucket: {pos 0, fp(bytes at 0)}
+      w.template lds_fill<true>(1u << LZ4HIP_PROBE_HLOG, (((x0 * 2654435761u) >> 3) & 0xFFFFu));  // every bucket: {pos 0, fp(bytes at 0)}
       w.sync();
     }
     Gen gen(w, out, src, n, st);
@@ -250,7 +250,7 @@ struct FastV2 {
         x32 = w.ldu32(src, pos);
       }
       const VU prod = x32 * 2654435761u;
-      const VU h = prod >> 19;
+      const VU h = prod >> (32 - LZ4HIP_PROBE_HLOG);
       const VU fp = (prod >> 3) & 0xFFFFu;
       LZ4HIP_PHASE2(0, w.bcast(h, 0));     // t[0]: window load + hash
       const VU e = w.template lds_rdu<true>(h);
