@@ -212,7 +212,9 @@ struct FastV2 {
       gen.one_done = false;
       const uint32_t ip = lean(gen.p_ip);
       gen.anchor = ip;
+      const uint64_t tx = st ? w.tick(ip) : 0;      // (profiling kernel: cycles and count of the exact path's sequences)
       r = gen.template loop<2>(true, ip + 1u, 0u, ip);
+      if (st) { st->t[6] += w.tick(r) - tx; st->t[7] += 1; }
     }
     return r;
   }
@@ -256,7 +258,7 @@ struct FastV2 {
       const VU e = w.template lds_rdu<true>(h);
       const VU newe = (pos << 16) | fp;
       const uint64_t tmask = w.ballot((e & 0xFFFFu) == fp) & ~1ull;
-      if (LZ4HIP_UNLIKELY(tmask == 0)) break;                    // no tentative hit in 63 probes (nothing committed yet)
+      if (LZ4HIP_UNLIKELY(tmask == 0)) { if (st) st->false_pos++; break; }   // no tentative hit in 63 probes (nothing committed yet; profiling: counted in false_pos)
       const uint32_t k0 = (uint32_t)ctz64(tmask);
       LZ4HIP_PHASE2(1, k0);                 // t[1]: table read + ballot
       const uint64_t inm = (2ull << k0) - 1ull;                  // lanes 0..k0 commit
@@ -286,7 +288,24 @@ struct FastV2 {
         cnt = 4u * (uint32_t)f + ((uint32_t)ctz32(w.bcast(fx, f)) >> 3);
       }
       LZ4HIP_PHASE2(4, cnt);                // t[4]: candidate fetch wait + forward count
-      if (LZ4HIP_UNLIKELY(det != 0 || cnt < 4u)) {               // collision, false positive or a match of >= 256 bytes: undo, exact path
+      // A bucket shared by two committing lanes (det: a lane got back another lane's entry instead of the one it had read) only
+      // matters if liblz4, which inserts and looks up position by position, would have decided differently: the later lane would
+      // have seen the earlier lane's entry instead of the old one.  For a lane below the hit that changes nothing unless the two
+      // fingerprints agree (its old entry was no tentative hit, or it would be the hit lane); for the hit lane it always does
+      // (the entry that made it the hit is gone).  The atomic max leaves the bucket holding the later position either way -- the
+      // state liblz4 ends up with.  So: exactly one lane with a foreign entry (= exactly two lanes in that bucket), not the hit
+      // lane's bucket, fingerprints differ -> carry on.  Anything else takes the exact path.
+      bool bad = cnt < 4u;                                       // false positive or a match of >= 256 bytes
+      if (LZ4HIP_UNLIKELY(det != 0)) {
+        if (det & (det - 1u)) {
+          bad = true;
+        } else {
+          const int dl = ctz64(det);
+          const uint32_t od = w.bcast(old, dl), hd = w.bcast(h, dl), fd = w.bcast(fp, dl);
+          bad = bad || hd == w.bcast(h, (int)k0) || (od & 0xFFFFu) == fd;
+        }
+      }
+      if (LZ4HIP_UNLIKELY(bad)) {                                // undo, exact path
         if (st) l_slow++;
         w.template lds_wr<true>(h, e, w.lanes(inm));
         w.sync();

@@ -14,8 +14,7 @@ from conftest import ROOT, rnd_inputs
 _u8p = C.POINTER(C.c_uint8)
 
 
-@pytest.fixture(scope="module")
-def sim():
+def load_sim():
     d = os.path.join(ROOT, "tests", "hostsim")
     so = os.path.join(d, "libhostsim.so")
     srcs = [os.path.join(d, f) for f in ("hostsim.cpp", "wave_host.h", "group_host.h")] + \
@@ -34,6 +33,11 @@ def sim():
     l.sim_decompress.restype = C.c_int
     l.sim_decompress.argtypes = [C.c_char_p, C.c_int, _u8p, C.c_int, C.c_int, C.c_int]
     return l
+
+
+@pytest.fixture(scope="module")
+def sim():
+    return load_sim()
 
 
 def sim_compress(sim, v, cap, seed=0, ms=False, v2=False):

@@ -12,7 +12,7 @@ if os.environ.get("CC"):
     amd.set_option("compress_core", int(os.environ["CC"]))
 ms = os.environ.get("CC", "1") == "1"
 v2 = os.environ.get("CC", "1") == "3"
-names_v2 = ["window+hash", "table+ballot", "commit+fetch issue", "atomic result", "fetch wait+count", "catch-up+park(+flush)", "-", "-"]
+names_v2 = ["window+hash", "table+ballot", "commit+fetch issue", "atomic result", "fetch wait+count", "catch-up+park(+flush)", "exact path (cycles/lean step)", "exact-path calls x steps"]
 names_ms = ["window+hash", "bucket+fp ballot", "cand fetch issue", "emit prev window", "wait cand+verdict", "chain walk", "commit+collision", "handover+prepare"]
 names = ["window+hash", "table+ballot", "issue commit/fetch", "emit prev", "atomic/collision", "wait candidate", "extend+bookkeep", "-"]
 for data in kinds:
@@ -35,3 +35,6 @@ for data in kinds:
     for i in range(8):
         print("   %-20s %8.0f cycles/step  %5.1f%%" % ((names_v2 if v2 else names_ms if ms else names)[i], p[4 + i] / steps, 100 * p[4 + i] / tot))
     print("   %-20s %8.0f cycles/step" % ("total", tot / steps))
+    if v2:
+        print("   exact path: %.0f calls per block, %.0f cycles per call, %.0f cycles per block; lean steps %.0f x %.0f cycles = %.0f per block"
+              % (p[11], p[10] / max(p[11], 1), p[10], steps, sum(p[4:10]) / steps, sum(p[4:10])))
