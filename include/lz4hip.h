@@ -113,7 +113,9 @@ int lz4hip_compress_fast_batch_dev(const uint8_t* src, const uint64_t* src_off, 
                                    uint8_t* dst, const uint64_t* dst_off, const int32_t* dst_cap,
                                    int32_t* out_len, uint32_t n_blocks, int device, void* stream);
 /* HC: levels follow liblz4 (< 1 -> 9, > 12 -> 12): 1..9 = hash-chain strategy with lazy evaluation, 10..12 = optimal
- * parser (lz4-java levels 10..17).  The call sizes an internal
+ * parser (lz4-java levels 10..17).  Levels 10..12 are FUNCTIONAL ONLY: byte-identical output, but the optimal parser's table
+ * walk is wave-uniform scalar work (about 1.0 / 0.7 GB/s per GPU at levels 10 / 12 -- no faster than the reference on the host's
+ * cores); levels 1..9 are the ones to use for throughput (level 9: ~12 GB/s per GPU on 1 MiB blocks).  The call sizes an internal
  * u16 workspace (2 bytes per source byte, stream-ordered allocation) and therefore synchronises `stream`
  * once before it enqueues the two kernels.                                                          */
 int lz4hip_compress_hc_batch_dev(const uint8_t* src, const uint64_t* src_off, const int32_t* src_len,
