@@ -129,10 +129,11 @@ uint32_t cu_count() {
 int launch_fast(const lz4hip::BatchArgs& a, hipStream_t st) {
   // scratch: three queue words + the routed-block list of the adaptive scheme
   uint32_t* scratch = nullptr;
-  hipError_t e = hipMallocAsync((void**)&scratch, (3 + (size_t)a.n) * sizeof(uint32_t), st);
-  if (e != hipSuccess) return (int)e;
   const uint32_t cus = cu_count();
   const int core = g_compress_core.load(std::memory_order_relaxed);
+  const size_t mail_words = core >= 5 ? lz4hip::compress_fast_v2w_scratch_words(cus) : 0u;   // rings of the finder/writer pairs
+  hipError_t e = hipMallocAsync((void**)&scratch, (3 + (size_t)a.n + mail_words) * sizeof(uint32_t), st);
+  if (e != hipSuccess) return (int)e;
   const uint32_t dense64 = 64u * (uint32_t)g_compress_switch.load(std::memory_order_relaxed);
   int le;
   switch (core) {
@@ -143,8 +144,12 @@ int launch_fast(const lz4hip::BatchArgs& a, hipStream_t st) {
       if (le == 0) le = lz4hip::launch_compress_fast_ms(a, scratch, scratch + 3, false, cus, st);
       break;
     case 3: le = lz4hip::launch_compress_fast_v2(a, scratch, nullptr, 0u, cus, st); break;
-    default:
+    case 4:
       le = lz4hip::launch_compress_fast_v2(a, scratch, scratch + 3, dense64, cus, st);
+      if (le == 0) le = lz4hip::launch_compress_fast_ms(a, scratch, scratch + 3, false, cus, st);
+      break;
+    default:   // 5: the lean core with a writer wavefront per chain, adaptive
+      le = lz4hip::launch_compress_fast_v2w(a, scratch, scratch + 3, dense64, cus, scratch + 3 + a.n, st);
       if (le == 0) le = lz4hip::launch_compress_fast_ms(a, scratch, scratch + 3, false, cus, st);
       break;
   }
@@ -744,7 +749,7 @@ int lz4hip_set_option(const char* name, int value) {
     return LZ4HIP_OK;
   }
   if (name && strcmp(name, "compress_core") == 0) {
-    if (value < 0 || value > 4) return fail(LZ4HIP_E_ARG, "compress_core must be 0..4");
+    if (value < 0 || value > 5) return fail(LZ4HIP_E_ARG, "compress_core must be 0..5");
     g_compress_core = value;
     return LZ4HIP_OK;
   }

@@ -151,6 +151,187 @@ int launch_compress_fast_v2(const BatchArgs& a, uint32_t* q, uint32_t* routed, u
   return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// lean core with a WRITER wavefront per chain.  A finder's 64-sequence batch write is ~20 scattered store instructions, and a
+// wavefront's memory operations retire in order: the finder's next candidate fetch waits for all of them (8.6 % of the kernel,
+// profiles/r02_compress_notes.txt).  LDS -- not wave slots -- is what limits a CU to five finders, and a writer needs no LDS:
+// here every finder hands its parked batches to a partner wavefront of the same workgroup through a small ring in global memory
+// (single producer, single consumer; release/acquire at agent scope), and the partner does all the output of the block:
+// literal copies, tokens, liblz4's capacity checks, the last literals and the block's result word.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t MAIL_RING = 4u;            // slots per finder/writer pair
+constexpr uint32_t MAIL_SLOT_WORDS = 256u;    // 3 x 64 sequence words + header {kind, block, count, x}
+enum : uint32_t { MAIL_BATCH = 1u, MAIL_LAST = 2u, MAIL_ABORT = 3u, MAIL_EXIT = 4u };
+constexpr uint32_t MAIL_PENDING = 0xFFFFFFFFu;   // MailOut::last(): the writer produces the result
+
+// Finder and writer are wavefronts of ONE workgroup, so everything is ordered at WORKGROUP scope: both see the CU's L1, and a
+// release / acquire is a wait for the wave's own accesses, no cache maintenance.  (At agent scope a release writes the XCD's L2
+// back and an acquire invalidates the CU's L1 for everybody on it: 2.3x .. 12x slower, measured.)
+__device__ __forceinline__ uint32_t mail_peek(const uint32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ uint32_t mail_peek_far(const uint32_t* p) {   // (every 64th poll of a wait: progress does not hang on the L1)
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void mail_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+__device__ __forceinline__ void mail_publish(uint32_t* p, uint32_t v) {   // every lane: this wave's earlier accesses are done first
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (__lane_id() == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// finder side: the Out policy of FastV2 / FastCore (same parking as ParkOut; a full batch goes to the partner instead of memory)
+struct MailOut {
+  using W = WaveDev;
+  using VU = W::VU;
+  static constexpr bool kUsesWindowRegs = false;
+  static constexpr uint32_t kNoCheck = 1u << 16;
+  W& w;
+  uint32_t* slots;   // MAIL_RING x MAIL_SLOT_WORDS
+  uint32_t* ctr;     // {published by the finder, consumed by the writer}
+  uint32_t head, tail_seen = 0, b = 0;
+  VU p_ms = 0u, p_ml = 0u, p_off = 0u;
+  uint32_t cnt = 0;
+  uint32_t dense64 = 0, flushes = 0, mark = 0;
+  bool bail = false;
+
+  __device__ __forceinline__ MailOut(W& w_, uint32_t* slots_, uint32_t* ctr_, uint32_t head_) : w(w_), slots(slots_), ctr(ctr_), head(head_) {}
+
+  __device__ __forceinline__ void post(uint32_t kind, uint32_t m, uint32_t x) {
+    for (uint32_t spin = 1; head - tail_seen >= MAIL_RING; spin++) {   // ring full: the writer is behind (it publishes `tail` once a slot is in its registers)
+      tail_seen = (spin & 63u) ? mail_peek(ctr + 1) : mail_peek_far(ctr + 1);
+      if (head - tail_seen >= MAIL_RING) __builtin_amdgcn_s_sleep(16);
+    }
+    uint32_t* s = slots + (head % MAIL_RING) * MAIL_SLOT_WORDS;
+    const uint32_t l = __lane_id();
+    s[l] = p_ms; s[64u + l] = p_ml; s[128u + l] = p_off;
+    if (l < 4u) s[192u + l] = l == 0u ? kind : (l == 1u ? b : (l == 2u ? m : x));
+    head++;
+    mail_publish(ctr, head);
+  }
+  __device__ __forceinline__ void park(uint32_t ms, uint32_t ml, uint32_t offx) {
+    p_ms = W::writelane(p_ms, ms, cnt);
+    p_ml = W::writelane(p_ml, ml, cnt);
+    p_off = W::writelane(p_off, offx, cnt);
+    if (++cnt == 64u) batch();
+  }
+  __device__ __forceinline__ void batch() {
+    const uint32_t m = cnt;
+    cnt = 0u;
+    if (m == 0u || bail) return;
+    if (dense64 != 0u && flushes < 2u && m == 64u) {   // the density probe of ParkOut::flush (same rule, same moment)
+      const uint32_t e31 = w.bcast(p_ms + p_ml, 31);
+      if (flushes == 0u) mark = e31;
+      else if (e31 - mark < dense64) { bail = true; return; }
+      flushes++;
+    }
+    post(MAIL_BATCH, m, 0u);
+  }
+  // ---- the Out interface of FastCore ----
+  __device__ __forceinline__ bool overlap_point() { return true; }
+  __device__ __forceinline__ void seq(uint32_t lit, uint32_t mc, uint32_t offset, uint32_t anchor, bool check_lits, bool, VU) {
+    park(anchor + lit, mc + 4u, offset | (check_lits ? 0u : kNoCheck));
+  }
+  __device__ __forceinline__ uint32_t last(uint32_t anchor) {
+    batch();
+    if (bail) return 0u;
+    post(MAIL_LAST, 0u, anchor);
+    return MAIL_PENDING;
+  }
+};
+
+// writer side: one wavefront, all blocks of its finder in order
+__device__ __forceinline__ void mail_writer(const BatchArgs& a, uint32_t* slots, uint32_t* ctr) {
+  WaveDev w(nullptr);
+  uint32_t tail = 0, cur = 0xFFFFFFFFu, op = 0, prev_end = 0;
+  bool ok = true;
+  const uint32_t l = __lane_id();
+  for (;;) {
+    for (uint32_t spin = 1; ((spin & 63u) ? mail_peek(ctr) : mail_peek_far(ctr)) == tail; spin++) __builtin_amdgcn_s_sleep(32);
+    mail_acquire();
+    const uint32_t* s = slots + (tail % MAIL_RING) * MAIL_SLOT_WORDS;
+    const uint32_t ms = s[l], ml = s[64u + l], off = s[128u + l];
+    const uint32_t hv = s[192u + (l & 3u)];
+    const uint32_t kind = __builtin_amdgcn_readlane(hv, 0), b = __builtin_amdgcn_readlane(hv, 1), m = __builtin_amdgcn_readlane(hv, 2), x = __builtin_amdgcn_readlane(hv, 3);
+    tail++;
+    mail_publish(ctr + 1, tail);   // the slot is in registers: the finder may reuse it
+    if (kind == MAIL_EXIT) return;
+    if (kind == MAIL_ABORT) { cur = 0xFFFFFFFFu; continue; }
+    if (b != cur) { cur = b; op = 0; prev_end = 0; ok = true; }
+    const int32_t n = uniform_i32(a.src_len[b]);
+    const int32_t cap = uniform_i32(a.dst_cap[b]);
+    ParkOut<WaveDev> out(w, uniform_ptr(a.src + a.src_off[b]), (uint32_t)n, uniform_ptr(a.dst + a.dst_off[b]), (uint32_t)cap);
+    out.op = op; out.prev_end = prev_end; out.ok = ok;
+    if (kind == MAIL_BATCH) {
+      out.p_ms = ms; out.p_ml = ml; out.p_off = off; out.cnt = m;
+      out.flush();
+      op = out.op; prev_end = out.prev_end; ok = out.ok;
+    } else {   // MAIL_LAST
+      const uint32_t r = ok ? out.emit_last(x) : 0u;
+      if (l == 0) a.out[b] = (int32_t)r;
+      cur = 0xFFFFFFFFu;
+    }
+  }
+}
+
+__global__ __launch_bounds__(64 * 2 * WAVES_PER_CU) void compress_fast_v2w_cu_kernel(BatchArgs a, uint32_t* q, uint32_t* routed, uint32_t dense64, uint32_t* mail_ctr, uint32_t* mail_slots) {
+  __shared__ __attribute__((aligned(16))) uint64_t tables[WAVES_PER_CU][LZ4HIP_TABLE_U64];
+  const uint32_t wv = threadIdx.x >> 6;
+  const uint32_t pair = blockIdx.x * WAVES_PER_CU + (wv < WAVES_PER_CU ? wv : wv - WAVES_PER_CU);
+  uint32_t* ctr = mail_ctr + 2u * pair;
+  uint32_t* slots = mail_slots + (size_t)pair * (MAIL_RING * MAIL_SLOT_WORDS);
+  if (wv >= WAVES_PER_CU) { mail_writer(a, slots, ctr); return; }
+  uint64_t* table = tables[wv];
+  WaveDev w(table);
+  uint32_t head = 0, tail_seen = 0;
+  for (;;) {
+    uint32_t b = 0;
+    if (__lane_id() == 0) b = atomicAdd(q, 1u);
+    b = __builtin_amdgcn_readfirstlane(b);
+    MailOut out(w, slots, ctr, head);
+    out.tail_seen = tail_seen;
+    if (b >= a.n) { out.post(MAIL_EXIT, 0u, 0u); return; }
+    out.b = b;
+    const int32_t n = uniform_i32(a.src_len[b]);
+    const int32_t cap = uniform_i32(a.dst_cap[b]);
+    if (n >= 0 && (uint32_t)n <= 0x7E000000u && cap >= 0) {
+      const uint8_t* s = uniform_ptr(a.src + a.src_off[b]);
+      out.dense64 = routed ? dense64 : 0u;
+      if (n < 65547) {
+        FastV2<WaveDev, MailOut> c(w, out, s, (uint32_t)n);
+        (void)c.run();
+      } else {
+        FastCore<WaveDev, false, MailOut> c(w, out, s, (uint32_t)n);
+        (void)c.run();
+      }
+      if (out.bail) {
+        out.post(MAIL_ABORT, 0u, 0u);
+        if (__lane_id() == 0) routed[atomicAdd(q + 1, 1u)] = b;
+      }
+    } else {
+      if (__lane_id() == 0) a.out[b] = 0;
+    }
+    head = out.head; tail_seen = out.tail_seen;
+    WaveDev::sync();  // the table is reused
+  }
+}
+// scratch words the two-wave kernel needs after the three queue words: counters of every pair, then (256-word aligned) the rings
+size_t compress_fast_v2w_scratch_words(uint32_t n_cus) {
+  const size_t pairs = (size_t)n_cus * WAVES_PER_CU;
+  return 2u * pairs + 256u + pairs * (MAIL_RING * MAIL_SLOT_WORDS);
+}
+int launch_compress_fast_v2w(const BatchArgs& a, uint32_t* q, uint32_t* routed, uint32_t dense64, uint32_t n_cus, uint32_t* mail, void* stream) {
+  if (a.n == 0) return 0;
+  const size_t pairs = (size_t)n_cus * WAVES_PER_CU;
+  hipError_t e = hipMemsetAsync(q, 0, 3 * sizeof(uint32_t), (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  e = hipMemsetAsync(mail, 0, 2u * pairs * sizeof(uint32_t), (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  uint32_t* slots = (uint32_t*)(((uintptr_t)(mail + 2u * pairs) + 1023u) & ~(uintptr_t)1023u);
+  const uint32_t wgs = (a.n + WAVES_PER_CU - 1u) / WAVES_PER_CU;
+  hipLaunchKernelGGL(compress_fast_v2w_cu_kernel, dim3(wgs < n_cus ? wgs : n_cus), dim3(64 * 2 * WAVES_PER_CU), 0, (hipStream_t)stream, a, q, routed, dense64, mail, slots);
+  return (int)hipGetLastError();
+}
+
 // window-parallel core (lz4_fast_ms_core.h): every sequence of a 64-position window per step
 __device__ __forceinline__ void compress_fast_ms_block(const BatchArgs& a, uint32_t b, uint64_t* table) {
   const int32_t n = uniform_i32(a.src_len[b]);

@@ -182,21 +182,21 @@ struct ParkOut {
 // memory waits fell from 66 % to 42 % of the wave's cycles -- but a step grew from 110 to 200 instructions, a wavefront issues one
 // instruction per ~4.4 cycles whatever its dependencies, and a mode switch (s_set_gpr_idx_on/off) costs ~80 cycles that overlap
 // with nothing: 49.5 .. 55.3 GB/s against 59.9 without the ring.
-template <class W>
+template <class W, class OUT = ParkOut<W>>
 struct FastV2 {
   using VU = typename W::VU;
   using VB = typename W::VB;
-  using Gen = FastCore<W, true, ParkOut<W>>;
+  using Gen = FastCore<W, true, OUT>;
   static constexpr uint32_t kFwdBytes = 256u;                       // forward compare of the lean step: 64 lanes x 4 bytes
   static constexpr uint32_t kTail = 12u + 64u + kFwdBytes + 16u;    // the lean loop stays this far from the block end
 
   W& w;
-  ParkOut<W>& out;
+  OUT& out;
   const uint8_t* src;
   uint32_t n;
   FastStats* st;
 
-  LZ4HIP_DEV FastV2(W& w_, ParkOut<W>& out_, const uint8_t* s, uint32_t n_, FastStats* st_ = nullptr) : w(w_), out(out_), src(s), n(n_), st(st_) {}
+  LZ4HIP_DEV FastV2(W& w_, OUT& out_, const uint8_t* s, uint32_t n_, FastStats* st_ = nullptr) : w(w_), out(out_), src(s), n(n_), st(st_) {}
 
   LZ4HIP_DEV uint32_t run() {
     if (n < 13u) return out.last(0u);
@@ -318,7 +318,7 @@ struct FastV2 {
       const uint64_t range = ((1ull << k0) - 1ull) & ~1ull;      // lanes 1..k0-1
       const uint64_t ne = (~eqm & range) | 1ull;
       const uint32_t back = k0 - 1u - (63u - (uint32_t)clz64(ne));
-      out.park(hpos - back, cnt + back, (hpos - mpos) | (k0 == 1u ? ParkOut<W>::kNoCheck : 0u));
+      out.park(hpos - back, cnt + back, (hpos - mpos) | (k0 == 1u ? OUT::kNoCheck : 0u));
       ip = hpos + cnt;
       prev_fa = fa;
       prev_hpos = hpos;
