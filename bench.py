@@ -372,7 +372,7 @@ def main():
             "verified": ok,
             "compress_GBps": round(nbytes / t_c / 1e9, 3), "decompress_GBps": round(nbytes / t_d / 1e9, 3),
             # compress: reads N, writes C (1 + 1/ratio B/B); decompress: reads C, writes N
-            "roofline": roof("compress_fast_v2_cu_kernel", nbytes + csum, t_c, tr.get("compress_fast_v2_cu_kernel")),
+            "roofline": roof("compress_fast_v2w_cu_kernel", nbytes + csum, t_c, kernel_traffic(tr, world, "compress_fast_v2w_cu_kernel") or tr.get("compress_fast_v2w_cu_kernel")),
             "roofline_decode": roof("decode_kernel", nbytes + csum, t_d, tr.get("decode_kernel")),
         }
         if tr:

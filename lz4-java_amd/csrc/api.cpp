@@ -72,11 +72,12 @@ std::atomic<int> g_decode_lanes{0};   // "decode_lanes"; 0 = kernel default
 std::atomic<int> g_decode_stage{-1};  // "decode_stage": 1 = LDS output staging in the plain loop
 std::atomic<int> g_decode_pipe{-1};   // "decode_pipe": 1/0 = pipelined interior loop on/off, -1 = kernel default
 
-// lz4hip_set_option "compress_core": 4 = adaptive two-pass, lean core + window-parallel core (default); 3 = lean core only
+// lz4hip_set_option "compress_core": 5 = adaptive two-pass, lean core with a writer wavefront per chain + window-parallel core
+// (default); 4 = the same with every wavefront writing its own sequences (round-2 default before the writers); 3 = lean core only
 // (lz4_fast_v2_core.h); 2 = adaptive, one-sequence-per-step core + window-parallel core; 1 = window-parallel core only
 // (lz4_fast_ms_core.h); 0 = one-sequence-per-step core only (lz4_fast_core.h).  "compress_switch" = bytes per sequence below
 // which a block counts as dense and goes to the window-parallel core (probe: sequences 32..95 of the block)
-std::atomic<int> g_compress_core{4};
+std::atomic<int> g_compress_core{5};
 std::atomic<int> g_compress_switch{20};
 
 // liblz4's level handling: < 1 -> 9, > 12 -> 12; 10..12 are the optimal parser (lz4-java levels 10..17)
@@ -870,7 +871,7 @@ int lz4hip_dbg_compress_fast_profile_dev(const uint8_t* src, const uint64_t* src
   if (ordinal(device, &ord)) return fail(LZ4HIP_E_ARG, "bad device index");
   DeviceGuard g(ord);
   lz4hip::BatchArgs a{src, src_off, src_len, dst, dst_off, dst_cap, out_len, n};
-  int e = lz4hip::launch_compress_fast_prof(a, prof, g_compress_core.load() == 2 ? 1 : (g_compress_core.load() == 4 ? 3 : g_compress_core.load()), stream);
+  int e = lz4hip::launch_compress_fast_prof(a, prof, g_compress_core.load() == 2 ? 1 : (g_compress_core.load() >= 4 ? 3 : g_compress_core.load()), stream);
   return e ? fail(LZ4HIP_E_HIP, "kernel launch", (hipError_t)e) : LZ4HIP_OK;
 }
 #endif  // LZ4HIP_DEV_TOOLS

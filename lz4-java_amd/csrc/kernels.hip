@@ -159,7 +159,13 @@ int launch_compress_fast_v2(const BatchArgs& a, uint32_t* q, uint32_t* routed, u
 // (single producer, single consumer; release/acquire at agent scope), and the partner does all the output of the block:
 // literal copies, tokens, liblz4's capacity checks, the last literals and the block's result word.
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t MAIL_RING = 4u;            // slots per finder/writer pair
+#ifndef LZ4HIP_MAIL_RING
+#define LZ4HIP_MAIL_RING 4
+#endif
+#ifndef LZ4HIP_MAIL_SLEEP
+#define LZ4HIP_MAIL_SLEEP 32
+#endif
+constexpr uint32_t MAIL_RING = LZ4HIP_MAIL_RING;   // slots per finder/writer pair
 constexpr uint32_t MAIL_SLOT_WORDS = 256u;    // 3 x 64 sequence words + header {kind, block, count, x}
 enum : uint32_t { MAIL_BATCH = 1u, MAIL_LAST = 2u, MAIL_ABORT = 3u, MAIL_EXIT = 4u };
 constexpr uint32_t MAIL_PENDING = 0xFFFFFFFFu;   // MailOut::last(): the writer produces the result
@@ -246,7 +252,7 @@ __device__ __forceinline__ void mail_writer(const BatchArgs& a, uint32_t* slots,
   bool ok = true;
   const uint32_t l = __lane_id();
   for (;;) {
-    for (uint32_t spin = 1; ((spin & 63u) ? mail_peek(ctr) : mail_peek_far(ctr)) == tail; spin++) __builtin_amdgcn_s_sleep(32);
+    for (uint32_t spin = 1; ((spin & 63u) ? mail_peek(ctr) : mail_peek_far(ctr)) == tail; spin++) __builtin_amdgcn_s_sleep(LZ4HIP_MAIL_SLEEP);
     mail_acquire();
     const uint32_t* s = slots + (tail % MAIL_RING) * MAIL_SLOT_WORDS;
     const uint32_t ms = s[l], ml = s[64u + l], off = s[128u + l];

@@ -208,7 +208,7 @@ def test_issue12_regression_blob_gpu(amd, ref):
         c = f.fastCompressor().compress(data)
         assert c == ref.compress_fast(data), core
         assert f.safeDecompressor().decompress(c, len(data)) == data and f.fastDecompressor().decompress(c, len(data)) == data
-    amd.set_option("compress_core", 4)
+    amd.set_option("compress_core", 5)
     for level in (1, 9, 12, 17):
         h = f.highCompressor(level).compress(data)
         assert h == ref.compress_hc(data, min(level, 12)) and f.safeDecompressor().decompress(h, len(data)) == data
@@ -428,7 +428,7 @@ def test_compress_core_variants_same_bytes(amd, ref, O, corpus, core, switch):
     try:
         res = gpu_compress_many(amd, blocks, caps)
     finally:
-        amd.set_option("compress_core", 4)
+        amd.set_option("compress_core", 5)
         amd.set_option("compress_switch", 20)
     for v, cap, (r, c) in zip(blocks, caps, res):
         er, eb = ref.compress_fast_raw(v, cap)

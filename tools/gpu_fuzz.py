@@ -42,7 +42,7 @@ for core in (0, 1, 2, 3, 4, 5):
         if r != er or (er > 0 and bytes(dst[o:o + r]) != eb[:er]):
             print("MISMATCH tight core", core, "input", i, "len", len(inputs[i]), "cap", caps[i], r, er); sys.exit(1)
     print("core %d: %d inputs bit-exact (full and tight capacities)" % (core, n), flush=True)
-amd.set_option("compress_core", 4)
+amd.set_option("compress_core", 5)
 caps = [len(v) for v in inputs]
 src, so, sl, dst, do = pack(exp_full, caps)
 # every lane count x plain / pipelined / staged interior loop

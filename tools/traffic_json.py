@@ -22,7 +22,7 @@ for db in glob.glob(os.path.join(d, "*", "pmc_results.db")):
         if "decode_kernel" in k and "decode_kernel<4, true, false, true>" not in k:
             continue   # the legacy "decode_kernel" key below is the headline launch (65536 x 64 KiB: 4 lanes, safe, staged) only
         key = None
-        for name in ("compress_fast_v2_cu_kernel", "compress_fast_cu_kernel", "compress_fast_ms_cu_kernel", "decode_kernel", "hc_parse_kernel", "hc_build_kernel", "xxh_multi_kernel"):
+        for name in ("compress_fast_v2w_cu_kernel", "compress_fast_v2_cu_kernel", "compress_fast_cu_kernel", "compress_fast_ms_cu_kernel", "decode_kernel", "hc_parse_kernel", "hc_build_kernel", "xxh_multi_kernel"):
             if name in k:
                 key = name
                 break
