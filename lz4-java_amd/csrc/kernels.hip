@@ -1,10 +1,12 @@
 // kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the LZ4 block engine.
 //
-//   compress_fast_v2_cu_kernel / compress_fast_cu_kernel / compress_fast_ms_cu_kernel
-//                        : one workgroup of 5 wavefronts per CU (5 x 32 KB tables of {position, fingerprint} entries = the CU's
-//                          whole LDS), every wavefront draws blocks from a queue; algorithms in lz4_fast_v2_core.h (lean finder
-//                          loop + sequences parked in lanes, written 64 at a time; the default), lz4_fast_core.h (one sequence
-//                          per step, written as found) and lz4_fast_ms_core.h (every sequence of a 64-position window per step).
+//   compress_fast_v2w_cu_kernel / compress_fast_v2_cu_kernel / compress_fast_cu_kernel / compress_fast_ms_cu_kernel
+//                        : one workgroup per CU with 5 finder wavefronts (5 x 32 KB tables of {position, fingerprint} entries =
+//                          the CU's whole LDS), every finder draws blocks from a queue; algorithms in lz4_fast_v2_core.h (lean
+//                          finder loop + sequences parked in lanes, 64 at a time), lz4_fast_core.h (one sequence per step, written
+//                          as found) and lz4_fast_ms_core.h (every sequence of a 64-position window per step).  The default,
+//                          v2w, adds a WRITER wavefront per finder (no LDS needed) that takes the parked batches through a ring
+//                          in global memory and does all the output.
 //                          Bound: the serial parse chain of a wavefront x 5 chains per CU (roofline: HBM, 1+1/ratio B/B).
 //   decode_kernel<GL, SAFE, PIPE, STAGE>
 //                        : GL lanes per block, 64/GL blocks per wavefront, algorithm in lz4_decode_core.h; PIPE = software-
