@@ -128,10 +128,19 @@ struct WaveDev {
   __device__ __forceinline__ static void st8(uint8_t* b, VU i, VU v, bool m) {
     // (non-temporal byte stores here were +3.5 % on the bench workload -- the output no longer pushes the source out of L2 --
     // but they reach memory as partial-line writes: WRITE_SIZE 2.1 -> 11.4 GB per launch, profiles/r01j; not worth it)
+#ifdef LZ4HIP_NT_OUT   // developer A/B builds
+    if (m) __builtin_nontemporal_store((uint8_t)v, b + i);
+#else
     if (m) b[i] = (uint8_t)v;
+#endif
   }
   __device__ __forceinline__ static void st32(uint8_t* b, VU i, VU v, bool m) {
+#ifdef LZ4HIP_NT_OUT
+    typedef uint32_t u32u __attribute__((aligned(1)));
+    if (m) __builtin_nontemporal_store((uint32_t)v, (u32u*)(b + i));
+#else
     if (m) __builtin_memcpy(b + i, &v, 4);
+#endif
   }
   // lane `l` of v replaced by the scalar s, both wave-uniform: ONE v_writelane_b32 (set_lane's compare + select is two VALU
   // instructions and needs the lane index in a VGPR)

@@ -1,4 +1,5 @@
 #!/bin/bash
+# usage (on the GPU box): tools/probe_v2.sh <variant> ...  -- single-interval phase probes of the lean core (LZ4HIP_V2_PROBE builds)
 # on the GPU box: per-interval timing of the lean loop, one interval per library variant (tools/build_variant.sh probeK -DLZ4HIP_V2_PROBE=K)
 cd $GRAFT_REPO_ROOT
 cp lz4-java_amd/liblz4hip.so /tmp/base.so
