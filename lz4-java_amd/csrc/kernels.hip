@@ -192,7 +192,8 @@ struct MailOut {
   using W = WaveDev;
   using VU = W::VU;
   static constexpr bool kUsesWindowRegs = false;
-  static constexpr uint32_t kNoCheck = 1u << 16;
+  static constexpr uint32_t kNoCheck = ParkOut<W>::kNoCheck, kFinal = ParkOut<W>::kFinal;
+  static constexpr bool kRawPark = true;   // the lean loop parks bare hits: liblz4's backward extension is the writer's work too (ParkOut::resolve_raw)
   W& w;
   uint32_t* slots;   // MAIL_RING x MAIL_SLOT_WORDS
   uint32_t* ctr;     // {published by the finder, consumed by the writer}
@@ -237,7 +238,7 @@ struct MailOut {
   // ---- the Out interface of FastCore ----
   __device__ __forceinline__ bool overlap_point() { return true; }
   __device__ __forceinline__ void seq(uint32_t lit, uint32_t mc, uint32_t offset, uint32_t anchor, bool check_lits, bool, VU) {
-    park(anchor + lit, mc + 4u, offset | (check_lits ? 0u : kNoCheck));
+    park(anchor + lit, mc + 4u, offset | (check_lits ? 0u : kNoCheck) | kFinal);   // the exact path hands over finished sequences
   }
   __device__ __forceinline__ uint32_t last(uint32_t anchor) {
     batch();
@@ -271,6 +272,7 @@ __device__ __forceinline__ void mail_writer(const BatchArgs& a, uint32_t* slots,
     out.op = op; out.prev_end = prev_end; out.ok = ok;
     if (kind == MAIL_BATCH) {
       out.p_ms = ms; out.p_ml = ml; out.p_off = off; out.cnt = m;
+      out.resolve_raw();
       out.flush();
       op = out.op; prev_end = out.prev_end; ok = out.ok;
     } else {   // MAIL_LAST

@@ -37,6 +37,8 @@ struct ParkOut {
   using VB = typename W::VB;
   static constexpr bool kUsesWindowRegs = false;
   static constexpr uint32_t kNoCheck = 1u << 16;  // flag in p_off: liblz4's _next_match path (no literal-capacity check)
+  static constexpr uint32_t kFinal = 1u << 17;    // flag in p_off (raw parking only): the entry is a finished sequence, not a raw hit
+  static constexpr bool kRawPark = false;         // the lean loop does liblz4's backward extension itself and parks finished sequences
 
   W& w;
   const uint8_t* src;
@@ -74,6 +76,35 @@ struct ParkOut {
     p_ml = W::writelane(p_ml, ml, cnt);
     p_off = W::writelane(p_off, offx, cnt);
     if (++cnt == 64u) flush();
+  }
+
+  // Raw parking (kRawPark policies): the lean loop parks the bare hit -- {hit position, forward length, offset} -- and liblz4's
+  // backward extension ("catch-up": while (ip > anchor && match > 0 && ip[-1] == match[-1]) ip--, match--) is done here, for the
+  // 64 parked hits at once, a lane each.  It changes neither where the finder continues (hit + forward length) nor the table, so
+  // it is output work.  anchor = end of the previous sequence; a hit AT the anchor is liblz4's _next_match path (kNoCheck).
+  // Entries of the exact path arrive finished (kFinal).
+  LZ4HIP_DEV void resolve_raw() {
+    if (cnt == 0u) return;
+    const VU j = w.lane();
+    const VB act = j < cnt;
+    const VB raw = act & ((p_off & kFinal) == 0u);
+    const VU endv = p_ms + p_ml;
+    const VU anchor = W::select(j == 0u, VU(prev_end), W::shfl_up1(endv));
+    const VU off = p_off & 0xFFFFu;
+    const VU mpos = p_ms - off;
+    const VU room = p_ms - anchor;
+    const VU maxback = W::vmin(room, mpos);
+    VU back = VU(0u);
+    VB go = raw & (maxback > 0u);
+    while (w.ballot(go)) {
+      const VU a = w.ld8(src, p_ms - 1u - back, go), b = w.ld8(src, mpos - 1u - back, go);
+      const VB eq = go & (a == b);
+      back = W::select(eq, back + 1u, back);
+      go = eq & (back < maxback);
+    }
+    p_ms = p_ms - back;
+    p_ml = p_ml + back;
+    p_off = W::select(raw, off | W::select(room == 0u, VU(kNoCheck), VU(0u)), p_off & ~kFinal);
   }
 
   // writes the parked sequences
@@ -175,6 +206,30 @@ struct ParkOut {
   }
 };
 
+// ParkOut with raw parking, in one wavefront: what the writer wavefront of the two-wave kernel does (kernels.hip MailOut +
+// mail_writer), runnable in the CPU lane simulator.
+template <class W>
+struct ParkOutRaw : ParkOut<W> {
+  using P = ParkOut<W>;
+  using VU = typename W::VU;
+  static constexpr bool kRawPark = true;
+  LZ4HIP_DEV ParkOutRaw(W& w_, const uint8_t* s, uint32_t n_, uint8_t* d, uint32_t cap_) : P(w_, s, n_, d, cap_) {}
+  LZ4HIP_DEV void park(uint32_t ms, uint32_t ml, uint32_t offx) {
+    P::p_ms = W::writelane(P::p_ms, ms, P::cnt);
+    P::p_ml = W::writelane(P::p_ml, ml, P::cnt);
+    P::p_off = W::writelane(P::p_off, offx, P::cnt);
+    if (++P::cnt == 64u) { P::resolve_raw(); P::flush(); }
+  }
+  LZ4HIP_DEV bool overlap_point() { return P::ok; }
+  LZ4HIP_DEV void seq(uint32_t lit, uint32_t mc, uint32_t offset, uint32_t anchor, bool check_lits, bool, VU) {
+    park(anchor + lit, mc + 4u, offset | (check_lits ? 0u : P::kNoCheck) | P::kFinal);
+  }
+  LZ4HIP_DEV uint32_t last(uint32_t anchor) {
+    P::resolve_raw();
+    return P::last(anchor);
+  }
+};
+
 // byU16 blocks (n < 65547).
 // Measured dead end, kept as a note (round 2, profiles/r02_compress_notes.txt): the block's recent 40 KB in a ring of 156 VGPRs the
 // compiler does not allocate (amdgpu_num_vgpr + VGPR-indexing mode with a wave-uniform slot index), so that the window, the row at
@@ -272,7 +327,8 @@ struct FastV2 {
       const VU fb = w.ldu32(src, j4 + mpos);
       const VU bidx = j + (mpos - k0);
       const VB bval = j + mpos >= VU(k0);
-      const VU bb = w.ldu8(src, W::select(bval, bidx, VU(0u)));
+      VU bb = VU(0u);
+      if constexpr (!OUT::kRawPark) bb = w.ldu8(src, W::select(bval, bidx, VU(0u)));   // (raw parking: the backward extension is output work)
       if (LZ4HIP_UNLIKELY(hpos + W::kPrefetchBytes > pf_end)) {
         if (pf_end < n) w.prefetch4k(src, pf_end, n);
         pf_end += W::kPrefetchBytes;
@@ -313,12 +369,16 @@ struct FastV2 {
       }
       w.sync();
       if (st) l_seq++;
-      // catch-up: equal bytes below the hit, down to lane 1 (= anchor) and position 0 of the candidate side
-      const uint64_t eqm = w.ballot(bval & ((x32 & 0xFFu) == bb));
-      const uint64_t range = ((1ull << k0) - 1ull) & ~1ull;      // lanes 1..k0-1
-      const uint64_t ne = (~eqm & range) | 1ull;
-      const uint32_t back = k0 - 1u - (63u - (uint32_t)clz64(ne));
-      out.park(hpos - back, cnt + back, (hpos - mpos) | (k0 == 1u ? OUT::kNoCheck : 0u));
+      if constexpr (OUT::kRawPark) {
+        out.park(hpos, cnt, hpos - mpos);
+      } else {
+        // catch-up: equal bytes below the hit, down to lane 1 (= anchor) and position 0 of the candidate side
+        const uint64_t eqm = w.ballot(bval & ((x32 & 0xFFu) == bb));
+        const uint64_t range = ((1ull << k0) - 1ull) & ~1ull;      // lanes 1..k0-1
+        const uint64_t ne = (~eqm & range) | 1ull;
+        const uint32_t back = k0 - 1u - (63u - (uint32_t)clz64(ne));
+        out.park(hpos - back, cnt + back, (hpos - mpos) | (k0 == 1u ? OUT::kNoCheck : 0u));
+      }
       ip = hpos + cnt;
       prev_fa = fa;
       prev_hpos = hpos;

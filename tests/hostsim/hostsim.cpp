@@ -73,6 +73,28 @@ int sim_compress_fast_v2(const uint8_t* src, int n, uint8_t* dst, int cap, uint6
   return (int)r;
 }
 
+// lean core with RAW parking (bare hits parked, liblz4's backward extension done 64 hits at a time at write time): the writer
+// wavefront's half of the two-wave kernel, in one wave
+int sim_compress_fast_v2raw(const uint8_t* src, int n, uint8_t* dst, int cap, uint64_t* stats4, uint64_t seed) {
+  if (n < 0 || (uint32_t)n > 0x7E000000u || cap < 0) return 0;
+  hostsim::WaveHost w;
+  if (seed) w.rng = seed;
+  w.bounds(src, (size_t)n, dst, (size_t)cap);
+  lz4hip::FastStats st{};
+  uint32_t r;
+  lz4hip::ParkOutRaw<hostsim::WaveHost> out(w, src, (uint32_t)n, dst, (uint32_t)cap);
+  if (n < 65547) {
+    lz4hip::FastV2<hostsim::WaveHost, lz4hip::ParkOutRaw<hostsim::WaveHost>> c(w, out, src, (uint32_t)n, &st);
+    r = c.run();
+  } else {
+    lz4hip::FastCore<hostsim::WaveHost, false, lz4hip::ParkOutRaw<hostsim::WaveHost>> c(w, out, src, (uint32_t)n, &st);
+    r = c.run();
+  }
+  if (stats4) { stats4[0] = st.steps; stats4[1] = st.slow_steps; stats4[2] = st.false_pos; stats4[3] = st.sequences; }
+  if (w.oob) return -1000;
+  return (int)r;
+}
+
 // lean core with the density probe of the adaptive scheme: -2 = left to the window-parallel core
 int sim_compress_fast_v2_probe(const uint8_t* src, int n, uint8_t* dst, int cap, uint32_t dense64) {
   if (n < 0 || (uint32_t)n > 0x7E000000u || cap < 0) return 0;

@@ -28,6 +28,8 @@ def load_sim():
     l.sim_compress_fast_ms.argtypes = [C.c_char_p, C.c_int, _u8p, C.c_int, C.POINTER(C.c_uint64), C.c_uint64]
     l.sim_compress_fast_v2.restype = C.c_int
     l.sim_compress_fast_v2.argtypes = [C.c_char_p, C.c_int, _u8p, C.c_int, C.POINTER(C.c_uint64), C.c_uint64]
+    l.sim_compress_fast_v2raw.restype = C.c_int
+    l.sim_compress_fast_v2raw.argtypes = [C.c_char_p, C.c_int, _u8p, C.c_int, C.POINTER(C.c_uint64), C.c_uint64]
     l.sim_compress_fast_probe.restype = C.c_int
     l.sim_compress_fast_probe.argtypes = [C.c_char_p, C.c_int, _u8p, C.c_int, C.c_uint32]
     l.sim_decompress.restype = C.c_int
@@ -40,10 +42,10 @@ def sim():
     return load_sim()
 
 
-def sim_compress(sim, v, cap, seed=0, ms=False, v2=False):
+def sim_compress(sim, v, cap, seed=0, ms=False, v2=False, raw=False):
     out = (C.c_uint8 * max(cap, 1))()
     st = (C.c_uint64 * 4)()
-    f = sim.sim_compress_fast_v2 if v2 else (sim.sim_compress_fast_ms if ms else sim.sim_compress_fast)
+    f = sim.sim_compress_fast_v2raw if raw else sim.sim_compress_fast_v2 if v2 else (sim.sim_compress_fast_ms if ms else sim.sim_compress_fast)
     r = f(bytes(v), len(v), out, cap, st, seed)
     return r, bytes(out[:max(r, 0)]), list(st)
 
@@ -136,6 +138,23 @@ def test_compress_v2_core_fuzz(sim, ref, O, corpus):
             seed = rng.getrandbits(63) | 1
             r, b, _ = sim_compress(sim, v, cap, seed=seed, v2=True)
             assert r == a[0] and (r <= 0 or b == a[1]), (len(v), cap, r, a[0], seed & 2)
+
+
+def test_compress_v2_raw_parking(sim, ref, O, corpus):
+    """the lean core parking bare hits, liblz4's backward extension done for 64 parked hits at once when they are written (what
+    the writer wavefront of the default GPU kernel does): same bytes, full and tight capacities"""
+    rng = random.Random(6)
+    for name, v in corpus.items():
+        r, b, _ = sim_compress(sim, v, ref.compress_bound(len(v)), raw=True)
+        assert b == ref.compress_fast(v), name
+    for v in rnd_inputs(O, corpus, 29, 500):
+        full = ref.compress_bound(len(v))
+        er, _ = ref.compress_fast_raw(v, full)
+        for cap in (full, max(0, er + rng.choice([-1, 0, 1, 2, -5, 5, -20, 20])), rng.randrange(0, full + 1)):
+            a = ref.compress_fast_raw(v, cap)
+            seed = rng.getrandbits(63) | 1
+            r, b, _ = sim_compress(sim, v, cap, seed=seed, raw=True)
+            assert r == a[0] and (r <= 0 or b == a[1]), (len(v), cap, r, a[0])
 
 
 def test_v2_density_probe_routes_blocks(sim, ref, O, corpus):

@@ -44,7 +44,8 @@ for i in range(cases):
     for _ in range(2):
         seed = rng.getrandbits(63) | 1
         r, b, st = T.sim_compress(sim, v, full, seed=seed, v2=True)
-        if r != want[0] or b != want[1]:
+        r2, b2, _ = T.sim_compress(sim, v, full, seed=seed, raw=True)
+        if r != want[0] or b != want[1] or r2 != want[0] or b2 != want[1]:
             bad += 1
             print("MISMATCH case %d type %d n %d seed %d" % (i, t, len(v), seed), flush=True)
 print("hostsim lean-core fuzz: %d cases x 2 lane orders, %d mismatches" % (cases, bad))
