@@ -314,59 +314,85 @@ struct FastV2 {
       const VU newe = (pos << 16) | fp;
       const uint64_t tmask = w.ballot((e & 0xFFFFu) == fp) & ~1ull;
       if (LZ4HIP_UNLIKELY(tmask == 0)) { if (st) st->false_pos++; break; }   // no tentative hit in 63 probes (nothing committed yet; profiling: counted in false_pos)
-      const uint32_t k0 = (uint32_t)ctz64(tmask);
-      LZ4HIP_PHASE2(1, k0);                 // t[1]: table read + ballot
-      const uint64_t inm = (2ull << k0) - 1ull;                  // lanes 0..k0 commit
-      const VU old = w.template lds_max<true>(h, newe, w.lanes(inm));
-      const uint32_t hpos = ip + k0 - 1u;
-      const uint32_t mpos = w.bcast(e, (int)k0) >> 16;
-      // candidate fetch: forward 64 x 4 bytes from both positions; backward: lane l (1..k0-1) holds src[ip+l-1] in its
-      // window word and needs src[mpos-k0+l] -- one contiguous byte load
-      // (32 or 16 lanes instead of 64 -- fewer candidate lines per fetch -- measured no different: 59.2 / 59.2 / 59.1 GB/s)
-      const VU fa = w.ldu32(src, j4 + hpos);
-      const VU fb = w.ldu32(src, j4 + mpos);
-      const VU bidx = j + (mpos - k0);
-      const VB bval = j + mpos >= VU(k0);
-      VU bb = VU(0u);
-      if constexpr (!OUT::kRawPark) bb = w.ldu8(src, W::select(bval, bidx, VU(0u)));   // (raw parking: the backward extension is output work)
-      if (LZ4HIP_UNLIKELY(hpos + W::kPrefetchBytes > pf_end)) {
-        if (pf_end < n) w.prefetch4k(src, pf_end, n);
-        pf_end += W::kPrefetchBytes;
-      }
-      LZ4HIP_PHASE2(2, mpos);               // t[2]: commit + fetch issue
-      const uint64_t det = w.ballot(old != e) & inm;
-      LZ4HIP_PHASE2(3, (uint32_t)det);      // t[3]: atomic result
-      const VU fx = fa ^ fb;
-      const uint64_t dm = w.ballot(fx != 0u);
-      uint32_t cnt = 0;
-      if (LZ4HIP_LIKELY(dm != 0)) {
-        const int f = ctz64(dm);
-        cnt = 4u * (uint32_t)f + ((uint32_t)ctz32(w.bcast(fx, f)) >> 3);
-      }
-      LZ4HIP_PHASE2(4, cnt);                // t[4]: candidate fetch wait + forward count
-      // A bucket shared by two committing lanes (det: a lane got back another lane's entry instead of the one it had read) only
-      // matters if liblz4, which inserts and looks up position by position, would have decided differently: the later lane would
-      // have seen the earlier lane's entry instead of the old one.  For a lane below the hit that changes nothing unless the two
-      // fingerprints agree (its old entry was no tentative hit, or it would be the hit lane); for the hit lane it always does
-      // (the entry that made it the hit is gone).  The atomic max leaves the bucket holding the later position either way -- the
-      // state liblz4 ends up with.  So: exactly one lane with a foreign entry (= exactly two lanes in that bucket), not the hit
-      // lane's bucket, fingerprints differ -> carry on.  Anything else takes the exact path.
-      bool bad = cnt < 4u;                                       // false positive or a match of >= 256 bytes
-      if (LZ4HIP_UNLIKELY(det != 0)) {
-        if (det & (det - 1u)) {
-          bad = true;
-        } else {
-          const int dl = ctz64(det);
-          const uint32_t od = w.bcast(old, dl), hd = w.bcast(h, dl), fd = w.bcast(fp, dl);
-          bad = bad || hd == w.bcast(h, (int)k0) || (od & 0xFFFFu) == fd;
+      LZ4HIP_PHASE2(1, (uint32_t)tmask);    // t[1]: table read + ballot
+      // The hit is the first tentative lane that survives: a tentative lane is ruled out, and the search goes on to the next one
+      // in the same window (raw-parking policies only; the others take the exact path as before), when
+      //   K  an earlier committing lane shares its bucket with a different fingerprint -- liblz4, inserting position by position,
+      //      would have found that lane's entry there, not the one that made this lane tentative;
+      //   F  its candidate's first 4 bytes differ (a fingerprint collision).
+      // Either way the lanes up to it are inserted positions (committed), exactly as in liblz4's continuing search.
+      uint64_t tm = tmask;
+      uint32_t lo = 0;                       // lanes below lo are committed
+      uint32_t k0, hpos, mpos, cnt;
+      uint64_t upto;
+      VU fa, bb = VU(0u);
+      VB bval = VB(false);
+      bool fail = false;
+      for (;;) {
+        k0 = (uint32_t)ctz64(tm);
+        upto = (2ull << k0) - 1ull;                               // lanes 0..k0
+        const uint64_t inm = upto & ~((1ull << lo) - 1ull);       // lanes lo..k0 commit now
+        const VU old = w.template lds_max<true>(h, newe, w.lanes(inm));
+        hpos = ip + k0 - 1u;
+        mpos = w.bcast(e, (int)k0) >> 16;
+        // candidate fetch: forward 64 x 4 bytes from both positions; backward (policies that extend backwards here): lane l
+        // (1..k0-1) holds src[ip+l-1] in its window word and needs src[mpos-k0+l] -- one contiguous byte load
+        // (32 or 16 lanes instead of 64 -- fewer candidate lines per fetch -- measured no different: 59.2 / 59.2 / 59.1 GB/s)
+        fa = w.ldu32(src, j4 + hpos);
+        const VU fb = w.ldu32(src, j4 + mpos);
+        if constexpr (!OUT::kRawPark) {   // (raw parking: the backward extension is output work)
+          const VU bidx = j + (mpos - k0);
+          bval = j + mpos >= VU(k0);
+          bb = w.ldu8(src, W::select(bval, bidx, VU(0u)));
         }
-      }
-      if (LZ4HIP_UNLIKELY(bad)) {                                // undo, exact path
+        if (LZ4HIP_UNLIKELY(hpos + W::kPrefetchBytes > pf_end)) {
+          if (pf_end < n) w.prefetch4k(src, pf_end, n);
+          pf_end += W::kPrefetchBytes;
+        }
+        LZ4HIP_PHASE2(2, mpos);               // t[2]: commit + fetch issue
+        const uint64_t det = w.ballot(old != e) & inm;
+        LZ4HIP_PHASE2(3, (uint32_t)det);      // t[3]: atomic result
+        const VU fx = fa ^ fb;
+        const uint64_t dm = w.ballot(fx != 0u);
+        cnt = 0;
+        if (LZ4HIP_LIKELY(dm != 0)) {
+          const int f = ctz64(dm);
+          cnt = 4u * (uint32_t)f + ((uint32_t)ctz32(w.bcast(fx, f)) >> 3);
+        }
+        LZ4HIP_PHASE2(4, cnt);                // t[4]: candidate fetch wait + forward count
+        // A bucket shared by two committing lanes (det: a lane got back another lane's entry instead of the one it had read) only
+        // matters if liblz4 would have decided differently: the later lane would have seen the earlier lane's entry instead of
+        // the old one.  For a lane below the hit that changes nothing unless the two fingerprints agree (its old entry was no
+        // tentative hit, or it would be the hit lane); for the hit lane it always does (case K).  The atomic max leaves the bucket
+        // holding the later position either way -- the state liblz4 ends up with.  Exactly one lane with a foreign entry means
+        // exactly one more lane in its bucket is new to it (lanes committed by an earlier trip of this loop are simply what it
+        // should see); two or more: exact path.
+        bool bad = dm == 0;                                        // a match of >= 256 bytes: exact path
+        bool ruled_out = dm != 0 && cnt < 4u;                      // case F
+        if (LZ4HIP_UNLIKELY(det != 0)) {
+          if (det & (det - 1u)) {
+            bad = true;
+          } else {
+            const int dl = ctz64(det);
+            const uint32_t od = w.bcast(old, dl), hd = w.bcast(h, dl), fd = w.bcast(fp, dl);
+            if ((od & 0xFFFFu) == fd) bad = true;
+            else if (hd == w.bcast(h, (int)k0)) ruled_out = true;  // case K
+          }
+        }
+        if (LZ4HIP_LIKELY(!bad && !ruled_out)) break;
+        if (OUT::kRawPark && !bad) {
+          tm &= ~upto;
+          lo = k0 + 1u;
+          if (tm) continue;                                        // the next tentative lane of this window
+        }
+        // undo everything this step committed, exact path
         if (st) l_slow++;
-        w.template lds_wr<true>(h, e, w.lanes(inm));
+        w.template lds_wr<true>(h, e, w.lanes(upto));
         w.sync();
+        fail = true;
         break;
       }
+      if (LZ4HIP_UNLIKELY(fail)) break;
       w.sync();
       if (st) l_seq++;
       if constexpr (OUT::kRawPark) {
