@@ -408,9 +408,9 @@ __global__ __launch_bounds__(64) void compress_fast_prof_kernel(BatchArgs a, uin
     WaveDev w(table);
     DirectOut<WaveDev> out(w, s, (uint32_t)n, d, (uint32_t)cap);
     if constexpr (MS == 3) {
-      ParkOut<WaveDev> po(w, s, (uint32_t)n, d, (uint32_t)cap);
-      if (n < 65547) { FastV2<WaveDev> c(w, po, s, (uint32_t)n, &st); r = c.run(); }
-      else { FastCore<WaveDev, false, ParkOut<WaveDev>> c(w, po, s, (uint32_t)n, &st); r = c.run(); }
+      ParkOutRaw<WaveDev> po(w, s, (uint32_t)n, d, (uint32_t)cap);   // (the finder of the default kernel parks raw hits; here one wave also writes them)
+      if (n < 65547) { FastV2<WaveDev, ParkOutRaw<WaveDev>> c(w, po, s, (uint32_t)n, &st); r = c.run(); }
+      else { FastCore<WaveDev, false, ParkOutRaw<WaveDev>> c(w, po, s, (uint32_t)n, &st); r = c.run(); }
     } else if constexpr (MS == 1) {
       if (n < 65547) { FastCoreMS<WaveDev, true> c(w, out, s, (uint32_t)n, &st); r = c.run(); }
       else { FastCoreMS<WaveDev, false> c(w, out, s, (uint32_t)n, &st); r = c.run(); }

@@ -313,7 +313,10 @@ struct FastV2 {
       const VU e = w.template lds_rdu<true>(h);
       const VU newe = (pos << 16) | fp;
       const uint64_t tmask = w.ballot((e & 0xFFFFu) == fp) & ~1ull;
-      if (LZ4HIP_UNLIKELY(tmask == 0)) { if (st) st->false_pos++; break; }   // no tentative hit in 63 probes (nothing committed yet; profiling: counted in false_pos)
+#ifndef LZ4HIP_COUNT_CAT
+#define LZ4HIP_COUNT_CAT 5   /* profiling builds: which way out of the lean loop FastStats::false_pos counts (5 = no hit in the window) */
+#endif
+      if (LZ4HIP_UNLIKELY(tmask == 0)) { if (st && LZ4HIP_COUNT_CAT == 5) st->false_pos++; break; }   // no tentative hit in 63 probes (nothing committed yet; profiling: counted in false_pos)
       LZ4HIP_PHASE2(1, (uint32_t)tmask);    // t[1]: table read + ballot
       // The hit is the first tentative lane that survives: a tentative lane is ruled out, and the search goes on to the next one
       // in the same window (raw-parking policies only; the others take the exact path as before), when
@@ -372,13 +375,16 @@ struct FastV2 {
         if (LZ4HIP_UNLIKELY(det != 0)) {
           if (det & (det - 1u)) {
             bad = true;
+            if (st && LZ4HIP_COUNT_CAT == 1) st->false_pos++;
           } else {
             const int dl = ctz64(det);
             const uint32_t od = w.bcast(old, dl), hd = w.bcast(h, dl), fd = w.bcast(fp, dl);
-            if ((od & 0xFFFFu) == fd) bad = true;
+            if ((od & 0xFFFFu) == fd) { bad = true; if (st && LZ4HIP_COUNT_CAT == 2) st->false_pos++; }
             else if (hd == w.bcast(h, (int)k0)) ruled_out = true;  // case K
           }
         }
+        if (st && LZ4HIP_COUNT_CAT == 3 && dm == 0) st->false_pos++;
+        if (st && LZ4HIP_COUNT_CAT == 4 && !bad && ruled_out && (tm & ~upto) == 0) st->false_pos++;
         if (LZ4HIP_LIKELY(!bad && !ruled_out)) break;
         if (OUT::kRawPark && !bad) {
           tm &= ~upto;
