@@ -6,7 +6,8 @@
 //                          finder loop + sequences parked in lanes, 64 at a time), lz4_fast_core.h (one sequence per step, written
 //                          as found) and lz4_fast_ms_core.h (every sequence of a 64-position window per step).  The default,
 //                          v2w, adds a WRITER wavefront per finder (no LDS needed) that takes the parked batches through a ring
-//                          in global memory and does all the output.
+//                          in global memory and does all the output, and three more finder/writer pairs per CU whose tables
+//                          live in global memory.
 //                          Bound: the serial parse chain of a wavefront x 5 chains per CU (roofline: HBM, 1+1/ratio B/B).
 //   decode_kernel<GL, SAFE, PIPE, STAGE>
 //                        : GL lanes per block, 64/GL blocks per wavefront, algorithm in lz4_decode_core.h; PIPE = software-
@@ -188,9 +189,9 @@ __device__ __forceinline__ void mail_publish(uint32_t* p, uint32_t v) {   // eve
 }
 
 // finder side: the Out policy of FastV2 / FastCore (same parking as ParkOut; a full batch goes to the partner instead of memory)
+template <class W>
 struct MailOut {
-  using W = WaveDev;
-  using VU = W::VU;
+  using VU = typename W::VU;
   static constexpr bool kUsesWindowRegs = false;
   static constexpr uint32_t kNoCheck = ParkOut<W>::kNoCheck, kFinal = ParkOut<W>::kFinal;
   static constexpr bool kRawPark = true;   // the lean loop parks bare hits: liblz4's backward extension is the writer's work too (ParkOut::resolve_raw)
@@ -283,21 +284,26 @@ __device__ __forceinline__ void mail_writer(const BatchArgs& a, uint32_t* slots,
   }
 }
 
-__global__ __launch_bounds__(64 * 2 * WAVES_PER_CU) void compress_fast_v2w_cu_kernel(BatchArgs a, uint32_t* q, uint32_t* routed, uint32_t dense64, uint32_t* mail_ctr, uint32_t* mail_slots) {
-  __shared__ __attribute__((aligned(16))) uint64_t tables[WAVES_PER_CU][LZ4HIP_TABLE_U64];
-  const uint32_t wv = threadIdx.x >> 6;
-  const uint32_t pair = blockIdx.x * WAVES_PER_CU + (wv < WAVES_PER_CU ? wv : wv - WAVES_PER_CU);
-  uint32_t* ctr = mail_ctr + 2u * pair;
-  uint32_t* slots = mail_slots + (size_t)pair * (MAIL_RING * MAIL_SLOT_WORDS);
-  if (wv >= WAVES_PER_CU) { mail_writer(a, slots, ctr); return; }
-  uint64_t* table = tables[wv];
-  WaveDev w(table);
+// LZ4HIP_GF finder/writer pairs per CU beyond the five LDS ones keep their tables in global memory (wave_dev.h WaveDevG): LDS
+// limits a CU to five tables, not to five chains.  A global-table chain runs at about a seventh of an LDS chain's speed (its
+// table read and its commit are L2 round trips), so three of them -- what a 1024-thread workgroup has room for -- are worth
+// +6 %: 65536 x 64 KiB blocks 54.0 -> 50.8 ms (GF = 1 / 2 / 3: 54.8 / 52.4 / 50.8).  Same algorithm sources, same bytes; which
+// kind of chain takes a block is decided by the queue.
+#ifndef LZ4HIP_GF
+#define LZ4HIP_GF 3
+#endif
+constexpr uint32_t GLOBAL_FINDERS = LZ4HIP_GF;
+constexpr uint32_t PAIRS_PER_CU = WAVES_PER_CU + GLOBAL_FINDERS;
+
+// one finder: draws blocks from the queue until it is empty (W = WaveDev: table in LDS; WaveDevG: table in global memory)
+template <class W>
+__device__ __forceinline__ void mail_finder(const BatchArgs& a, uint32_t* q, uint32_t* routed, uint32_t dense64, W& w, uint32_t* slots, uint32_t* ctr) {
   uint32_t head = 0, tail_seen = 0;
   for (;;) {
     uint32_t b = 0;
     if (__lane_id() == 0) b = atomicAdd(q, 1u);
     b = __builtin_amdgcn_readfirstlane(b);
-    MailOut out(w, slots, ctr, head);
+    MailOut<W> out(w, slots, ctr, head);
     out.tail_seen = tail_seen;
     if (b >= a.n) { out.post(MAIL_EXIT, 0u, 0u); return; }
     out.b = b;
@@ -307,10 +313,10 @@ __global__ __launch_bounds__(64 * 2 * WAVES_PER_CU) void compress_fast_v2w_cu_ke
       const uint8_t* s = uniform_ptr(a.src + a.src_off[b]);
       out.dense64 = routed ? dense64 : 0u;
       if (n < 65547) {
-        FastV2<WaveDev, MailOut> c(w, out, s, (uint32_t)n);
+        FastV2<W, MailOut<W>> c(w, out, s, (uint32_t)n);
         (void)c.run();
       } else {
-        FastCore<WaveDev, false, MailOut> c(w, out, s, (uint32_t)n);
+        FastCore<W, false, MailOut<W>> c(w, out, s, (uint32_t)n);
         (void)c.run();
       }
       if (out.bail) {
@@ -321,24 +327,50 @@ __global__ __launch_bounds__(64 * 2 * WAVES_PER_CU) void compress_fast_v2w_cu_ke
       if (__lane_id() == 0) a.out[b] = 0;
     }
     head = out.head; tail_seen = out.tail_seen;
-    WaveDev::sync();  // the table is reused
+    W::sync();  // the table is reused
   }
 }
-// scratch words the two-wave kernel needs after the three queue words: counters of every pair, then (256-word aligned) the rings
+
+// wavefronts of a workgroup: [0, 5) LDS finders, [5, 10) their writers, [10, 10 + GF) global-table finders, then their writers
+__global__ __launch_bounds__(64 * 2 * PAIRS_PER_CU) void compress_fast_v2w_cu_kernel(BatchArgs a, uint32_t* q, uint32_t* routed, uint32_t dense64, uint32_t* mail_ctr, uint32_t* mail_slots, uint64_t* gtables) {
+  __shared__ __attribute__((aligned(16))) uint64_t tables[WAVES_PER_CU][LZ4HIP_TABLE_U64];
+  const uint32_t wv = threadIdx.x >> 6;
+  const bool lds_side = wv < 2u * WAVES_PER_CU;
+  const uint32_t k = lds_side ? wv : wv - 2u * WAVES_PER_CU;                 // index within its side
+  const uint32_t per_side = lds_side ? WAVES_PER_CU : GLOBAL_FINDERS;
+  const bool writer = k >= per_side;
+  const uint32_t fi = (lds_side ? 0u : WAVES_PER_CU) + (writer ? k - per_side : k);   // finder index on this CU
+  const uint32_t pair = blockIdx.x * PAIRS_PER_CU + fi;
+  uint32_t* ctr = mail_ctr + 2u * pair;
+  uint32_t* slots = mail_slots + (size_t)pair * (MAIL_RING * MAIL_SLOT_WORDS);
+  if (writer) { mail_writer(a, slots, ctr); return; }
+  if (lds_side) {
+    WaveDev w(tables[k]);
+    mail_finder(a, q, routed, dense64, w, slots, ctr);
+  } else {
+    if constexpr (GLOBAL_FINDERS > 0) {
+      WaveDevG w(gtables + ((size_t)blockIdx.x * GLOBAL_FINDERS + k) * 4096u);
+      mail_finder(a, q, routed, dense64, w, slots, ctr);
+    }
+  }
+}
+// scratch words the two-wave kernel needs after the three queue words: counters of every pair, then (1 KB aligned) the rings,
+// then (with global-table finders) their 32 KB tables
 size_t compress_fast_v2w_scratch_words(uint32_t n_cus) {
-  const size_t pairs = (size_t)n_cus * WAVES_PER_CU;
-  return 2u * pairs + 256u + pairs * (MAIL_RING * MAIL_SLOT_WORDS);
+  const size_t pairs = (size_t)n_cus * PAIRS_PER_CU;
+  return 2u * pairs + 256u + pairs * (MAIL_RING * MAIL_SLOT_WORDS) + (size_t)n_cus * GLOBAL_FINDERS * 8192u;
 }
 int launch_compress_fast_v2w(const BatchArgs& a, uint32_t* q, uint32_t* routed, uint32_t dense64, uint32_t n_cus, uint32_t* mail, void* stream) {
   if (a.n == 0) return 0;
-  const size_t pairs = (size_t)n_cus * WAVES_PER_CU;
+  const size_t pairs = (size_t)n_cus * PAIRS_PER_CU;
   hipError_t e = hipMemsetAsync(q, 0, 3 * sizeof(uint32_t), (hipStream_t)stream);
   if (e != hipSuccess) return (int)e;
   e = hipMemsetAsync(mail, 0, 2u * pairs * sizeof(uint32_t), (hipStream_t)stream);
   if (e != hipSuccess) return (int)e;
   uint32_t* slots = (uint32_t*)(((uintptr_t)(mail + 2u * pairs) + 1023u) & ~(uintptr_t)1023u);
-  const uint32_t wgs = (a.n + WAVES_PER_CU - 1u) / WAVES_PER_CU;
-  hipLaunchKernelGGL(compress_fast_v2w_cu_kernel, dim3(wgs < n_cus ? wgs : n_cus), dim3(64 * 2 * WAVES_PER_CU), 0, (hipStream_t)stream, a, q, routed, dense64, mail, slots);
+  uint64_t* gtables = (uint64_t*)(slots + pairs * (MAIL_RING * MAIL_SLOT_WORDS));
+  const uint32_t wgs = (a.n + PAIRS_PER_CU - 1u) / PAIRS_PER_CU;
+  hipLaunchKernelGGL(compress_fast_v2w_cu_kernel, dim3(wgs < n_cus ? wgs : n_cus), dim3(64 * 2 * PAIRS_PER_CU), 0, (hipStream_t)stream, a, q, routed, dense64, mail, slots, gtables);
   return (int)hipGetLastError();
 }
 
