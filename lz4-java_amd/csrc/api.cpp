@@ -73,7 +73,7 @@ std::atomic<int> g_decode_stage{-1};  // "decode_stage": 1 = LDS output staging 
 std::atomic<int> g_decode_pipe{-1};   // "decode_pipe": 1/0 = pipelined interior loop on/off, -1 = kernel default
 
 // lz4hip_set_option "compress_core": 5 = adaptive two-pass, lean core with a writer wavefront per chain + window-parallel core
-// (default); 4 = the same with every wavefront writing its own sequences (round-2 default before the writers); 3 = lean core only
+// (default); 6 = the same with three more chains per CU whose tables live in global memory (+6 %, 7x the memory traffic); 4 = the same with every wavefront writing its own sequences (round-2 default before the writers); 3 = lean core only
 // (lz4_fast_v2_core.h); 2 = adaptive, one-sequence-per-step core + window-parallel core; 1 = window-parallel core only
 // (lz4_fast_ms_core.h); 0 = one-sequence-per-step core only (lz4_fast_core.h).  "compress_switch" = bytes per sequence below
 // which a block counts as dense and goes to the window-parallel core (probe: sequences 32..95 of the block)
@@ -132,7 +132,7 @@ int launch_fast(const lz4hip::BatchArgs& a, hipStream_t st) {
   uint32_t* scratch = nullptr;
   const uint32_t cus = cu_count();
   const int core = g_compress_core.load(std::memory_order_relaxed);
-  const size_t mail_words = core >= 5 ? lz4hip::compress_fast_v2w_scratch_words(cus) : 0u;   // rings of the finder/writer pairs
+  const size_t mail_words = core == 5 ? lz4hip::compress_fast_v2w_scratch_words(cus) : (core >= 6 ? lz4hip::compress_fast_v2wg_scratch_words(cus) : 0u);   // rings of the finder/writer pairs (+ global tables)
   hipError_t e = hipMallocAsync((void**)&scratch, (3 + (size_t)a.n + mail_words) * sizeof(uint32_t), st);
   if (e != hipSuccess) return (int)e;
   const uint32_t dense64 = 64u * (uint32_t)g_compress_switch.load(std::memory_order_relaxed);
@@ -149,8 +149,12 @@ int launch_fast(const lz4hip::BatchArgs& a, hipStream_t st) {
       le = lz4hip::launch_compress_fast_v2(a, scratch, scratch + 3, dense64, cus, st);
       if (le == 0) le = lz4hip::launch_compress_fast_ms(a, scratch, scratch + 3, false, cus, st);
       break;
-    default:   // 5: the lean core with a writer wavefront per chain, adaptive
+    case 5:    // the lean core with a writer wavefront per chain, adaptive (the default)
       le = lz4hip::launch_compress_fast_v2w(a, scratch, scratch + 3, dense64, cus, scratch + 3 + a.n, st);
+      if (le == 0) le = lz4hip::launch_compress_fast_ms(a, scratch, scratch + 3, false, cus, st);
+      break;
+    default:   // 6: the same plus three chains per CU with their tables in global memory
+      le = lz4hip::launch_compress_fast_v2wg(a, scratch, scratch + 3, dense64, cus, scratch + 3 + a.n, st);
       if (le == 0) le = lz4hip::launch_compress_fast_ms(a, scratch, scratch + 3, false, cus, st);
       break;
   }
@@ -750,7 +754,7 @@ int lz4hip_set_option(const char* name, int value) {
     return LZ4HIP_OK;
   }
   if (name && strcmp(name, "compress_core") == 0) {
-    if (value < 0 || value > 5) return fail(LZ4HIP_E_ARG, "compress_core must be 0..5");
+    if (value < 0 || value > 6) return fail(LZ4HIP_E_ARG, "compress_core must be 0..6");
     g_compress_core = value;
     return LZ4HIP_OK;
   }

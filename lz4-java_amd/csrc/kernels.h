@@ -25,6 +25,9 @@ int launch_compress_fast_v2(const BatchArgs& a, uint32_t* q, uint32_t* routed, u
 // the same with a writer wavefront per chain (`mail`: compress_fast_v2w_scratch_words(n_cus) words of device scratch)
 size_t compress_fast_v2w_scratch_words(uint32_t n_cus);
 int launch_compress_fast_v2w(const BatchArgs& a, uint32_t* q, uint32_t* routed, uint32_t dense64, uint32_t n_cus, uint32_t* mail, void* stream);
+// and with three more finder/writer pairs per CU whose tables live in global memory (+6 %, 7x the memory traffic: not the default)
+size_t compress_fast_v2wg_scratch_words(uint32_t n_cus);
+int launch_compress_fast_v2wg(const BatchArgs& a, uint32_t* q, uint32_t* routed, uint32_t dense64, uint32_t n_cus, uint32_t* mail, void* stream);
 int launch_compress_fast(const BatchArgs& a, uint32_t* q, uint32_t* routed, uint32_t dense64, uint32_t n_cus, void* stream);
 int launch_compress_fast_ms(const BatchArgs& a, uint32_t* q, const uint32_t* routed, bool first, uint32_t n_cus, void* stream);
 #ifdef LZ4HIP_DEV_TOOLS

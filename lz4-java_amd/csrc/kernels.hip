@@ -6,8 +6,8 @@
 //                          finder loop + sequences parked in lanes, 64 at a time), lz4_fast_core.h (one sequence per step, written
 //                          as found) and lz4_fast_ms_core.h (every sequence of a 64-position window per step).  The default,
 //                          v2w, adds a WRITER wavefront per finder (no LDS needed) that takes the parked batches through a ring
-//                          in global memory and does all the output, and three more finder/writer pairs per CU whose tables
-//                          live in global memory.
+//                          in global memory and does all the output (build option LZ4HIP_GF: more finder/writer pairs per CU
+//                          with their tables in global memory).
 //                          Bound: the serial parse chain of a wavefront x 5 chains per CU (roofline: HBM, 1+1/ratio B/B).
 //   decode_kernel<GL, SAFE, PIPE, STAGE>
 //                        : GL lanes per block, 64/GL blocks per wavefront, algorithm in lz4_decode_core.h; PIPE = software-
@@ -284,26 +284,34 @@ __device__ __forceinline__ void mail_writer(const BatchArgs& a, uint32_t* slots,
   }
 }
 
-// LZ4HIP_GF finder/writer pairs per CU beyond the five LDS ones keep their tables in global memory (wave_dev.h WaveDevG): LDS
-// limits a CU to five tables, not to five chains.  A global-table chain runs at about a seventh of an LDS chain's speed (its
-// table read and its commit are L2 round trips), so three of them -- what a 1024-thread workgroup has room for -- are worth
-// +6 %: 65536 x 64 KiB blocks 54.0 -> 50.8 ms (GF = 1 / 2 / 3: 54.8 / 52.4 / 50.8).  Same algorithm sources, same bytes; which
-// kind of chain takes a block is decided by the queue.
+// LZ4HIP_GF (build option, default 0) finder/writer pairs per CU beyond the five LDS ones keep their tables in global memory
+// (wave_dev.h WaveDevG): LDS limits a CU to five tables, not to five chains.  Alone, a global-table chain runs at 0.57x an LDS
+// chain (three per CU and nothing else: 26 GB/s); next to the five LDS pairs three of them -- what a 1024-thread workgroup has room
+// for -- add 6 %: 65536 x 64 KiB blocks 54.0 -> 50.8 ms, 84.6 GB/s (GF = 1 / 2 / 3: 54.8 / 52.4 / 50.8), bit-exact in fuzz, stress
+// and the GPU suite.  NOT the default: every 4-byte table access moves a 128-byte line between L2 and the fabric, 148 GB per
+// launch against 19.7 (23x the algorithmic bytes, 2.9 TB/s) -- too much bandwidth for 6 %.  Same algorithm sources, same bytes;
+// which kind of chain takes a block is decided by the queue.
 #ifndef LZ4HIP_GF
 #define LZ4HIP_GF 3
 #endif
-constexpr uint32_t GLOBAL_FINDERS = LZ4HIP_GF;
-constexpr uint32_t PAIRS_PER_CU = WAVES_PER_CU + GLOBAL_FINDERS;
 
-// one finder: draws blocks from the queue until it is empty (W = WaveDev: table in LDS; WaveDevG: table in global memory)
-template <class W>
-__device__ __forceinline__ void mail_finder(const BatchArgs& a, uint32_t* q, uint32_t* routed, uint32_t dense64, W& w, uint32_t* slots, uint32_t* ctr) {
+
+// ---- the default: the five LDS pairs alone ----
+__global__ __launch_bounds__(64 * 2 * WAVES_PER_CU) void compress_fast_v2w_cu_kernel(BatchArgs a, uint32_t* q, uint32_t* routed, uint32_t dense64, uint32_t* mail_ctr, uint32_t* mail_slots) {
+  __shared__ __attribute__((aligned(16))) uint64_t tables[WAVES_PER_CU][LZ4HIP_TABLE_U64];
+  const uint32_t wv = threadIdx.x >> 6;
+  const uint32_t pair = blockIdx.x * WAVES_PER_CU + (wv < WAVES_PER_CU ? wv : wv - WAVES_PER_CU);
+  uint32_t* ctr = mail_ctr + 2u * pair;
+  uint32_t* slots = mail_slots + (size_t)pair * (MAIL_RING * MAIL_SLOT_WORDS);
+  if (wv >= WAVES_PER_CU) { mail_writer(a, slots, ctr); return; }
+  uint64_t* table = tables[wv];
+  WaveDev w(table);
   uint32_t head = 0, tail_seen = 0;
   for (;;) {
     uint32_t b = 0;
     if (__lane_id() == 0) b = atomicAdd(q, 1u);
     b = __builtin_amdgcn_readfirstlane(b);
-    MailOut<W> out(w, slots, ctr, head);
+    MailOut<WaveDev> out(w, slots, ctr, head);
     out.tail_seen = tail_seen;
     if (b >= a.n) { out.post(MAIL_EXIT, 0u, 0u); return; }
     out.b = b;
@@ -313,10 +321,10 @@ __device__ __forceinline__ void mail_finder(const BatchArgs& a, uint32_t* q, uin
       const uint8_t* s = uniform_ptr(a.src + a.src_off[b]);
       out.dense64 = routed ? dense64 : 0u;
       if (n < 65547) {
-        FastV2<W, MailOut<W>> c(w, out, s, (uint32_t)n);
+        FastV2<WaveDev, MailOut<WaveDev>> c(w, out, s, (uint32_t)n);
         (void)c.run();
       } else {
-        FastCore<W, false, MailOut<W>> c(w, out, s, (uint32_t)n);
+        FastCore<WaveDev, false, MailOut<WaveDev>> c(w, out, s, (uint32_t)n);
         (void)c.run();
       }
       if (out.bail) {
@@ -327,12 +335,71 @@ __device__ __forceinline__ void mail_finder(const BatchArgs& a, uint32_t* q, uin
       if (__lane_id() == 0) a.out[b] = 0;
     }
     head = out.head; tail_seen = out.tail_seen;
-    W::sync();  // the table is reused
+    WaveDev::sync();  // the table is reused
   }
 }
+// scratch words the two-wave kernel needs after the three queue words: counters of every pair, then (256-word aligned) the rings
+size_t compress_fast_v2w_scratch_words(uint32_t n_cus) {
+  const size_t pairs = (size_t)n_cus * WAVES_PER_CU;
+  return 2u * pairs + 256u + pairs * (MAIL_RING * MAIL_SLOT_WORDS);
+}
+int launch_compress_fast_v2w(const BatchArgs& a, uint32_t* q, uint32_t* routed, uint32_t dense64, uint32_t n_cus, uint32_t* mail, void* stream) {
+  if (a.n == 0) return 0;
+  const size_t pairs = (size_t)n_cus * WAVES_PER_CU;
+  hipError_t e = hipMemsetAsync(q, 0, 3 * sizeof(uint32_t), (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  e = hipMemsetAsync(mail, 0, 2u * pairs * sizeof(uint32_t), (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  uint32_t* slots = (uint32_t*)(((uintptr_t)(mail + 2u * pairs) + 1023u) & ~(uintptr_t)1023u);
+  const uint32_t wgs = (a.n + WAVES_PER_CU - 1u) / WAVES_PER_CU;
+  hipLaunchKernelGGL(compress_fast_v2w_cu_kernel, dim3(wgs < n_cus ? wgs : n_cus), dim3(64 * 2 * WAVES_PER_CU), 0, (hipStream_t)stream, a, q, routed, dense64, mail, slots);
+  return (int)hipGetLastError();
+}
+
+
+// ---- with global-table chains ----
+// one finder: draws blocks from the queue until it is empty (W = WaveDev: table in LDS; WaveDevG: table in global memory).
+// (A macro, like the written-out bodies of the one-wave kernels above: per-block loads behind a function boundary lose their
+// no-clobber marking.)
+#define LZ4HIP_MAIL_FINDER(W, w)                                                                                              \
+  {                                                                                                                           \
+    uint32_t head = 0, tail_seen = 0;                                                                                         \
+    for (;;) {                                                                                                                \
+      uint32_t b = 0;                                                                                                         \
+      if (__lane_id() == 0) b = atomicAdd(q, 1u);                                                                             \
+      b = __builtin_amdgcn_readfirstlane(b);                                                                                  \
+      MailOut<W> out(w, slots, ctr, head);                                                                                    \
+      out.tail_seen = tail_seen;                                                                                              \
+      if (b >= a.n) { out.post(MAIL_EXIT, 0u, 0u); return; }                                                                  \
+      out.b = b;                                                                                                              \
+      const int32_t n = uniform_i32(a.src_len[b]);                                                                            \
+      const int32_t cap = uniform_i32(a.dst_cap[b]);                                                                          \
+      if (n >= 0 && (uint32_t)n <= 0x7E000000u && cap >= 0) {                                                                 \
+        const uint8_t* s = uniform_ptr(a.src + a.src_off[b]);                                                                 \
+        out.dense64 = routed ? dense64 : 0u;                                                                                  \
+        if (n < 65547) {                                                                                                      \
+          FastV2<W, MailOut<W>> c(w, out, s, (uint32_t)n);                                                                    \
+          (void)c.run();                                                                                                      \
+        } else {                                                                                                              \
+          FastCore<W, false, MailOut<W>> c(w, out, s, (uint32_t)n);                                                           \
+          (void)c.run();                                                                                                      \
+        }                                                                                                                     \
+        if (out.bail) {                                                                                                       \
+          out.post(MAIL_ABORT, 0u, 0u);                                                                                       \
+          if (__lane_id() == 0) routed[atomicAdd(q + 1, 1u)] = b;                                                             \
+        }                                                                                                                     \
+      } else {                                                                                                                \
+        if (__lane_id() == 0) a.out[b] = 0;                                                                                   \
+      }                                                                                                                       \
+      head = out.head; tail_seen = out.tail_seen;                                                                             \
+      W::sync(); /* the table is reused */                                                                                    \
+    }                                                                                                                         \
+  }
 
 // wavefronts of a workgroup: [0, 5) LDS finders, [5, 10) their writers, [10, 10 + GF) global-table finders, then their writers
-__global__ __launch_bounds__(64 * 2 * PAIRS_PER_CU) void compress_fast_v2w_cu_kernel(BatchArgs a, uint32_t* q, uint32_t* routed, uint32_t dense64, uint32_t* mail_ctr, uint32_t* mail_slots, uint64_t* gtables) {
+template <uint32_t GLOBAL_FINDERS>
+__global__ __launch_bounds__(64 * 2 * (WAVES_PER_CU + GLOBAL_FINDERS)) void compress_fast_v2wg_cu_kernel(BatchArgs a, uint32_t* q, uint32_t* routed, uint32_t dense64, uint32_t* mail_ctr, uint32_t* mail_slots, uint64_t* gtables) {
+  constexpr uint32_t PAIRS_PER_CU = WAVES_PER_CU + GLOBAL_FINDERS;
   __shared__ __attribute__((aligned(16))) uint64_t tables[WAVES_PER_CU][LZ4HIP_TABLE_U64];
   const uint32_t wv = threadIdx.x >> 6;
   const bool lds_side = wv < 2u * WAVES_PER_CU;
@@ -345,23 +412,28 @@ __global__ __launch_bounds__(64 * 2 * PAIRS_PER_CU) void compress_fast_v2w_cu_ke
   uint32_t* slots = mail_slots + (size_t)pair * (MAIL_RING * MAIL_SLOT_WORDS);
   if (writer) { mail_writer(a, slots, ctr); return; }
   if (lds_side) {
+#ifdef LZ4HIP_PROBE_NO_LDS_FINDERS   // developer timing probe: the global-table chains alone
+    { WaveDev w(tables[k]); MailOut<WaveDev> out(w, slots, ctr, 0u); out.post(MAIL_EXIT, 0u, 0u); return; }
+#endif
     WaveDev w(tables[k]);
-    mail_finder(a, q, routed, dense64, w, slots, ctr);
+    LZ4HIP_MAIL_FINDER(WaveDev, w)
   } else {
-    if constexpr (GLOBAL_FINDERS > 0) {
+    {
       WaveDevG w(gtables + ((size_t)blockIdx.x * GLOBAL_FINDERS + k) * 4096u);
-      mail_finder(a, q, routed, dense64, w, slots, ctr);
+      LZ4HIP_MAIL_FINDER(WaveDevG, w)
     }
   }
 }
 // scratch words the two-wave kernel needs after the three queue words: counters of every pair, then (1 KB aligned) the rings,
 // then (with global-table finders) their 32 KB tables
-size_t compress_fast_v2w_scratch_words(uint32_t n_cus) {
+size_t compress_fast_v2wg_scratch_words(uint32_t n_cus) {
+  constexpr uint32_t GLOBAL_FINDERS = LZ4HIP_GF, PAIRS_PER_CU = WAVES_PER_CU + GLOBAL_FINDERS;
   const size_t pairs = (size_t)n_cus * PAIRS_PER_CU;
   return 2u * pairs + 256u + pairs * (MAIL_RING * MAIL_SLOT_WORDS) + (size_t)n_cus * GLOBAL_FINDERS * 8192u;
 }
-int launch_compress_fast_v2w(const BatchArgs& a, uint32_t* q, uint32_t* routed, uint32_t dense64, uint32_t n_cus, uint32_t* mail, void* stream) {
+int launch_compress_fast_v2wg(const BatchArgs& a, uint32_t* q, uint32_t* routed, uint32_t dense64, uint32_t n_cus, uint32_t* mail, void* stream) {
   if (a.n == 0) return 0;
+  constexpr uint32_t GLOBAL_FINDERS = LZ4HIP_GF, PAIRS_PER_CU = WAVES_PER_CU + GLOBAL_FINDERS;
   const size_t pairs = (size_t)n_cus * PAIRS_PER_CU;
   hipError_t e = hipMemsetAsync(q, 0, 3 * sizeof(uint32_t), (hipStream_t)stream);
   if (e != hipSuccess) return (int)e;
@@ -370,9 +442,10 @@ int launch_compress_fast_v2w(const BatchArgs& a, uint32_t* q, uint32_t* routed, 
   uint32_t* slots = (uint32_t*)(((uintptr_t)(mail + 2u * pairs) + 1023u) & ~(uintptr_t)1023u);
   uint64_t* gtables = (uint64_t*)(slots + pairs * (MAIL_RING * MAIL_SLOT_WORDS));
   const uint32_t wgs = (a.n + PAIRS_PER_CU - 1u) / PAIRS_PER_CU;
-  hipLaunchKernelGGL(compress_fast_v2w_cu_kernel, dim3(wgs < n_cus ? wgs : n_cus), dim3(64 * 2 * PAIRS_PER_CU), 0, (hipStream_t)stream, a, q, routed, dense64, mail, slots, gtables);
+  hipLaunchKernelGGL(compress_fast_v2wg_cu_kernel<GLOBAL_FINDERS>, dim3(wgs < n_cus ? wgs : n_cus), dim3(64 * 2 * PAIRS_PER_CU), 0, (hipStream_t)stream, a, q, routed, dense64, mail, slots, gtables);
   return (int)hipGetLastError();
 }
+
 
 // window-parallel core (lz4_fast_ms_core.h): every sequence of a 64-position window per step
 __device__ __forceinline__ void compress_fast_ms_block(const BatchArgs& a, uint32_t b, uint64_t* table) {

@@ -203,7 +203,7 @@ def test_issue12_regression_blob_gpu(amd, ref):
     import os
     data = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "issue12.bin"), "rb").read()[9:]
     f = amd.LZ4Factory.hipInstance()
-    for core in (0, 1, 2, 3, 4, 5):
+    for core in (0, 1, 2, 3, 4, 5, 6):
         amd.set_option("compress_core", core)
         c = f.fastCompressor().compress(data)
         assert c == ref.compress_fast(data), core
@@ -410,7 +410,7 @@ def test_cpp_host_mirror_runs():
     assert subprocess.call([exe]) == 0
 
 
-@pytest.mark.parametrize("core,switch", [(0, 20), (1, 20), (2, 0), (2, 20), (2, 1024), (3, 20), (4, 0), (4, 20), (4, 1024), (5, 0), (5, 20), (5, 1024)])
+@pytest.mark.parametrize("core,switch", [(0, 20), (1, 20), (2, 0), (2, 20), (2, 1024), (3, 20), (4, 0), (4, 20), (4, 1024), (5, 0), (5, 20), (5, 1024), (6, 0), (6, 20)])
 def test_compress_core_variants_same_bytes(amd, ref, O, corpus, core, switch):
     """compress_core 0 (one sequence per step, written as found), 1 (window-parallel only), 3 (lean core only), 2 and 4 (adaptive
     two-pass over core 0 / the lean core) with extreme routing thresholds produce the same bytes as the default (4, threshold 20

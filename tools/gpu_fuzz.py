@@ -25,7 +25,7 @@ def pack(blocks, caps):
         so.append(p); sl.append(len(b)); do.append(q); p += len(b); q += c
     return src, so, sl, bytearray(max(q, 1)), do
 
-for core in (0, 1, 2, 3, 4, 5):
+for core in (0, 1, 2, 3, 4, 5, 6):
     amd.set_option("compress_core", core)
     caps = [ref.compress_bound(len(v)) for v in inputs]
     src, so, sl, dst, do = pack(inputs, caps)
