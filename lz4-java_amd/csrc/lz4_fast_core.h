@@ -32,6 +32,12 @@
 #ifndef LZ4HIP_PROBE_HLOG
 #define LZ4HIP_PROBE_HLOG 13
 #endif
+// fingerprint bits kept per byU16 table entry (16 = the {pos16, fp16} u32 entries; narrower values exist to measure the
+// false-tentative-hit cost of smaller tables: any width is bit-exact, a false tentative hit is ruled out by its candidate bytes)
+#ifndef LZ4HIP_FP_BITS
+#define LZ4HIP_FP_BITS 16
+#endif
+#define LZ4HIP_FP_MASK ((1u << LZ4HIP_FP_BITS) - 1u)
 #include <stdint.h>
 #include <stddef.h>
 
@@ -352,7 +358,7 @@ struct FastCore {
     uint32_t fp0;
     {
       const uint32_t x0 = w.sld32(src, 0);
-      if constexpr (U16) fp0 = ((x0 * 2654435761u) >> 3) & 0xFFFFu;
+      if constexpr (U16) fp0 = ((x0 * 2654435761u) >> 3) & LZ4HIP_FP_MASK;
       else fp0 = (x0 * 2654435761u) >> 16;
     }
     w.template lds_fill<U16>(1u << HLOG, (E)fp0);
@@ -395,7 +401,7 @@ struct FastCore {
         x32 = sp_x32;
         const VU prod = x32 * 2654435761u;
         h = prod >> (32 - HLOG);
-        fp = (prod >> 3) & 0xFFFFu;
+        fp = (prod >> 3) & LZ4HIP_FP_MASK;
       } else {
         x32 = W::lo32(sp_x64);
         h = W::lo32(((sp_x64 << 24) * 889523592379ull) >> (64 - HLOG));

@@ -257,7 +257,7 @@ struct FastV2 {
     if (n < 13u) return out.last(0u);
     {
       const uint32_t x0 = w.sld32(src, 0);
-      w.template lds_fill<true>(1u << LZ4HIP_PROBE_HLOG, (((x0 * 2654435761u) >> 3) & 0xFFFFu));  // every bucket: {pos 0, fp(bytes at 0)}
+      w.template lds_fill<true>(1u << LZ4HIP_PROBE_HLOG, (((x0 * 2654435761u) >> 3) & LZ4HIP_FP_MASK));  // every bucket: {pos 0, fp(bytes at 0)}
       w.sync();
     }
     Gen gen(w, out, src, n, st);
@@ -308,7 +308,7 @@ struct FastV2 {
       }
       const VU prod = x32 * 2654435761u;
       const VU h = prod >> (32 - LZ4HIP_PROBE_HLOG);
-      const VU fp = (prod >> 3) & 0xFFFFu;
+      const VU fp = (prod >> 3) & LZ4HIP_FP_MASK;
       LZ4HIP_PHASE2(0, w.bcast(h, 0));     // t[0]: window load + hash
       const VU e = w.template lds_rdu<true>(h);
       const VU newe = (pos << 16) | fp;
@@ -318,6 +318,14 @@ struct FastV2 {
 #endif
       if (LZ4HIP_UNLIKELY(tmask == 0)) { if (st && LZ4HIP_COUNT_CAT == 5) st->false_pos++; break; }   // no tentative hit in 63 probes (nothing committed yet; profiling: counted in false_pos)
       LZ4HIP_PHASE2(1, (uint32_t)tmask);    // t[1]: table read + ballot
+#ifndef LZ4HIP_V2_PVERIFY
+#define LZ4HIP_V2_PVERIFY 0   /* 1: the candidate bytes of EVERY tentative lane behind the first are gathered in the first lane's round trip */
+#endif
+      // (parallel verification: with narrow fingerprints most tentative lanes are false; their 4 candidate bytes come back with the
+      // first tentative lane's rows, so a ruled-out first lane is followed directly by the first lane whose candidate verifies --
+      // one more round trip at most, and to a line the gather has just touched)
+      VU c4 = VU(0u);
+      if (LZ4HIP_V2_PVERIFY && OUT::kRawPark) c4 = w.ld32(src, e >> 16, w.lanes(tmask & (tmask - 1ull)));
       // The hit is the first tentative lane that survives: a tentative lane is ruled out, and the search goes on to the next one
       // in the same window (raw-parking policies only; the others take the exact path as before), when
       //   K  an earlier committing lane shares its bucket with a different fingerprint -- liblz4, inserting position by position,
@@ -388,6 +396,7 @@ struct FastV2 {
         if (LZ4HIP_LIKELY(!bad && !ruled_out)) break;
         if (OUT::kRawPark && !bad) {
           tm &= ~upto;
+          if (LZ4HIP_V2_PVERIFY) tm &= w.ballot(c4 == x32);        // tentative lanes whose candidate bytes differ are not hits
           lo = k0 + 1u;
           if (tm) continue;                                        // the next tentative lane of this window
         }
