@@ -194,6 +194,7 @@ struct MailOut {
   using VU = typename W::VU;
   static constexpr bool kUsesWindowRegs = false;
   static constexpr uint32_t kNoCheck = ParkOut<W>::kNoCheck, kFinal = ParkOut<W>::kFinal;
+  static constexpr bool kAsmPark = true;   // (lz4_fast_v2_asm.h parks into p_ms / p_ml / p_off and counts in cnt)
   static constexpr bool kRawPark = true;   // the lean loop parks bare hits: liblz4's backward extension is the writer's work too (ParkOut::resolve_raw)
   W& w;
   uint32_t* slots;   // MAIL_RING x MAIL_SLOT_WORDS

@@ -19,6 +19,9 @@
 //     ~5 instructions per sequence instead of ~60, and nothing of it sits between two steps of the chain.
 #pragma once
 #include "lz4_fast_core.h"
+#if defined(__HIPCC__)
+#include "lz4_fast_v2_asm.h"
+#endif
 
 #ifndef LZ4HIP_V2_PROBE
 #define LZ4HIP_V2_PROBE 0   /* profiling kernel: 0 = all phases, k + 1 = only the interval that ends at phase point k */
@@ -39,6 +42,7 @@ struct ParkOut {
   static constexpr uint32_t kNoCheck = 1u << 16;  // flag in p_off: liblz4's _next_match path (no literal-capacity check)
   static constexpr uint32_t kFinal = 1u << 17;    // flag in p_off (raw parking only): the entry is a finished sequence, not a raw hit
   static constexpr bool kRawPark = false;         // the lean loop does liblz4's backward extension itself and parks finished sequences
+  static constexpr bool kAsmPark = false;         // (true: the hand-scheduled loop of lz4_fast_v2_asm.h parks into p_ms / p_ml / p_off itself)
 
   W& w;
   const uint8_t* src;
@@ -287,6 +291,19 @@ struct FastV2 {
     VU prev_fa = VU(0u);
     uint32_t prev_hpos = 0x80000000u;   // (no row yet: ip - prev_hpos is huge)
     while (ip <= lim && !out.bail) {
+#if defined(__HIP_DEVICE_COMPILE__) && LZ4HIP_V2_ASM
+      // The common steps run in the hand-scheduled loop of lz4_fast_v2_asm.h; it comes back when 64 hits are parked, at the loop
+      // limit, or in front of a step it does not handle -- nothing of that step is left in the table, and the C++ step below
+      // takes it from the same state with every rule.
+      if constexpr (W::kAsmLean && OUT::kAsmPark) {
+        if (!st) {
+          const uint32_t code = lean_asm_run(ip, prev_hpos, pf_end, out.cnt, prev_fa, out.p_ms, out.p_ml, out.p_off, lim, src,
+                                             (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)w.lds, n);
+          if (out.cnt == 64u) { out.batch(); continue; }
+          if (code == 1u) break;
+        }
+      }
+#endif
       if (st) l_steps++;
       uint64_t tk = (st && LZ4HIP_V2_PROBE == 0) ? w.tick(ip) : tk_keep;
       // profiling kernel only.  LZ4HIP_V2_PROBE = k + 1 measures ONLY the interval that ends at phase point k (one pair of clock

@@ -14,6 +14,7 @@ struct WaveDev {
   template <bool U16> struct Entry;
 
   void* lds;  // 32 KB table of this wavefront
+  static constexpr bool kAsmLean = true;   // the table is in LDS: the hand-scheduled lean loop (lz4_fast_v2_asm.h) applies
 
   __device__ __forceinline__ explicit WaveDev(void* l) : lds(l) {}
 
@@ -212,6 +213,7 @@ template <> struct WaveDev::Entry<false> { using S = uint64_t; using V = uint64_
 // the five LDS chains.  Same algorithm sources, same bytes.  The table belongs to one wavefront, so its atomics are ordered at
 // WORKGROUP scope (no cross-XCD coherence traffic; agent scope: slower); a wavefront's accesses to one address stay in program order.
 struct WaveDevG : WaveDev {
+  static constexpr bool kAsmLean = false;
   __device__ __forceinline__ explicit WaveDevG(void* table) : WaveDev(table) {}
   template <bool U16> __device__ __forceinline__ void lds_fill(uint32_t count, typename Entry<U16>::S val) {
     using S = typename Entry<U16>::S;
