@@ -497,6 +497,16 @@ int launch_compress_fast_ms(const BatchArgs& a, uint32_t* q, const uint32_t* rou
   return (int)hipGetLastError();
 }
 
+#if LZ4HIP_V2_ASM_PROF
+// developer builds: reads (and clears) the phase counters of the hand-scheduled lean step
+extern "C" __attribute__((visibility("default"))) int lz4hip_dev_asm_prof(unsigned long long* out16) {
+  hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_asm_prof), 16 * sizeof(unsigned long long));
+  if (e != hipSuccess) return (int)e;
+  unsigned long long z[16] = {0};
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_asm_prof), z, sizeof(z));
+}
+#endif
+
 #ifdef LZ4HIP_DEV_TOOLS
 // developer diagnostics: same algorithm with per-phase shader-clock accumulation; prof[b*12 + i] =
 // {steps, slow_steps, false_pos, sequences, t[0..7]} of block b

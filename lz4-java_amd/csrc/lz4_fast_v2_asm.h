@@ -32,7 +32,24 @@
 #define LZ4HIP_V2_LOOK 0   /* lookahead prefetch: bit 0 = tentative lanes of this window behind the hit, bit 1 = the 64 positions after the window */
 #endif
 
+#ifndef LZ4HIP_V2_ASM_PROF
+#define LZ4HIP_V2_ASM_PROF 0   /* developer builds: shader-clock time per phase of the hand-scheduled step, summed into g_asm_prof */
+#endif
+
 namespace lz4hip {
+
+#if LZ4HIP_V2_ASM_PROF
+// [0..3] cycles: window + hash + table read | hit selection + commit + row requests | waiting for the rows | count + park;
+// [4] steps, [5] exits with code 2, [6] cycles inside lean(), [7] cycles inside run(), [8] blocks, [9] exact-path calls
+__device__ unsigned long long g_asm_prof[16];
+#define LZ4HIP_TICK0 "  s_memtime s[92:93]\n  s_waitcnt lgkmcnt(0)\n"
+#define LZ4HIP_TICK(acc) "  s_memtime s[94:95]\n  s_waitcnt lgkmcnt(0)\n  s_sub_u32 s96, s94, s92\n  s_add_u32 %[" acc "], %[" acc "], s96\n  s_mov_b32 s92, s94\n"
+#define LZ4HIP_COUNT(acc) "  s_add_u32 %[" acc "], %[" acc "], 1\n"
+#else
+#define LZ4HIP_TICK0 ""
+#define LZ4HIP_TICK(acc) ""
+#define LZ4HIP_COUNT(acc) ""
+#endif
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define LZ4HIP_STR2(x) #x
@@ -55,8 +72,11 @@ namespace lz4hip {
 //   s[86:87] lanes committed by earlier tries   s[88:89] scratch mask   s[90:91] lookahead mask
 __device__ __forceinline__ uint32_t lean_asm_run(uint32_t& ip, uint32_t& php, uint32_t& pfe, uint32_t& pc, uint32_t& pfa,
                                                  uint32_t& pms, uint32_t& pml, uint32_t& pof, uint32_t lim, const uint8_t* src,
-                                                 uint32_t tbl, uint32_t n) {
+                                                 uint32_t tbl, uint32_t n, uint32_t* pr) {
   uint32_t code;
+#if LZ4HIP_V2_ASM_PROF
+  uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, c0 = 0, c1 = 0;
+#endif
   const uint32_t lane = __lane_id();
   const uint32_t cj = lane == 0u ? 0xFFFFFFFEu : lane - 1u;
   const uint32_t j4 = lane * 4u, j16 = lane * 16u;
@@ -68,6 +88,7 @@ __device__ __forceinline__ uint32_t lean_asm_run(uint32_t& ip, uint32_t& php, ui
       "  s_sub_u32 s70, %[ip], %[php]\n"
       "  s_cmpk_gt_u32 s70, 189\n"
       "  s_cbranch_scc1 L_exit2_%=\n"
+      LZ4HIP_TICK0
       // window: bytes [ip - 2, ip + 66) out of the row at the previous hit
       "  v_add_u32 v100, s70, %[cj]\n"
       "  v_and_b32 v101, -4, v100\n"
@@ -84,6 +105,7 @@ __device__ __forceinline__ uint32_t lean_asm_run(uint32_t& ip, uint32_t& php, ui
       "  v_bfe_u32 v108, v105, 3, 16\n"
       "  v_lshl_or_b32 v109, v109, 16, v108\n"
       "  s_waitcnt lgkmcnt(0)\n"
+      LZ4HIP_TICK("t0")
       "  v_cmp_eq_u32_sdwa s[78:79], v107, v108 src0_sel:WORD_0 src1_sel:DWORD\n"
       "  s_and_b64 s[78:79], s[78:79], -2\n"
       "  s_cbranch_scc0 L_exit2_%=\n"
@@ -109,6 +131,7 @@ __device__ __forceinline__ uint32_t lean_asm_run(uint32_t& ip, uint32_t& php, ui
       "  s_cmp_gt_u32 s77, %[pfe]\n"
       "  s_cbranch_scc1 L_touch_%=\n"
       "L_back_%=:\n"
+      LZ4HIP_TICK("t1")
 #if LZ4HIP_V2_LOOK & 1
       // lookahead A: the tentative lanes of this window behind the hit's first four bytes
       "  s_lshl_b64 s[88:89], -16, s71\n"
@@ -135,7 +158,8 @@ __device__ __forceinline__ uint32_t lean_asm_run(uint32_t& ip, uint32_t& php, ui
       // the atomic's result: a lane that got back another lane's entry
       "  v_cmp_ne_u32_e64 s[88:89], v110, v107\n"
       "  s_and_b64 s[88:89], s[88:89], s[84:85]\n"
-      "  s_cbranch_scc1 L_undo_%=\n"
+      "  s_cbranch_scc1 L_coll_%=\n"
+      "L_cont_%=:\n"
 #if LZ4HIP_V2_LOOK & 2
       "  s_waitcnt lgkmcnt(0)\n"
       "  v_cmp_eq_u32_sdwa s[90:91], v117, v118 src0_sel:WORD_0 src1_sel:DWORD\n"
@@ -145,6 +169,7 @@ __device__ __forceinline__ uint32_t lean_asm_run(uint32_t& ip, uint32_t& php, ui
       "  s_mov_b64 exec, -1\n"
 #endif
       "  s_waitcnt vmcnt(" LZ4HIP_ROWS_WAIT ")\n"
+      LZ4HIP_TICK("t2")
       "  v_xor_b32 v113, v112, v113\n"
       "  v_cmp_ne_u32_e32 vcc, 0, v113\n"
       "  v_ffbl_b32 v114, v113\n"
@@ -165,6 +190,8 @@ __device__ __forceinline__ uint32_t lean_asm_run(uint32_t& ip, uint32_t& php, ui
       "  s_mov_b32 %[php], s72\n"
       "  v_mov_b32 %[pfa], v112\n"
       "  s_add_u32 %[pc], %[pc], 1\n"
+      LZ4HIP_TICK("t3")
+      LZ4HIP_COUNT("c0")
       "  s_cmp_eq_u32 %[pc], 64\n"
       "  s_cbranch_scc0 L_top_%=\n"
       "  s_mov_b32 %[code], 3\n"
@@ -181,8 +208,29 @@ __device__ __forceinline__ uint32_t lean_asm_run(uint32_t& ip, uint32_t& php, ui
       "  ds_write_b32 v106, v107\n"
       "  s_mov_b64 exec, -1\n"
       "L_exit2_%=:\n"
+      LZ4HIP_COUNT("c1")
       "  s_mov_b32 %[code], 2\n"
       "  s_branch L_out_%=\n"
+      // Two committing lanes share a bucket (a lane got back another lane's entry).  The rule of the C++ step: with exactly ONE
+      // such lane, and the foreign entry's fingerprint different from that lane's own, liblz4 -- inserting position by position --
+      // would not have decided differently for it (its old entry was no hit and neither is the foreign one), and the atomic max
+      // has left the bucket as liblz4 leaves it: carry on -- unless the bucket is the hit lane's (the entry that made it tentative
+      // is not the one liblz4 would have found there): that lane is ruled out.  Everything else is for the exact path.
+      "L_coll_%=:\n"
+      "  s_bcnt1_i32_b64 s76, s[88:89]\n"
+      "  s_cmp_eq_u32 s76, 1\n"
+      "  s_cbranch_scc0 L_undo_%=\n"
+      "  s_ff1_i32_b64 s75, s[88:89]\n"
+      "  v_readlane_b32 s76, v110, s75\n"
+      "  v_readlane_b32 s77, v108, s75\n"
+      "  s_and_b32 s76, s76, 0xffff\n"
+      "  s_cmp_eq_u32 s76, s77\n"
+      "  s_cbranch_scc1 L_undo_%=\n"
+      "  v_readlane_b32 s76, v106, s75\n"
+      "  v_readlane_b32 s77, v106, s71\n"
+      "  s_cmp_eq_u32 s76, s77\n"
+      "  s_cbranch_scc0 L_cont_%=\n"
+      "  s_branch L_ruled_%=\n"
       // the source is touched 1 KB ahead of the parse (one 1 KB wave load per 1 KB of progress)
       "L_touch_%=:\n"
       "  s_cmp_ge_u32 %[pfe], %[n]\n"
@@ -200,11 +248,21 @@ __device__ __forceinline__ uint32_t lean_asm_run(uint32_t& ip, uint32_t& php, ui
       "  s_waitcnt vmcnt(0) lgkmcnt(0)\n"
       : [ip] "+s"(ip), [php] "+s"(php), [pfe] "+s"(pfe), [pc] "+s"(pc), [pfa] "+v"(pfa), [pms] "+v"(pms), [pml] "+v"(pml),
         [pof] "+v"(pof), [code] "=&s"(code)
+#if LZ4HIP_V2_ASM_PROF
+        , [t0] "+s"(t0), [t1] "+s"(t1), [t2] "+s"(t2), [t3] "+s"(t3), [c0] "+s"(c0), [c1] "+s"(c1)
+#endif
       : [lim] "s"(lim), [src] "s"(src), [tbl] "v"(tbl), [n] "s"(n), [ntop] "s"(ntop), [kmul] "s"(kmul), [cj] "v"(cj), [j4] "v"(j4),
         [j16] "v"(j16)
       : "memory", "vcc", "scc", "m0", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111",
         "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "s70", "s71", "s72", "s73",
-        "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91");
+        "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91"
+#if LZ4HIP_V2_ASM_PROF
+        , "s92", "s93", "s94", "s95", "s96"
+#endif
+  );
+#if LZ4HIP_V2_ASM_PROF
+  pr[0] += t0; pr[1] += t1; pr[2] += t2; pr[3] += t3; pr[4] += c0; pr[5] += c1;
+#endif
   return code;
 }
 #endif  // __HIP_DEVICE_COMPILE__

@@ -265,21 +265,41 @@ struct FastV2 {
       w.sync();
     }
     Gen gen(w, out, src, n, st);
+#if defined(__HIP_DEVICE_COMPILE__) && LZ4HIP_V2_ASM_PROF
+    const uint64_t prof_t0 = w.tick(n);
+    uint64_t prof_lean = 0, prof_calls = 0;
+#endif
     // the head of the block is a plain run from position 1: exact path, one sequence
     uint32_t r = gen.template loop<2>(false, 1u, 0u, 0u);
     while (gen.one_done && !out.bail) {
       gen.one_done = false;
+#if defined(__HIP_DEVICE_COMPILE__) && LZ4HIP_V2_ASM_PROF
+      const uint64_t prof_l0 = w.tick(gen.p_ip);
       const uint32_t ip = lean(gen.p_ip);
+      prof_lean += w.tick(ip) - prof_l0; prof_calls++;
+#else
+      const uint32_t ip = lean(gen.p_ip);
+#endif
       gen.anchor = ip;
       const uint64_t tx = st ? w.tick(ip) : 0;      // (profiling kernel: cycles and count of the exact path's sequences)
       r = gen.template loop<2>(true, ip + 1u, 0u, ip);
       if (st) { st->t[6] += w.tick(r) - tx; st->t[7] += 1; }
     }
+#if defined(__HIP_DEVICE_COMPILE__) && LZ4HIP_V2_ASM_PROF
+    if (w.lane() == 0u) {
+      for (int i = 0; i < 6; i++) atomicAdd(&g_asm_prof[i], (unsigned long long)aprof[i]);
+      atomicAdd(&g_asm_prof[6], (unsigned long long)prof_lean);
+      atomicAdd(&g_asm_prof[7], (unsigned long long)(w.tick(r) - prof_t0));
+      atomicAdd(&g_asm_prof[8], 1ull);
+      atomicAdd(&g_asm_prof[9], (unsigned long long)prof_calls);
+    }
+#endif
     return r;
   }
 
   // The lean loop.  Enters and leaves in the post-match state at `ip` (== anchor; table committed up to the previous step);
   // returns the position at which the exact path has to take the next sequence.
+  uint32_t aprof[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // (LZ4HIP_V2_ASM_PROF developer builds)
   LZ4HIP_DEV uint32_t lean(uint32_t ip) {
     if (n < kTail + 8u) return ip;
     const uint32_t lim = n - kTail;
@@ -298,7 +318,7 @@ struct FastV2 {
       if constexpr (W::kAsmLean && OUT::kAsmPark) {
         if (!st) {
           const uint32_t code = lean_asm_run(ip, prev_hpos, pf_end, out.cnt, prev_fa, out.p_ms, out.p_ml, out.p_off, lim, src,
-                                             (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)w.lds, n);
+                                             (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)w.lds, n, aprof);
           if (out.cnt == 64u) { out.batch(); continue; }
           if (code == 1u) break;
         }
