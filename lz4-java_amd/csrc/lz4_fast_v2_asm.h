@@ -20,6 +20,12 @@
 //     instead of paying a full Infinity-Cache / HBM round trip (the candidate side is a random line of the block; misses cost
 //     ~340 cycles per step on average).  A prefetch is a hint: a stale table entry costs a useless line, never a wrong byte.
 //
+// The lookahead was built (candidate lines of the window's other tentative lanes, and of the 64 positions behind the window,
+// requested behind the rows and never waited for) and measured: -2 % .. -4 % (profiles/r03_compress_notes.txt) -- the phase
+// timers show why: the rows arrive ~480 cycles after their request on average, i.e. most candidate lines already come from L2,
+// and a line in L1 is not much closer than that.  What the hand-written loop buys is issue time and the order of things:
+// requests first, bookkeeping in their shadow.
+//
 // Exit codes: 1 = ip > lim; 2 = the step at `ip` is for the C++ loop (nothing of it is left in the table); 3 = 64 hits parked.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -27,9 +33,6 @@
 
 #ifndef LZ4HIP_V2_ASM
 #define LZ4HIP_V2_ASM 1
-#endif
-#ifndef LZ4HIP_V2_LOOK
-#define LZ4HIP_V2_LOOK 0   /* lookahead prefetch: bit 0 = tentative lanes of this window behind the hit, bit 1 = the 64 positions after the window */
 #endif
 
 #ifndef LZ4HIP_V2_ASM_PROF
@@ -54,14 +57,6 @@ __device__ unsigned long long g_asm_prof[16];
 #if defined(__HIP_DEVICE_COMPILE__)
 #define LZ4HIP_STR2(x) #x
 #define LZ4HIP_STR(x) LZ4HIP_STR2(x)
-#if (LZ4HIP_V2_LOOK & 1) && (LZ4HIP_V2_LOOK & 2)
-#define LZ4HIP_ROWS_WAIT "2"
-#elif LZ4HIP_V2_LOOK
-#define LZ4HIP_ROWS_WAIT "1"
-#else
-#define LZ4HIP_ROWS_WAIT "0"
-#endif
-
 // registers of the block (fixed, declared as clobbers):
 //   v100 shift (o & 3)      v101 4 * (o >> 2)         v102/v103 row words     v104 window word x32    v105 hash product
 //   v106 LDS address        v107 table entry e        v108 fingerprint        v109 new entry          v110 atomic's old value
@@ -88,13 +83,14 @@ __device__ __forceinline__ uint32_t lean_asm_run(uint32_t& ip, uint32_t& php, ui
       "  s_sub_u32 s70, %[ip], %[php]\n"
       "  s_cmpk_gt_u32 s70, 189\n"
       "  s_cbranch_scc1 L_exit2_%=\n"
-      LZ4HIP_TICK0
       // window: bytes [ip - 2, ip + 66) out of the row at the previous hit
       "  v_add_u32 v100, s70, %[cj]\n"
       "  v_and_b32 v101, -4, v100\n"
       "  v_and_b32 v100, 3, v100\n"
       "  ds_bpermute_b32 v102, v101, %[pfa]\n"
       "  ds_bpermute_b32 v103, v101, %[pfa] offset:4\n"
+      LZ4HIP_TICK0
+      "L_win_%=:\n"
       "  v_add_u32 v109, %[ip], %[cj]\n"
       "  s_waitcnt lgkmcnt(0)\n"
       "  v_alignbyte_b32 v104, v103, v102, v100\n"
@@ -104,72 +100,43 @@ __device__ __forceinline__ uint32_t lean_asm_run(uint32_t& ip, uint32_t& php, ui
       "  ds_read_b32 v107, v106\n"
       "  v_bfe_u32 v108, v105, 3, 16\n"
       "  v_lshl_or_b32 v109, v109, 16, v108\n"
+      "  s_mov_b64 s[86:87], 0\n"
       "  s_waitcnt lgkmcnt(0)\n"
       LZ4HIP_TICK("t0")
       "  v_cmp_eq_u32_sdwa s[78:79], v107, v108 src0_sel:WORD_0 src1_sel:DWORD\n"
+      "  v_lshrrev_b32 v115, 16, v107\n"
       "  s_and_b64 s[78:79], s[78:79], -2\n"
       "  s_cbranch_scc0 L_exit2_%=\n"
-      "  s_mov_b64 s[80:81], s[78:79]\n"
-      "  s_mov_b64 s[86:87], 0\n"
+      // the first tentative lane k0: its rows are requested first (the candidate side is the slow one), then lanes .. k0 commit
       "L_try_%=:\n"
       "  s_ff1_i32_b64 s71, s[78:79]\n"
+      "  v_readlane_b32 s73, v115, s71\n"
+      "  s_add_u32 s72, %[ip], s71\n"
       "  s_lshl_b64 s[82:83], -2, s71\n"
+      "  v_add_u32 v111, s73, %[j4]\n"
+      "  global_load_dword v113, v111, %[src]\n"
+      "  s_add_u32 s72, s72, -1\n"
+      "  v_add_u32 v111, s72, %[j4]\n"
+      "  global_load_dword v112, v111, %[src]\n"
       "  s_not_b64 s[82:83], s[82:83]\n"
       "  s_andn2_b64 s[84:85], s[82:83], s[86:87]\n"
       "  s_mov_b64 exec, s[84:85]\n"
       "  ds_max_rtn_u32 v110, v106, v109\n"
       "  s_mov_b64 exec, -1\n"
-      "  v_readlane_b32 s73, v107, s71\n"
-      "  s_add_u32 s72, %[ip], s71\n"
-      "  s_lshr_b32 s73, s73, 16\n"
-      "  s_add_u32 s72, s72, -1\n"
-      "  v_add_u32 v111, s72, %[j4]\n"
-      "  global_load_dword v112, v111, %[src]\n"
-      "  v_add_u32 v111, s73, %[j4]\n"
-      "  global_load_dword v113, v111, %[src]\n"
       "  s_add_u32 s77, s72, 1024\n"
       "  s_cmp_gt_u32 s77, %[pfe]\n"
       "  s_cbranch_scc1 L_touch_%=\n"
       "L_back_%=:\n"
       LZ4HIP_TICK("t1")
-#if LZ4HIP_V2_LOOK & 1
-      // lookahead A: the tentative lanes of this window behind the hit's first four bytes
-      "  s_lshl_b64 s[88:89], -16, s71\n"
-      "  s_and_b64 s[88:89], s[88:89], s[80:81]\n"
-      "  v_lshrrev_b32 v111, 16, v107\n"
-      "  s_mov_b64 exec, s[88:89]\n"
-      "  global_load_dword v115, v111, %[src]\n"
-      "  s_mov_b64 exec, -1\n"
-#endif
-#if LZ4HIP_V2_LOOK & 2
-      // lookahead B: the 64 positions behind the window (row words 16 lanes further on; lanes past the row read garbage: a hint)
-      "  ds_bpermute_b32 v116, v101, %[pfa] offset:64\n"
-      "  ds_bpermute_b32 v117, v101, %[pfa] offset:68\n"
-      "  s_waitcnt lgkmcnt(0)\n"
-      "  v_alignbyte_b32 v116, v117, v116, v100\n"
-      "  v_mul_lo_u32 v116, v116, %[kmul]\n"
-      "  v_lshrrev_b32 v117, 19, v116\n"
-      "  v_lshl_add_u32 v117, v117, 2, %[tbl]\n"
-      "  ds_read_b32 v117, v117\n"
-      "  v_bfe_u32 v118, v116, 3, 16\n"
-#else
-      "  s_waitcnt lgkmcnt(0)\n"
-#endif
       // the atomic's result: a lane that got back another lane's entry
+      "  s_waitcnt lgkmcnt(0)\n"
       "  v_cmp_ne_u32_e64 s[88:89], v110, v107\n"
       "  s_and_b64 s[88:89], s[88:89], s[84:85]\n"
       "  s_cbranch_scc1 L_coll_%=\n"
       "L_cont_%=:\n"
-#if LZ4HIP_V2_LOOK & 2
-      "  s_waitcnt lgkmcnt(0)\n"
-      "  v_cmp_eq_u32_sdwa s[90:91], v117, v118 src0_sel:WORD_0 src1_sel:DWORD\n"
-      "  v_lshrrev_b32 v117, 16, v117\n"
-      "  s_mov_b64 exec, s[90:91]\n"
-      "  global_load_dword v119, v117, %[src]\n"
-      "  s_mov_b64 exec, -1\n"
-#endif
-      "  s_waitcnt vmcnt(" LZ4HIP_ROWS_WAIT ")\n"
+      "  s_waitcnt vmcnt(0)\n"
       LZ4HIP_TICK("t2")
+      "L_post_%=:\n"
       "  v_xor_b32 v113, v112, v113\n"
       "  v_cmp_ne_u32_e32 vcc, 0, v113\n"
       "  v_ffbl_b32 v114, v113\n"
@@ -180,7 +147,14 @@ __device__ __forceinline__ uint32_t lean_asm_run(uint32_t& ip, uint32_t& php, ui
       "  s_lshl2_add_u32 s74, s75, s76\n"
       "  s_cmp_lt_u32 s74, 4\n"
       "  s_cbranch_scc1 L_ruled_%=\n"
-      // a hit: park {position, forward length, offset}
+      // a hit of s74 bytes at s72.  The next step's window words are requested from the new row at once (the next step starts at
+      // s72 + s74, so its window lies s74 bytes into the row); parking {position, forward length, offset} and the loop's exit
+      // tests run while they are on their way.
+      "  v_add_u32 v100, s74, %[cj]\n"
+      "  v_and_b32 v101, -4, v100\n"
+      "  v_and_b32 v100, 3, v100\n"
+      "  ds_bpermute_b32 v102, v101, v112\n"
+      "  ds_bpermute_b32 v103, v101, v112 offset:4\n"
       "  s_mov_b32 m0, %[pc]\n"
       "  s_sub_u32 s77, s72, s73\n"
       "  v_writelane_b32 %[pms], s72, m0\n"
@@ -190,12 +164,15 @@ __device__ __forceinline__ uint32_t lean_asm_run(uint32_t& ip, uint32_t& php, ui
       "  s_mov_b32 %[php], s72\n"
       "  v_mov_b32 %[pfa], v112\n"
       "  s_add_u32 %[pc], %[pc], 1\n"
-      LZ4HIP_TICK("t3")
       LZ4HIP_COUNT("c0")
       "  s_cmp_eq_u32 %[pc], 64\n"
-      "  s_cbranch_scc0 L_top_%=\n"
-      "  s_mov_b32 %[code], 3\n"
-      "  s_branch L_out_%=\n"
+      "  s_cbranch_scc1 L_exit3_%=\n"
+      "  s_cmpk_gt_u32 s74, 189\n"
+      "  s_cbranch_scc1 L_exit2_%=\n"
+      "  s_cmp_gt_u32 %[ip], %[lim]\n"
+      "  s_cbranch_scc1 L_exit1_%=\n"
+      LZ4HIP_TICK("t3")
+      "  s_branch L_win_%=\n"
       // the hit lane's candidate differs in its first four bytes (a fingerprint collision): the lanes up to it are inserted
       // positions, the search goes on to the next tentative lane of the window
       "L_ruled_%=:\n"
@@ -238,10 +215,19 @@ __device__ __forceinline__ uint32_t lean_asm_run(uint32_t& ip, uint32_t& php, ui
       "  v_add_u32 v111, %[pfe], %[j16]\n"
       "  v_min_u32 v111, %[ntop], v111\n"
       "  global_load_dwordx4 v[120:123], v111, %[src]\n"
-      "  s_waitcnt vmcnt(0)\n"
+      "  s_add_u32 %[pfe], %[pfe], 1024\n"
+      "  s_waitcnt lgkmcnt(0)\n"
+      "  v_cmp_ne_u32_e64 s[88:89], v110, v107\n"
+      "  s_and_b64 s[88:89], s[88:89], s[84:85]\n"
+      "  s_cbranch_scc1 L_coll_%=\n"
+      "  s_waitcnt vmcnt(1)\n"      // the two rows; the touch stays in flight (it is older than the next step's rows)
+      "  s_branch L_post_%=\n"
       "L_touched_%=:\n"
       "  s_add_u32 %[pfe], %[pfe], 1024\n"
       "  s_branch L_back_%=\n"
+      "L_exit3_%=:\n"
+      "  s_mov_b32 %[code], 3\n"
+      "  s_branch L_out_%=\n"
       "L_exit1_%=:\n"
       "  s_mov_b32 %[code], 1\n"
       "L_out_%=:\n"
