@@ -61,12 +61,10 @@ int lz4hip_version(void);
  * block in the decoder (0 = default by batch size, 4/8/16/32/64); "decode_pipe" = 1 / 0 / -1 (default by batch size): the
  * software-pipelined interior loop of the decoder (faster when the batch is too small to fill the GPU); "decode_stage" =
  * 1 / 0 / -1 (default by batch size): the decoder's interior loop writes through an LDS staging buffer so that output
- * reaches memory as whole 128-byte lines (faster when the batch is bandwidth-bound); "compress_core" = 6 (the default scheme plus three chains per CU whose tables
- * live in global memory: +6 % for 7x the memory traffic), 5 (default: adaptive two-pass -- blocks of long
- * sequences are finished by the lean core (lz4_fast_v2_core.h), whose parked batches a partner wavefront writes out, blocks of
- * short sequences by the window-parallel core), 4 (the same, every wavefront writing its own sequences), 3 (lean
- * core only), 2 (adaptive over the round-1 one-sequence-per-step core), 1 (window-parallel core only) or 0 (one-sequence-per-step
- * core only); "compress_switch" = routing threshold of the adaptive schemes in bytes per sequence (default 20).  The knobs are
+ * reaches memory as whole 128-byte lines (faster when the batch is bandwidth-bound); "compress_core" = 5 (default: adaptive two-pass -- blocks of long
+ * sequences are finished by the lean core (lz4_fast_v2_core.h), whose parked hits a partner wavefront writes out, blocks of
+ * short sequences by the window-parallel core), 3 (lean core only) or 1 (window-parallel core only);
+ * "compress_switch" = routing threshold of the adaptive schemes in bytes per sequence (default 20).  The knobs are
  * process-wide atomics read once per launch; every setting produces the same bytes.                                       */
 int lz4hip_set_option(const char* name, int value);
 

@@ -72,10 +72,9 @@ std::atomic<int> g_decode_lanes{0};   // "decode_lanes"; 0 = kernel default
 std::atomic<int> g_decode_stage{-1};  // "decode_stage": 1 = LDS output staging in the plain loop
 std::atomic<int> g_decode_pipe{-1};   // "decode_pipe": 1/0 = pipelined interior loop on/off, -1 = kernel default
 
-// lz4hip_set_option "compress_core": 5 = adaptive two-pass, lean core with a writer wavefront per chain + window-parallel core
-// (default); 6 = the same with three more chains per CU whose tables live in global memory (+6 %, 7x the memory traffic); 4 = the same with every wavefront writing its own sequences (round-2 default before the writers); 3 = lean core only
-// (lz4_fast_v2_core.h); 2 = adaptive, one-sequence-per-step core + window-parallel core; 1 = window-parallel core only
-// (lz4_fast_ms_core.h); 0 = one-sequence-per-step core only (lz4_fast_core.h).  "compress_switch" = bytes per sequence below
+// lz4hip_set_option "compress_core": 5 = adaptive two-pass (default): the lean core with a writer wavefront per chain finishes
+// the blocks of long sequences, the window-parallel core the others; 3 = lean core only; 1 = window-parallel core only (the
+// forced modes exist so that the suite can put every input through each kernel).  "compress_switch" = bytes per sequence below
 // which a block counts as dense and goes to the window-parallel core (probe: sequences 32..95 of the block)
 std::atomic<int> g_compress_core{5};
 std::atomic<int> g_compress_switch{20};
@@ -132,29 +131,16 @@ int launch_fast(const lz4hip::BatchArgs& a, hipStream_t st) {
   uint32_t* scratch = nullptr;
   const uint32_t cus = cu_count();
   const int core = g_compress_core.load(std::memory_order_relaxed);
-  const size_t mail_words = core == 5 ? lz4hip::compress_fast_v2w_scratch_words(cus) : (core >= 6 ? lz4hip::compress_fast_v2wg_scratch_words(cus) : 0u);   // rings of the finder/writer pairs (+ global tables)
+  const size_t mail_words = core != 1 ? lz4hip::compress_fast_v2w_scratch_words(cus) : 0u;   // rings of the finder/writer pairs
   hipError_t e = hipMallocAsync((void**)&scratch, (3 + (size_t)a.n + mail_words) * sizeof(uint32_t), st);
   if (e != hipSuccess) return (int)e;
   const uint32_t dense64 = 64u * (uint32_t)g_compress_switch.load(std::memory_order_relaxed);
   int le;
   switch (core) {
-    case 0: le = lz4hip::launch_compress_fast(a, scratch, nullptr, 0u, cus, st); break;
     case 1: le = lz4hip::launch_compress_fast_ms(a, scratch, nullptr, true, cus, st); break;
-    case 2:
-      le = lz4hip::launch_compress_fast(a, scratch, scratch + 3, dense64, cus, st);
-      if (le == 0) le = lz4hip::launch_compress_fast_ms(a, scratch, scratch + 3, false, cus, st);
-      break;
-    case 3: le = lz4hip::launch_compress_fast_v2(a, scratch, nullptr, 0u, cus, st); break;
-    case 4:
-      le = lz4hip::launch_compress_fast_v2(a, scratch, scratch + 3, dense64, cus, st);
-      if (le == 0) le = lz4hip::launch_compress_fast_ms(a, scratch, scratch + 3, false, cus, st);
-      break;
-    case 5:    // the lean core with a writer wavefront per chain, adaptive (the default)
+    case 3: le = lz4hip::launch_compress_fast_v2w(a, scratch, nullptr, 0u, cus, scratch + 3 + a.n, st); break;
+    default:   // 5: adaptive
       le = lz4hip::launch_compress_fast_v2w(a, scratch, scratch + 3, dense64, cus, scratch + 3 + a.n, st);
-      if (le == 0) le = lz4hip::launch_compress_fast_ms(a, scratch, scratch + 3, false, cus, st);
-      break;
-    default:   // 6: the same plus three chains per CU with their tables in global memory
-      le = lz4hip::launch_compress_fast_v2wg(a, scratch, scratch + 3, dense64, cus, scratch + 3 + a.n, st);
       if (le == 0) le = lz4hip::launch_compress_fast_ms(a, scratch, scratch + 3, false, cus, st);
       break;
   }
@@ -754,7 +740,7 @@ int lz4hip_set_option(const char* name, int value) {
     return LZ4HIP_OK;
   }
   if (name && strcmp(name, "compress_core") == 0) {
-    if (value < 0 || value > 6) return fail(LZ4HIP_E_ARG, "compress_core must be 0..6");
+    if (value != 1 && value != 3 && value != 5) return fail(LZ4HIP_E_ARG, "compress_core must be 1, 3 or 5");
     g_compress_core = value;
     return LZ4HIP_OK;
   }
@@ -875,7 +861,7 @@ int lz4hip_dbg_compress_fast_profile_dev(const uint8_t* src, const uint64_t* src
   if (ordinal(device, &ord)) return fail(LZ4HIP_E_ARG, "bad device index");
   DeviceGuard g(ord);
   lz4hip::BatchArgs a{src, src_off, src_len, dst, dst_off, dst_cap, out_len, n};
-  int e = lz4hip::launch_compress_fast_prof(a, prof, g_compress_core.load() == 2 ? 1 : (g_compress_core.load() >= 4 ? 3 : g_compress_core.load()), stream);
+  int e = lz4hip::launch_compress_fast_prof(a, prof, g_compress_core.load() == 1 ? 1 : 3, stream);
   return e ? fail(LZ4HIP_E_HIP, "kernel launch", (hipError_t)e) : LZ4HIP_OK;
 }
 #endif  // LZ4HIP_DEV_TOOLS

@@ -12,23 +12,18 @@ struct BatchArgs {
   int32_t* out; uint32_t n;
 };
 
-// Fast compress, three cores (same bytes):
-//   launch_compress_fast_v2  lean finder loop, sequences parked in lanes and written 64 at a time (lz4_fast_v2_core.h): the default
-//   launch_compress_fast     one sequence per step, written as found (lz4_fast_core.h)
+// Fast compress, two kernels (same bytes):
+//   launch_compress_fast_v2w lean finder loop (lz4_fast_v2_core.h; common step hand-scheduled, lz4_fast_v2_asm.h) with a writer
+//                            wavefront per finder: bare hits parked in lanes, handed over 64 at a time: the default
 //   launch_compress_fast_ms  every sequence of a 64-position window per step (lz4_fast_ms_core.h): best when sequences are short
-// All fill each CU with one workgroup of 5 wavefronts (5 x 32 KB tables = the CU's whole LDS) that draw blocks from a queue.
+// Both fill each CU with one workgroup of 5 finder wavefronts (5 x 32 KB tables = the CU's whole LDS) that draw blocks from a queue.
 // q = three device uint32_t (queue words), n_cus = compute units of the device.
-// Adaptive two-pass use: launch_compress_fast{,_v2}(q, routed = u32[n] device scratch, dense64) finishes the blocks with long
+// Adaptive two-pass use: launch_compress_fast_v2w(q, routed = u32[n] device scratch, dense64) finishes the blocks with long
 // sequences and lists the others in routed[] (sequences 32..95 cover fewer than dense64 bytes); launch_compress_fast_ms(q, routed,
 // first = false) then does exactly those.  routed == nullptr: the kernel does every block (first = true zeroes q).
-int launch_compress_fast_v2(const BatchArgs& a, uint32_t* q, uint32_t* routed, uint32_t dense64, uint32_t n_cus, void* stream);
-// the same with a writer wavefront per chain (`mail`: compress_fast_v2w_scratch_words(n_cus) words of device scratch)
+// `mail`: compress_fast_v2w_scratch_words(n_cus) words of device scratch (the finder/writer rings)
 size_t compress_fast_v2w_scratch_words(uint32_t n_cus);
 int launch_compress_fast_v2w(const BatchArgs& a, uint32_t* q, uint32_t* routed, uint32_t dense64, uint32_t n_cus, uint32_t* mail, void* stream);
-// and with three more finder/writer pairs per CU whose tables live in global memory (+6 %, 7x the memory traffic: not the default)
-size_t compress_fast_v2wg_scratch_words(uint32_t n_cus);
-int launch_compress_fast_v2wg(const BatchArgs& a, uint32_t* q, uint32_t* routed, uint32_t dense64, uint32_t n_cus, uint32_t* mail, void* stream);
-int launch_compress_fast(const BatchArgs& a, uint32_t* q, uint32_t* routed, uint32_t dense64, uint32_t n_cus, void* stream);
 int launch_compress_fast_ms(const BatchArgs& a, uint32_t* q, const uint32_t* routed, bool first, uint32_t n_cus, void* stream);
 #ifdef LZ4HIP_DEV_TOOLS
 int launch_compress_fast_prof(const BatchArgs& a, uint64_t* prof, int core, void* stream);  // developer build only (tools/build_variant.sh dev -DLZ4HIP_DEV_TOOLS)

@@ -1,13 +1,12 @@
 // kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the LZ4 block engine.
 //
-//   compress_fast_v2w_cu_kernel / compress_fast_v2_cu_kernel / compress_fast_cu_kernel / compress_fast_ms_cu_kernel
+//   compress_fast_v2w_cu_kernel / compress_fast_ms_cu_kernel
 //                        : one workgroup per CU with 5 finder wavefronts (5 x 32 KB tables of {position, fingerprint} entries =
-//                          the CU's whole LDS), every finder draws blocks from a queue; algorithms in lz4_fast_v2_core.h (lean
-//                          finder loop + sequences parked in lanes, 64 at a time), lz4_fast_core.h (one sequence per step, written
-//                          as found) and lz4_fast_ms_core.h (every sequence of a 64-position window per step).  The default,
-//                          v2w, adds a WRITER wavefront per finder (no LDS needed) that takes the parked batches through a ring
-//                          in global memory and does all the output (build option LZ4HIP_GF: more finder/writer pairs per CU
-//                          with their tables in global memory).
+//                          the CU's whole LDS), every finder draws blocks from a queue.  v2w (the default): the lean finder of
+//                          lz4_fast_v2_core.h -- its common step hand-scheduled in lz4_fast_v2_asm.h, every other step replayed
+//                          by the exact step of lz4_fast_core.h -- parks bare hits in lanes, 64 at a time, and a WRITER wavefront
+//                          per finder (no LDS needed) takes the batches through a ring in global memory and does all the output.
+//                          ms: every sequence of a 64-position window per step (lz4_fast_ms_core.h), for blocks of short sequences.
 //                          Bound: the serial parse chain of a wavefront x 5 chains per CU (roofline: HBM, 1+1/ratio B/B).
 //   decode_kernel<GL, SAFE, PIPE, STAGE>
 //                        : GL lanes per block, 64/GL blocks per wavefront, algorithm in lz4_decode_core.h; PIPE = software-
@@ -71,88 +70,9 @@ constexpr uint32_t WAVES_PER_CU = LZ4HIP_WPC;
 // boundary the per-block loads lose their no-clobber marking, become vector loads, and the whole scalar parser state follows
 // them into vector registers -- 42 -> 83 VGPRs, -22 %.  Inside the loop every per-block value goes back to scalar registers
 // through readfirstlane for the same reason.)
-__global__ __launch_bounds__(64 * WAVES_PER_CU) void compress_fast_cu_kernel(BatchArgs a, uint32_t* q, uint32_t* routed, uint32_t dense64) {
-  __shared__ __attribute__((aligned(16))) uint64_t tables[WAVES_PER_CU][LZ4HIP_TABLE_U64];  // 160 KB: the whole LDS of the CU
-  uint64_t* table = tables[threadIdx.x >> 6];
-  for (;;) {
-    uint32_t b = 0;
-    if (__lane_id() == 0) b = atomicAdd(q, 1u);
-    b = __builtin_amdgcn_readfirstlane(b);
-    if (b >= a.n) return;
-    const int32_t n = uniform_i32(a.src_len[b]);
-    const int32_t cap = uniform_i32(a.dst_cap[b]);
-    uint32_t r = 0;
-    if (n >= 0 && (uint32_t)n <= 0x7E000000u && cap >= 0) {
-      const uint8_t* s = uniform_ptr(a.src + a.src_off[b]);
-      uint8_t* d = uniform_ptr(a.dst + a.dst_off[b]);
-      WaveDev w(table);
-      DirectOut<WaveDev> out(w, s, (uint32_t)n, d, (uint32_t)cap);
-      bool bailed;
-      if (n < 65547) {
-        FastCore<WaveDev, true> c(w, out, s, (uint32_t)n);
-        c.dense64 = routed ? dense64 : 0u;
-        r = c.run();
-        bailed = c.bailed;
-      } else {
-        FastCore<WaveDev, false> c(w, out, s, (uint32_t)n);
-        c.dense64 = routed ? dense64 : 0u;
-        r = c.run();
-        bailed = c.bailed;
-      }
-      if (bailed) {
-        if (__lane_id() == 0) routed[atomicAdd(q + 1, 1u)] = b;
-        continue;
-      }
-    }
-    if (__lane_id() == 0) a.out[b] = (int32_t)r;
-    WaveDev::sync();  // the table is reused
-  }
-}
-
-// lean core (lz4_fast_v2_core.h): minimal finder loop + sequences parked in lanes and written 64 at a time; same CU-filling
-// shape and the same routing contract as compress_fast_cu_kernel (routed == nullptr: every block is finished here)
-__global__ __launch_bounds__(64 * WAVES_PER_CU) void compress_fast_v2_cu_kernel(BatchArgs a, uint32_t* q, uint32_t* routed, uint32_t dense64) {
-  __shared__ __attribute__((aligned(16))) uint64_t tables[WAVES_PER_CU][LZ4HIP_TABLE_U64];
-  uint64_t* table = tables[threadIdx.x >> 6];
-  for (;;) {
-    uint32_t b = 0;
-    if (__lane_id() == 0) b = atomicAdd(q, 1u);
-    b = __builtin_amdgcn_readfirstlane(b);
-    if (b >= a.n) return;
-    const int32_t n = uniform_i32(a.src_len[b]);
-    const int32_t cap = uniform_i32(a.dst_cap[b]);
-    uint32_t r = 0;
-    if (n >= 0 && (uint32_t)n <= 0x7E000000u && cap >= 0) {
-      const uint8_t* s = uniform_ptr(a.src + a.src_off[b]);
-      uint8_t* d = uniform_ptr(a.dst + a.dst_off[b]);
-      WaveDev w(table);
-      ParkOut<WaveDev> out(w, s, (uint32_t)n, d, (uint32_t)cap);
-      out.dense64 = routed ? dense64 : 0u;
-      if (n < 65547) {
-        FastV2<WaveDev> c(w, out, s, (uint32_t)n);
-        r = c.run();
-      } else {
-        FastCore<WaveDev, false, ParkOut<WaveDev>> c(w, out, s, (uint32_t)n);
-        r = c.run();
-      }
-      if (out.bail) {
-        if (__lane_id() == 0) routed[atomicAdd(q + 1, 1u)] = b;
-        WaveDev::sync();
-        continue;
-      }
-    }
-    if (__lane_id() == 0) a.out[b] = (int32_t)r;
-    WaveDev::sync();  // the table is reused
-  }
-}
-int launch_compress_fast_v2(const BatchArgs& a, uint32_t* q, uint32_t* routed, uint32_t dense64, uint32_t n_cus, void* stream) {
-  if (a.n == 0) return 0;
-  hipError_t e = hipMemsetAsync(q, 0, 3 * sizeof(uint32_t), (hipStream_t)stream);
-  if (e != hipSuccess) return (int)e;
-  const uint32_t wgs = (a.n + WAVES_PER_CU - 1u) / WAVES_PER_CU;
-  hipLaunchKernelGGL(compress_fast_v2_cu_kernel, dim3(wgs < n_cus ? wgs : n_cus), dim3(64 * WAVES_PER_CU), 0, (hipStream_t)stream, a, q, routed, dense64);
-  return (int)hipGetLastError();
-}
+// (Rounds 1 and 2 also shipped the one-sequence-per-step core and the lean core WITHOUT writer wavefronts as kernels of their own,
+// and a variant with three more chains per CU whose tables lived in global memory (+6 % for 7x the memory traffic): superseded,
+// removed in round 3 -- git history has them.  FastCore stays: it is the exact path of the lean core and the byU32 core.)
 
 // ------------------------------------------------------------------------------------------------
 // lean core with a WRITER wavefront per chain.  A finder's 64-sequence batch write is ~20 scattered store instructions, and a
@@ -285,18 +205,6 @@ __device__ __forceinline__ void mail_writer(const BatchArgs& a, uint32_t* slots,
   }
 }
 
-// LZ4HIP_GF (build option, default 0) finder/writer pairs per CU beyond the five LDS ones keep their tables in global memory
-// (wave_dev.h WaveDevG): LDS limits a CU to five tables, not to five chains.  Alone, a global-table chain runs at 0.57x an LDS
-// chain (three per CU and nothing else: 26 GB/s); next to the five LDS pairs three of them -- what a 1024-thread workgroup has room
-// for -- add 6 %: 65536 x 64 KiB blocks 54.0 -> 50.8 ms, 84.6 GB/s (GF = 1 / 2 / 3: 54.8 / 52.4 / 50.8), bit-exact in fuzz, stress
-// and the GPU suite.  NOT the default: every 4-byte table access moves a 128-byte line between L2 and the fabric, 148 GB per
-// launch against 19.7 (23x the algorithmic bytes, 2.9 TB/s) -- too much bandwidth for 6 %.  Same algorithm sources, same bytes;
-// which kind of chain takes a block is decided by the queue.
-#ifndef LZ4HIP_GF
-#define LZ4HIP_GF 3
-#endif
-
-
 // ---- the default: the five LDS pairs alone ----
 __global__ __launch_bounds__(64 * 2 * WAVES_PER_CU) void compress_fast_v2w_cu_kernel(BatchArgs a, uint32_t* q, uint32_t* routed, uint32_t dense64, uint32_t* mail_ctr, uint32_t* mail_slots) {
   __shared__ __attribute__((aligned(16))) uint64_t tables[WAVES_PER_CU][LZ4HIP_TABLE_U64];
@@ -354,96 +262,6 @@ int launch_compress_fast_v2w(const BatchArgs& a, uint32_t* q, uint32_t* routed, 
   uint32_t* slots = (uint32_t*)(((uintptr_t)(mail + 2u * pairs) + 1023u) & ~(uintptr_t)1023u);
   const uint32_t wgs = (a.n + WAVES_PER_CU - 1u) / WAVES_PER_CU;
   hipLaunchKernelGGL(compress_fast_v2w_cu_kernel, dim3(wgs < n_cus ? wgs : n_cus), dim3(64 * 2 * WAVES_PER_CU), 0, (hipStream_t)stream, a, q, routed, dense64, mail, slots);
-  return (int)hipGetLastError();
-}
-
-
-// ---- with global-table chains ----
-// one finder: draws blocks from the queue until it is empty (W = WaveDev: table in LDS; WaveDevG: table in global memory).
-// (A macro, like the written-out bodies of the one-wave kernels above: per-block loads behind a function boundary lose their
-// no-clobber marking.)
-#define LZ4HIP_MAIL_FINDER(W, w)                                                                                              \
-  {                                                                                                                           \
-    uint32_t head = 0, tail_seen = 0;                                                                                         \
-    for (;;) {                                                                                                                \
-      uint32_t b = 0;                                                                                                         \
-      if (__lane_id() == 0) b = atomicAdd(q, 1u);                                                                             \
-      b = __builtin_amdgcn_readfirstlane(b);                                                                                  \
-      MailOut<W> out(w, slots, ctr, head);                                                                                    \
-      out.tail_seen = tail_seen;                                                                                              \
-      if (b >= a.n) { out.post(MAIL_EXIT, 0u, 0u); return; }                                                                  \
-      out.b = b;                                                                                                              \
-      const int32_t n = uniform_i32(a.src_len[b]);                                                                            \
-      const int32_t cap = uniform_i32(a.dst_cap[b]);                                                                          \
-      if (n >= 0 && (uint32_t)n <= 0x7E000000u && cap >= 0) {                                                                 \
-        const uint8_t* s = uniform_ptr(a.src + a.src_off[b]);                                                                 \
-        out.dense64 = routed ? dense64 : 0u;                                                                                  \
-        if (n < 65547) {                                                                                                      \
-          FastV2<W, MailOut<W>> c(w, out, s, (uint32_t)n);                                                                    \
-          (void)c.run();                                                                                                      \
-        } else {                                                                                                              \
-          FastCore<W, false, MailOut<W>> c(w, out, s, (uint32_t)n);                                                           \
-          (void)c.run();                                                                                                      \
-        }                                                                                                                     \
-        if (out.bail) {                                                                                                       \
-          out.post(MAIL_ABORT, 0u, 0u);                                                                                       \
-          if (__lane_id() == 0) routed[atomicAdd(q + 1, 1u)] = b;                                                             \
-        }                                                                                                                     \
-      } else {                                                                                                                \
-        if (__lane_id() == 0) a.out[b] = 0;                                                                                   \
-      }                                                                                                                       \
-      head = out.head; tail_seen = out.tail_seen;                                                                             \
-      W::sync(); /* the table is reused */                                                                                    \
-    }                                                                                                                         \
-  }
-
-// wavefronts of a workgroup: [0, 5) LDS finders, [5, 10) their writers, [10, 10 + GF) global-table finders, then their writers
-template <uint32_t GLOBAL_FINDERS>
-__global__ __launch_bounds__(64 * 2 * (WAVES_PER_CU + GLOBAL_FINDERS)) void compress_fast_v2wg_cu_kernel(BatchArgs a, uint32_t* q, uint32_t* routed, uint32_t dense64, uint32_t* mail_ctr, uint32_t* mail_slots, uint64_t* gtables) {
-  constexpr uint32_t PAIRS_PER_CU = WAVES_PER_CU + GLOBAL_FINDERS;
-  __shared__ __attribute__((aligned(16))) uint64_t tables[WAVES_PER_CU][LZ4HIP_TABLE_U64];
-  const uint32_t wv = threadIdx.x >> 6;
-  const bool lds_side = wv < 2u * WAVES_PER_CU;
-  const uint32_t k = lds_side ? wv : wv - 2u * WAVES_PER_CU;                 // index within its side
-  const uint32_t per_side = lds_side ? WAVES_PER_CU : GLOBAL_FINDERS;
-  const bool writer = k >= per_side;
-  const uint32_t fi = (lds_side ? 0u : WAVES_PER_CU) + (writer ? k - per_side : k);   // finder index on this CU
-  const uint32_t pair = blockIdx.x * PAIRS_PER_CU + fi;
-  uint32_t* ctr = mail_ctr + 2u * pair;
-  uint32_t* slots = mail_slots + (size_t)pair * (MAIL_RING * MAIL_SLOT_WORDS);
-  if (writer) { mail_writer(a, slots, ctr); return; }
-  if (lds_side) {
-#ifdef LZ4HIP_PROBE_NO_LDS_FINDERS   // developer timing probe: the global-table chains alone
-    { WaveDev w(tables[k]); MailOut<WaveDev> out(w, slots, ctr, 0u); out.post(MAIL_EXIT, 0u, 0u); return; }
-#endif
-    WaveDev w(tables[k]);
-    LZ4HIP_MAIL_FINDER(WaveDev, w)
-  } else {
-    {
-      WaveDevG w(gtables + ((size_t)blockIdx.x * GLOBAL_FINDERS + k) * 4096u);
-      LZ4HIP_MAIL_FINDER(WaveDevG, w)
-    }
-  }
-}
-// scratch words the two-wave kernel needs after the three queue words: counters of every pair, then (1 KB aligned) the rings,
-// then (with global-table finders) their 32 KB tables
-size_t compress_fast_v2wg_scratch_words(uint32_t n_cus) {
-  constexpr uint32_t GLOBAL_FINDERS = LZ4HIP_GF, PAIRS_PER_CU = WAVES_PER_CU + GLOBAL_FINDERS;
-  const size_t pairs = (size_t)n_cus * PAIRS_PER_CU;
-  return 2u * pairs + 256u + pairs * (MAIL_RING * MAIL_SLOT_WORDS) + (size_t)n_cus * GLOBAL_FINDERS * 8192u;
-}
-int launch_compress_fast_v2wg(const BatchArgs& a, uint32_t* q, uint32_t* routed, uint32_t dense64, uint32_t n_cus, uint32_t* mail, void* stream) {
-  if (a.n == 0) return 0;
-  constexpr uint32_t GLOBAL_FINDERS = LZ4HIP_GF, PAIRS_PER_CU = WAVES_PER_CU + GLOBAL_FINDERS;
-  const size_t pairs = (size_t)n_cus * PAIRS_PER_CU;
-  hipError_t e = hipMemsetAsync(q, 0, 3 * sizeof(uint32_t), (hipStream_t)stream);
-  if (e != hipSuccess) return (int)e;
-  e = hipMemsetAsync(mail, 0, 2u * pairs * sizeof(uint32_t), (hipStream_t)stream);
-  if (e != hipSuccess) return (int)e;
-  uint32_t* slots = (uint32_t*)(((uintptr_t)(mail + 2u * pairs) + 1023u) & ~(uintptr_t)1023u);
-  uint64_t* gtables = (uint64_t*)(slots + pairs * (MAIL_RING * MAIL_SLOT_WORDS));
-  const uint32_t wgs = (a.n + PAIRS_PER_CU - 1u) / PAIRS_PER_CU;
-  hipLaunchKernelGGL(compress_fast_v2wg_cu_kernel<GLOBAL_FINDERS>, dim3(wgs < n_cus ? wgs : n_cus), dim3(64 * 2 * PAIRS_PER_CU), 0, (hipStream_t)stream, a, q, routed, dense64, mail, slots, gtables);
   return (int)hipGetLastError();
 }
 
@@ -507,6 +325,12 @@ extern "C" __attribute__((visibility("default"))) int lz4hip_dev_asm_prof(unsign
 }
 #endif
 
+#if LZ4HIP_ASM_DBG & 4
+extern "C" __attribute__((visibility("default"))) int lz4hip_dev_asm_dbg(unsigned int* out1600) {
+  return (int)hipMemcpyFromSymbol(out1600, HIP_SYMBOL(g_asm_dbg), 1600 * sizeof(unsigned int));
+}
+#endif
+
 #ifdef LZ4HIP_DEV_TOOLS
 // developer diagnostics: same algorithm with per-phase shader-clock accumulation; prof[b*12 + i] =
 // {steps, slow_steps, false_pos, sequences, t[0..7]} of block b
@@ -550,15 +374,6 @@ int launch_compress_fast_prof(const BatchArgs& a, uint64_t* prof, int core, void
   return (int)hipGetLastError();
 }
 #endif  // LZ4HIP_DEV_TOOLS
-
-int launch_compress_fast(const BatchArgs& a, uint32_t* q, uint32_t* routed, uint32_t dense64, uint32_t n_cus, void* stream) {
-  if (a.n == 0) return 0;
-  hipError_t e = hipMemsetAsync(q, 0, 3 * sizeof(uint32_t), (hipStream_t)stream);
-  if (e != hipSuccess) return (int)e;
-  const uint32_t wgs = (a.n + WAVES_PER_CU - 1u) / WAVES_PER_CU;
-  hipLaunchKernelGGL(compress_fast_cu_kernel, dim3(wgs < n_cus ? wgs : n_cus), dim3(64 * WAVES_PER_CU), 0, (hipStream_t)stream, a, q, routed, dense64);
-  return (int)hipGetLastError();
-}
 
 // ------------------------------------------------------------------------------------------------
 // HC compress (levels 1..9): phase 1 builds delta[] (workspace `ws`, one u16 per input byte, indexed by

@@ -317,10 +317,24 @@ struct FastV2 {
       // takes it from the same state with every rule.
       if constexpr (W::kAsmLean && OUT::kAsmPark) {
         if (!st) {
-          const uint32_t code = lean_asm_run(ip, prev_hpos, pf_end, out.cnt, prev_fa, out.p_ms, out.p_ml, out.p_off, lim, src,
+#if LZ4HIP_ASM_DBG & 4
+          const uint32_t dbg_ip = ip, dbg_pc = out.cnt, dbg_php = prev_hpos;
+#endif
+          // (the loop requests the rows of the NEXT hit before it has compared the next position with its limit: that hit lies
+          // up to 191 bytes behind the limit it is given, so it gets one that much earlier; the C++ steps do the rest)
+          const uint32_t code = lean_asm_run(ip, prev_hpos, pf_end, out.cnt, prev_fa, out.p_ms, out.p_ml, out.p_off,
+                                             lim >= 192u ? lim - 192u : 0u, src,
                                              (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)w.lds, n, aprof);
+#if LZ4HIP_ASM_DBG & 4
+          if (w.lane() == 0u) {
+            const unsigned long long k = atomicAdd(&g_asm_prof[15], 1ull);
+            if (k < 200) { g_asm_dbg[k * 8 + 0] = dbg_ip; g_asm_dbg[k * 8 + 1] = dbg_php; g_asm_dbg[k * 8 + 2] = dbg_pc; g_asm_dbg[k * 8 + 3] = code;
+                           g_asm_dbg[k * 8 + 4] = ip; g_asm_dbg[k * 8 + 5] = prev_hpos; g_asm_dbg[k * 8 + 6] = out.cnt; g_asm_dbg[k * 8 + 7] = 0; }
+          }
+#endif
+          (void)code;
           if (out.cnt == 64u) { out.batch(); continue; }
-          if (code == 1u) break;
+          if (ip > lim) break;
         }
       }
 #endif

@@ -208,37 +208,4 @@ struct WaveDev {
 template <> struct WaveDev::Entry<true> { using S = uint32_t; using V = uint32_t; };
 template <> struct WaveDev::Entry<false> { using S = uint64_t; using V = uint64_t; };
 
-// The same interface with the match table in GLOBAL memory (32 KB per wavefront, L2-resident): LDS limits a CU to five tables,
-// not to five wavefronts, and a chain whose table operations are L2 round trips (~2x the step time) still adds throughput next to
-// the five LDS chains.  Same algorithm sources, same bytes.  The table belongs to one wavefront, so its atomics are ordered at
-// WORKGROUP scope (no cross-XCD coherence traffic; agent scope: slower); a wavefront's accesses to one address stay in program order.
-struct WaveDevG : WaveDev {
-  static constexpr bool kAsmLean = false;
-  __device__ __forceinline__ explicit WaveDevG(void* table) : WaveDev(table) {}
-  template <bool U16> __device__ __forceinline__ void lds_fill(uint32_t count, typename Entry<U16>::S val) {
-    using S = typename Entry<U16>::S;
-    typedef __attribute__((address_space(1))) S* G;
-    G t = (G)(uintptr_t)lds;
-    for (uint32_t i = __lane_id(); i < count; i += 64u) t[i] = val;
-  }
-  template <bool U16> __device__ __forceinline__ auto lds_rdu(VU h) {
-    using S = typename Entry<U16>::S;
-    return __hip_atomic_load(&((S*)lds)[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  }
-  template <bool U16> __device__ __forceinline__ auto lds_rd(VU h, bool m) {
-    using S = typename Entry<U16>::S;
-    return m ? __hip_atomic_load(&((S*)lds)[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : (S)0;
-  }
-  template <bool U16> __device__ __forceinline__ auto lds_max(VU h, typename Entry<U16>::V v, bool m) {
-    using S = typename Entry<U16>::S;
-    S old = 0;
-    if (m) old = __hip_atomic_fetch_max(&((S*)lds)[h], (S)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    return old;
-  }
-  template <bool U16> __device__ __forceinline__ void lds_wr(VU h, typename Entry<U16>::V v, bool m) {
-    using S = typename Entry<U16>::S;
-    if (m) __hip_atomic_store(&((S*)lds)[h], (S)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  }
-};
-
 }  // namespace lz4hip

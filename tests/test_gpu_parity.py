@@ -197,13 +197,33 @@ def test_offsets_inside_bigger_buffers(amd, ref, corpus):
     assert bytes(out[7:7 + len(data)]) == data and out[:7] == b"\x22" * 7 and out[7 + len(data):] == b"\x22" * 13
 
 
+def test_regression_inputs(amd, ref):
+    """tests/golden/regress/*.bin: inputs that once made a kernel under development differ from the reference (round 3: a false
+    tentative hit AT the first probe position of a window, left to the C++ step with a row that did not cover ip - 2), through
+    every compress core, alone and in one batch"""
+    import glob, os
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "regress", "*.bin")))
+    assert files
+    blocks = [open(f, "rb").read() for f in files]
+    for core in (1, 3, 5):
+        amd.set_option("compress_core", core)
+        try:
+            res = gpu_compress_many(amd, blocks, [ref.compress_bound(len(b)) for b in blocks])
+            for b in blocks:
+                res += gpu_compress_many(amd, [b], [ref.compress_bound(len(b))])
+        finally:
+            amd.set_option("compress_core", 5)
+        for b, (r, c) in zip(blocks + blocks, res):
+            assert c == ref.compress_fast(b), (core, len(b))
+
+
 def test_issue12_regression_blob_gpu(amd, ref):
     """LZ4Test.testRoundtripIssue12 (LZ4Test.java:487-541), bytes [9:]: every HIP compressor's output equals the reference
     library's and decodes back through both HIP decompressors"""
     import os
     data = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "issue12.bin"), "rb").read()[9:]
     f = amd.LZ4Factory.hipInstance()
-    for core in (0, 1, 2, 3, 4, 5, 6):
+    for core in (1, 3, 5):
         amd.set_option("compress_core", core)
         c = f.fastCompressor().compress(data)
         assert c == ref.compress_fast(data), core
@@ -410,11 +430,10 @@ def test_cpp_host_mirror_runs():
     assert subprocess.call([exe]) == 0
 
 
-@pytest.mark.parametrize("core,switch", [(0, 20), (1, 20), (2, 0), (2, 20), (2, 1024), (3, 20), (4, 0), (4, 20), (4, 1024), (5, 0), (5, 20), (5, 1024), (6, 0), (6, 20)])
+@pytest.mark.parametrize("core,switch", [(1, 20), (3, 20), (5, 0), (5, 20), (5, 1024)])
 def test_compress_core_variants_same_bytes(amd, ref, O, corpus, core, switch):
-    """compress_core 0 (one sequence per step, written as found), 1 (window-parallel only), 3 (lean core only), 2 and 4 (adaptive
-    two-pass over core 0 / the lean core) with extreme routing thresholds produce the same bytes as the default (4, threshold 20
-    bytes per sequence)"""
+    """compress_core 1 (window-parallel core only), 3 (lean core + writer wavefronts only) and 5 (adaptive two-pass over both) with
+    extreme routing thresholds produce the reference's bytes, like the default (5, threshold 20 bytes per sequence)"""
     import random as _r
     rng = _r.Random(304)
     blocks, caps = [], []
