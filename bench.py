@@ -19,8 +19,11 @@ on all ranks / wall time (max over ranks) -- inputs resident in HBM.  `roofline`
 kernel (fast compress); `roofline_decode` the decoder; `cpu_baseline` is the reference's own liblz4 1.9.3
 (oracle/_ref) timed on this box's host cores on a bounded sample of the same blocks.  `configs` carries the
 other BASELINE.json workloads, each timed outside the headline region with its own roofline and cpu_baseline:
-decompress_fast on the headline blocks, configs[2] (safe decode of 4 MiB blocks), configs[3] (HC level 9 of
-1 MiB blocks), configs[4] (XXH32 / XXH64 of 4 KiB buffers).
+decompress_fast on the headline blocks, configs[2] (safe decode of 4 MiB blocks) and the byU32 fast compress of the same blocks,
+configs[3] (HC level 9 of 1 MiB blocks), configs[4] (XXH32 / XXH64 of 4 KiB buffers), real text (65536 slices of Calgary book1:
+the stand-in for configs[0]'s Silesia/dickens block, compressed bytes checked against the reference library), and
+`end_to_end`: the host-pointer batch API on the headline blocks from pageable host memory, PCIe included (never `value`).
+Every cpu_baseline carries best-of-N and the median over the N runs, for all host threads and for one thread.
 """
 import argparse
 import hashlib
@@ -89,6 +92,14 @@ def cpu_bench(args, env=None):
     r = json.loads(out.decode().strip().splitlines()[-1])
     r["_kind"], r["_lib"] = kind, (os.path.relpath(lib, ROOT) if lib.startswith(ROOT) else lib)
     return r
+
+
+def decode_kernel_name(n_blocks, safe=True):
+    """the decoder instantiation launch_decompress (kernels.hip) picks by batch size: lanes per block, SAFE, PIPE, STAGE"""
+    s = "true" if safe else "false"
+    if n_blocks >= 40960:
+        return "decode_kernel<4, %s, false, true>" % s
+    return "decode_kernel<%d, %s, true, false>" % (8 if n_blocks >= 8192 else 16, s)
 
 
 def cpu_entry(fn):
@@ -259,9 +270,86 @@ def main():
         wall, tk = timed(lambda: amd.DeviceBatch.decompress_fast(comp, co, cc, back, so, sl, dlen), 3)
         okf = all_ok(bool(torch.equal(back, src)) and bool(torch.equal(dlen, clen)))
         extra["decompress_fast"] = {"workload": "the headline blocks, LZ4_decompress_fast", "value": round(world * nbytes / wall / 1e9, 3), "unit": "GB/s",
-                                    "verified": okf, "roofline": roof("decode_kernel<4, false, false, true>", nbytes + csum, tk,
-                                                                              kernel_traffic(tr, world, "decode_kernel<4, false, false, true>") if n >= 40960 else None)}
+                                    "verified": okf, "roofline": roof(decode_kernel_name(n, False), nbytes + csum, tk, kernel_traffic(tr, world, decode_kernel_name(n, False)))}
         ok = ok and okf
+
+        # ---- end to end: what a JNI caller reaches (LZ4JNI.c:53-84: pin, ONE call, release) is the host-pointer batch API ----
+        # lz4hip_compress_fast_batch / lz4hip_decompress_safe_batch on a sample of the headline blocks lying in PAGEABLE host memory:
+        # staging, H2D, kernels, D2H all inside the timed call.  Never `value`.
+        if rank == 0:
+            import numpy as np
+            ne = min(n, 16384)
+            h_src = bytearray(src[:ne * blk].cpu().numpy().tobytes())
+            h_dst, h_back = bytearray(ne * cap), bytearray(ne * blk)
+            so_h, sl_h = np.arange(ne, dtype=np.uint64) * blk, np.full(ne, blk, dtype=np.int32)
+            do_h, dc_h = np.arange(ne, dtype=np.uint64) * cap, np.full(ne, cap, dtype=np.int32)
+            tc, td = [], []
+            for _ in range(4):
+                t0 = time.perf_counter()
+                sizes = amd.LZ4HIPBatch.compress(h_src, so_h, sl_h, h_dst, do_h, dc_h)
+                t1 = time.perf_counter()
+                res = amd.LZ4HIPBatch.decompressSafe(h_dst, do_h, sizes, h_back, so_h, sl_h)
+                t2 = time.perf_counter()
+                tc.append(t1 - t0); td.append(t2 - t1)
+            oke = bytes(h_back) == bytes(h_src) and bool((np.asarray(res) == blk).all()) and \
+                bool((np.asarray(sizes) == clen[:ne].cpu().numpy()).all())
+            tc, td = sorted(tc[1:]), sorted(td[1:])          # (the first call allocates the staging pool)
+            eb = float(ne) * blk
+            extra["end_to_end"] = {"workload": "%d of the headline blocks in pageable host memory through lz4hip_compress_fast_batch / "
+                                               "lz4hip_decompress_safe_batch (staging + PCIe both ways + kernels), best / median of 3 calls" % ne,
+                                   "unit": "GB/s", "verified": oke,
+                                   "compress_GBps": round(eb / tc[0] / 1e9, 3), "compress_GBps_median": round(eb / tc[1] / 1e9, 3),
+                                   "decompress_GBps": round(eb / td[0] / 1e9, 3), "decompress_GBps_median": round(eb / td[1] / 1e9, 3),
+                                   "roundtrip_GBps": round(eb / (tc[0] + td[0]) / 1e9, 3),
+                                   "note": "compare with cpu_baseline (all threads, one_thread) of the headline: the reference works on host memory in place"}
+            ok = ok and oke
+            del h_src, h_dst, h_back
+
+        # ---- real text: BASELINE configs[0] names a 64 KiB Silesia/dickens block; the only real data of the reference are
+        # src/test-resources/calgary/* (LZ4Test.java:335-348), so: every block = 64 KiB of Calgary book1 (English prose, the same
+        # class) from a different offset.  Compressed bytes of a sample of blocks are compared with the reference library's. ----
+        bpath = os.path.join(ROOT, "tests", "golden", "book1_200000.bin")
+        if os.path.exists(bpath):
+            import numpy as np
+            book = np.frombuffer(open(bpath, "rb").read(), dtype=np.uint8)
+            span = len(book) - blk
+            bdev = torch.from_numpy(book.copy()).to(dev)
+            offs = (torch.arange(n, dtype=i64, device=dev) + rank * n) * 7919 % span
+            ar = torch.arange(blk, dtype=i64, device=dev)
+            for c0 in range(0, n, 1024):
+                c1 = min(n, c0 + 1024)
+                src[c0 * blk:c1 * blk] = bdev[(offs[c0:c1, None] + ar[None, :]).reshape(-1)]
+            del ar
+            torch.cuda.synchronize()
+            wc, tkc = timed(lambda: amd.DeviceBatch.compress_fast(src, so, sl, comp, co, cc, clen), 2)
+            csb = int(clen.sum().item())
+            back.zero_()
+            wd, tkd = timed(lambda: amd.DeviceBatch.decompress_safe(comp, co, clen, back, so, sl, dlen), 2)
+            okb = bool(torch.equal(back, src)) and bool(torch.equal(dlen, sl))
+            from oracle import oracle as O
+            if O.ref_path():     # the reference's own liblz4 (oracle/_ref travels with the repo): bytes of 48 blocks
+                chk = O.ref()
+                cl = clen.cpu().tolist()
+                for i in list(range(0, n, max(1, n // 47)))[:48]:
+                    want = chk.compress_fast(book[int(offs[i]):int(offs[i]) + blk].tobytes())
+                    okb = okb and cl[i] == len(want) and comp[i * cap:i * cap + cl[i]].cpu().numpy().tobytes() == want
+            okb = all_ok(okb)
+            extra["real_book1"] = {"workload": "%d x 64 KiB slices of Calgary book1 per GPU (stand-in for configs[0]'s Silesia/dickens block), fast compress + "
+                                               "safe decompress, ratio %.3f; compressed bytes of 48 blocks vs the reference library" % (n, nbytes / csb),
+                                   "unit": "GB/s", "verified": okb,
+                                   "compress_GBps": round(world * nbytes / wc / 1e9, 3), "decompress_GBps": round(world * nbytes / wd / 1e9, 3),
+                                   "roofline_compress": roof("compress_fast_v2w_cu_kernel + compress_fast_ms_cu_kernel", nbytes + csb, tkc, None),
+                                   "roofline_decode": roof(decode_kernel_name(n), nbytes + csb, tkd, None)}
+            ok = ok and okb
+            if want_cpu:
+                def fb():
+                    r = cpu_bench([min(n, 64 * cores), blk, cores, 3, 0, args.litmax, args.win], {"CPU_BENCH_FILE": bpath})
+                    return {"compress_GBps": round(r["compress_GBps"], 3), "decompress_safe_GBps": round(r["decompress_safe_GBps"], 3),
+                            "compress_GBps_median": round(r["compress_GBps_median"], 3), "decompress_safe_GBps_median": round(r["decompress_safe_GBps_median"], 3),
+                            "unit": "GB/s", "cores": cores, "kind": r["_kind"],
+                            "sample": "%d x 64 KiB slices of book1, %d threads, best (and median) of 3" % (r["n_blocks"], cores)}
+                extra["real_book1"]["cpu_baseline"] = cpu_entry(fb)
+            del bdev, offs
         del comp, back
         torch.cuda.empty_cache()
 
@@ -278,23 +366,30 @@ def main():
         amd.DeviceBatch.gen_blocks(s3, b3, b3, n3, first_idx=(1 << 24) + rank * n3, litmax=args.litmax, win=4096)
         c3 = torch.empty(n3 * cap3, dtype=u8, device=dev)
         B3 = batch(n3, b3, cap3)
-        amd.DeviceBatch.compress_fast(s3, B3["so"], B3["sl"], c3, B3["co"], B3["cc"], B3["clen"])   # setup (bit-exactness of these bytes: tests/)
-        torch.cuda.synchronize()
+        # the setup of configs[2] is a measurement of its own: fast compress of 4 MiB blocks (byU32 table, 5-byte hash -- the LZ4Frame
+        # default block size, LZ4FrameOutputStream.java:169-171); bit-exactness of these bytes: tests/test_gpu_scale.py
+        wall3c, tk3c = timed(lambda: amd.DeviceBatch.compress_fast(s3, B3["so"], B3["sl"], c3, B3["co"], B3["cc"], B3["clen"]), 1, warm=0)
         cs3 = int(B3["clen"].sum().item())
+        extra["compress_4MiB"] = {"workload": "%d x 4 MiB blocks per GPU, App.F win 4096, LZ4_compress_default (byU32), ratio %.3f" % (n3, n3 * b3 / cs3),
+                                  "value": round(world * float(n3) * b3 / wall3c / 1e9, 3), "unit": "GB/s", "verified": None,
+                                  "roofline": roof("compress_fast_v2w_cu_kernel", float(n3) * b3 + cs3, tk3c, None)}
         bk3 = torch.zeros(n3 * b3, dtype=u8, device=dev)
         wall, tk = timed(lambda: amd.DeviceBatch.decompress_safe(c3, B3["co"], B3["clen"], bk3, B3["so"], B3["sl"], B3["dlen"]), 2)
         ok3 = all_ok(bool(torch.equal(bk3, s3)))
+        extra["compress_4MiB"]["verified"] = ok3   # (its bytes decode back to the input)
         extra["configs2_decode_4MiB"] = {"workload": "%d x 4 MiB blocks per GPU in one launch (BASELINE configs[2]: 16384 blocks in all, sharded over the ranks), "
                                                      "App.F win 4096, LZ4_decompress_safe of fast-compressed blocks, ratio %.3f" % (n3, n3 * b3 / cs3),
                                          "value": round(world * float(n3) * b3 / wall / 1e9, 3), "unit": "GB/s", "verified": ok3,
-                                         "roofline": roof("decode_kernel<8, true, true, false>", float(n3) * b3 + cs3, tk,
-                                                          kernel_traffic(tr, world, "decode_kernel<8, true, true, false>") if 8192 <= n3 < 40960 else None)}
+                                         "roofline": roof(decode_kernel_name(n3), float(n3) * b3 + cs3, tk,
+                                                          kernel_traffic(tr, world, decode_kernel_name(n3)) if n3 == (tr.get("configs2_blocks") or 16384) else None)}
         ok = ok and ok3
         if want_cpu:
             def f3():
-                r = cpu_bench([min(256, 2 * cores), b3, cores, 2, 1 << 24, args.litmax, 4096])
-                return {"value": round(r["decompress_safe_GBps"], 3), "unit": "GB/s", "cores": cores, "kind": r["_kind"],
-                        "sample": "%d x 4 MiB blocks (same generator), %d threads, best of 2, LZ4_decompress_safe" % (r["n_blocks"], cores)}
+                r = cpu_bench([min(256, 2 * cores), b3, cores, 3, 1 << 24, args.litmax, 4096])
+                return {"value": round(r["decompress_safe_GBps"], 3), "median": round(r["decompress_safe_GBps_median"], 3),
+                        "per_core": round(r["decompress_safe_GBps"] / cores, 4), "compress_GBps": round(r["compress_GBps"], 3),
+                        "unit": "GB/s", "cores": cores, "kind": r["_kind"],
+                        "sample": "%d x 4 MiB blocks (same generator), %d threads, best (and median) of 3, LZ4_decompress_safe / LZ4_compress_default" % (r["n_blocks"], cores)}
             extra["configs2_decode_4MiB"]["cpu_baseline"] = cpu_entry(f3)
         del s3, c3, bk3, B3
         torch.cuda.empty_cache()
@@ -313,15 +408,19 @@ def main():
         ok4 = all_ok(bool(torch.equal(bk4, s4)) and bool((B4["clen"] > 0).all()))
         extra["configs3_hc9_1MiB"] = {"workload": "%d x 1 MiB blocks per GPU, App.F win 4096, LZ4_compress_HC level 9, ratio %.3f" % (n4, n4 * b4 / cs4),
                                       "value": round(world * float(n4) * b4 / wall / 1e9, 3), "unit": "GB/s", "verified": ok4,
-                                      # build + parse: reads N, writes + re-reads the u16 chain deltas (4 N), writes C
-                                      "roofline": roof("hc_build_kernel + hc_parse_kernel", float(n4) * b4 * 5 + cs4, tk,
-                                                       kernel_traffic(tr, world, "hc_build_kernel", "hc_parse_kernel"))}
+                                      # compress reads N, writes C.  (The two-kernel scheme also writes and re-reads a u16 chain
+                                      # delta per input byte -- 4 N of workspace traffic, reported apart, not algorithmic bytes.)
+                                      "roofline": roof("hc_build_kernel + hc_parse_kernel", float(n4) * b4 + cs4, tk,
+                                                       kernel_traffic(tr, world, "hc_build_kernel", "hc_parse_kernel")),
+                                      "workspace_bytes_per_launch": int(4 * n4 * b4),
+                                      "note": "levels 10-12 (liblz4's optimal parser) are functional only: ~1 GB/s, not benchmarked here"}
         ok = ok and ok4
         if want_cpu:
             def f4():
-                r = cpu_bench([min(512, 2 * cores), b4, cores, 1, 2 << 24, args.litmax, 4096], {"LZ4_HC_LEVEL": "9"})
-                return {"value": round(r["compress_GBps"], 3), "unit": "GB/s", "cores": cores, "kind": r["_kind"],
-                        "sample": "%d x 1 MiB blocks (same generator), %d threads, one pass, LZ4_compress_HC level 9" % (r["n_blocks"], cores)}
+                r = cpu_bench([min(512, 2 * cores), b4, cores, 2, 2 << 24, args.litmax, 4096], {"LZ4_HC_LEVEL": "9"})
+                return {"value": round(r["compress_GBps"], 3), "median": round(r["compress_GBps_median"], 3), "per_core": round(r["compress_GBps"] / cores, 4),
+                        "unit": "GB/s", "cores": cores, "kind": r["_kind"],
+                        "sample": "%d x 1 MiB blocks (same generator), %d threads, best (and median) of 2, LZ4_compress_HC level 9" % (r["n_blocks"], cores)}
             extra["configs3_hc9_1MiB"]["cpu_baseline"] = cpu_entry(f4)
         del c4, bk4, B4
         torch.cuda.empty_cache()
@@ -335,15 +434,14 @@ def main():
         # (sub-millisecond launches: a few of them first, or the first timed kernel runs before the clocks are back up -- 5.4 vs 6.1 TB/s)
         w32, t32 = timed(lambda: amd.DeviceBatch.xxh32(s4, off5, len5, 0x9747b28c, h32), 20, warm=5)
         w64, t64 = timed(lambda: amd.DeviceBatch.xxh64(s4, off5, len5, 0x9747b28c, h64), 20, warm=5)
-        ok5 = True
-        try:   # a sample against python-xxhash where it is installed (the full check against the reference library: tests/)
-            import xxhash
-            host = s4[:64 * b5].cpu().numpy().tobytes()
-            a32, a64 = h32[:64].cpu().tolist(), h64[:64].cpu().tolist()
-            ok5 = all((a32[i] & 0xFFFFFFFF) == xxhash.xxh32_intdigest(host[i * b5:(i + 1) * b5], 0x9747b28c) and
-                      (a64[i] & 0xFFFFFFFFFFFFFFFF) == xxhash.xxh64_intdigest(host[i * b5:(i + 1) * b5], 0x9747b28c) for i in range(64))
-        except ImportError:
-            pass
+        # a sample of the hashes against the checker (the reference's own library where oracle/_ref travels, else the C restatement);
+        # the full check of every hash: tests/test_gpu_scale.py
+        from oracle import oracle as O
+        chk = O.ref() if O.ref_path() else O.port()
+        host = s4[:64 * b5].cpu().numpy().tobytes()
+        a32, a64 = h32[:64].cpu().tolist(), h64[:64].cpu().tolist()
+        ok5 = all((a32[i] & 0xFFFFFFFF) == chk.xxh32(host[i * b5:(i + 1) * b5], 0x9747b28c) and
+                  (a64[i] & 0xFFFFFFFFFFFFFFFF) == chk.xxh64(host[i * b5:(i + 1) * b5], 0x9747b28c) for i in range(64))
         ok5 = all_ok(ok5)
         extra["configs4_xxhash_4KiB"] = {"workload": "%d x 4 KiB buffers per GPU, seed 0x9747b28c" % n5, "unit": "GB/s", "verified": ok5,
                                          "xxh32": {"value": round(world * float(n5) * b5 / w32 / 1e9, 3), "roofline": roof("xxh_multi_kernel<unsigned int, 4>", float(n5) * (b5 + 4), t32, kernel_traffic(tr, world, "xxh_multi_kernel<unsigned int, 4>"))},
@@ -352,7 +450,9 @@ def main():
         if want_cpu:
             def f5():
                 r = cpu_bench([min(n5, 4096 * cores), b5, cores, 3, 0, args.litmax, 4096], {"XXH_MODE": "1"})
-                return {"xxh32_GBps": round(r["xxh32_GBps"], 3), "xxh64_GBps": round(r["xxh64_GBps"], 3), "unit": "GB/s", "cores": cores, "kind": r["_kind"],
+                return {"xxh32_GBps": round(r["xxh32_GBps"], 3), "xxh64_GBps": round(r["xxh64_GBps"], 3),
+                        "xxh32_GBps_median": round(r["xxh32_GBps_median"], 3), "xxh64_GBps_median": round(r["xxh64_GBps_median"], 3),
+                        "unit": "GB/s", "cores": cores, "kind": r["_kind"],
                         "sample": "%d x 4 KiB buffers, %d threads, best of 3, XXH32 / XXH64 one-shot" % (r["n_blocks"], cores)}
             extra["configs4_xxhash_4KiB"]["cpu_baseline"] = cpu_entry(f5)
         del s4
@@ -372,8 +472,8 @@ def main():
             "verified": ok,
             "compress_GBps": round(nbytes / t_c / 1e9, 3), "decompress_GBps": round(nbytes / t_d / 1e9, 3),
             # compress: reads N, writes C (1 + 1/ratio B/B); decompress: reads C, writes N
-            "roofline": roof("compress_fast_v2w_cu_kernel", nbytes + csum, t_c, kernel_traffic(tr, world, "compress_fast_v2w_cu_kernel") or tr.get("compress_fast_v2w_cu_kernel")),
-            "roofline_decode": roof("decode_kernel", nbytes + csum, t_d, tr.get("decode_kernel")),
+            "roofline": roof("compress_fast_v2w_cu_kernel", nbytes + csum, t_c, kernel_traffic(tr, world, "compress_fast_v2w_cu_kernel")),
+            "roofline_decode": roof(decode_kernel_name(n), nbytes + csum, t_d, kernel_traffic(tr, world, decode_kernel_name(n))),
         }
         if tr:
             out["traffic_source"] = tr.get("source")
@@ -383,12 +483,18 @@ def main():
         if want_cpu:
             def f1():
                 sample = min(n, 64 * cores)
-                r = cpu_bench([sample, blk, cores, 3, 0, args.litmax, args.win])
-                return {"value": round(r["roundtrip_GBps"], 3), "unit": "GB/s", "cores": cores, "kind": r["_kind"],
-                        "sample": "%d x %d B blocks (same generator/seed), %d threads, best of 3; LZ4_compress_default + LZ4_decompress_safe; no JVM/JNI overhead"
-                                  % (sample, blk, cores),
+                r = cpu_bench([sample, blk, cores, 5, 0, args.litmax, args.win])
+                r1 = cpu_bench([min(n, 256), blk, 1, 3, 0, args.litmax, args.win])     # one host thread: the per-core figure
+                return {"value": round(r["roundtrip_GBps"], 3), "median": round(r["roundtrip_GBps_median"], 3), "unit": "GB/s", "cores": cores, "kind": r["_kind"],
+                        "sample": "%d x %d B blocks (same generator/seed), %d threads, best (and median) of 5; LZ4_compress_default + LZ4_decompress_safe; "
+                                  "no JVM/JNI overhead; one_thread: %d blocks, best of 3" % (sample, blk, cores, min(n, 256)),
                         "compress_GBps": round(r["compress_GBps"], 3), "decompress_safe_GBps": round(r["decompress_safe_GBps"], 3),
-                        "decompress_fast_GBps": round(r["decompress_fast_GBps"], 3), "lib": r["_lib"]}
+                        "decompress_fast_GBps": round(r["decompress_fast_GBps"], 3),
+                        "compress_GBps_median": round(r["compress_GBps_median"], 3), "decompress_safe_GBps_median": round(r["decompress_safe_GBps_median"], 3),
+                        "per_core": {"compress_GBps": round(r["compress_GBps"] / cores, 4), "decompress_safe_GBps": round(r["decompress_safe_GBps"] / cores, 4)},
+                        "one_thread": {"compress_GBps": round(r1["compress_GBps"], 4), "decompress_safe_GBps": round(r1["decompress_safe_GBps"], 4),
+                                       "roundtrip_GBps": round(r1["roundtrip_GBps"], 4)},
+                        "lib": r["_lib"]}
             out["cpu_baseline"] = cpu_entry(f1)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -12,7 +12,8 @@
  * prints one JSON line.  With LZ4_HC_LEVEL=<1..9> in the environment the compress leg is LZ4_compress_HC at that level
  * (LZ4JNI.c:122; row a4) instead of LZ4_compress_default ("reference" kind only).  With XXH_MODE=1 the buffers are hashed
  * instead: XXH32 and XXH64 (seed 0x9747b28c) of every block (src/jni/net_jpountz_xxhash_XXHashJNI.c:54,164; row a6), and the
- * line reports xxh32_GBps / xxh64_GBps.
+ * line reports xxh32_GBps / xxh64_GBps.  With CPU_BENCH_FILE=<path> the blocks are slices of that file (offset (i * 7919) mod
+ * (length - block size): the real-text leg of bench.py) instead of generated ones.  Every rate is reported twice: best of <reps> and (..._median) the median over them.
  */
 #define _GNU_SOURCE
 #include <dlfcn.h>
@@ -46,7 +47,10 @@ static xxh32_fn x32; static xxh64_fn x64;
 static uint64_t* hsum;
 static int phase;  /* 0 gen, 1 compress, 2 dsafe, 3 dfast, 4 xxh32, 5 xxh64 */
 static volatile int bad = 0;
+static uint8_t* file_buf; static long file_len;   /* CPU_BENCH_FILE: block i = 64 KiB-class slice of that file at offset (i * 7919) % (len - block) */
 
+static int cmp_d(const void* a, const void* b) { double x = *(const double*)a, y = *(const double*)b; return x < y ? -1 : x > y; }
+static double median(double* v, int n) { qsort(v, (size_t)n, sizeof(double), cmp_d); return n & 1 ? v[n / 2] : 0.5 * (v[n / 2 - 1] + v[n / 2]); }
 static double now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 
 static void* worker(void* arg) {
@@ -56,7 +60,9 @@ static void* worker(void* arg) {
     uint8_t* s = src + (size_t)i * block_size; uint8_t* c = comp + (size_t)i * bound; uint8_t* d = back + (size_t)i * block_size;
     int r;
     switch (phase) {
-      case 0: gen(s, block_size, 0x4C5A3447ull, first_idx + (uint64_t)i, litmax, win); break;
+      case 0: if (file_buf) memcpy(s, file_buf + ((uint64_t)(first_idx + i) * 7919u) % (uint64_t)(file_len - block_size), (size_t)block_size);
+              else gen(s, block_size, 0x4C5A3447ull, first_idx + (uint64_t)i, litmax, win);
+              break;
       case 1: r = hc_level ? r_hc((const char*)s, (char*)c, block_size, bound, hc_level)
                            : (is_ref ? r_c((const char*)s, (char*)c, block_size, bound) : p_c(s, block_size, c, bound));
               clen[i] = r; if (r <= 0) bad = 1; break;
@@ -101,36 +107,51 @@ int main(int argc, char** argv) {
     if (!p_c || !p_ds || !p_df) { fprintf(stderr, "missing lz4o_* symbols\n"); return 4; }
   }
   bound = block_size + block_size / 255 + 16;
+  if (getenv("CPU_BENCH_FILE")) {
+    FILE* f = fopen(getenv("CPU_BENCH_FILE"), "rb");
+    if (!f) { fprintf(stderr, "cannot open CPU_BENCH_FILE\n"); return 6; }
+    fseek(f, 0, SEEK_END); file_len = ftell(f); fseek(f, 0, SEEK_SET);
+    file_buf = malloc((size_t)file_len);
+    if (!file_buf || file_len <= block_size || fread(file_buf, 1, (size_t)file_len, f) != (size_t)file_len) { fprintf(stderr, "CPU_BENCH_FILE too short\n"); return 6; }
+    fclose(f);
+  }
   if (getenv("XXH_MODE")) {
     x32 = (xxh32_fn)dlsym(lib, is_ref ? "XXH32" : "lz4o_xxh32_raw"); x64 = (xxh64_fn)dlsym(lib, is_ref ? "XXH64" : "lz4o_xxh64_raw");
     if (!x32 || !x64) { fprintf(stderr, "missing XXH32/XXH64 symbols\n"); return 4; }
     src = malloc((size_t)n_blocks * block_size); hsum = calloc(256, sizeof(uint64_t));
     if (!src || !hsum) { fprintf(stderr, "malloc\n"); return 5; }
     run_phase(0);
-    double b32 = 1e30, b64 = 1e30;
+    double b32 = 1e30, b64 = 1e30, t32[64], t64[64];
+    if (reps > 64) reps = 64;
     run_phase(4);
-    for (int r = 0; r < reps; r++) { double t = run_phase(4); if (t < b32) b32 = t; t = run_phase(5); if (t < b64) b64 = t; }
+    for (int r = 0; r < reps; r++) { double t = run_phase(4); t32[r] = t; if (t < b32) b32 = t; t = run_phase(5); t64[r] = t; if (t < b64) b64 = t; }
     uint64_t chk = 0; for (int i = 0; i < 256; i++) chk += hsum[i];
     double bytes = (double)n_blocks * block_size;
-    printf("{\"kind\": \"%s\", \"threads\": %d, \"n_blocks\": %d, \"block_size\": %d, \"check\": %llu, \"xxh32_GBps\": %.4f, \"xxh64_GBps\": %.4f}\n",
-           argv[1], n_threads, n_blocks, block_size, (unsigned long long)chk, bytes / b32 / 1e9, bytes / b64 / 1e9);
+    printf("{\"kind\": \"%s\", \"threads\": %d, \"n_blocks\": %d, \"block_size\": %d, \"check\": %llu, \"xxh32_GBps\": %.4f, \"xxh64_GBps\": %.4f, "
+           "\"xxh32_GBps_median\": %.4f, \"xxh64_GBps_median\": %.4f}\n",
+           argv[1], n_threads, n_blocks, block_size, (unsigned long long)chk, bytes / b32 / 1e9, bytes / b64 / 1e9,
+           bytes / median(t32, reps) / 1e9, bytes / median(t64, reps) / 1e9);
     return 0;
   }
   src = malloc((size_t)n_blocks * block_size); comp = malloc((size_t)n_blocks * bound); back = malloc((size_t)n_blocks * block_size);
   clen = malloc(sizeof(int) * n_blocks);
   if (!src || !comp || !back || !clen) { fprintf(stderr, "malloc\n"); return 5; }
   run_phase(0);
-  double best[4] = {0, 1e30, 1e30, 1e30};
+  double best[4] = {0, 1e30, 1e30, 1e30}, all[4][64];
+  if (reps > 64) reps = 64;
   run_phase(1); run_phase(2);  /* warm-up */
   for (int r = 0; r < reps; r++)
-    for (int ph = 1; ph <= 3; ph++) { double t = run_phase(ph); if (t < best[ph]) best[ph] = t; }
+    for (int ph = 1; ph <= 3; ph++) { double t = run_phase(ph); all[ph][r] = t; if (t < best[ph]) best[ph] = t; }
+  double med[4] = {0, median(all[1], reps), median(all[2], reps), median(all[3], reps)};
   if (memcmp(src, back, (size_t)n_blocks * block_size) != 0) bad = 1;
   long long csum = 0; for (int i = 0; i < n_blocks; i++) csum += clen[i];
   double bytes = (double)n_blocks * block_size;
   if (hc_level) printf("{\"hc_level\": %d, ", hc_level); else printf("{");
   printf("\"kind\": \"%s\", \"threads\": %d, \"n_blocks\": %d, \"block_size\": %d, \"ratio\": %.4f, \"ok\": %s, "
-         "\"compress_GBps\": %.4f, \"decompress_safe_GBps\": %.4f, \"decompress_fast_GBps\": %.4f, \"roundtrip_GBps\": %.4f}\n",
+         "\"compress_GBps\": %.4f, \"decompress_safe_GBps\": %.4f, \"decompress_fast_GBps\": %.4f, \"roundtrip_GBps\": %.4f, "
+         "\"compress_GBps_median\": %.4f, \"decompress_safe_GBps_median\": %.4f, \"decompress_fast_GBps_median\": %.4f, \"roundtrip_GBps_median\": %.4f}\n",
          argv[1], n_threads, n_blocks, block_size, bytes / (double)csum, bad ? "false" : "true",
-         bytes / best[1] / 1e9, bytes / best[2] / 1e9, bytes / best[3] / 1e9, bytes / (best[1] + best[2]) / 1e9);
+         bytes / best[1] / 1e9, bytes / best[2] / 1e9, bytes / best[3] / 1e9, bytes / (best[1] + best[2]) / 1e9,
+         bytes / med[1] / 1e9, bytes / med[2] / 1e9, bytes / med[3] / 1e9, bytes / (med[1] + med[2]) / 1e9);
   return bad ? 1 : 0;
 }
