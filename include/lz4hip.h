@@ -125,7 +125,7 @@ int lz4hip_compress_hc_batch_dev(const uint8_t* src, const uint64_t* src_off, co
  * it synchronises `stream` ONCE per call (every other *_dev entry never synchronises).  The _ws form is fully asynchronous: the
  * caller states src_span = max over blocks of src_off + src_len (any upper bound, e.g. the size of the source buffer) and passes a
  * device workspace of at least lz4hip_hc_workspace_bytes(src_span, n_blocks, level) bytes that stays valid until the work is done.
- * A block whose range exceeds src_span is a caller error (undefined results for that batch).                                   */
+ * A block whose range reaches past src_span is not compressed: its out_len is 0 and nothing is written past the workspace.        */
 size_t lz4hip_hc_workspace_bytes(uint64_t src_span, uint32_t n_blocks, int level);
 int lz4hip_compress_hc_batch_dev_ws(const uint8_t* src, const uint64_t* src_off, const int32_t* src_len,
                                     uint8_t* dst, const uint64_t* dst_off, const int32_t* dst_cap,

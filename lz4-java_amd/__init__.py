@@ -617,7 +617,7 @@ class DeviceBatch:
         the caching allocator keeps it alive until the stream has used it"""
         import torch
         dev, st = cls._stream_dev(src)
-        span = src.numel()
+        span = src.numel() * src.element_size()     # BYTES of the source tensor (the workspace holds one u16 per source byte)
         nb = lib().lz4hip_hc_workspace_bytes(span, src_off.numel(), level)
         ws = torch.empty(max(nb, 1), dtype=torch.uint8, device=src.device)
         _chk(lib().lz4hip_compress_hc_batch_dev_ws(src.data_ptr(), src_off.data_ptr(), src_len.data_ptr(), dst.data_ptr(),

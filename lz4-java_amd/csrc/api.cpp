@@ -272,11 +272,12 @@ struct DevCtx {
     }
   }
   void give_back(SlotPair* p) {
-    {
-      std::lock_guard<std::mutex> lk(mu);
-      if (std::find(all.begin(), all.end(), p) - all.begin() >= (ptrdiff_t)KEEP_PAIRS) p->trim(8u << 20);
-      idle.push_back(p);
-    }
+    // (trimming frees pinned and device memory -- hipFree / hipHostFree synchronise the device -- so it happens BEFORE the pool
+    // lock is taken: the pair still belongs to this caller, and nobody's acquire / give_back waits behind it)
+    bool extra;
+    { std::lock_guard<std::mutex> lk(mu); extra = std::find(all.begin(), all.end(), p) - all.begin() >= (ptrdiff_t)KEEP_PAIRS; }
+    if (extra) p->trim(8u << 20);
+    { std::lock_guard<std::mutex> lk(mu); idle.push_back(p); }
     cv.notify_one();
   }
   void release() {   // lz4hip_shutdown: nothing is in flight
@@ -467,7 +468,7 @@ int xxh_shard(bool is64, int ord, const uint8_t* buf, const uint64_t* off, const
     if (s.i1 == s.i0) return LZ4HIP_OK;
     if ((e = hipEventSynchronize(s.done)) != hipSuccess) return bad("hipEventSynchronize", e);
     const uint32_t nb = s.i1 - s.i0;
-    memcpy(out + s.i0, (const uint8_t*)s.h_meta.p + (size_t)nb * 12u, (size_t)nb * sizeof(T));
+    memcpy(out + s.i0, (const uint8_t*)s.h_meta.p + (((size_t)nb * 12u + 7u) & ~(size_t)7u), (size_t)nb * sizeof(T));
     s.i0 = s.i1 = 0;
     return LZ4HIP_OK;
   };
@@ -487,7 +488,8 @@ int xxh_shard(bool is64, int ord, const uint8_t* buf, const uint64_t* off, const
     const uint32_t nb = j - i;
     s.so.resize(nb);
     { size_t so = 0; for (uint32_t t = 0; t < nb; t++) { s.so[t] = so; so += (len_of(i + t) + 15u) & ~(size_t)15u; } }
-    const size_t meta = (size_t)nb * (12u + sizeof(T));   // off[nb] u64 | len[nb] i32 | hash[nb]
+    const size_t hoff = ((size_t)nb * 12u + 7u) & ~(size_t)7u;   // off[nb] u64 | len[nb] i32 | (pad to 8) | hash[nb]
+    const size_t meta = hoff + (size_t)nb * sizeof(T);
     if ((e = s.h_src.reserve(sb + 64)) != hipSuccess || (e = s.h_meta.reserve(meta)) != hipSuccess || (e = s.d_src.reserve(sb + 64)) != hipSuccess ||
         (e = s.d_meta.reserve(meta)) != hipSuccess) { rc = bad("staging allocation", e); break; }
     uint8_t* hs = (uint8_t*)s.h_src.p;
@@ -499,10 +501,10 @@ int xxh_shard(bool is64, int ord, const uint8_t* buf, const uint64_t* off, const
     uint8_t* dm = (uint8_t*)s.d_meta.p;
     if (sb && (e = hipMemcpyAsync(s.d_src.p, hs, sb, hipMemcpyHostToDevice, s.st)) != hipSuccess) { rc = bad("H2D src", e); break; }
     if ((e = hipMemcpyAsync(dm, hm, (size_t)nb * 12u, hipMemcpyHostToDevice, s.st)) != hipSuccess) { rc = bad("H2D meta", e); break; }
-    const int le = is64 ? lz4hip::launch_xxh64((const uint8_t*)s.d_src.p, (const uint64_t*)dm, (const int32_t*)(dm + (size_t)nb * 8u), seed, (uint64_t*)(dm + (size_t)nb * 12u), nb, s.st)
-                        : lz4hip::launch_xxh32((const uint8_t*)s.d_src.p, (const uint64_t*)dm, (const int32_t*)(dm + (size_t)nb * 8u), (uint32_t)seed, (uint32_t*)(dm + (size_t)nb * 12u), nb, s.st);
+    const int le = is64 ? lz4hip::launch_xxh64((const uint8_t*)s.d_src.p, (const uint64_t*)dm, (const int32_t*)(dm + (size_t)nb * 8u), seed, (uint64_t*)(dm + hoff), nb, s.st)
+                        : lz4hip::launch_xxh32((const uint8_t*)s.d_src.p, (const uint64_t*)dm, (const int32_t*)(dm + (size_t)nb * 8u), (uint32_t)seed, (uint32_t*)(dm + hoff), nb, s.st);
     if (le) { rc = bad("kernel launch", (hipError_t)le); break; }
-    if ((e = hipMemcpyAsync(hm + (size_t)nb * 12u, dm + (size_t)nb * 12u, (size_t)nb * sizeof(T), hipMemcpyDeviceToHost, s.st)) != hipSuccess) { rc = bad("D2H hashes", e); break; }
+    if ((e = hipMemcpyAsync(hm + hoff, dm + hoff, (size_t)nb * sizeof(T), hipMemcpyDeviceToHost, s.st)) != hipSuccess) { rc = bad("D2H hashes", e); break; }
     if ((e = hipEventRecord(s.done, s.st)) != hipSuccess) { rc = bad("hipEventRecord", e); break; }
     s.i0 = i; s.i1 = j;
     i = j;
@@ -564,7 +566,9 @@ struct Combiner {
 };
 Combiner g_comb[4][13];   // [op][HC level]
 
-void run_combined(Op op, int level, std::vector<Req*>& batch) {
+// one host batch for all of `batch`; returns its rc (every request gets its out[]); may throw (allocation of the index vectors,
+// thread creation inside host_batch)
+int run_batch_once(Op op, int level, const std::vector<Req*>& batch) {
   static uint8_t dummy_in = 0, dummy_out = 0;
   const uint32_t n = (uint32_t)batch.size();
   const uint8_t* sbase = nullptr; uint8_t* dbase = nullptr;
@@ -579,6 +583,23 @@ void run_combined(Op op, int level, std::vector<Req*>& batch) {
   for (uint32_t i = 0; i < n; i++) { so[i] = (uint64_t)(batch[i]->src - sbase); dof[i] = (uint64_t)(batch[i]->dst - dbase); sl[i] = batch[i]->len; dc[i] = batch[i]->cap; }
   const int rc = host_batch(op, sbase, so.data(), sl.data(), dbase, dof.data(), dc.data(), out.data(), n, level);
   for (uint32_t i = 0; i < n; i++) { batch[i]->rc = rc; batch[i]->out = out[i]; if (rc) batch[i]->err = g_err; }
+  return rc;
+}
+
+// Combined callers do not share a fate: when the shared batch fails as a whole (staging could not be allocated because of ONE
+// caller's huge block, a HIP error) every request is run again on its own, so only the caller whose request is the cause sees
+// the failure.  Exceptions (bad_alloc of the index vectors, system_error from thread creation) become LZ4HIP_E_NOMEM for the
+// requests concerned; nothing propagates into the leader's bookkeeping.
+void run_combined(Op op, int level, std::vector<Req*>& batch) noexcept {
+  int rc;
+  try { rc = run_batch_once(op, level, batch); }
+  catch (...) { rc = LZ4HIP_E_NOMEM; for (Req* r : batch) { r->rc = rc; r->out = 0; r->err = "out of memory while combining single-block calls"; } }
+  if (rc == 0 || batch.size() < 2) return;
+  for (Req* r : batch) {
+    std::vector<Req*> one;
+    try { one.push_back(r); (void)run_batch_once(op, level, one); }
+    catch (...) { r->rc = LZ4HIP_E_NOMEM; r->out = 0; r->err = "out of memory"; }
+  }
 }
 
 int single(Op op, const uint8_t* src, int src_len, uint8_t* dst, int dst_cap, int level = 0) {
@@ -586,14 +607,15 @@ int single(Op op, const uint8_t* src, int src_len, uint8_t* dst, int dst_cap, in
   Combiner& c = g_comb[(int)op][level < 0 || level > 12 ? 0 : level];
   {
     std::unique_lock<std::mutex> lk(c.mu);
-    c.q.push_back(&r);
+    try { c.q.push_back(&r); }
+    catch (...) { return fail(LZ4HIP_E_NOMEM, "out of memory"); }
     while (!r.done) {
       if (!c.leader) {
         c.leader = true;
         std::vector<Req*> batch;
-        batch.swap(c.q);          // (contains r: only a leader takes requests out of the queue)
+        batch.swap(c.q);          // (contains r: only a leader takes requests out of the queue; swap does not throw)
         lk.unlock();
-        run_combined(op, level, batch);
+        run_combined(op, level, batch);   // noexcept: the leader always comes back to hand the results out
         lk.lock();
         for (Req* x : batch) x->done = true;
         c.leader = false;

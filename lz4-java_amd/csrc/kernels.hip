@@ -28,6 +28,7 @@
 #include "lz4_fast_core.h"
 #include "lz4_fast_ms_core.h"
 #include "lz4_fast_v2_core.h"
+#include "mail_ring.h"
 #include "lz4_decode_core.h"
 #include "lz4_hc_core.h"
 #include "xxh_core.h"
@@ -79,130 +80,39 @@ constexpr uint32_t WAVES_PER_CU = LZ4HIP_WPC;
 // wavefront's memory operations retire in order: the finder's next candidate fetch waits for all of them (8.6 % of the kernel,
 // profiles/r02_compress_notes.txt).  LDS -- not wave slots -- is what limits a CU to five finders, and a writer needs no LDS:
 // here every finder hands its parked batches to a partner wavefront of the same workgroup through a small ring in global memory
-// (single producer, single consumer; release/acquire at agent scope), and the partner does all the output of the block:
+// (single producer, single consumer; ordered at WORKGROUP scope, see below -- which is only valid because both wavefronts belong to
+// one workgroup and share the CU's L1: the kernel must not be built with -mtgsplit), and the partner does all the output of the block:
 // literal copies, tokens, liblz4's capacity checks, the last literals and the block's result word.
 // ------------------------------------------------------------------------------------------------
-#ifndef LZ4HIP_MAIL_RING
-#define LZ4HIP_MAIL_RING 4
-#endif
 #ifndef LZ4HIP_MAIL_SLEEP
 #define LZ4HIP_MAIL_SLEEP 32
 #endif
-constexpr uint32_t MAIL_RING = LZ4HIP_MAIL_RING;   // slots per finder/writer pair
-constexpr uint32_t MAIL_SLOT_WORDS = 256u;    // 3 x 64 sequence words + header {kind, block, count, x}
-enum : uint32_t { MAIL_BATCH = 1u, MAIL_LAST = 2u, MAIL_ABORT = 3u, MAIL_EXIT = 4u };
-constexpr uint32_t MAIL_PENDING = 0xFFFFFFFFu;   // MailOut::last(): the writer produces the result
-
-// Finder and writer are wavefronts of ONE workgroup, so everything is ordered at WORKGROUP scope: both see the CU's L1, and a
+// The protocol itself -- MailOut (finder side), mail_writer (writer side) -- lives in mail_ring.h, written against the wave
+// backend W and a memory-ordering policy M so that the CPU suite runs the same source with two host threads per pair
+// (tests/hostsim, tests/test_hostsim.py::test_mail_ring_*).  MailDev is the device policy:
+// finder and writer are wavefronts of ONE workgroup, so everything is ordered at WORKGROUP scope: both see the CU's L1, and a
 // release / acquire is a wait for the wave's own accesses, no cache maintenance.  (At agent scope a release writes the XCD's L2
 // back and an acquire invalidates the CU's L1 for everybody on it: 2.3x .. 12x slower, measured.)
-__device__ __forceinline__ uint32_t mail_peek(const uint32_t* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ uint32_t mail_peek_far(const uint32_t* p) {   // (every 64th poll of a wait: progress does not hang on the L1)
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void mail_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
-__device__ __forceinline__ void mail_publish(uint32_t* p, uint32_t v) {   // every lane: this wave's earlier accesses are done first
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  if (__lane_id() == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
-// finder side: the Out policy of FastV2 / FastCore (same parking as ParkOut; a full batch goes to the partner instead of memory)
-template <class W>
-struct MailOut {
-  using VU = typename W::VU;
-  static constexpr bool kUsesWindowRegs = false;
-  static constexpr uint32_t kNoCheck = ParkOut<W>::kNoCheck, kFinal = ParkOut<W>::kFinal;
-  static constexpr bool kAsmPark = true;   // (lz4_fast_v2_asm.h parks into p_ms / p_ml / p_off and counts in cnt)
-  static constexpr bool kRawPark = true;   // the lean loop parks bare hits: liblz4's backward extension is the writer's work too (ParkOut::resolve_raw)
-  W& w;
-  uint32_t* slots;   // MAIL_RING x MAIL_SLOT_WORDS
-  uint32_t* ctr;     // {published by the finder, consumed by the writer}
-  uint32_t head, tail_seen = 0, b = 0;
-  VU p_ms = 0u, p_ml = 0u, p_off = 0u;
-  uint32_t cnt = 0;
-  uint32_t dense64 = 0, flushes = 0, mark = 0;
-  bool bail = false;
-
-  __device__ __forceinline__ MailOut(W& w_, uint32_t* slots_, uint32_t* ctr_, uint32_t head_) : w(w_), slots(slots_), ctr(ctr_), head(head_) {}
-
-  __device__ __forceinline__ void post(uint32_t kind, uint32_t m, uint32_t x) {
-    for (uint32_t spin = 1; head - tail_seen >= MAIL_RING; spin++) {   // ring full: the writer is behind (it publishes `tail` once a slot is in its registers)
-      tail_seen = (spin & 63u) ? mail_peek(ctr + 1) : mail_peek_far(ctr + 1);
-      if (head - tail_seen >= MAIL_RING) __builtin_amdgcn_s_sleep(16);
-    }
-    uint32_t* s = slots + (head % MAIL_RING) * MAIL_SLOT_WORDS;
-    const uint32_t l = __lane_id();
-    s[l] = p_ms; s[64u + l] = p_ml; s[128u + l] = p_off;
-    if (l < 4u) s[192u + l] = l == 0u ? kind : (l == 1u ? b : (l == 2u ? m : x));
-    head++;
-    mail_publish(ctr, head);
+struct MailDev {
+  __device__ __forceinline__ static uint32_t peek(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+  // (every 64th poll of a wait: progress does not hang on the L1)
+  __device__ __forceinline__ static uint32_t peek_far(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  __device__ __forceinline__ static void acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+  __device__ __forceinline__ static void publish(uint32_t* p, uint32_t v) {   // every lane: this wave's earlier accesses are done first
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (__lane_id() == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
-  __device__ __forceinline__ void park(uint32_t ms, uint32_t ml, uint32_t offx) {
-    p_ms = W::writelane(p_ms, ms, cnt);
-    p_ml = W::writelane(p_ml, ml, cnt);
-    p_off = W::writelane(p_off, offx, cnt);
-    if (++cnt == 64u) batch();
-  }
-  __device__ __forceinline__ void batch() {
-    const uint32_t m = cnt;
-    cnt = 0u;
-    if (m == 0u || bail) return;
-    if (dense64 != 0u && flushes < 2u && m == 64u) {   // the density probe of ParkOut::flush (same rule, same moment)
-      const uint32_t e31 = w.bcast(p_ms + p_ml, 31);
-      if (flushes == 0u) mark = e31;
-      else if (e31 - mark < dense64) { bail = true; return; }
-      flushes++;
-    }
-    post(MAIL_BATCH, m, 0u);
-  }
-  // ---- the Out interface of FastCore ----
-  __device__ __forceinline__ bool overlap_point() { return true; }
-  __device__ __forceinline__ void seq(uint32_t lit, uint32_t mc, uint32_t offset, uint32_t anchor, bool check_lits, bool, VU) {
-    park(anchor + lit, mc + 4u, offset | (check_lits ? 0u : kNoCheck) | kFinal);   // the exact path hands over finished sequences
-  }
-  __device__ __forceinline__ uint32_t last(uint32_t anchor) {
-    batch();
-    if (bail) return 0u;
-    post(MAIL_LAST, 0u, anchor);
-    return MAIL_PENDING;
-  }
+  __device__ __forceinline__ static void nap_finder() { __builtin_amdgcn_s_sleep(16); }
+  __device__ __forceinline__ static void nap_writer() { __builtin_amdgcn_s_sleep(LZ4HIP_MAIL_SLEEP); }
+  template <class T> __device__ __forceinline__ static T* uptr(T* q) { return uniform_ptr(q); }
+  __device__ __forceinline__ static int32_t u32(int32_t v) { return uniform_i32(v); }
+  __device__ __forceinline__ static void block_begin(WaveDev&, const uint8_t*, uint32_t, uint8_t*, uint32_t) {}
+  __device__ __forceinline__ static void result(int32_t* out, uint32_t b, int32_t r) { if (__lane_id() == 0) out[b] = r; }
 };
-
-// writer side: one wavefront, all blocks of its finder in order
+template <class W> using MailOut = MailOutT<W, MailDev>;
 __device__ __forceinline__ void mail_writer(const BatchArgs& a, uint32_t* slots, uint32_t* ctr) {
   WaveDev w(nullptr);
-  uint32_t tail = 0, cur = 0xFFFFFFFFu, op = 0, prev_end = 0;
-  bool ok = true;
-  const uint32_t l = __lane_id();
-  for (;;) {
-    for (uint32_t spin = 1; ((spin & 63u) ? mail_peek(ctr) : mail_peek_far(ctr)) == tail; spin++) __builtin_amdgcn_s_sleep(LZ4HIP_MAIL_SLEEP);
-    mail_acquire();
-    const uint32_t* s = slots + (tail % MAIL_RING) * MAIL_SLOT_WORDS;
-    const uint32_t ms = s[l], ml = s[64u + l], off = s[128u + l];
-    const uint32_t hv = s[192u + (l & 3u)];
-    const uint32_t kind = __builtin_amdgcn_readlane(hv, 0), b = __builtin_amdgcn_readlane(hv, 1), m = __builtin_amdgcn_readlane(hv, 2), x = __builtin_amdgcn_readlane(hv, 3);
-    tail++;
-    mail_publish(ctr + 1, tail);   // the slot is in registers: the finder may reuse it
-    if (kind == MAIL_EXIT) return;
-    if (kind == MAIL_ABORT) { cur = 0xFFFFFFFFu; continue; }
-    if (b != cur) { cur = b; op = 0; prev_end = 0; ok = true; }
-    const int32_t n = uniform_i32(a.src_len[b]);
-    const int32_t cap = uniform_i32(a.dst_cap[b]);
-    ParkOut<WaveDev> out(w, uniform_ptr(a.src + a.src_off[b]), (uint32_t)n, uniform_ptr(a.dst + a.dst_off[b]), (uint32_t)cap);
-    out.op = op; out.prev_end = prev_end; out.ok = ok;
-    if (kind == MAIL_BATCH) {
-      out.p_ms = ms; out.p_ml = ml; out.p_off = off; out.cnt = m;
-      out.resolve_raw();
-      out.flush();
-      op = out.op; prev_end = out.prev_end; ok = out.ok;
-    } else {   // MAIL_LAST
-      const uint32_t r = ok ? out.emit_last(x) : 0u;
-      if (l == 0) a.out[b] = (int32_t)r;
-      cur = 0xFFFFFFFFu;
-    }
-  }
+  mail_writer_t<WaveDev, MailDev>(w, a, slots, ctr);
 }
 
 // ---- the default: the five LDS pairs alone ----
@@ -379,20 +289,22 @@ int launch_compress_fast_prof(const BatchArgs& a, uint64_t* prof, int core, void
 // HC compress (levels 1..9): phase 1 builds delta[] (workspace `ws`, one u16 per input byte, indexed by
 // the block's source offset), phase 2 parses.  One wavefront per block in both.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void hc_build_kernel(BatchArgs a, uint16_t* ws) {
+// (`span` = u16 entries the workspace holds: a block whose source range reaches past it -- a caller-supplied span that was too
+// small -- is not touched and reports LZ4HIP's generic failure 0, instead of writing chain deltas past the workspace)
+__global__ __launch_bounds__(64) void hc_build_kernel(BatchArgs a, uint16_t* ws, uint64_t span) {
   __shared__ __attribute__((aligned(16))) uint32_t head[32768];  // 128 KB: liblz4's HC hashTable
   const uint32_t b = blockIdx.x;
   const int32_t n = a.src_len[b];
-  if (n < 0 || (uint32_t)n > 0x7E000000u) return;
+  if (n < 0 || (uint32_t)n > 0x7E000000u || a.src_off[b] + (uint64_t)n > span) return;
   WaveDev w(head);
   HcBuild<WaveDev>::run(w, a.src + a.src_off[b], (uint32_t)n, ws + a.src_off[b]);
 }
-__global__ __launch_bounds__(64) void hc_parse_kernel(BatchArgs a, const uint16_t* ws, int level, int* opt_ws) {
+__global__ __launch_bounds__(64) void hc_parse_kernel(BatchArgs a, const uint16_t* ws, int level, int* opt_ws, uint64_t span) {
   const uint32_t b = blockIdx.x;
   const int32_t n = a.src_len[b];
   const int32_t cap = a.dst_cap[b];
   int r = 0;
-  if (n >= 0 && (uint32_t)n <= 0x7E000000u && cap >= 0) {
+  if (n >= 0 && (uint32_t)n <= 0x7E000000u && cap >= 0 && a.src_off[b] + (uint64_t)n <= span) {
     WaveDev w(nullptr);
     HcParse<WaveDev> p(w, a.src + a.src_off[b], n, ws + a.src_off[b], a.dst + a.dst_off[b], cap, level);
     r = level >= 10 ? p.run_opt(level, opt_ws + (size_t)b * HC_OPT_INTS) : p.run();
@@ -421,8 +333,8 @@ int launch_compress_hc(const BatchArgs& a, int level, void* ws, uint64_t span, v
   if (a.n == 0) return 0;
   const size_t d = (((size_t)span * 2u + 64u) + 255u) & ~(size_t)255u;
   int* const opt = level >= 10 ? (int*)((uint8_t*)ws + d) : nullptr;
-  hipLaunchKernelGGL(hc_build_kernel, dim3(a.n), dim3(64), 0, (hipStream_t)stream, a, (uint16_t*)ws);
-  hipLaunchKernelGGL(hc_parse_kernel, dim3(a.n), dim3(64), 0, (hipStream_t)stream, a, (const uint16_t*)ws, level, opt);
+  hipLaunchKernelGGL(hc_build_kernel, dim3(a.n), dim3(64), 0, (hipStream_t)stream, a, (uint16_t*)ws, span);
+  hipLaunchKernelGGL(hc_parse_kernel, dim3(a.n), dim3(64), 0, (hipStream_t)stream, a, (const uint16_t*)ws, level, opt, span);
   return (int)hipGetLastError();
 }
 

@@ -177,6 +177,18 @@ struct WaveDev {
     if (i < len) d[i] = s[i];
   }
 
+  // ---- one word per lane to / from a 64-word array in global memory; a 4-word header (finder / writer ring, mail_ring.h) ----
+  __device__ __forceinline__ static void st_lanes(uint32_t* base, VU v) { base[__lane_id()] = v; }
+  __device__ __forceinline__ static VU ld_lanes(const uint32_t* base) { return base[__lane_id()]; }
+  __device__ __forceinline__ static void st_hdr(uint32_t* h, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    const uint32_t l = __lane_id();
+    if (l < 4u) h[l] = l == 0u ? a : (l == 1u ? b : (l == 2u ? c : d));
+  }
+  __device__ __forceinline__ static void ld_hdr(const uint32_t* h, uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d) {
+    const uint32_t hv = h[__lane_id() & 3u];
+    a = __builtin_amdgcn_readlane(hv, 0); b = __builtin_amdgcn_readlane(hv, 1); c = __builtin_amdgcn_readlane(hv, 2); d = __builtin_amdgcn_readlane(hv, 3);
+  }
+
   // ---- LDS table ----
   template <bool U16> __device__ __forceinline__ void lds_fill(uint32_t count, typename Entry<U16>::S val) {
     using S = typename Entry<U16>::S;

@@ -11,7 +11,43 @@
 #include "../../lz4-java_amd/csrc/lz4_decode_core.h"
 #include "group_host.h"
 #include "../../lz4-java_amd/csrc/lz4_hc_core.h"
+#define LZ4HIP_MAIL_RING 2   /* two slots: every third post wraps and waits for the writer */
+#include "../../lz4-java_amd/csrc/mail_ring.h"
+#include <atomic>
+#include <thread>
 #include <vector>
+
+// ---- the finder / writer ring of the default compress kernel (csrc/mail_ring.h) with HOST threads: one thread plays the finder
+// wavefront, one the writer wavefront of a pair; several pairs share the block queue like the wavefronts of a workgroup do.
+namespace hostsim {
+struct SimBatch {   // the fields mail_writer_t reads of kernels.h BatchArgs
+  const uint8_t* src; const uint64_t* src_off; const int32_t* src_len;
+  uint8_t* dst; const uint64_t* dst_off; const int32_t* dst_cap;
+  int32_t* out; uint32_t n;
+};
+struct MailHost {
+  static thread_local uint64_t rng;     // naps of random length shake the interleavings
+  static std::atomic<int> oob;
+  static void jitter() {
+    rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+    const int k = (int)((rng >> 33) & 7u);
+    if (k == 0) std::this_thread::sleep_for(std::chrono::microseconds(20));
+    else if (k < 4) std::this_thread::yield();
+  }
+  static uint32_t peek(const uint32_t* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
+  static uint32_t peek_far(const uint32_t* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
+  static void acquire() { __atomic_thread_fence(__ATOMIC_ACQUIRE); }
+  static void publish(uint32_t* p, uint32_t v) { jitter(); __atomic_thread_fence(__ATOMIC_RELEASE); __atomic_store_n(p, v, __ATOMIC_RELAXED); }
+  static void nap_finder() { jitter(); }
+  static void nap_writer() { jitter(); }
+  template <class T> static T* uptr(T* q) { return q; }
+  static int32_t u32(int32_t v) { return v; }
+  static void block_begin(WaveHost& w, const uint8_t* s, uint32_t n, uint8_t* d, uint32_t cap) { if (w.oob) oob = 1; w.bounds(s, n, d, cap); }
+  static void result(int32_t* out, uint32_t b, int32_t r) { out[b] = r; }
+};
+thread_local uint64_t MailHost::rng = 1;
+std::atomic<int> MailHost::oob{0};
+}  // namespace hostsim
 
 extern "C" {
 
@@ -164,6 +200,66 @@ int sim_compress_hc(const uint8_t* src, int n, uint8_t* dst, int cap, int level,
   const int r = level >= 10 ? p.run_opt(level, opt.data()) : p.run();
   if (w.oob) return -1000;
   return r;
+}
+
+// The two-wave kernel's shape on the host: `pairs` finder threads draw blocks from one queue (the body of
+// compress_fast_v2w_cu_kernel: lean core for n < 65547, the exact core over the same output policy otherwise; a block the density
+// probe rejects is an ABORT message and an entry of routed[]), each with its own writer thread behind a two-slot ring.
+// out[b] = compressed size (0 = does not fit), -2 = routed (listed in routed[0 .. *n_routed)).  returns 0, or -1000 on an
+// out-of-slot access of any simulated wavefront.
+int sim_mail_ring(const uint8_t* src, const uint64_t* src_off, const int32_t* src_len, uint8_t* dst, const uint64_t* dst_off,
+                  const int32_t* dst_cap, int32_t* out, uint32_t n, uint32_t pairs, uint32_t dense64, uint32_t* routed, uint32_t* n_routed,
+                  uint64_t seed) {
+  using W = hostsim::WaveHost;
+  using M = hostsim::MailHost;
+  using Out = lz4hip::MailOutT<W, M>;
+  hostsim::SimBatch a{src, src_off, src_len, dst, dst_off, dst_cap, out, n};
+  std::atomic<uint32_t> q{0}, nr{0};
+  M::oob = 0;
+  std::vector<std::vector<uint32_t>> slots(pairs, std::vector<uint32_t>(lz4hip::MAIL_RING * lz4hip::MAIL_SLOT_WORDS, 0xDEADBEEFu));
+  std::vector<std::vector<uint32_t>> ctr(pairs, std::vector<uint32_t>(2, 0u));
+  std::vector<std::thread> th;
+  for (uint32_t p = 0; p < pairs; p++) {
+    th.emplace_back([&, p] {   // the writer wavefront
+      M::rng = seed * 977u + p * 2u + 1u;
+      W w;
+      lz4hip::mail_writer_t<W, M>(w, a, slots[p].data(), ctr[p].data());
+      if (w.oob) M::oob = 1;
+    });
+    th.emplace_back([&, p] {   // the finder wavefront
+      M::rng = seed * 977u + p * 2u + 2u;
+      W w;
+      w.rng = seed ? seed + p : w.rng;
+      uint32_t head = 0, tail_seen = 0;
+      for (;;) {
+        const uint32_t b = q.fetch_add(1);
+        Out o(w, slots[p].data(), ctr[p].data(), head);
+        o.tail_seen = tail_seen;
+        if (b >= a.n) { o.post(lz4hip::MAIL_EXIT, 0u, 0u); break; }
+        o.b = b;
+        const int32_t bn = a.src_len[b], cap = a.dst_cap[b];
+        if (bn >= 0 && (uint32_t)bn <= 0x7E000000u && cap >= 0) {
+          const uint8_t* s = a.src + a.src_off[b];
+          w.bounds(s, (size_t)bn, nullptr, 0);      // (a finder never writes the output)
+          o.dense64 = routed ? dense64 : 0u;
+          if (bn < 65547) { lz4hip::FastV2<W, Out> c(w, o, s, (uint32_t)bn); (void)c.run(); }
+          else { lz4hip::FastCore<W, false, Out> c(w, o, s, (uint32_t)bn); (void)c.run(); }
+          if (o.bail) {
+            o.post(lz4hip::MAIL_ABORT, 0u, 0u);
+            routed[nr.fetch_add(1)] = b;
+            a.out[b] = -2;
+          }
+        } else {
+          a.out[b] = 0;
+        }
+        head = o.head; tail_seen = o.tail_seen;
+      }
+      if (w.oob) M::oob = 1;
+    });
+  }
+  for (auto& t : th) t.join();
+  if (n_routed) *n_routed = nr.load();
+  return M::oob ? -1000 : 0;
 }
 
 }  // extern "C"

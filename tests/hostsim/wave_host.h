@@ -113,6 +113,11 @@ struct WaveHost {
     for (int l = 0; l < 64; l++) if (m.v[l] && out_ok(b + i.v[l], 4)) memcpy(b + i.v[l], &v.v[l], 4);
   }
   static VU writelane(const VU& v, uint32_t s, uint32_t l) { VU r = v; r.v[l & 63u] = s; return r; }
+  // finder / writer ring (csrc/mail_ring.h): one word per lane to / from a 64-word array, a 4-word header
+  static void st_lanes(uint32_t* base, const VU& v) { for (int l = 0; l < 64; l++) base[l] = v.v[l]; }
+  static VU ld_lanes(const uint32_t* base) { VU r; for (int l = 0; l < 64; l++) r.v[l] = base[l]; return r; }
+  static void st_hdr(uint32_t* h, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { h[0] = a; h[1] = b; h[2] = c; h[3] = d; }
+  static void ld_hdr(const uint32_t* h, uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d) { a = h[0]; b = h[1]; c = h[2]; d = h[3]; }
   static VU shfl_down1(const VU& v) { VU r; for (int l = 0; l < 63; l++) r.v[l] = v.v[l + 1]; r.v[63] = 0xDEADBEEFu; return r; }
   static VU alignbyte(const VU& hi, const VU& lo, const VU& sh) {
     VU r; for (int l = 0; l < 64; l++) r.v[l] = (uint32_t)((((uint64_t)hi.v[l] << 32) | lo.v[l]) >> (8u * (sh.v[l] & 3u))); return r;

@@ -197,6 +197,31 @@ def test_offsets_inside_bigger_buffers(amd, ref, corpus):
     assert bytes(out[7:7 + len(data)]) == data and out[:7] == b"\x22" * 7 and out[7 + len(data):] == b"\x22" * 13
 
 
+def test_small_batches_finder_writer_edges(amd, ref, O, corpus):
+    """Many small fast-compress launches (1..48 blocks of random sizes and capacities) against the reference library: the finder /
+    writer hand-over of the default kernel at its edges -- fewer blocks than wavefronts (most writers get nothing but EXIT), blocks of
+    a few bytes, single-batch blocks, ring wrap inside a launch, byU32 blocks next to tiny ones.  (tools/gpu_small_batches.py is the
+    long version; the protocol itself also runs with host threads in tests/test_hostsim.py::test_mail_ring_*.)"""
+    rng = random.Random(12)
+    book = corpus["book1[:200000]"]
+    for it in range(120):
+        nb = rng.choice([1, 1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 16, 33, 48])
+        blocks = []
+        for _ in range(nb):
+            n = rng.choice([0, 1, 12, 13, 14, 20, 64, 200, 1000, 5000, 20000, 65536, 65546, 65547, 70000]) if rng.random() < 0.6 else rng.randrange(0, 3000)
+            t = rng.randrange(4)
+            if t == 0: v = rng.randbytes(n)
+            elif t == 1: o = rng.randrange(len(book) - n); v = book[o:o + n]
+            elif t == 2: v = O.gen_block(n, rng.randrange(1 << 20), litmax=rng.choice([2, 38, 200]), win=rng.choice([8, 300, 65535]))
+            else: v = bytes(rng.randrange(3) for _ in range(min(n, 8000)))
+            blocks.append(v)
+        caps = [ref.compress_bound(len(v)) if rng.random() < 0.7 else rng.randrange(0, ref.compress_bound(len(v)) + 1) for v in blocks]
+        res = gpu_compress_many(amd, blocks, caps)
+        for v, cap, (r, c) in zip(blocks, caps, res):
+            er, eb = ref.compress_fast_raw(v, cap)
+            assert r == er and (er <= 0 or c == eb[:er]), (it, len(v), cap, r, er)
+
+
 def test_regression_inputs(amd, ref):
     """tests/golden/regress/*.bin: inputs that once made a kernel under development differ from the reference (round 3: a false
     tentative hit AT the first probe position of a window, left to the C++ step with a row that did not cover ip - 2), through

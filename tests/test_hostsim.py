@@ -19,8 +19,9 @@ def load_sim():
     so = os.path.join(d, "libhostsim.so")
     srcs = [os.path.join(d, f) for f in ("hostsim.cpp", "wave_host.h", "group_host.h")] + \
            [os.path.join(ROOT, "lz4-java_amd", "csrc", f) for f in ("lz4_fast_core.h", "lz4_fast_ms_core.h", "lz4_fast_v2_core.h", "lz4_decode_core.h", "lz4_hc_core.h")]
+    srcs.append(os.path.join(ROOT, "lz4-java_amd", "csrc", "mail_ring.h"))
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, os.path.join(d, "hostsim.cpp")])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", so, os.path.join(d, "hostsim.cpp")])
     l = C.CDLL(so)
     l.sim_compress_fast.restype = C.c_int
     l.sim_compress_fast.argtypes = [C.c_char_p, C.c_int, _u8p, C.c_int, C.POINTER(C.c_uint64), C.c_uint64]
@@ -34,6 +35,9 @@ def load_sim():
     l.sim_compress_fast_probe.argtypes = [C.c_char_p, C.c_int, _u8p, C.c_int, C.c_uint32]
     l.sim_decompress.restype = C.c_int
     l.sim_decompress.argtypes = [C.c_char_p, C.c_int, _u8p, C.c_int, C.c_int, C.c_int]
+    l.sim_mail_ring.restype = C.c_int
+    l.sim_mail_ring.argtypes = [C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_int32), _u8p, C.POINTER(C.c_uint64), C.POINTER(C.c_int32),
+                                C.POINTER(C.c_int32), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint64]
     return l
 
 
@@ -374,3 +378,67 @@ def test_hc_core_optimal_parser(sim, ref, golden, corpus, O):
             assert sim_hc(sim, v, lvl, ref.compress_bound(n))[1] == ref.compress_hc(v, lvl), (period, lvl)
 
 
+
+
+def run_mail_ring(sim, blocks, caps, pairs, dense64, seed):
+    n = len(blocks)
+    src = b"".join(blocks)
+    so, do, p, q = [], [], 0, 0
+    for b, c in zip(blocks, caps):
+        so.append(p); do.append(q); p += len(b); q += c
+    dst = (C.c_uint8 * max(q, 1))()
+    out = (C.c_int32 * n)(*([-99] * n))
+    routed = (C.c_uint32 * n)()
+    nr = C.c_uint32(0)
+    rc = sim.sim_mail_ring(src, (C.c_uint64 * n)(*so), (C.c_int32 * n)(*[len(b) for b in blocks]), dst, (C.c_uint64 * n)(*do),
+                           (C.c_int32 * n)(*caps), out, n, pairs, dense64, routed if dense64 else None, C.byref(nr), seed)
+    assert rc == 0, "a simulated wavefront touched memory outside its block / slot"
+    res = [(out[i], bytes(dst[do[i]:do[i] + max(out[i], 0)])) for i in range(n)]
+    return res, sorted(routed[:nr.value])
+
+
+def test_mail_ring_two_threads(sim, ref, O, corpus):
+    """The finder / writer hand-over of the default compress kernel (csrc/mail_ring.h: MailOutT + mail_writer_t, the source the
+    GPU runs) with HOST threads -- a finder and a writer thread per pair, two or three pairs on one block queue, a ring of two
+    slots (every third post wraps and meets back-pressure), random naps around every publish: blocks of every size class incl.
+    empty, shorter than a batch, several batches, byU32; full and tight capacities; all bytes against the reference library."""
+    rng = random.Random(7)
+    book = corpus["book1[:200000]"]
+    blocks = [b"", b"a" * 5, b"b" * 12, b"c" * 13, bytes(rng.randrange(2) for _ in range(500)), O.gen_block(1000, 3), O.gen_block(20000, 4),
+              O.gen_block(65536, 5), O.gen_block(65536, 6, litmax=4, win=64), rng.randbytes(9000), book[1000:31000], O.gen_block(70000, 8, win=4096),
+              bytes(30000), O.gen_block(65546, 9), corpus["pic[:65536]"][:40000], O.gen_block(3000, 10, litmax=2, win=8)] * 2
+    rng.shuffle(blocks)
+    for pairs, seed in ((1, 1), (2, 2), (3, 3), (2, 4)):
+        caps = []
+        for v in blocks:
+            full = ref.compress_bound(len(v))
+            er, _ = ref.compress_fast_raw(v, full)
+            caps.append(rng.choice([full, full, max(0, er - 1), er, er + 3, rng.randrange(0, full + 1)]))
+        res, routed = run_mail_ring(sim, blocks, caps, pairs, 0, seed)
+        assert routed == []
+        for v, cap, (r, c) in zip(blocks, caps, res):
+            er, eb = ref.compress_fast_raw(v, cap)
+            assert r == er and (er <= 0 or c == eb[:er]), (pairs, seed, len(v), cap, r, er)
+
+
+def test_mail_ring_abort_after_routed_block(sim, ref, O, corpus):
+    """with the density probe on, blocks of short sequences are ABORT messages (the writer forgets them mid-block, after it may
+    already have written batches of theirs) and land in the routed list; the blocks before and behind them on the same pair
+    come out right, and EXIT ends every writer"""
+    rng = random.Random(9)
+    book = corpus["book1[:200000]"]
+    dense = [book[i * 3000:i * 3000 + 65536] for i in range(4)] + [bytes(rng.randrange(3) for _ in range(40000))]
+    sparse = [O.gen_block(65536, 20 + i) for i in range(4)] + [O.gen_block(20000, 30), b"", O.gen_block(200, 31)]
+    blocks = []
+    for i in range(max(len(dense), len(sparse))):
+        blocks += dense[i:i + 1] + sparse[i:i + 1]
+    caps = [ref.compress_bound(len(v)) for v in blocks]
+    for pairs, seed in ((1, 5), (2, 6)):
+        res, routed = run_mail_ring(sim, blocks, caps, pairs, 64 * 20, seed)
+        assert routed, "no block was routed: the ABORT path was not exercised"
+        for i, (v, (r, c)) in enumerate(zip(blocks, res)):
+            if i in routed:
+                assert r == -2
+            else:
+                assert c == ref.compress_fast(v), (pairs, i, len(v))
+        assert any(any(v is d for d in dense) for i, v in enumerate(blocks) if i in routed)
