@@ -98,7 +98,10 @@ struct GroupDev {
   // block is evicted from L2 between the small stores that fill it and reaches HBM several times (WRITE_SIZE 11.8 GB for
   // 4.3 GB of output, profiles/r01n).  Staging holds the output bytes [fl, fl + kStage); everything below fl is in memory.
   // Match sources are read from memory only, so the caller flushes everything first when a source reaches past fl. ----
-  static constexpr uint32_t kStage = 576u;   // >= 127 (open line) + what two sequences of the interior loop typically add + a step + slack
+#ifndef LZ4HIP_KSTAGE
+#define LZ4HIP_KSTAGE 576   /* bytes of staging per block (developer A/B builds: smaller = more blocks resident per CU, more flushes) */
+#endif
+  static constexpr uint32_t kStage = LZ4HIP_KSTAGE;   // >= 127 (open line) + what two sequences of the interior loop typically add + a step + slack
   uint8_t* stg = nullptr;
   uint32_t fl = 0;
   __device__ __forceinline__ void st_begin(uint8_t* lds, uint32_t op) { stg = lds; fl = op; }
