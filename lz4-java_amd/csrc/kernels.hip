@@ -146,7 +146,7 @@ __global__ __launch_bounds__(64 * 2 * WAVES_PER_CU) void compress_fast_v2w_cu_ke
         FastV2<WaveDev, MailOut<WaveDev>> c(w, out, s, (uint32_t)n);
         (void)c.run();
       } else {
-        FastCore<WaveDev, false, MailOut<WaveDev>> c(w, out, s, (uint32_t)n);
+        FastV2<WaveDev, MailOut<WaveDev>, false> c(w, out, s, (uint32_t)n);   // byU32 blocks: the lean loop in C++ + the exact core
         (void)c.run();
       }
       if (out.bail) {
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(64) void compress_fast_prof_kernel(BatchArgs a, uin
     if constexpr (MS == 3) {
       ParkOutRaw<WaveDev> po(w, s, (uint32_t)n, d, (uint32_t)cap);   // (the finder of the default kernel parks raw hits; here one wave also writes them)
       if (n < 65547) { FastV2<WaveDev, ParkOutRaw<WaveDev>> c(w, po, s, (uint32_t)n, &st); r = c.run(); }
-      else { FastCore<WaveDev, false, ParkOutRaw<WaveDev>> c(w, po, s, (uint32_t)n, &st); r = c.run(); }
+      else { FastV2<WaveDev, ParkOutRaw<WaveDev>, false> c(w, po, s, (uint32_t)n, &st); r = c.run(); }
     } else if constexpr (MS == 1) {
       if (n < 65547) { FastCoreMS<WaveDev, true> c(w, out, s, (uint32_t)n, &st); r = c.run(); }
       else { FastCoreMS<WaveDev, false> c(w, out, s, (uint32_t)n, &st); r = c.run(); }

@@ -241,11 +241,17 @@ struct ParkOutRaw : ParkOut<W> {
 // memory waits fell from 66 % to 42 % of the wave's cycles -- but a step grew from 110 to 200 instructions, a wavefront issues one
 // instruction per ~4.4 cycles whatever its dependencies, and a mode switch (s_set_gpr_idx_on/off) costs ~80 cycles that overlap
 // with nothing: 49.5 .. 55.3 GB/s against 59.9 without the ring.
-template <class W, class OUT = ParkOut<W>>
+// U16 = true: blocks < 65547 bytes (liblz4's byU16 table, 4-byte hash); false: larger blocks (byU32: 4096 entries of
+// {position, fingerprint} in 64 bits, 5-byte hash, candidates more than 65535 bytes back are no hits) -- round 3: the LZ4 Frame
+// default block size is 4 MiB (LZ4FrameOutputStream.java:169-171), until then those blocks ran on the one-sequence core alone.
+template <class W, class OUT = ParkOut<W>, bool U16 = true>
 struct FastV2 {
   using VU = typename W::VU;
+  using VU64 = typename W::VU64;
   using VB = typename W::VB;
-  using Gen = FastCore<W, true, OUT>;
+  using Gen = FastCore<W, U16, OUT>;
+  using VE = typename Gen::VE;
+  using E = typename Gen::E;
   static constexpr uint32_t kFwdBytes = 256u;                       // forward compare of the lean step: 64 lanes x 4 bytes
   static constexpr uint32_t kTail = 12u + 64u + kFwdBytes + 16u;    // the lean loop stays this far from the block end
 
@@ -261,7 +267,9 @@ struct FastV2 {
     if (n < 13u) return out.last(0u);
     {
       const uint32_t x0 = w.sld32(src, 0);
-      w.template lds_fill<true>(1u << LZ4HIP_PROBE_HLOG, (((x0 * 2654435761u) >> 3) & LZ4HIP_FP_MASK));  // every bucket: {pos 0, fp(bytes at 0)}
+      // every bucket: {pos 0, fp(bytes at 0)}
+      if constexpr (U16) w.template lds_fill<true>(1u << Gen::HLOG, (((x0 * 2654435761u) >> 3) & LZ4HIP_FP_MASK));
+      else w.template lds_fill<false>(1u << Gen::HLOG, (E)((x0 * 2654435761u) >> 16));
       w.sync();
     }
     Gen gen(w, out, src, n, st);
@@ -315,7 +323,7 @@ struct FastV2 {
       // The common steps run in the hand-scheduled loop of lz4_fast_v2_asm.h; it comes back when 64 hits are parked, at the loop
       // limit, or in front of a step it does not handle -- nothing of that step is left in the table, and the C++ step below
       // takes it from the same state with every rule.
-      if constexpr (W::kAsmLean && OUT::kAsmPark) {
+      if constexpr (U16 && W::kAsmLean && OUT::kAsmPark) {
         if (!st) {
 #if LZ4HIP_ASM_DBG & 4
           const uint32_t dbg_ip = ip, dbg_pc = out.cnt, dbg_php = prev_hpos;
@@ -349,21 +357,32 @@ struct FastV2 {
 #ifndef LZ4HIP_V2_WIN_FROM_ROW
 #define LZ4HIP_V2_WIN_FROM_ROW 1   /* the next window is taken out of the 256 bytes the forward compare fetched at the hit (two lane permutes) */
 #endif
-      VU x32;
-      if (LZ4HIP_V2_WIN_FROM_ROW && LZ4HIP_LIKELY(ip - prev_hpos <= 189u)) {   // bytes [ip - 2, ip + 66) lie inside prev_fa = row at prev_hpos
+      VU x32, x32b = VU(0u);   // bytes [pos, pos + 4) and (byU32: the 5-byte hash) [pos + 4, pos + 8)
+      if (LZ4HIP_V2_WIN_FROM_ROW && LZ4HIP_LIKELY(ip - prev_hpos <= (U16 ? 189u : 185u))) {   // bytes [ip - 2, ip + 66 (+ 4)) lie inside prev_fa = row at prev_hpos
         const VU o = cj + (ip - prev_hpos);
         const VU d = o >> 2;
-        x32 = W::alignbyte(W::shfl(prev_fa, d + 1u), W::shfl(prev_fa, d), o & 3u);
+        const VU w1 = W::shfl(prev_fa, d + 1u);
+        x32 = W::alignbyte(w1, W::shfl(prev_fa, d), o & 3u);
+        if constexpr (!U16) x32b = W::alignbyte(W::shfl(prev_fa, d + 2u), w1, o & 3u);
       } else {
-        x32 = w.ldu32(src, pos);
+        if constexpr (U16) x32 = w.ldu32(src, pos);
+        else { const VU64 x64 = w.ldu64(src, pos); x32 = W::lo32(x64); x32b = W::lo32(x64 >> 32); }
       }
-      const VU prod = x32 * 2654435761u;
-      const VU h = prod >> (32 - LZ4HIP_PROBE_HLOG);
-      const VU fp = (prod >> 3) & LZ4HIP_FP_MASK;
+      VU h, fp;
+      if constexpr (U16) {
+        const VU prod = x32 * 2654435761u;
+        h = prod >> (32 - Gen::HLOG);
+        fp = (prod >> 3) & LZ4HIP_FP_MASK;
+      } else {
+        const VU64 x64 = W::u64(x32) | (W::u64(x32b) << 32);
+        h = W::lo32(((x64 << 24) * 889523592379ull) >> (64 - Gen::HLOG));
+        fp = (x32 * 2654435761u) >> 16;
+      }
       LZ4HIP_PHASE2(0, w.bcast(h, 0));     // t[0]: window load + hash
-      const VU e = w.template lds_rdu<true>(h);
-      const VU newe = (pos << 16) | fp;
-      const uint64_t tmask = w.ballot((e & 0xFFFFu) == fp) & ~1ull;
+      const VE e = w.template lds_rdu<U16>(h);
+      const VE newe = Gen::mk_entry(pos, fp);
+      uint64_t tmask = w.ballot(Gen::e_fp(e) == fp) & ~1ull;
+      if constexpr (!U16) tmask &= w.ballot(Gen::e_pos(e) + Gen::MAXD >= pos);   // (byU32: a candidate more than 65535 bytes back is no hit)
 #ifndef LZ4HIP_COUNT_CAT
 #define LZ4HIP_COUNT_CAT 5   /* profiling builds: which way out of the lean loop FastStats::false_pos counts (5 = no hit in the window) */
 #endif
@@ -376,7 +395,7 @@ struct FastV2 {
       // first tentative lane's rows, so a ruled-out first lane is followed directly by the first lane whose candidate verifies --
       // one more round trip at most, and to a line the gather has just touched)
       VU c4 = VU(0u);
-      if (LZ4HIP_V2_PVERIFY && OUT::kRawPark) c4 = w.ld32(src, e >> 16, w.lanes(tmask & (tmask - 1ull)));
+      if (LZ4HIP_V2_PVERIFY && OUT::kRawPark) c4 = w.ld32(src, Gen::e_pos(e), w.lanes(tmask & (tmask - 1ull)));
       // The hit is the first tentative lane that survives: a tentative lane is ruled out, and the search goes on to the next one
       // in the same window (raw-parking policies only; the others take the exact path as before), when
       //   K  an earlier committing lane shares its bucket with a different fingerprint -- liblz4, inserting position by position,
@@ -394,9 +413,9 @@ struct FastV2 {
         k0 = (uint32_t)ctz64(tm);
         upto = (2ull << k0) - 1ull;                               // lanes 0..k0
         const uint64_t inm = upto & ~((1ull << lo) - 1ull);       // lanes lo..k0 commit now
-        const VU old = w.template lds_max<true>(h, newe, w.lanes(inm));
+        const VE old = w.template lds_max<U16>(h, newe, w.lanes(inm));
         hpos = ip + k0 - 1u;
-        mpos = w.bcast(e, (int)k0) >> 16;
+        mpos = Gen::se_pos(w.template bcast_e<U16>(e, (int)k0));
         // candidate fetch: forward 64 x 4 bytes from both positions; backward (policies that extend backwards here): lane l
         // (1..k0-1) holds src[ip+l-1] in its window word and needs src[mpos-k0+l] -- one contiguous byte load
         // (32 or 16 lanes instead of 64 -- fewer candidate lines per fetch -- measured no different: 59.2 / 59.2 / 59.1 GB/s)
@@ -437,8 +456,8 @@ struct FastV2 {
             if (st && LZ4HIP_COUNT_CAT == 1) st->false_pos++;
           } else {
             const int dl = ctz64(det);
-            const uint32_t od = w.bcast(old, dl), hd = w.bcast(h, dl), fd = w.bcast(fp, dl);
-            if ((od & 0xFFFFu) == fd) { bad = true; if (st && LZ4HIP_COUNT_CAT == 2) st->false_pos++; }
+            const uint32_t od = w.bcast(Gen::e_fp(old), dl), hd = w.bcast(h, dl), fd = w.bcast(fp, dl);
+            if (od == fd) { bad = true; if (st && LZ4HIP_COUNT_CAT == 2) st->false_pos++; }
             else if (hd == w.bcast(h, (int)k0)) ruled_out = true;  // case K
           }
         }
@@ -453,7 +472,7 @@ struct FastV2 {
         }
         // undo everything this step committed, exact path
         if (st) l_slow++;
-        w.template lds_wr<true>(h, e, w.lanes(upto));
+        w.template lds_wr<U16>(h, e, w.lanes(upto));
         w.sync();
         fail = true;
         break;

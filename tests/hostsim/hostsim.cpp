@@ -101,7 +101,7 @@ int sim_compress_fast_v2(const uint8_t* src, int n, uint8_t* dst, int cap, uint6
     lz4hip::FastV2<hostsim::WaveHost> c(w, out, src, (uint32_t)n, &st);
     r = c.run();
   } else {
-    lz4hip::FastCore<hostsim::WaveHost, false, lz4hip::ParkOut<hostsim::WaveHost>> c(w, out, src, (uint32_t)n, &st);
+    lz4hip::FastV2<hostsim::WaveHost, lz4hip::ParkOut<hostsim::WaveHost>, false> c(w, out, src, (uint32_t)n, &st);
     r = c.run();
   }
   if (stats4) { stats4[0] = st.steps; stats4[1] = st.slow_steps; stats4[2] = st.false_pos; stats4[3] = st.sequences; }
@@ -123,7 +123,7 @@ int sim_compress_fast_v2raw(const uint8_t* src, int n, uint8_t* dst, int cap, ui
     lz4hip::FastV2<hostsim::WaveHost, lz4hip::ParkOutRaw<hostsim::WaveHost>> c(w, out, src, (uint32_t)n, &st);
     r = c.run();
   } else {
-    lz4hip::FastCore<hostsim::WaveHost, false, lz4hip::ParkOutRaw<hostsim::WaveHost>> c(w, out, src, (uint32_t)n, &st);
+    lz4hip::FastV2<hostsim::WaveHost, lz4hip::ParkOutRaw<hostsim::WaveHost>, false> c(w, out, src, (uint32_t)n, &st);
     r = c.run();
   }
   if (stats4) { stats4[0] = st.steps; stats4[1] = st.slow_steps; stats4[2] = st.false_pos; stats4[3] = st.sequences; }
@@ -140,7 +140,7 @@ int sim_compress_fast_v2_probe(const uint8_t* src, int n, uint8_t* dst, int cap,
   out.dense64 = dense64;
   uint32_t r;
   if (n < 65547) { lz4hip::FastV2<hostsim::WaveHost> c(w, out, src, (uint32_t)n); r = c.run(); }
-  else { lz4hip::FastCore<hostsim::WaveHost, false, lz4hip::ParkOut<hostsim::WaveHost>> c(w, out, src, (uint32_t)n); r = c.run(); }
+  else { lz4hip::FastV2<hostsim::WaveHost, lz4hip::ParkOut<hostsim::WaveHost>, false> c(w, out, src, (uint32_t)n); r = c.run(); }
   if (w.oob) return -1000;
   return out.bail ? -2 : (int)r;
 }
@@ -243,7 +243,7 @@ int sim_mail_ring(const uint8_t* src, const uint64_t* src_off, const int32_t* sr
           w.bounds(s, (size_t)bn, nullptr, 0);      // (a finder never writes the output)
           o.dense64 = routed ? dense64 : 0u;
           if (bn < 65547) { lz4hip::FastV2<W, Out> c(w, o, s, (uint32_t)bn); (void)c.run(); }
-          else { lz4hip::FastCore<W, false, Out> c(w, o, s, (uint32_t)bn); (void)c.run(); }
+          else { lz4hip::FastV2<W, Out, false> c(w, o, s, (uint32_t)bn); (void)c.run(); }
           if (o.bail) {
             o.post(lz4hip::MAIL_ABORT, 0u, 0u);
             routed[nr.fetch_add(1)] = b;
