@@ -174,6 +174,26 @@ int lz4hip_xxh32_stream_digest(lz4hip_xxh_stream* st, uint32_t* out);    /* XXH3
 int lz4hip_xxh64_stream_digest(lz4hip_xxh_stream* st, uint64_t* out);    /* XXH64_digest, XXHashJNI.c:238-243 */
 void lz4hip_xxh_stream_free(lz4hip_xxh_stream* st);                      /* XXH32_free / XXH64_free          */
 
+/* ---- container blocks assembled on the device ---------------------------
+ * The data blocks of an LZ4 Frame (kind 0: what LZ4FrameOutputStream.writeBlock emits per block,
+ * /root/reference/src/java/net/jpountz/lz4/LZ4FrameOutputStream.java:199-235 -- 4-byte size word with the "stored uncompressed"
+ * bit, payload, and with flags & 1 the XXH32 (seed 0) of the stored payload) or of lz4-java's LZ4Block container (kind 1:
+ * LZ4BlockOutputStream.flushBufferedData, LZ4BlockOutputStream.java:203-227 -- 21-byte header {"LZ4Block", method | level,
+ * compressed length, original length, XXH32(original, seed 0x9747b28c) & 0x0FFFFFFF}, payload) for src[0, n_bytes) cut into
+ * block_size pieces.  Compression, raw-fallback decision, size scan, headers, payload compaction and checksums all run on the
+ * device behind one another; frame header, end mark and content checksum stay with the caller (a few bytes, independent of the
+ * data).  level 0 = LZ4_compress_default, 1..17 = lz4-java HC levels.  Bytes are identical to the reference writers' for the
+ * same input, block size and flags (tests/test_gpu_streams.py: the `lz4` CLI reads and reproduces them).
+ *   lz4hip_container_blocks      host pointers (H2D of the data, D2H of the finished blocks only); *out_bytes = bytes written
+ *   lz4hip_container_blocks_dev  device pointers, asynchronous on `stream`; *total_dev (device) = bytes written -- if it exceeds
+ *                                dst_cap nothing beyond dst_cap was written and the result is unusable; ws = device scratch of
+ *                                lz4hip_container_workspace_bytes(n_bytes, block_size, level) bytes                              */
+size_t lz4hip_container_workspace_bytes(uint64_t n_bytes, uint32_t block_size, int level);
+int lz4hip_container_blocks(int kind, int flags, int level, const uint8_t* src, uint64_t n_bytes, uint32_t block_size,
+                            uint8_t* dst, uint64_t dst_cap, uint64_t* out_bytes);
+int lz4hip_container_blocks_dev(int kind, int flags, int level, const uint8_t* src, uint64_t n_bytes, uint32_t block_size,
+                                uint8_t* dst, uint64_t dst_cap, uint64_t* total_dev, void* ws, size_t ws_bytes, int device, void* stream);
+
 /* ---- workload helper (not part of the reference API) ------------------------------------------
  * Fills n_blocks slots of `block_len` bytes at dst + i*stride with the SURVEY.md App. F synthetic
  * blocks idx = first_idx + i (deterministic, seed-addressed).  Device pointer, async on stream.

@@ -71,6 +71,10 @@ C_ABI = {
     "lz4hip_xxh32_stream_digest": (C.c_int, [C.c_void_p, _u32p]),
     "lz4hip_xxh64_stream_digest": (C.c_int, [C.c_void_p, _u64p]),
     "lz4hip_xxh_stream_free": (None, [C.c_void_p]),
+    "lz4hip_container_workspace_bytes": (C.c_size_t, [C.c_uint64, C.c_uint32, C.c_int]),
+    "lz4hip_container_blocks": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, _u64p]),
+    "lz4hip_container_blocks_dev": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p,
+                                              C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "lz4hip_gen_blocks_dev": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
                                         C.c_uint32, C.c_int, C.c_void_p]),
 }
@@ -557,6 +561,22 @@ class LZ4HIPBatch:
                                             _arr(C.c_int32, dstCap), out, n, level))
         return list(out[:n])
 
+    FRAME_BLOCKS, LZ4BLOCK_BLOCKS = 0, 1
+
+    @staticmethod
+    def containerBlocks(kind, data, blockSize, blockChecksum=False, level=0):
+        """the data blocks of an LZ4 Frame (kind FRAME_BLOCKS) or of lz4-java's LZ4Block container (LZ4BLOCK_BLOCKS) for `data` cut
+        into blockSize pieces, assembled on the device (compress, raw fallback, headers, compaction, checksums): the bytes the
+        reference's LZ4FrameOutputStream.writeBlock / LZ4BlockOutputStream.flushBufferedData emit for the same blocks"""
+        n = (len(data) + blockSize - 1) // blockSize
+        cap = len(data) + n * (8 if kind == 0 else 21)
+        dst = bytearray(max(cap, 1))
+        sp, sk = _ro_ptr(data)
+        dp, dk = _rw_ptr(dst)
+        out = C.c_uint64(0)
+        _chk(lib().lz4hip_container_blocks(kind, 1 if blockChecksum else 0, level, sp, len(data), blockSize, dp, cap, C.byref(out)))
+        return bytes(dst[:out.value])
+
     @classmethod
     def decompressSafe(cls, src, srcOff, srcLen, dst, dstOff, dstCap):
         return cls._call("lz4hip_decompress_safe_batch", src, srcOff, srcLen, dst, dstOff, dstCap)
@@ -623,6 +643,20 @@ class DeviceBatch:
         _chk(lib().lz4hip_compress_hc_batch_dev_ws(src.data_ptr(), src_off.data_ptr(), src_len.data_ptr(), dst.data_ptr(),
                                                    dst_off.data_ptr(), dst_cap.data_ptr(), out.data_ptr(), src_off.numel(), level, dev, st,
                                                    span, ws.data_ptr(), nb))
+        ws.record_stream(torch.cuda.current_stream(src.device))
+
+    @classmethod
+    def container_blocks(cls, kind, src, block_size, dst, total, block_checksum=False, level=0):
+        """device-resident container assembly, asynchronous on the current stream: src (uint8 tensor) cut into block_size pieces ->
+        the LZ4 Frame (kind 0) / LZ4Block (kind 1) data blocks in dst; total = int64 tensor[1] receiving the bytes written (more
+        than dst.numel(): the result is unusable)"""
+        import torch
+        dev, st = cls._stream_dev(src)
+        nbytes = src.numel() * src.element_size()
+        wsb = lib().lz4hip_container_workspace_bytes(nbytes, block_size, level)
+        ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=src.device)
+        _chk(lib().lz4hip_container_blocks_dev(kind, 1 if block_checksum else 0, level, src.data_ptr(), nbytes, block_size, dst.data_ptr(),
+                                               dst.numel() * dst.element_size(), total.data_ptr(), ws.data_ptr(), wsb, dev, st))
         ws.record_stream(torch.cuda.current_stream(src.device))
 
     @classmethod

@@ -631,6 +631,108 @@ int single(Op op, const uint8_t* src, int src_len, uint8_t* dst, int dst_cap, in
 
 }  // namespace
 
+// ---- device-side container assembly (kernels.hip launch_container_blocks) ------------------------------------------------------
+namespace {
+struct ContainerPlan { size_t cws, hcws, qwords, total; uint32_t n; };
+ContainerPlan container_plan(uint64_t n_bytes, uint32_t block_size, int hc_lv) {
+  ContainerPlan p{};
+  p.n = (uint32_t)((n_bytes + block_size - 1u) / block_size);
+  p.cws = (lz4hip::container_ws_bytes(n_bytes, block_size) + 255u) & ~(size_t)255u;
+  p.hcws = hc_lv > 0 ? ((lz4hip::hc_ws_bytes(n_bytes, p.n, hc_lv) + 255u) & ~(size_t)255u) : 0u;
+  p.qwords = 3u + (size_t)p.n + lz4hip::compress_fast_v2w_scratch_words(cu_count());
+  p.total = p.cws + p.hcws + p.qwords * sizeof(uint32_t) + 256u;
+  return p;
+}
+int container_args(int kind, uint64_t n_bytes, uint32_t block_size, int level, int* hc_lv) {
+  *hc_lv = 0;
+  if (kind != 0 && kind != 1) return fail(LZ4HIP_E_ARG, "container kind must be 0 (LZ4 Frame blocks) or 1 (LZ4Block blocks)");
+  if (block_size < 64u || block_size > (32u << 20)) return fail(LZ4HIP_E_ARG, "block size must be 64 .. 32 MiB");   // LZ4BlockOutputStream.java:50-51
+  if (n_bytes / block_size >= 0x7FFFFFFFull) return fail(LZ4HIP_E_ARG, "too many blocks");
+  if (level != 0 && hc_level(level, hc_lv)) return fail(LZ4HIP_E_UNSUPPORTED, "unsupported compression level");
+  return 0;
+}
+}  // namespace
+
+extern "C" {
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
+size_t lz4hip_container_workspace_bytes(uint64_t n_bytes, uint32_t block_size, int level) {
+  int lv = 0;
+  if (ensure_init() || block_size < 64u || (level != 0 && hc_level(level, &lv))) return 0;
+  return container_plan(n_bytes, block_size, lv).total;
+}
+int lz4hip_container_blocks_dev(int kind, int flags, int level, const uint8_t* src, uint64_t n_bytes, uint32_t block_size, uint8_t* dst, uint64_t dst_cap,
+                                uint64_t* total_dev, void* ws, size_t ws_bytes, int device, void* stream) {
+  int rc = ensure_init();
+  if (rc) return fail(rc, "no HIP device: liblz4hip has no CPU fallback");
+  int lv;
+  if ((rc = container_args(kind, n_bytes, block_size, level, &lv)) != 0) return rc;
+  if ((n_bytes && !src) || !dst || !total_dev || !ws) return fail(LZ4HIP_E_ARG, "null pointer argument");
+  const ContainerPlan p = container_plan(n_bytes, block_size, lv);
+  if (ws_bytes < p.total) return fail(LZ4HIP_E_ARG, "container workspace too small (lz4hip_container_workspace_bytes)");
+  int ord;
+  if (ordinal(device, &ord)) return fail(LZ4HIP_E_ARG, "bad device index");
+  DeviceGuard g(ord);
+  uint8_t* w = (uint8_t*)(((uintptr_t)ws + 255u) & ~(uintptr_t)255u);
+  const int e = lz4hip::launch_container_blocks(kind, flags & 1, lv, src, n_bytes, block_size, dst, dst_cap, (unsigned long long*)total_dev, w,
+                                                p.hcws ? w + p.cws : nullptr, (uint32_t*)(w + p.cws + p.hcws),
+                                                64u * (uint32_t)g_compress_switch.load(std::memory_order_relaxed), cu_count(),
+                                                g_compress_core.load(std::memory_order_relaxed), stream);
+  if (e) return fail(LZ4HIP_E_HIP, "kernel launch", (hipError_t)e);
+  return LZ4HIP_OK;
+}
+int lz4hip_container_blocks(int kind, int flags, int level, const uint8_t* src, uint64_t n_bytes, uint32_t block_size, uint8_t* dst, uint64_t dst_cap,
+                            uint64_t* out_bytes) {
+  int rc = ensure_init();
+  if (rc) return fail(rc, "no HIP device: liblz4hip has no CPU fallback");
+  int lv;
+  if ((rc = container_args(kind, n_bytes, block_size, level, &lv)) != 0) return rc;
+  if ((n_bytes && !src) || !dst || !out_bytes) return fail(LZ4HIP_E_ARG, "null pointer argument");
+  *out_bytes = 0;
+  if (n_bytes == 0) return LZ4HIP_OK;
+  int ord;
+  if (ordinal(0, &ord)) return fail(LZ4HIP_E_NO_DEVICE, "no device");
+  DeviceGuard g(ord);
+  const ContainerPlan p = container_plan(n_bytes, block_size, lv);
+  const uint64_t worst = n_bytes + (uint64_t)p.n * (kind == 0 ? 8u : 21u);
+  hipStream_t st = nullptr;
+  uint8_t *d_src = nullptr, *d_dst = nullptr, *d_ws = nullptr;
+  uint64_t* d_total = nullptr;
+  hipError_t he = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+  auto done = [&](int r) {
+    if (d_src) (void)hipFreeAsync(d_src, st);
+    if (d_dst) (void)hipFreeAsync(d_dst, st);
+    if (d_ws) (void)hipFreeAsync(d_ws, st);
+    if (d_total) (void)hipFreeAsync(d_total, st);
+    if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    return r;
+  };
+  if (he != hipSuccess) return fail(LZ4HIP_E_HIP, "hipStreamCreate", he);
+  if ((he = hipMallocAsync((void**)&d_src, n_bytes, st)) != hipSuccess || (he = hipMallocAsync((void**)&d_dst, worst, st)) != hipSuccess ||
+      (he = hipMallocAsync((void**)&d_ws, p.total, st)) != hipSuccess || (he = hipMallocAsync((void**)&d_total, 8, st)) != hipSuccess)
+    return done(fail(he == hipErrorOutOfMemory ? LZ4HIP_E_NOMEM : LZ4HIP_E_HIP, "device allocation", he));
+  if ((he = hipMemcpyAsync(d_src, src, n_bytes, hipMemcpyHostToDevice, st)) != hipSuccess) return done(fail(LZ4HIP_E_HIP, "H2D", he));
+  uint8_t* w = (uint8_t*)(((uintptr_t)d_ws + 255u) & ~(uintptr_t)255u);
+  const int e = lz4hip::launch_container_blocks(kind, flags & 1, lv, d_src, n_bytes, block_size, d_dst, worst, (unsigned long long*)d_total, w,
+                                                p.hcws ? w + p.cws : nullptr, (uint32_t*)(w + p.cws + p.hcws),
+                                                64u * (uint32_t)g_compress_switch.load(std::memory_order_relaxed), cu_count(),
+                                                g_compress_core.load(std::memory_order_relaxed), st);
+  if (e) return done(fail(LZ4HIP_E_HIP, "kernel launch", (hipError_t)e));
+  uint64_t total = 0;
+  if ((he = hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, st)) != hipSuccess || (he = hipStreamSynchronize(st)) != hipSuccess)
+    return done(fail(LZ4HIP_E_HIP, "container size", he));
+  if (total > dst_cap) return done(fail(LZ4HIP_E_ARG, "destination too small for the container blocks"));
+  if (total && (he = hipMemcpyAsync(dst, d_dst, total, hipMemcpyDeviceToHost, st)) != hipSuccess) return done(fail(LZ4HIP_E_HIP, "D2H", he));
+  if ((he = hipStreamSynchronize(st)) != hipSuccess) return done(fail(LZ4HIP_E_HIP, "hipStreamSynchronize", he));
+  *out_bytes = total;
+  return done(LZ4HIP_OK);
+}
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
+}  // extern "C"
+
 // ---- streaming xxhash (StreamingXXHash32JNI / StreamingXXHash64JNI: XXHashJNI.c:89-145, :199-255) ------------------------
 struct lz4hip_xxh_stream {
   bool is64;

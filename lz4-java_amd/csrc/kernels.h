@@ -34,6 +34,14 @@ size_t hc_ws_bytes(uint64_t span, uint32_t n_blocks, int level);
 int launch_compress_hc(const BatchArgs& a, int level, void* ws, uint64_t span, void* stream);
 // after a compress launch: moves the out[i] > 0 useful bytes of every slot to pack + sum(out[0..i)); poff: u64[n] scratch
 int launch_pack(const BatchArgs& a, uint64_t* poff, uint8_t* pack, void* stream);
+// Device-side container assembly (kernels.hip): the data blocks of an LZ4 Frame (kind 0; block_checksum: XXH32 of each stored
+// payload) or of lz4-java's LZ4Block container (kind 1) for src[0, n_bytes) cut into block_size pieces -> dst, *total = bytes
+// written (if it exceeds dst_cap nothing past dst_cap was written and the caller must not use the result).  ws: device scratch of
+// container_ws_bytes(); hc_level > 0: LZ4 HC at that level (hc_ws = hc_ws_bytes(n_bytes, n, level)), else the fast compressor
+// (q_scratch = 3 + n + compress_fast_v2w_scratch_words(n_cus) words; core as "compress_core").
+size_t container_ws_bytes(uint64_t n_bytes, uint32_t block_size);
+int launch_container_blocks(int kind, int block_checksum, int hc_level, const uint8_t* src, uint64_t n_bytes, uint32_t block_size, uint8_t* dst, uint64_t dst_cap,
+                            unsigned long long* total, void* ws, void* hc_ws, uint32_t* q_scratch, uint32_t dense64, uint32_t n_cus, int core, void* stream);
 // lanes_per_block: lanes of a wavefront that share one block in the decoder (4..64); 0 = default
 // pipe: 1 = pipelined interior loop (lz4_decode_core.h PIPE), 0 = plain, -1 = default for the batch size
 // stage: 1 = the plain interior loop writes through LDS staging (whole-line output), 0 / -1 = off

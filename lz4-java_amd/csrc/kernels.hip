@@ -386,6 +386,146 @@ int launch_pack(const BatchArgs& a, uint64_t* poff, uint8_t* pack, void* stream)
 }
 
 // ------------------------------------------------------------------------------------------------
+// Device-side container assembly: the data blocks of an LZ4 Frame
+// (LZ4FrameOutputStream.writeBlock, /root/reference/src/java/net/jpountz/lz4/LZ4FrameOutputStream.java:199-235: size word with the
+// "stored uncompressed" bit, payload, optional XXH32 of the stored payload) or of lz4-java's "LZ4Block" container
+// (LZ4BlockOutputStream.flushBufferedData, LZ4BlockOutputStream.java:203-227: 21-byte header {magic, method | level, compressed
+// length, original length, XXH32(original, seed 0x9747b28c) & 0x0FFFFFFF}, payload) are laid out in device memory behind the
+// compress launch: raw-fallback decision, exclusive scan of the stored sizes, headers, payload compaction, checksums -- all on
+// the launch stream, so nothing but the finished container bytes crosses PCIe and no host pass sits between compress and D2H.
+// kind 0 = LZ4 Frame blocks, 1 = LZ4Block blocks.
+// ------------------------------------------------------------------------------------------------
+// block i = src[i * block_size .. +len_i), its compress slot = slots + i * bound
+__global__ void container_layout_kernel(uint64_t n_bytes, uint32_t block_size, uint32_t bound, uint32_t n, uint64_t* src_off, int32_t* src_len,
+                                        uint64_t* slot_off, int32_t* slot_cap) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t o = (uint64_t)i * block_size;
+  src_off[i] = o;
+  src_len[i] = (int32_t)(n_bytes - o < block_size ? n_bytes - o : block_size);
+  slot_off[i] = (uint64_t)i * bound;
+  slot_cap[i] = (int32_t)bound;
+}
+// stored length of every block (the compressed bytes, or the block itself when compression does not gain: clen >= len, the
+// reference's test in both writers) and where its header goes: one workgroup, exclusive scan; total -> *total
+__global__ __launch_bounds__(1024) void container_scan_kernel(int kind, int block_checksum, uint32_t n, const int32_t* src_len, const int32_t* clen,
+                                                               int32_t* stored, uint64_t* hdr_off, unsigned long long* total) {
+  __shared__ uint64_t part[1024];
+  const uint32_t t = threadIdx.x;
+  const uint32_t per = (n + 1023u) / 1024u;
+  const uint32_t i0 = t * per < n ? t * per : n, i1 = (i0 + per < n) ? i0 + per : n;
+  const uint64_t fixed = kind == 0 ? (block_checksum ? 8u : 4u) : 21u;
+  uint64_t s = 0;
+  for (uint32_t i = i0; i < i1; i++) {
+    const int32_t l = src_len[i], c = clen[i];
+    const bool raw = c <= 0 || c >= l;
+    stored[i] = raw ? (l | (int32_t)0x80000000) : c;     // (sign bit: stored uncompressed)
+    s += fixed + (uint64_t)(raw ? l : c);
+  }
+  part[t] = s;
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024u; d <<= 1) {
+    const uint64_t v = t >= d ? part[t - d] : 0ull;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  uint64_t run = part[t] - s;
+  for (uint32_t i = i0; i < i1; i++) { hdr_off[i] = run; run += fixed + (uint64_t)(stored[i] & 0x7FFFFFFF); }
+  if (t == 1023u) *total = part[1023];
+}
+// header + payload of every block (one workgroup per block); hashes: kind 1 only (XXH32 of the ORIGINAL blocks, seed 0x9747b28c)
+__global__ __launch_bounds__(256) void container_copy_kernel(int kind, uint32_t level_nibble, const uint8_t* src, const uint64_t* src_off, const int32_t* src_len,
+                                                             const uint8_t* slots, const uint64_t* slot_off, const int32_t* stored, const uint64_t* hdr_off,
+                                                             const uint32_t* hashes, uint8_t* dst, uint64_t dst_cap, uint64_t* pay_off, int32_t* pay_len) {
+  const uint32_t b = blockIdx.x;
+  const int32_t st = stored[b];
+  const bool raw = st < 0;
+  const uint32_t len = (uint32_t)(st & 0x7FFFFFFF);
+  const uint32_t hl = kind == 0 ? 4u : 21u;
+  const uint64_t ho = hdr_off[b];
+  if (threadIdx.x == 0) { pay_off[b] = ho + hl; pay_len[b] = (int32_t)len; }
+  if (ho + hl + len + (kind == 0 ? 4u : 0u) > dst_cap) return;   // (the host checks *total against the capacity before it reads anything)
+  uint8_t* h = dst + ho;
+  if (threadIdx.x < hl) {
+    uint8_t v;
+    const uint32_t t = threadIdx.x;
+    if (kind == 0) {
+      const uint32_t w = len | (raw ? 0x80000000u : 0u);
+      v = (uint8_t)(w >> (8u * t));
+    } else {
+      const uint32_t olen = (uint32_t)src_len[b], chk = hashes[b] & 0x0FFFFFFFu;
+      if (t < 8u) v = (uint8_t)"LZ4Block"[t];
+      else if (t == 8u) v = (uint8_t)((raw ? 0x10u : 0x20u) | level_nibble);
+      else if (t < 13u) v = (uint8_t)(len >> (8u * (t - 9u)));
+      else if (t < 17u) v = (uint8_t)(olen >> (8u * (t - 13u)));
+      else v = (uint8_t)(chk >> (8u * (t - 17u)));
+    }
+    h[t] = v;
+  }
+  const uint8_t* s = raw ? src + src_off[b] : slots + slot_off[b];
+  uint8_t* d = h + hl;
+  // (neither side is 16-byte aligned in general: unaligned 16-byte accesses are single instructions here)
+  const uint32_t body = len & ~15u;
+  for (uint32_t i = threadIdx.x * 16u; i < body; i += 256u * 16u) {
+    uint4 v;
+    __builtin_memcpy(&v, s + i, 16);
+    __builtin_memcpy(d + i, &v, 16);
+  }
+  const uint32_t i = body + threadIdx.x;
+  if (i < len) d[i] = s[i];
+}
+// kind 0 with block checksums: the XXH32 (seed 0) of each stored payload goes behind it
+__global__ void container_put_hashes_kernel(uint32_t n, const uint64_t* pay_off, const int32_t* pay_len, const uint32_t* hashes, uint8_t* dst, uint64_t dst_cap) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t o = pay_off[i] + (uint64_t)pay_len[i];
+  if (o + 4u > dst_cap) return;
+  const uint32_t h = hashes[i];
+  dst[o] = (uint8_t)h; dst[o + 1] = (uint8_t)(h >> 8); dst[o + 2] = (uint8_t)(h >> 16); dst[o + 3] = (uint8_t)(h >> 24);
+}
+size_t container_ws_bytes(uint64_t n_bytes, uint32_t block_size) {
+  const uint64_t n = (n_bytes + block_size - 1u) / block_size;
+  const uint64_t bound = (uint64_t)block_size + block_size / 255u + 16u;
+  // src_off, slot_off, hdr_off, pay_off (u64) | src_len, slot_cap, clen, stored, pay_len (i32) | hashes (u32) | total (u64) | slots
+  return (size_t)(((n * (4u * 8u + 6u * 4u) + 8u + 255u) & ~(uint64_t)255u) + n * ((bound + 15u) & ~(uint64_t)15u));
+}
+int launch_container_blocks(int kind, int block_checksum, int hc_level, const uint8_t* src, uint64_t n_bytes, uint32_t block_size, uint8_t* dst, uint64_t dst_cap,
+                            unsigned long long* total, void* ws, void* hc_ws, uint32_t* q_scratch, uint32_t dense64, uint32_t n_cus, int core, void* stream) {
+  if (n_bytes == 0) { return (int)hipMemsetAsync(total, 0, 8, (hipStream_t)stream); }
+  hipStream_t st = (hipStream_t)stream;
+  const uint32_t n = (uint32_t)((n_bytes + block_size - 1u) / block_size);
+  const uint32_t bound = (uint32_t)(((uint64_t)block_size + block_size / 255u + 16u + 15u) & ~15ull);
+  uint8_t* p = (uint8_t*)ws;
+  uint64_t* src_off = (uint64_t*)p; uint64_t* slot_off = src_off + n; uint64_t* hdr_off = slot_off + n; uint64_t* pay_off = hdr_off + n;
+  int32_t* src_len = (int32_t*)(pay_off + n); int32_t* slot_cap = src_len + n; int32_t* clen = slot_cap + n; int32_t* stored = clen + n; int32_t* pay_len = stored + n;
+  uint32_t* hashes = (uint32_t*)(pay_len + n);
+  uint8_t* slots = p + (((size_t)n * (4u * 8u + 6u * 4u) + 8u + 255u) & ~(size_t)255u);
+  hipLaunchKernelGGL(container_layout_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, n_bytes, block_size, bound, n, src_off, src_len, slot_off, slot_cap);
+  BatchArgs a{src, src_off, src_len, slots, slot_off, slot_cap, clen, n};
+  int e;
+  if (hc_level > 0) e = launch_compress_hc(a, hc_level, hc_ws, n_bytes, stream);
+  else if (core == 1) e = launch_compress_fast_ms(a, q_scratch, nullptr, true, n_cus, stream);
+  else if (core == 3) e = launch_compress_fast_v2w(a, q_scratch, nullptr, 0u, n_cus, q_scratch + 3 + n, stream);
+  else {
+    e = launch_compress_fast_v2w(a, q_scratch, q_scratch + 3, dense64, n_cus, q_scratch + 3 + n, stream);
+    if (e == 0) e = launch_compress_fast_ms(a, q_scratch, q_scratch + 3, false, n_cus, stream);
+  }
+  if (e) return e;
+  if (kind == 1 && (e = launch_xxh32(src, src_off, src_len, 0x9747b28cu, hashes, n, stream)) != 0) return e;
+  hipLaunchKernelGGL(container_scan_kernel, dim3(1), dim3(1024), 0, st, kind, block_checksum, n, (const int32_t*)src_len, (const int32_t*)clen, stored, hdr_off, total);
+  uint32_t nib = 0;   // LZ4BlockOutputStream.compressionLevel (:57-69): max(0, ceil(log2(blockSize)) - 10)
+  if (kind == 1) { uint32_t cl = 32u - (uint32_t)__builtin_clz(block_size - 1u); if (cl < 10u) cl = 10u; nib = cl - 10u; }
+  hipLaunchKernelGGL(container_copy_kernel, dim3(n), dim3(256), 0, st, kind, nib, src, (const uint64_t*)src_off, (const int32_t*)src_len, (const uint8_t*)slots,
+                     (const uint64_t*)slot_off, (const int32_t*)stored, (const uint64_t*)hdr_off, (const uint32_t*)hashes, dst, dst_cap, pay_off, pay_len);
+  if (kind == 0 && block_checksum) {
+    if ((e = launch_xxh32(dst, pay_off, pay_len, 0u, hashes, n, stream)) != 0) return e;
+    hipLaunchKernelGGL(container_put_hashes_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, n, (const uint64_t*)pay_off, (const int32_t*)pay_len, (const uint32_t*)hashes, dst, dst_cap);
+  }
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // decode
 // ------------------------------------------------------------------------------------------------
 template <int GL, bool SAFE, bool PIPE, bool STAGE>

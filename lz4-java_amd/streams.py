@@ -48,6 +48,12 @@ class HIPEngine:
     decompressFast = staticmethod(LZ4HIPBatch.decompressFast)
     xxh32 = staticmethod(LZ4HIPBatch.xxh32)
 
+    def containerBlocks(self, kind, data, blockSize, blockChecksum=False):
+        """round 3: the container bytes of a batch of blocks are laid out on the device behind the compress launch (raw fallback,
+        size scan, headers, payload compaction, checksums) -- no host pass between compress and the copy back.  Engines without
+        this method (the CPU suite's oracle-backed one) make the writers assemble on the host, byte for byte the same."""
+        return LZ4HIPBatch.containerBlocks(kind, data, blockSize, blockChecksum, 0 if self.hcLevel is None else self.hcLevel)
+
     @staticmethod
     def newStreamingHash32(seed):
         """content checksum state (LZ4FrameOutputStream.java:116: `XXHashFactory...newStreamingHash32(0)`)"""
@@ -219,8 +225,11 @@ class LZ4FrameOutputStream(io.RawIOBase):
         del self.buffer[:nbytes]
         if self.content is not None:
             self.content.update(data, 0, len(data))  # :211-213: the content checksum streams over the uncompressed bytes
-        dst, bound, lens, sizes = _compress_batch(self.engine, data, self.maxBlockSize)
         block_checksum = self.flg.isEnabled(FLG.Bits.BLOCK_CHECKSUM)
+        if hasattr(self.engine, "containerBlocks"):   # assembled on the device
+            self.out.write(self.engine.containerBlocks(LZ4HIPBatch.FRAME_BLOCKS, data, self.maxBlockSize, block_checksum))
+            return
+        dst, bound, lens, sizes = _compress_batch(self.engine, data, self.maxBlockSize)
         outb = bytearray()
         spans = []
         for i, (raw_len, clen) in enumerate(zip(lens, sizes)):
@@ -579,6 +588,9 @@ class LZ4BlockOutputStream(io.RawIOBase):
             return
         data = bytes(self.buffer[:nbytes])
         del self.buffer[:nbytes]
+        if self.checksum is None and hasattr(self.engine, "containerBlocks"):   # assembled on the device (default XXH32 checksum)
+            self.out.write(self.engine.containerBlocks(LZ4HIPBatch.LZ4BLOCK_BLOCKS, data, self.blockSize))
+            return
         dst, bound, lens, sizes = _compress_batch(self.engine, data, self.blockSize)
         if self.checksum is None:
             checks = [c & _CHECK_MASK for c in self.engine.xxh32(data, [i * self.blockSize for i in range(len(lens))], lens, DEFAULT_SEED)]

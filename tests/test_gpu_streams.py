@@ -107,3 +107,64 @@ def test_cpp_stream_mirror_runs_and_interoperates(S, engine):
         blk = open(os.path.join(d, "cpp_stream.blk"), "rb").read()
         assert blk == sc.block_stream_bytes(S, data, engine, 1 << 16)
         assert S.LZ4BlockInputStream(io.BytesIO(blk), engine=engine).read() == data
+
+
+class _HostAssembly:
+    """the HIP engine WITHOUT the device-side container assembly: the writers then assemble on the host (the round-1/2 path)"""
+
+    def __init__(self, eng):
+        self._e = eng
+        self.hcLevel = eng.hcLevel
+        self.compress, self.decompressSafe, self.decompressFast, self.xxh32 = eng.compress, eng.decompressSafe, eng.decompressFast, eng.xxh32
+        self.newStreamingHash32 = eng.newStreamingHash32
+
+
+def test_device_assembled_containers_equal_host_assembled(S, amd, O, corpus, ref):
+    """frames and LZ4Block streams whose blocks are laid out ON THE DEVICE (raw fallback, size scan, headers,
+    payload compaction, block / original-data checksums: lz4hip_container_blocks) are byte-identical to the ones assembled on the host
+    around the batch launches -- which the other cases of this file pin to the `lz4` CLI and to the reference's layout -- for every
+    block size class, with and without block checksums, fast and HC, incl. empty input, a short tail block, incompressible blocks
+    (stored raw) next to compressible ones, and the raw C entry point itself"""
+    import os, random
+    rng = random.Random(77)
+    book = corpus["book1[:200000]"]
+    inputs = [b"", b"x", b"abcd" * 40, rng.randbytes(70000), book[:150000], O.gen_block(300000, 11, win=4096),
+              rng.randbytes(65536) + book[:65536] + bytes(65536) + rng.randbytes(100), O.gen_block(1 << 20, 12) + book[:12345]]
+    for hc in (None, 9):
+        dev, host = S.HIPEngine(hc), _HostAssembly(S.HIPEngine(hc))
+        for v in inputs if hc is None else inputs[:6]:
+            for bs in (S.BLOCKSIZE.SIZE_64KB, S.BLOCKSIZE.SIZE_256KB, S.BLOCKSIZE.SIZE_4MB):
+                for bits in ((S.FLG.Bits.BLOCK_INDEPENDENCE,), (S.FLG.Bits.BLOCK_INDEPENDENCE, S.FLG.Bits.BLOCK_CHECKSUM, S.FLG.Bits.CONTENT_CHECKSUM)):
+                    got = []
+                    for eng in (dev, host):
+                        o = io.BytesIO()
+                        w = S.LZ4FrameOutputStream(o, bs, -1, *bits, engine=eng, batchBlocks=5)
+                        w.write(v); w.close()
+                        got.append(o.getvalue())
+                    assert got[0] == got[1], ("frame", hc, len(v), bs, bits)
+                    assert S.LZ4FrameInputStream(io.BytesIO(got[0]), engine=dev).read() == v
+            for block in (64, 1000, 65536, 1 << 20):
+                got = []
+                for eng in (dev, host):
+                    o = io.BytesIO()
+                    w = S.LZ4BlockOutputStream(o, block, engine=eng, batchBlocks=7)
+                    w.write(v); w.close()
+                    got.append(o.getvalue())
+                assert got[0] == got[1], ("lz4block", hc, len(v), block)
+                assert S.LZ4BlockInputStream(io.BytesIO(got[0]), engine=dev).read() == v
+    # the C entry points: a destination that is too small is an error, never a truncated container; the device-pointer form
+    import torch
+    v = inputs[4]
+    want = amd.LZ4HIPBatch.containerBlocks(0, v, 65536, True)
+    import ctypes as C
+    dst = bytearray(len(want) - 1)
+    out = C.c_uint64(0)
+    rc = amd.lib().lz4hip_container_blocks(0, 1, 0, v, len(v), 65536, (C.c_uint8 * len(dst)).from_buffer(dst), len(dst), C.byref(out))
+    assert rc != 0 and out.value == 0
+    dev0 = torch.device("cuda:0")
+    src = torch.frombuffer(bytearray(v), dtype=torch.uint8).to(dev0)
+    d = torch.zeros(len(v) + 64, dtype=torch.uint8, device=dev0)
+    total = torch.zeros(1, dtype=torch.int64, device=dev0)
+    amd.DeviceBatch.container_blocks(0, src, 65536, d, total, block_checksum=True)
+    torch.cuda.synchronize()
+    assert int(total.item()) == len(want) and d[:len(want)].cpu().numpy().tobytes() == want
