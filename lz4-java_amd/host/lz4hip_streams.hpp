@@ -54,6 +54,18 @@ struct BatchEngine {
     if (!off.empty()) chk(lz4hip_xxh32_batch(buf, off.data(), len.data(), seed, out.data(), (uint32_t)off.size()));
     return out;
   }
+  // round 3: the container bytes of a batch of blocks laid out on the DEVICE behind the compress launch (lz4hip_container_blocks:
+  // raw fallback, size scan, headers, payload compaction, checksums); hostAssembly = true keeps the round-1/2 path (compress batch,
+  // then assembly on the host) -- same bytes either way
+  bool hostAssembly = false;
+  bytes containerBlocks(int kind, const bytes& data, int blockSize, bool blockChecksum) const {
+    const size_t n = (data.size() + (size_t)blockSize - 1) / (size_t)blockSize;
+    bytes o(data.size() + n * (kind == 0 ? 8u : 21u) + 1u);
+    uint64_t got = 0;
+    chk(lz4hip_container_blocks(kind, blockChecksum ? 1 : 0, hcLevel, data.data(), data.size(), (uint32_t)blockSize, o.data(), o.size(), &got));
+    o.resize((size_t)got);
+    return o;
+  }
   uint32_t xxh32_one(const uint8_t* buf, size_t n, uint32_t seed) const {
     static const uint8_t dummy = 0;
     return xxh32(n ? buf : &dummy, {0}, {(int32_t)n}, seed)[0];
@@ -177,8 +189,13 @@ class LZ4FrameOutputStream {
     bytes data(buf_.begin(), buf_.begin() + (std::ptrdiff_t)nbytes);
     buf_.erase(buf_.begin(), buf_.begin() + (std::ptrdiff_t)nbytes);
     if (flg_.isEnabled(frame::CONTENT_CHECKSUM)) content().update(data.data(), data.size());  // :211-213
-    const detail::Compressed c = detail::compressBlocks(e_, data, maxBlockSize_);
     const bool bc = flg_.isEnabled(frame::BLOCK_CHECKSUM);
+    if (!e_.hostAssembly) {
+      const bytes blocks = e_.containerBlocks(0, data, maxBlockSize_, bc);
+      out_.write((const char*)blocks.data(), (std::streamsize)blocks.size());
+      return;
+    }
+    const detail::Compressed c = detail::compressBlocks(e_, data, maxBlockSize_);
     bytes o;
     std::vector<uint64_t> spanOff;
     std::vector<int32_t> spanLen;
@@ -439,6 +456,11 @@ class LZ4BlockOutputStream {
     if (nbytes == 0) return;
     bytes data(buf_.begin(), buf_.begin() + (std::ptrdiff_t)nbytes);
     buf_.erase(buf_.begin(), buf_.begin() + (std::ptrdiff_t)nbytes);
+    if (!checksum_ && !e_.hostAssembly) {
+      const bytes blocks = e_.containerBlocks(1, data, blockSize_, false);
+      out_.write((const char*)blocks.data(), (std::streamsize)blocks.size());
+      return;
+    }
     const detail::Compressed c = detail::compressBlocks(e_, data, blockSize_);
     std::vector<uint64_t> so(c.lens.size());
     for (size_t i = 0; i < so.size(); i++) so[i] = i * (size_t)blockSize_;

@@ -52,6 +52,14 @@ int main(int argc, char** argv) {
         CHECK(thrown([&] { f.write(data.data(), 1); }) == frame::CLOSED_STREAM);
       }
       dump(dir + "/" + c.name, sink.str());
+      {   // the same frame with the blocks assembled on the host (round-1/2 path) instead of on the device: same bytes
+        std::ostringstream sink2;
+        BatchEngine he; he.hostAssembly = true;
+        LZ4FrameOutputStream f2(sink2, c.bs, c.known ? (int64_t)data.size() : -1, c.bits, he, 3);
+        for (size_t i = 0; i < data.size(); i += 100003) f2.write(data.data() + i, std::min<size_t>(100003, data.size() - i));
+        f2.close();
+        CHECK(sink2.str() == sink.str());
+      }
       std::istringstream src(sink.str());
       LZ4FrameInputStream in(src, false, BatchEngine(), 2);
       if (c.known) CHECK(in.isExpectedContentSizeDefined() && in.getExpectedContentSize() == (int64_t)data.size());
@@ -94,6 +102,12 @@ int main(int argc, char** argv) {
       std::ostringstream sink;
       { LZ4BlockOutputStream f(sink, 1 << 16, BatchEngine(), false, 5); for (size_t i = 0; i < data.size(); i += 70001) f.write(data.data() + i, std::min<size_t>(70001, data.size() - i)); }
       dump(dir + "/cpp_stream.blk", sink.str());
+      {   // blocks assembled on the host instead of on the device: same bytes
+        std::ostringstream sink2;
+        BatchEngine he; he.hostAssembly = true;
+        { LZ4BlockOutputStream f2(sink2, 1 << 16, he, false, 5); for (size_t i = 0; i < data.size(); i += 70001) f2.write(data.data() + i, std::min<size_t>(70001, data.size() - i)); }
+        CHECK(sink2.str() == sink.str());
+      }
       { std::istringstream s(sink.str()); LZ4BlockInputStream in(s, true, BatchEngine(), 7); CHECK(in.readAll() == data); }
       std::string bad = sink.str();
       bad[3] ^= 1;
