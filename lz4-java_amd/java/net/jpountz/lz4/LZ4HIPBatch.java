@@ -74,4 +74,33 @@ public final class LZ4HIPBatch {
   public static void compressHC(int level, ByteBuffer src, long[] srcOff, int[] srcLen, ByteBuffer dest, long[] destOff, int[] destCap, int[] outLen) {
     run(3, level, src, srcOff, srcLen, dest, destOff, destCap, outLen);
   }
+
+  /** Container kinds of {@link #containerBlocks}. */
+  public static final int FRAME_BLOCKS = 0, LZ4BLOCK_BLOCKS = 1;
+
+  /**
+   * The data blocks of an LZ4 Frame ({@link #FRAME_BLOCKS}: what {@code LZ4FrameOutputStream.writeBlock} emits per block;
+   * {@code blockChecksum} adds the XXH32 of each stored payload) or of the LZ4Block container ({@link #LZ4BLOCK_BLOCKS}: what
+   * {@code LZ4BlockOutputStream.flushBufferedData} emits) for {@code src[srcOff, srcOff+len)} cut into {@code blockSize} pieces,
+   * assembled on the device: compression, raw fallback, headers, payload compaction and checksums happen behind one another
+   * there, only the finished bytes come back.  {@code level} 0 = fast, 1..17 = HC.  Returns the bytes written at {@code dest[destOff..)}.
+   */
+  public static long containerBlocks(int kind, boolean blockChecksum, int level, ByteBuffer src, long srcOff, long len, int blockSize,
+                                     ByteBuffer dest, long destOff) {
+    if (!src.isDirect() || !dest.isDirect()) {
+      throw new IllegalArgumentException("LZ4HIPBatch needs direct ByteBuffers");
+    }
+    if (dest.isReadOnly()) {
+      throw new java.nio.ReadOnlyBufferException();
+    }
+    if (srcOff < 0 || len < 0 || destOff < 0 || srcOff + len > src.capacity() || destOff > dest.capacity()) {
+      throw new ArrayIndexOutOfBoundsException();
+    }
+    final long r = LZ4HIPJNI.LZ4HIP_containerBlocks(kind, blockChecksum ? 1 : 0, level, src, srcOff, len, blockSize, dest, destOff,
+        dest.capacity() - destOff);
+    if (r < 0) {
+      throw new LZ4Exception("liblz4hip status " + (-r) + ": " + LZ4HIPJNI.lastError());
+    }
+    return r;
+  }
 }

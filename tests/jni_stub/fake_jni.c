@@ -72,6 +72,7 @@ JNIEXPORT jint JNICALL Java_net_jpountz_lz4_LZ4HIPJNI_LZ4HIP_1decompress_1fast(J
 JNIEXPORT jint JNICALL Java_net_jpountz_lz4_LZ4HIPJNI_LZ4HIP_1compressBound(JNIEnv*, jclass, jint);
 JNIEXPORT jstring JNICALL Java_net_jpountz_lz4_LZ4HIPJNI_lastError(JNIEnv*, jclass);
 JNIEXPORT jint JNICALL Java_net_jpountz_lz4_LZ4HIPJNI_LZ4HIP_1batch(JNIEnv*, jclass, jint, jint, jobject, jlongArray, jintArray, jobject, jlongArray, jintArray, jintArray, jint);
+JNIEXPORT jlong JNICALL Java_net_jpountz_lz4_LZ4HIPJNI_LZ4HIP_1containerBlocks(JNIEnv*, jclass, jint, jint, jint, jobject, jlong, jlong, jint, jobject, jlong, jlong);
 JNIEXPORT jint JNICALL Java_net_jpountz_xxhash_XXHashHIPJNI_XXH32(JNIEnv*, jclass, jbyteArray, jint, jint, jint);
 JNIEXPORT jint JNICALL Java_net_jpountz_xxhash_XXHashHIPJNI_XXH32BB(JNIEnv*, jclass, jobject, jint, jint, jint);
 JNIEXPORT jlong JNICALL Java_net_jpountz_xxhash_XXHashHIPJNI_XXH64(JNIEnv*, jclass, jbyteArray, jint, jint, jlong);
@@ -192,7 +193,22 @@ int main(int argc, char** argv) {
     memset(dback->data, 0, (size_t)n * blk);
     r = Java_net_jpountz_lz4_LZ4HIPJNI_LZ4HIP_1batch(env, NULL, 2, 0, (jobject)ddst, (jlongArray)dof, (jintArray)dc, (jobject)dback, (jlongArray)bo, (jintArray)bl, (jintArray)res, n);
     CHECK(no_exc() && r == 0 && memcmp(dback->data, dsrc->data + 100, (size_t)n * blk) == 0);
-    for (int i = 0; i < n; i++) CHECK(((jint*)res->data)[i] == ((jint*)cl->data)[i]); }
+    for (int i = 0; i < n; i++) CHECK(((jint*)res->data)[i] == ((jint*)cl->data)[i]);
+    /* container blocks assembled on the device (LZ4HIPBatch.containerBlocks): frame blocks of the same n blocks = n x {size word,
+       payload}; every payload is the compressed block the batch call produced, the size words say so */
+    r = Java_net_jpountz_lz4_LZ4HIPJNI_LZ4HIP_1batch(env, NULL, 0, 0, (jobject)dsrc, (jlongArray)so, (jintArray)sl, (jobject)ddst, (jlongArray)dof, (jintArray)dc, (jintArray)ol, n);
+    CHECK(no_exc() && r == 0);
+    { const jlong got = Java_net_jpountz_lz4_LZ4HIPJNI_LZ4HIP_1containerBlocks(env, NULL, 0, 0, 0, (jobject)dsrc, 100, (jlong)n * blk, blk, (jobject)dback, 0, (jlong)dback->bytes);
+      CHECK(no_exc() && got > 0);
+      size_t p = 0;
+      for (int i = 0; i < n; i++) {
+        const uint32_t w = (uint32_t)dback->data[p] | ((uint32_t)dback->data[p + 1] << 8) | ((uint32_t)dback->data[p + 2] << 16) | ((uint32_t)dback->data[p + 3] << 24);
+        const jint c = ((jint*)ol->data)[i];
+        CHECK(w == (uint32_t)c && memcmp(dback->data + p + 4, ddst->data + (size_t)i * bound, (size_t)c) == 0);
+        p += 4 + (size_t)c;
+      }
+      CHECK((jlong)p == got);
+      CHECK(Java_net_jpountz_lz4_LZ4HIPJNI_LZ4HIP_1containerBlocks(env, NULL, 0, 0, 0, (jobject)dsrc, 100, (jlong)n * blk, blk, (jobject)dback, 0, 10) < 0); } }
 
   /* ---- 5. xxhash: one-shot (heap + direct), batch, streaming; known answers of SURVEY App. D ---- */
   memcpy(src->data + 7, README_IN, 14);
