@@ -99,7 +99,7 @@ public final class LZ4HIPBatch {
     final long r = LZ4HIPJNI.LZ4HIP_containerBlocks(kind, blockChecksum ? 1 : 0, level, src, srcOff, len, blockSize, dest, destOff,
         dest.capacity() - destOff);
     if (r < 0) {
-      throw new LZ4Exception("liblz4hip status " + (-r) + ": " + LZ4HIPJNI.lastError());
+      throw new LZ4Exception("liblz4hip status " + r + ": " + LZ4HIPJNI.lastError());
     }
     return r;
   }

@@ -62,7 +62,7 @@ enum LZ4HIPJNI {
   static native int LZ4HIP_batch(int op, int level, ByteBuffer src, long[] srcOff, int[] srcLen,
                                  ByteBuffer dest, long[] destOff, int[] destCap, int[] outLen, int nBlocks);
 
-  /** Container blocks assembled on the device (LZ4HIPBatch.containerBlocks); returns bytes written or -(status). */
+  /** Container blocks assembled on the device (LZ4HIPBatch.containerBlocks); returns bytes written or the negative lz4hip_status. */
   static native long LZ4HIP_containerBlocks(int kind, int flags, int level, ByteBuffer src, long srcOff, long len, int blockSize,
       ByteBuffer dest, long destOff, long destCap);
 

@@ -169,16 +169,16 @@ JNIEXPORT jint JNICALL Java_net_jpountz_lz4_LZ4HIPJNI_LZ4HIP_1batch(JNIEnv* env,
 /* the data blocks of an LZ4 Frame (kind 0) / of lz4-java's LZ4Block container (kind 1) for src[srcOff, srcOff + len) cut into
  * blockSize pieces, assembled on the device (include/lz4hip.h lz4hip_container_blocks): what LZ4FrameOutputStream.writeBlock /
  * LZ4BlockOutputStream.flushBufferedData emit block by block, in one call.  Direct buffers; returns the bytes written at
- * dest[destOff ..), or -(status) */
+ * dest[destOff ..), or the (negative) lz4hip_status */
 JNIEXPORT jlong JNICALL Java_net_jpountz_lz4_LZ4HIPJNI_LZ4HIP_1containerBlocks(JNIEnv* env, jclass cls, jint kind, jint flags, jint level, jobject src,
     jlong srcOff, jlong len, jint blockSize, jobject dest, jlong destOff, jlong destCap) {
   (void)cls;
   const uint8_t* s = (const uint8_t*)(*env)->GetDirectBufferAddress(env, src);
   uint8_t* d = (uint8_t*)(*env)->GetDirectBufferAddress(env, dest);
-  if (s == NULL || d == NULL || srcOff < 0 || len < 0 || destOff < 0 || destCap < 0 || blockSize <= 0) return -(jlong)LZ4HIP_E_ARG;
+  if (s == NULL || d == NULL || srcOff < 0 || len < 0 || destOff < 0 || destCap < 0 || blockSize <= 0) return (jlong)LZ4HIP_E_ARG;
   uint64_t out = 0;
   const int rc = lz4hip_container_blocks(kind, flags, level, s + srcOff, (uint64_t)len, (uint32_t)blockSize, d + destOff, (uint64_t)destCap, &out);
-  return rc == 0 ? (jlong)out : -(jlong)rc;
+  return rc == 0 ? (jlong)out : (jlong)rc;   /* (status codes are negative) */
 }
 
 /* ---- xxhash (XXHashJNI.c:42-82, :152-192 counterparts) ---- */
