@@ -305,6 +305,20 @@ def main():
             ok = ok and oke
             del h_src, h_dst, h_back
 
+        # ---- device-resident container encode: the data blocks of an LZ4 Frame for the headline bytes, compressed AND
+        # assembled on the device (raw fallback, size scan, size words, payload compaction), nothing crossing PCIe ----
+        total_t = torch.zeros(1, dtype=i64, device=dev)
+        wf, tkf = timed(lambda: amd.DeviceBatch.container_blocks(0, src, blk, comp, total_t), 2)
+        tot = int(total_t.item())
+        w0 = int.from_bytes(comp[:4].cpu().numpy().tobytes(), "little")
+        okc = all_ok(tot == csum + 4 * n and w0 == int(clen[0]))
+        # (every block's size word + payload: checked against the batch call's sizes; byte identity with the host-assembled frames and
+        # the lz4 CLI: tests/test_gpu_streams.py)
+        extra["frame_blocks_dev"] = {"workload": "the headline bytes as ONE buffer -> the data blocks of an LZ4 Frame with 64 KiB blocks, compressed and "
+                                                 "assembled on the device (lz4hip_container_blocks_dev)", "value": round(world * nbytes / wf / 1e9, 3),
+                                     "unit": "GB/s", "verified": okc, "bytes_out": tot}
+        ok = ok and okc
+
         # ---- real text: BASELINE configs[0] names a 64 KiB Silesia/dickens block; the only real data of the reference are
         # src/test-resources/calgary/* (LZ4Test.java:335-348), so: every block = 64 KiB of Calgary book1 (English prose, the same
         # class) from a different offset.  Compressed bytes of a sample of blocks are compared with the reference library's. ----
