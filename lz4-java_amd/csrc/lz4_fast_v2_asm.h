@@ -38,6 +38,9 @@
 #ifndef LZ4HIP_ASM_DBG
 #define LZ4HIP_ASM_DBG 0
 #endif
+#ifndef LZ4HIP_V2_PF
+#define LZ4HIP_V2_PF 0   /* developer A/B: candidate lines of the next windows' tentative slots requested at the end of the shadow */
+#endif
 #ifndef LZ4HIP_V2_ASM_PROF
 #define LZ4HIP_V2_ASM_PROF 0   /* developer builds: shader-clock time per phase of the hand-scheduled step, summed into g_asm_prof */
 #endif
@@ -198,7 +201,11 @@ __device__ __forceinline__ uint32_t lean_asm_run(uint32_t& ip, uint32_t& php, ui
       // ---- top of the loop: the rows of the hit at s72 (candidate s73) arrive
       "L_arrive_%=:\n"
       LZ4HIP_TICK("t1")
+#if LZ4HIP_V2_PF
+      "  s_waitcnt vmcnt(2)\n"
+#else
       "  s_waitcnt vmcnt(0)\n"
+#endif
       LZ4HIP_TICK("t2")
       "L_arrived_%=:\n"
       "  v_xor_b32 v122, v120, v121\n"
@@ -276,6 +283,14 @@ __device__ __forceinline__ uint32_t lean_asm_run(uint32_t& ip, uint32_t& php, ui
       "  v_mov_b32 v117, v107\n"
       "  v_mov_b32 v119, v111\n"
       LZ4HIP_BUILD_E2
+#if LZ4HIP_V2_PF
+      // (A/B) the candidate lines of every tentative slot among the 128: the next hit's candidate is one of them
+      "  s_mov_b64 exec, s[78:79]\n"
+      "  global_load_dword v131, v109, %[src]\n"
+      "  s_mov_b64 exec, s[80:81]\n"
+      "  global_load_dword v132, v113, %[src]\n"
+      "  s_mov_b64 exec, -1\n"
+#endif
       "  s_add_u32 s75, s72, 1024\n"
       "  s_cmp_gt_u32 s75, %[pfe]\n"
       "  s_cbranch_scc0 L_arrive_%=\n"
@@ -287,7 +302,11 @@ __device__ __forceinline__ uint32_t lean_asm_run(uint32_t& ip, uint32_t& php, ui
       "  v_min_u32 v123, %[ntop], v123\n"
       "  global_load_dwordx4 v[124:127], v123, %[src]\n"
       "  s_add_u32 %[pfe], %[pfe], 1024\n"
+#if LZ4HIP_V2_PF
+      "  s_waitcnt vmcnt(3)\n"
+#else
       "  s_waitcnt vmcnt(1)\n"
+#endif
       "  s_branch L_arrived_%=\n"
       "L_touched_%=:\n"
       "  s_add_u32 %[pfe], %[pfe], 1024\n"
@@ -380,7 +399,7 @@ __device__ __forceinline__ uint32_t lean_asm_run(uint32_t& ip, uint32_t& php, ui
         [j16] "v"(j16)
       : "memory", "vcc", "scc", "m0", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111",
         "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126",
-        "v127", "v128", "v129", "v130", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82",
+        "v127", "v128", "v129", "v130", "v131", "v132", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82",
         "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s94", "s95"
 #if LZ4HIP_V2_ASM_PROF
         , "s92", "s93", "s96", "s97", "s98"
