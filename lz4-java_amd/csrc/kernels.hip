@@ -199,7 +199,7 @@ __device__ __forceinline__ void compress_fast_ms_block(const BatchArgs& a, uint3
   }
   if (__lane_id() == 0) a.out[b] = (int32_t)r;
 }
-// CU-filling form (see compress_fast_cu_kernel): WAVES_PER_CU wavefronts per workgroup drawing from q[2] either the blocks
+// CU-filling form (see the residency note above): WAVES_PER_CU wavefronts per workgroup drawing from q[2] either the blocks
 // listed in routed[0 .. q[1]) (second pass of the adaptive scheme; an empty list costs one queue draw per wavefront) or, with
 // routed == nullptr, every block of the batch
 __global__ __launch_bounds__(64 * WAVES_PER_CU) void compress_fast_ms_cu_kernel(BatchArgs a, uint32_t* q, const uint32_t* routed) {
