@@ -167,3 +167,58 @@ def test_fast_decoder_contract_pinned(amd):
         if r >= 0:
             assert hashlib.sha256(bytes(dst[o:o + e["dst_len"]])).hexdigest() == e["sha256"]
         assert dst[o + e["dst_len"]] == 0xA5   # nothing past the slot
+
+
+def test_mixed_64k_blocks_every_core_vs_reference(amd, ref, O, corpus):
+    """4000 blocks of 20 KiB .. 65546 bytes, each a patchwork of text, image, geophysical data, random bytes, zero runs, short
+    repeated patterns and App. F pieces (every kind of step the finder meets: short and long matches, matches over 65 and 256
+    bytes, dense and sparse hits, long literal runs), compressed in ONE batch by each core -- 3 = the lean finder (the hand-scheduled
+    loop) forced on ALL of them incl. the text-like ones, 1 = the window-parallel core, 5 = the adaptive pairing -- and EVERY
+    block's bytes compared with LZ4_compress_default of the reference library"""
+    import numpy as np
+    import torch
+    dev = torch.device("cuda:0")
+    rng = random.Random(1234)
+    book, pic, geo = corpus["book1[:200000]"], corpus["pic[:65536]"], corpus["geo[:65536]"]
+    syn = [O.gen_block(65536, 900 + i, litmax=lm, win=w) for i, (lm, w) in enumerate([(38, 65535), (4, 300), (200, 65535), (38, 64), (12, 4096)])]
+
+    def piece(k):
+        t = rng.randrange(8)
+        if t == 0: o = rng.randrange(len(book) - k); return book[o:o + k]
+        if t == 1: o = rng.randrange(len(pic) - min(k, 60000)); return pic[o:o + k]
+        if t == 2: o = rng.randrange(len(geo) - min(k, 60000)); return geo[o:o + k]
+        if t == 3: return rng.randbytes(k)
+        if t == 4: return bytes(k)
+        if t == 5: p = rng.randbytes(rng.randrange(1, 40)); return (p * (k // len(p) + 1))[:k]
+        if t == 6: s = syn[rng.randrange(len(syn))]; o = rng.randrange(len(s) - min(k, 60000)); return s[o:o + k]
+        return bytes(rng.randrange(3) for _ in range(min(k, 3000)))
+    blocks = []
+    for _ in range(4000):
+        n = rng.choice([65536, 65536, 65546, rng.randrange(20000, 65536)])
+        b = bytearray()
+        while len(b) < n:
+            b += piece(rng.choice([50, 300, 2000, 9000, 30000]))
+        blocks.append(bytes(b[:n]))
+    want = _pool(ref.compress_fast, blocks)
+    slot = 65546
+    cap = amd.maxCompressedLength(slot)
+    n = len(blocks)
+    host = np.zeros(n * slot, dtype=np.uint8)
+    for i, b in enumerate(blocks):
+        host[i * slot:i * slot + len(b)] = np.frombuffer(b, dtype=np.uint8)
+    src = torch.from_numpy(host).to(dev)
+    B = _batch(torch, dev, n, slot, cap)
+    B["sl"] = torch.tensor([len(b) for b in blocks], dtype=torch.int32, device=dev)
+    comp = torch.empty(n * cap, dtype=torch.uint8, device=dev)
+    for core in (3, 1, 5):
+        amd.set_option("compress_core", core)
+        try:
+            comp.zero_()
+            amd.DeviceBatch.compress_fast(src, B["so"], B["sl"], comp, B["co"], B["cc"], B["clen"])
+            torch.cuda.synchronize()
+        finally:
+            amd.set_option("compress_core", 5)
+        clen = B["clen"].cpu().tolist()
+        hc = comp.view(n, cap).cpu().numpy()
+        bad = [i for i in range(n) if clen[i] != len(want[i]) or hc[i][:clen[i]].tobytes() != want[i]]
+        assert not bad, (core, bad[:10], [len(blocks[i]) for i in bad[:10]])
