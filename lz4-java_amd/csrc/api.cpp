@@ -8,6 +8,7 @@
 #include <string.h>
 #include <limits.h>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <new>
@@ -181,14 +182,15 @@ int dev_batch(Op op, const uint8_t* src, const uint64_t* src_off, const int32_t*
 
 // ---- host-pointer path ---------------------------------------------------------------------------
 // ---- staging of the host-pointer batch API --------------------------------------------------------------------------
-// A host batch is cut into chunks of <= CHUNK_SRC source bytes.  Each chunk is packed into a PINNED staging buffer (user
-// memory is pageable: hipMemcpyAsync from it would be staged by the runtime at a fraction of the link rate), copied to the
-// device, processed, and its destination slots are copied back into a second pinned buffer, from which the bytes each block
-// actually produced go to the caller's slots.  Two buffer sets per device alternate, so the CPU packs chunk c+1 and unpacks
-// chunk c-1 while the GPU works on chunk c.  Buffers, streams and events are created once per device and kept
+// A host batch is cut into chunks (64 MiB of source for the codec calls, CHUNK_SRC for the hashes).  Each chunk is packed into a
+// PINNED staging buffer (user memory is pageable: hipMemcpyAsync from it would be staged by the runtime at a fraction of the link
+// rate), copied to the device, processed, and its destination slots are copied back into a second pinned buffer, from which the
+// bytes each block actually produced go to the caller's slots.  Several buffer sets per device rotate, so the CPU packs chunk c+1
+// and unpacks chunk c-1 while the GPU works on chunk c.  Buffers, streams and events are created once per device and kept
 // (lz4hip_shutdown releases them) -- the per-call hipMalloc/hipFree/stream churn of the first version cost more than the
 // work for single blocks.
-constexpr size_t CHUNK_SRC = 128u << 20;   // source bytes per chunk
+constexpr size_t CHUNK_SRC = 128u << 20;   // source bytes per chunk (hash path)
+inline int env_int(const char* name, int dflt, int lo, int hi) { const char* v = getenv(name); if (!v) return dflt; int x = atoi(v); return x < lo ? lo : x > hi ? hi : x; }
 constexpr uint32_t CHUNK_BLOCKS = 1u << 20;
 constexpr int COPY_THREADS = 16;           // host threads packing / unpacking a chunk
 
@@ -212,8 +214,9 @@ struct GrowBuf {
 };
 
 struct ChunkSlot {
-  hipStream_t st = nullptr;
-  hipEvent_t done = nullptr;
+  hipStream_t st = nullptr;                       // kernels (hash path: everything)
+  hipStream_t st_in = nullptr, st_out = nullptr;  // host_shard: the H2D and D2H copies run on streams that never see a kernel
+  hipEvent_t done = nullptr, ev_in = nullptr, ev_k = nullptr;
   GrowBuf h_src, h_dst, h_meta, d_src, d_dst, d_meta, d_ws, d_pack, d_poff;
   bool packed = false;                // compress ops: only the useful bytes of the slots come back (device-side packing)
   uint32_t i0 = 0, i1 = 0;            // blocks of the chunk in flight
@@ -227,20 +230,22 @@ struct ChunkSlot {
 // pairs, each on its own streams -- and hands the pair back.  (Round 1 held one per-device mutex for the whole batch: every
 // concurrent caller of the host API ran one at a time.)
 struct SlotPair {
-  ChunkSlot slot[2];
+  static constexpr int SETS = 6;   // (host_shard uses g_host_sets of them, the hash path alternates between the first two)
+  ChunkSlot slot[SETS];
   hipError_t init() {
     for (auto& s : slot) {
       hipError_t e;
-      if ((e = hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking)) != hipSuccess) return e;
-      if ((e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming)) != hipSuccess) return e;
+      for (hipStream_t* q : {&s.st, &s.st_in, &s.st_out})
+        if ((e = hipStreamCreateWithFlags(q, hipStreamNonBlocking)) != hipSuccess) return e;
+      for (hipEvent_t* v : {&s.done, &s.ev_in, &s.ev_k})
+        if ((e = hipEventCreateWithFlags(v, hipEventDisableTiming)) != hipSuccess) return e;
     }
     return hipSuccess;
   }
   void release() {
     for (auto& s : slot) {
-      if (s.st) (void)hipStreamDestroy(s.st);
-      if (s.done) (void)hipEventDestroy(s.done);
-      s.st = nullptr; s.done = nullptr;
+      for (hipStream_t* q : {&s.st, &s.st_in, &s.st_out}) { if (*q) (void)hipStreamDestroy(*q); *q = nullptr; }
+      for (hipEvent_t* v : {&s.done, &s.ev_in, &s.ev_k}) { if (*v) (void)hipEventDestroy(*v); *v = nullptr; }
       for (GrowBuf* g : {&s.h_src, &s.h_dst, &s.h_meta, &s.d_src, &s.d_dst, &s.d_meta, &s.d_ws, &s.d_pack, &s.d_poff}) g->release();
     }
   }
@@ -291,7 +296,8 @@ DevCtx g_ctx[64];
 template <class F>
 void par_blocks(uint32_t i0, uint32_t i1, size_t bytes, F f) {  // f(i) for i in [i0, i1), on several threads when it is worth it
   const uint32_t n = i1 - i0;
-  const int T = (bytes < (4u << 20) || n < 2) ? 1 : (int)std::min<uint32_t>(COPY_THREADS, n);
+  static const int copy_threads = env_int("LZ4HIP_HOST_COPY_THREADS", COPY_THREADS, 1, 128);
+  const int T = (bytes < (4u << 20) || n < 2) ? 1 : (int)std::min<uint32_t>((uint32_t)copy_threads, n);
   if (T == 1) { for (uint32_t i = i0; i < i1; i++) f(i); return; }
   std::vector<std::thread> th;
   for (int t = 0; t < T; t++) {
@@ -301,15 +307,20 @@ void par_blocks(uint32_t i0, uint32_t i1, size_t bytes, F f) {  // f(i) for i in
   for (auto& x : th) x.join();
 }
 
-// one device's share [b0, b1) of a host batch
+// one device's share [b0, b1) of a host batch.  Three stages run side by side on three buffer sets: the calling thread PACKS chunk
+// c + 1 into pinned memory and enqueues it, the GPU works on chunk c (its H2D, kernels and D2H on the set's own stream), and a
+// finisher thread per chunk waits for chunk c - 1 and hands its bytes to the caller's slots.  (Rounds 1-2 did pack, the
+// synchronous D2H of the packed bytes and the unpack one after the other on the calling thread: 44 ms per GiB, twice what the
+// link needs -- tools/host_path_probe.py.)
 int host_shard(Op op, int level, int ord, const uint8_t* src, const uint64_t* src_off, const int32_t* src_len, uint8_t* dst,
                const uint64_t* dst_off, const int32_t* dst_cap, int32_t* out, uint32_t b0, uint32_t b1, std::string* err) {
-  auto bad = [&](const char* what, hipError_t e) {
+  auto bad_to = [](std::string* where, const char* what, hipError_t e) {
     char buf[512];
     snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
-    *err = buf;
+    *where = buf;
     return e == hipErrorOutOfMemory ? (int)LZ4HIP_E_NOMEM : (int)LZ4HIP_E_HIP;
   };
+  auto bad = [&](const char* what, hipError_t e) { return bad_to(err, what, e); };
   if (b1 == b0) return LZ4HIP_OK;
   if (ord < 0 || ord >= 64) { *err = "device ordinal out of range"; return LZ4HIP_E_ARG; }
   hipError_t e;
@@ -320,11 +331,20 @@ int host_shard(Op op, int level, int ord, const uint8_t* src, const uint64_t* sr
   struct Return { DevCtx& c; SlotPair* p; ~Return() { c.give_back(p); } } give_back_on_exit{cx, pair};
   auto slen_of = [&](uint32_t i) -> size_t { return src_len[i] > 0 ? (size_t)src_len[i] : 0; };
   auto dcap_of = [&](uint32_t i) -> size_t { return dst_cap[i] > 0 ? (size_t)dst_cap[i] : 0; };
+  const bool prof = getenv("LZ4HIP_HOST_PROF") != nullptr;   // developer diagnostics: where the time of the stages goes
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  std::atomic<double> t_wait{0}, t_d2h{0}, t_unpack{0};
+  auto add = [](std::atomic<double>& a, double v) { double o = a.load(); while (!a.compare_exchange_weak(o, o + v)) {} };
 
-  // hand the results of the chunk in `s` to the caller (waits for it)
-  auto finish = [&](ChunkSlot& s) -> int {
+  // hand the results of the chunk in `s` to the caller (waits for it): runs on the chunk's finisher thread
+  struct Fin { std::thread th; int rc = LZ4HIP_OK; std::string err; bool live = false; } fin[SlotPair::SETS];
+  auto finish = [&](ChunkSlot& s, Fin& f) -> int {
     if (s.i1 == s.i0) return LZ4HIP_OK;
-    if ((e = hipEventSynchronize(s.done)) != hipSuccess) return bad("hipEventSynchronize", e);
+    hipError_t fe;
+    if ((fe = hipSetDevice(ord)) != hipSuccess) return bad_to(&f.err, "hipSetDevice", fe);
+    double c0 = now();
+    if ((fe = hipEventSynchronize(s.done)) != hipSuccess) return bad_to(&f.err, "hipEventSynchronize", fe);
+    add(t_wait, now() - c0); c0 = now();
     const uint32_t nb = s.i1 - s.i0;
     const int32_t* hout = (const int32_t*)((const uint8_t*)s.h_meta.p + (size_t)nb * 24u);
     memcpy(out + s.i0, hout, (size_t)nb * 4u);
@@ -333,32 +353,64 @@ int host_shard(Op op, int level, int ord, const uint8_t* src, const uint64_t* sr
     if (s.packed) {   // the sizes are here: fetch exactly the useful bytes (already packed on the device), then hand them out
       uint64_t total = 0;
       for (uint32_t t = 0; t < nb; t++) { s.dof[t] = total; total += hout[t] > 0 ? (uint64_t)hout[t] : 0ull; }
-      if (total && (e = hipMemcpyAsync(s.h_dst.p, s.d_pack.p, (size_t)total, hipMemcpyDeviceToHost, s.st)) != hipSuccess) return bad("D2H packed", e);
-      if ((e = hipStreamSynchronize(s.st)) != hipSuccess) return bad("hipStreamSynchronize", e);
+      if ((fe = hipStreamWaitEvent(s.st_out, s.ev_k, 0)) != hipSuccess) return bad_to(&f.err, "hipStreamWaitEvent", fe);   // (the pack kernel)
+      if (total && (fe = hipMemcpyAsync(s.h_dst.p, s.d_pack.p, (size_t)total, hipMemcpyDeviceToHost, s.st_out)) != hipSuccess) return bad_to(&f.err, "D2H packed", fe);
+      if ((fe = hipStreamSynchronize(s.st_out)) != hipSuccess) return bad_to(&f.err, "hipStreamSynchronize", fe);
       s.dst_bytes = (size_t)total;
     }
+    add(t_d2h, now() - c0); c0 = now();
     par_blocks(s.i0, s.i1, s.dst_bytes, [=, &s](uint32_t i) {
       int64_t produced;   // (bytes past a result stay untouched in the caller's slot)
       if (op == OP_DECODE_FAST) produced = out[i] > 0 ? dst_cap[i] : 0;
       else produced = out[i] > 0 ? out[i] : 0;
       if (produced > 0) memcpy(dst + dst_off[i], hd + s.dof[i - i0], (size_t)produced);
     });
-    s.i0 = s.i1 = 0;
+    add(t_unpack, now() - c0);
     return LZ4HIP_OK;
   };
+  // the buffer set is free again once its finisher is through
+  auto reap = [&](int k) -> int {
+    Fin& f = fin[k];
+    if (!f.live) return LZ4HIP_OK;
+    f.th.join();
+    f.live = false;
+    pair->slot[k].i0 = pair->slot[k].i1 = 0;
+    if (f.rc != LZ4HIP_OK) *err = f.err;
+    return f.rc;
+  };
+  auto start_finisher = [&](int k) {
+    Fin& f = fin[k];
+    ChunkSlot& s = pair->slot[k];
+    f.rc = LZ4HIP_OK;
+    try {
+      f.th = std::thread([&finish, &s, &f] { f.rc = finish(s, f); });
+      f.live = true;
+    } catch (...) {   // no thread to be had: this chunk is finished on the calling thread
+      f.rc = finish(s, f);
+      f.live = false;
+      s.i0 = s.i1 = 0;
+    }
+    return f.live ? LZ4HIP_OK : (f.rc != LZ4HIP_OK ? (*err = f.err, f.rc) : LZ4HIP_OK);
+  };
 
+  const int SETS = env_int("LZ4HIP_HOST_SETS", 6, 2, SlotPair::SETS);
+  const size_t chunk_src = (size_t)env_int("LZ4HIP_HOST_CHUNK_MB", 64, 1, 1024) << 20;
   int rc = LZ4HIP_OK;
   uint32_t i = b0;
   int k = 0;
+  double t_reap = 0, t_pack = 0, t_enq = 0, t_alloc = 0;
+  const double t_begin = now();
   while (i < b1 && rc == LZ4HIP_OK) {
     ChunkSlot& s = pair->slot[k];
-    if ((rc = finish(s)) != LZ4HIP_OK) break;   // the chunk that used this buffer set two rounds ago
+    double t0 = now();
+    if ((rc = reap(k)) != LZ4HIP_OK) break;   // the chunk that used this buffer set three rounds ago
+    t_reap += now() - t0; t0 = now();
     // the next chunk: blocks [i, j)
     uint32_t j = i;
     size_t sb = 0, db = 0;
     while (j < b1 && j - i < CHUNK_BLOCKS) {
       const size_t a = (slen_of(j) + 15u) & ~(size_t)15u, c = (dcap_of(j) + 15u) & ~(size_t)15u;
-      if (j > i && sb + a > CHUNK_SRC) break;
+      if (j > i && sb + a > chunk_src) break;
       sb += a; db += c; j++;
     }
     const uint32_t nb = j - i;
@@ -373,6 +425,7 @@ int host_shard(Op op, int level, int ord, const uint8_t* src, const uint64_t* sr
       rc = bad("staging allocation", e);
       break;
     }
+    t_alloc += now() - t0; t0 = now();
     uint8_t* hs = (uint8_t*)s.h_src.p;
     { const uint32_t base = i;
       par_blocks(i, j, sb, [=, &s](uint32_t t) { if (src_len[t] > 0) memcpy(hs + s.so[t - base], src + src_off[t], (size_t)src_len[t]); }); }
@@ -381,9 +434,11 @@ int host_shard(Op op, int level, int ord, const uint8_t* src, const uint64_t* sr
     memcpy(hm + (size_t)nb * 8u, s.dof.data(), (size_t)nb * 8u);
     memcpy(hm + (size_t)nb * 16u, src_len + i, (size_t)nb * 4u);
     memcpy(hm + (size_t)nb * 20u, dst_cap + i, (size_t)nb * 4u);
+    t_pack += now() - t0; t0 = now();
     uint8_t* dm = (uint8_t*)s.d_meta.p;
-    if (sb && (e = hipMemcpyAsync(s.d_src.p, hs, sb, hipMemcpyHostToDevice, s.st)) != hipSuccess) { rc = bad("H2D src", e); break; }
-    if ((e = hipMemcpyAsync(dm, hm, (size_t)nb * 24u, hipMemcpyHostToDevice, s.st)) != hipSuccess) { rc = bad("H2D meta", e); break; }
+    if (sb && (e = hipMemcpyAsync(s.d_src.p, hs, sb, hipMemcpyHostToDevice, s.st_in)) != hipSuccess) { rc = bad("H2D src", e); break; }
+    if ((e = hipMemcpyAsync(dm, hm, (size_t)nb * 24u, hipMemcpyHostToDevice, s.st_in)) != hipSuccess) { rc = bad("H2D meta", e); break; }
+    if ((e = hipEventRecord(s.ev_in, s.st_in)) != hipSuccess || (e = hipStreamWaitEvent(s.st, s.ev_in, 0)) != hipSuccess) { rc = bad("H2D event", e); break; }
     lz4hip::BatchArgs a{(const uint8_t*)s.d_src.p, (const uint64_t*)dm, (const int32_t*)(dm + (size_t)nb * 16u), (uint8_t*)s.d_dst.p,
                         (const uint64_t*)(dm + (size_t)nb * 8u), (const int32_t*)(dm + (size_t)nb * 20u), (int32_t*)(dm + (size_t)nb * 24u), nb};
     int le = 0;
@@ -394,25 +449,38 @@ int host_shard(Op op, int level, int ord, const uint8_t* src, const uint64_t* sr
       case OP_COMPRESS_HC: le = lz4hip::launch_compress_hc(a, level, s.d_ws.p, sb, s.st); break;
     }
     if (le) { rc = bad("kernel launch", (hipError_t)le); break; }
-    if ((e = hipMemcpyAsync(hm + (size_t)nb * 24u, dm + (size_t)nb * 24u, (size_t)nb * 4u, hipMemcpyDeviceToHost, s.st)) != hipSuccess) { rc = bad("D2H out", e); break; }
     s.packed = (op == OP_COMPRESS_FAST || op == OP_COMPRESS_HC);
+    // the sizes travel first; compress ops: the finisher fetches exactly the packed bytes once it has them
+    if ((e = hipEventRecord(s.ev_k, s.st)) != hipSuccess || (e = hipStreamWaitEvent(s.st_out, s.ev_k, 0)) != hipSuccess) { rc = bad("kernel event", e); break; }
+    if ((e = hipMemcpyAsync(hm + (size_t)nb * 24u, dm + (size_t)nb * 24u, (size_t)nb * 4u, hipMemcpyDeviceToHost, s.st_out)) != hipSuccess) { rc = bad("D2H out", e); break; }
     if (s.packed) {
-      if ((e = hipEventRecord(s.done, s.st)) != hipSuccess) { rc = bad("hipEventRecord", e); break; }   // sizes on the host
+      if ((e = hipEventRecord(s.done, s.st_out)) != hipSuccess) { rc = bad("hipEventRecord", e); break; }   // sizes on the host
       if ((le = lz4hip::launch_pack(a, (uint64_t*)s.d_poff.p, (uint8_t*)s.d_pack.p, s.st)) != 0) { rc = bad("kernel launch", (hipError_t)le); break; }
+      if ((e = hipEventRecord(s.ev_k, s.st)) != hipSuccess) { rc = bad("hipEventRecord", e); break; }       // packed bytes ready (the finisher waits for it)
     } else {
-      if (db && (e = hipMemcpyAsync(s.h_dst.p, s.d_dst.p, db, hipMemcpyDeviceToHost, s.st)) != hipSuccess) { rc = bad("D2H dst", e); break; }
-      if ((e = hipEventRecord(s.done, s.st)) != hipSuccess) { rc = bad("hipEventRecord", e); break; }
+      if (db && (e = hipMemcpyAsync(s.h_dst.p, s.d_dst.p, db, hipMemcpyDeviceToHost, s.st_out)) != hipSuccess) { rc = bad("D2H dst", e); break; }
+      if ((e = hipEventRecord(s.done, s.st_out)) != hipSuccess) { rc = bad("hipEventRecord", e); break; }
     }
     s.i0 = i; s.i1 = j; s.src_bytes = sb; s.dst_bytes = db;
+    rc = start_finisher(k);
     i = j;
-    k ^= 1;
+    k = (k + 1) % SETS;
+    t_enq += now() - t0;
   }
-  // drain (also after an error: nothing may stay in flight on the cached buffers)
-  for (int t = 0; t < 2; t++) {
-    ChunkSlot& s = pair->slot[(k + t) & 1];
-    if (rc == LZ4HIP_OK) rc = finish(s);
-    else { (void)hipStreamSynchronize(s.st); s.i0 = s.i1 = 0; }
+  const double t_loop = now() - t_begin;
+  // drain (also after an error: nothing may stay in flight on the cached buffers, no finisher may outlive this call)
+  for (int t = 0; t < SETS; t++) {
+    const int kk = (k + t) % SETS;
+    std::string keep = *err;
+    const int r = reap(kk);
+    if (rc == LZ4HIP_OK) rc = r; else *err = keep;   // (the first error is the one reported)
+    ChunkSlot& s = pair->slot[kk];
+    if (rc != LZ4HIP_OK) { (void)hipStreamSynchronize(s.st_in); (void)hipStreamSynchronize(s.st); (void)hipStreamSynchronize(s.st_out); s.i0 = s.i1 = 0; }
   }
+  if (prof)
+    fprintf(stderr, "[lz4hip host_shard op %d, %u blocks] total %.1f ms: loop %.1f (reap %.1f | alloc %.1f | pack %.1f | enqueue %.1f), drain %.1f; finishers: wait %.1f + d2h %.1f + unpack %.1f\n",
+            (int)op, b1 - b0, 1e3 * (now() - t_begin), 1e3 * t_loop, 1e3 * t_reap, 1e3 * t_alloc, 1e3 * t_pack, 1e3 * t_enq,
+            1e3 * (now() - t_begin - t_loop), 1e3 * t_wait.load(), 1e3 * t_d2h.load(), 1e3 * t_unpack.load());
   return rc;
 }
 
