@@ -216,6 +216,7 @@ struct GrowBuf {
 struct ChunkSlot {
   hipStream_t st = nullptr;                       // kernels (hash path: everything)
   hipStream_t st_in = nullptr, st_out = nullptr;  // host_shard: the H2D and D2H copies run on streams that never see a kernel
+  hipStream_t q_in = nullptr, q_out = nullptr;    // the copy streams of the chunk in flight (= st for a call that is one chunk)
   hipEvent_t done = nullptr, ev_in = nullptr, ev_k = nullptr;
   GrowBuf h_src, h_dst, h_meta, d_src, d_dst, d_meta, d_ws, d_pack, d_poff;
   bool packed = false;                // compress ops: only the useful bytes of the slots come back (device-side packing)
@@ -338,6 +339,10 @@ int host_shard(Op op, int level, int ord, const uint8_t* src, const uint64_t* sr
 
   // hand the results of the chunk in `s` to the caller (waits for it): runs on the chunk's finisher thread
   struct Fin { std::thread th; int rc = LZ4HIP_OK; std::string err; bool live = false; } fin[SlotPair::SETS];
+  struct JoinAll {   // no finisher outlives this call, whichever way it is left (an exception of the packing code included)
+    Fin* f;
+    ~JoinAll() { for (int t = 0; t < SlotPair::SETS; t++) if (f[t].th.joinable()) f[t].th.join(); }
+  } join_all{fin};
   auto finish = [&](ChunkSlot& s, Fin& f) -> int {
     if (s.i1 == s.i0) return LZ4HIP_OK;
     hipError_t fe;
@@ -353,9 +358,9 @@ int host_shard(Op op, int level, int ord, const uint8_t* src, const uint64_t* sr
     if (s.packed) {   // the sizes are here: fetch exactly the useful bytes (already packed on the device), then hand them out
       uint64_t total = 0;
       for (uint32_t t = 0; t < nb; t++) { s.dof[t] = total; total += hout[t] > 0 ? (uint64_t)hout[t] : 0ull; }
-      if ((fe = hipStreamWaitEvent(s.st_out, s.ev_k, 0)) != hipSuccess) return bad_to(&f.err, "hipStreamWaitEvent", fe);   // (the pack kernel)
-      if (total && (fe = hipMemcpyAsync(s.h_dst.p, s.d_pack.p, (size_t)total, hipMemcpyDeviceToHost, s.st_out)) != hipSuccess) return bad_to(&f.err, "D2H packed", fe);
-      if ((fe = hipStreamSynchronize(s.st_out)) != hipSuccess) return bad_to(&f.err, "hipStreamSynchronize", fe);
+      if (s.q_out != s.st && (fe = hipStreamWaitEvent(s.q_out, s.ev_k, 0)) != hipSuccess) return bad_to(&f.err, "hipStreamWaitEvent", fe);   // (the pack kernel)
+      if (total && (fe = hipMemcpyAsync(s.h_dst.p, s.d_pack.p, (size_t)total, hipMemcpyDeviceToHost, s.q_out)) != hipSuccess) return bad_to(&f.err, "D2H packed", fe);
+      if ((fe = hipStreamSynchronize(s.q_out)) != hipSuccess) return bad_to(&f.err, "hipStreamSynchronize", fe);
       s.dst_bytes = (size_t)total;
     }
     add(t_d2h, now() - c0); c0 = now();
@@ -436,9 +441,13 @@ int host_shard(Op op, int level, int ord, const uint8_t* src, const uint64_t* sr
     memcpy(hm + (size_t)nb * 20u, dst_cap + i, (size_t)nb * 4u);
     t_pack += now() - t0; t0 = now();
     uint8_t* dm = (uint8_t*)s.d_meta.p;
-    if (sb && (e = hipMemcpyAsync(s.d_src.p, hs, sb, hipMemcpyHostToDevice, s.st_in)) != hipSuccess) { rc = bad("H2D src", e); break; }
-    if ((e = hipMemcpyAsync(dm, hm, (size_t)nb * 24u, hipMemcpyHostToDevice, s.st_in)) != hipSuccess) { rc = bad("H2D meta", e); break; }
-    if ((e = hipEventRecord(s.ev_in, s.st_in)) != hipSuccess || (e = hipStreamWaitEvent(s.st, s.ev_in, 0)) != hipSuccess) { rc = bad("H2D event", e); break; }
+    // a call that is ONE chunk (single blocks, small batches) has nothing to overlap: one stream, no finisher thread
+    const bool single = (i == b0 && j == b1);
+    s.q_in = single ? s.st : s.st_in;
+    s.q_out = single ? s.st : s.st_out;
+    if (sb && (e = hipMemcpyAsync(s.d_src.p, hs, sb, hipMemcpyHostToDevice, s.q_in)) != hipSuccess) { rc = bad("H2D src", e); break; }
+    if ((e = hipMemcpyAsync(dm, hm, (size_t)nb * 24u, hipMemcpyHostToDevice, s.q_in)) != hipSuccess) { rc = bad("H2D meta", e); break; }
+    if (!single && ((e = hipEventRecord(s.ev_in, s.q_in)) != hipSuccess || (e = hipStreamWaitEvent(s.st, s.ev_in, 0)) != hipSuccess)) { rc = bad("H2D event", e); break; }
     lz4hip::BatchArgs a{(const uint8_t*)s.d_src.p, (const uint64_t*)dm, (const int32_t*)(dm + (size_t)nb * 16u), (uint8_t*)s.d_dst.p,
                         (const uint64_t*)(dm + (size_t)nb * 8u), (const int32_t*)(dm + (size_t)nb * 20u), (int32_t*)(dm + (size_t)nb * 24u), nb};
     int le = 0;
@@ -451,18 +460,24 @@ int host_shard(Op op, int level, int ord, const uint8_t* src, const uint64_t* sr
     if (le) { rc = bad("kernel launch", (hipError_t)le); break; }
     s.packed = (op == OP_COMPRESS_FAST || op == OP_COMPRESS_HC);
     // the sizes travel first; compress ops: the finisher fetches exactly the packed bytes once it has them
-    if ((e = hipEventRecord(s.ev_k, s.st)) != hipSuccess || (e = hipStreamWaitEvent(s.st_out, s.ev_k, 0)) != hipSuccess) { rc = bad("kernel event", e); break; }
-    if ((e = hipMemcpyAsync(hm + (size_t)nb * 24u, dm + (size_t)nb * 24u, (size_t)nb * 4u, hipMemcpyDeviceToHost, s.st_out)) != hipSuccess) { rc = bad("D2H out", e); break; }
+    if (!single && ((e = hipEventRecord(s.ev_k, s.st)) != hipSuccess || (e = hipStreamWaitEvent(s.q_out, s.ev_k, 0)) != hipSuccess)) { rc = bad("kernel event", e); break; }
+    if ((e = hipMemcpyAsync(hm + (size_t)nb * 24u, dm + (size_t)nb * 24u, (size_t)nb * 4u, hipMemcpyDeviceToHost, s.q_out)) != hipSuccess) { rc = bad("D2H out", e); break; }
     if (s.packed) {
-      if ((e = hipEventRecord(s.done, s.st_out)) != hipSuccess) { rc = bad("hipEventRecord", e); break; }   // sizes on the host
+      if ((e = hipEventRecord(s.done, s.q_out)) != hipSuccess) { rc = bad("hipEventRecord", e); break; }   // sizes on the host
       if ((le = lz4hip::launch_pack(a, (uint64_t*)s.d_poff.p, (uint8_t*)s.d_pack.p, s.st)) != 0) { rc = bad("kernel launch", (hipError_t)le); break; }
-      if ((e = hipEventRecord(s.ev_k, s.st)) != hipSuccess) { rc = bad("hipEventRecord", e); break; }       // packed bytes ready (the finisher waits for it)
+      if (!single && (e = hipEventRecord(s.ev_k, s.st)) != hipSuccess) { rc = bad("hipEventRecord", e); break; }   // packed bytes ready (the finisher waits for it)
     } else {
-      if (db && (e = hipMemcpyAsync(s.h_dst.p, s.d_dst.p, db, hipMemcpyDeviceToHost, s.st_out)) != hipSuccess) { rc = bad("D2H dst", e); break; }
-      if ((e = hipEventRecord(s.done, s.st_out)) != hipSuccess) { rc = bad("hipEventRecord", e); break; }
+      if (db && (e = hipMemcpyAsync(s.h_dst.p, s.d_dst.p, db, hipMemcpyDeviceToHost, s.q_out)) != hipSuccess) { rc = bad("D2H dst", e); break; }
+      if ((e = hipEventRecord(s.done, s.q_out)) != hipSuccess) { rc = bad("hipEventRecord", e); break; }
     }
     s.i0 = i; s.i1 = j; s.src_bytes = sb; s.dst_bytes = db;
-    rc = start_finisher(k);
+    if (single) {
+      Fin& f = fin[k];
+      if ((rc = finish(s, f)) != LZ4HIP_OK) *err = f.err;
+      s.i0 = s.i1 = 0;
+    } else {
+      rc = start_finisher(k);
+    }
     i = j;
     k = (k + 1) % SETS;
     t_enq += now() - t0;
