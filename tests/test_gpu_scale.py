@@ -222,3 +222,43 @@ def test_mixed_64k_blocks_every_core_vs_reference(amd, ref, O, corpus):
         hc = comp.view(n, cap).cpu().numpy()
         bad = [i for i in range(n) if clen[i] != len(want[i]) or hc[i][:clen[i]].tobytes() != want[i]]
         assert not bad, (core, bad[:10], [len(blocks[i]) for i in bad[:10]])
+
+
+def test_host_batch_many_chunks_ragged_concurrent_callers(amd, ref, O):
+    """The host-pointer batch API over SEVERAL staging chunks (round 3: pack | GPU | finisher threads on rotating buffer sets,
+    csrc/api.cpp host_shard): ~330 MB of ragged blocks (0 .. 64 KiB, some incompressible, some with capacities one byte short)
+    from two concurrent callers; every size and a sample of the compressed bytes against the reference library, every block back
+    through the safe decoder's host path."""
+    import numpy as np
+    rng = random.Random(5)
+    base = [O.gen_block(65536, s) for s in range(24)] + [rng.randbytes(65536) for _ in range(4)] + [bytes(65536)]
+    n = 5200
+    lens = [rng.choice([65536, 65536, 65536, rng.randrange(0, 65537), rng.randrange(13, 2000)]) for _ in range(n)]
+    srcs = [base[i % len(base)][:ln] for i, ln in enumerate(lens)]
+    src = b"".join(srcs)
+    so = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
+    want = _pool(lambda v: len(ref.compress_fast(v)), srcs)
+    caps = [amd.maxCompressedLength(ln) if i % 7 else max(0, want[i] - 1) for i, ln in enumerate(lens)]   # every 7th: one byte short -> 0
+    do = np.concatenate([[0], np.cumsum(caps)[:-1]]).astype(np.uint64)
+
+    def caller(_):
+        dst = bytearray(int(sum(caps)) + 1)
+        out = amd.LZ4HIPBatch.compress(src, so, np.array(lens, dtype=np.int32), dst, do, np.array(caps, dtype=np.int32))
+        return dst, out
+    with cf.ThreadPoolExecutor(2) as ex:
+        results = list(ex.map(caller, range(2)))
+    for dst, out in results:
+        for i in range(n):
+            exp = want[i] if caps[i] >= want[i] else 0
+            assert out[i] == exp, (i, lens[i], caps[i], int(out[i]), exp)
+        for i in rng.sample(range(n), 300):
+            if out[i] > 0:
+                assert bytes(dst[int(do[i]):int(do[i]) + int(out[i])]) == ref.compress_fast(srcs[i]), i
+    dst, out = results[0]
+    ok = [i for i in range(n) if out[i] > 0]
+    back = bytearray(len(src) + 1)
+    got = amd.LZ4HIPBatch.decompressSafe(dst, do[ok], np.array([out[i] for i in ok], dtype=np.int32), back, so[ok],
+                                     np.array([lens[i] for i in ok], dtype=np.int32))
+    assert list(got) == [lens[i] for i in ok]
+    for i in ok:
+        assert bytes(back[int(so[i]):int(so[i]) + lens[i]]) == srcs[i], i
