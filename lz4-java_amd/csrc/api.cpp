@@ -78,7 +78,7 @@ std::atomic<int> g_decode_pipe{-1};   // "decode_pipe": 1/0 = pipelined interior
 // forced modes exist so that the suite can put every input through each kernel).  "compress_switch" = bytes per sequence below
 // which a block counts as dense and goes to the window-parallel core (probe: sequences 32..95 of the block)
 std::atomic<int> g_compress_core{5};
-std::atomic<int> g_compress_switch{20};
+std::atomic<int> g_compress_switch{16};   // (tools/switch_probe.py: 20 sent word-like data of 9 bytes per sequence to the slower core; 12 loses text)
 
 // liblz4's level handling: < 1 -> 9, > 12 -> 12; 10..12 are the optimal parser (lz4-java levels 10..17)
 int hc_level(int level, int* out) {

@@ -473,7 +473,7 @@ def test_compress_core_variants_same_bytes(amd, ref, O, corpus, core, switch):
         res = gpu_compress_many(amd, blocks, caps)
     finally:
         amd.set_option("compress_core", 5)
-        amd.set_option("compress_switch", 20)
+        amd.set_option("compress_switch", 16)
     for v, cap, (r, c) in zip(blocks, caps, res):
         er, eb = ref.compress_fast_raw(v, cap)
         assert r == er and (er <= 0 or c == eb), (len(v), cap, r, er)
