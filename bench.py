@@ -98,8 +98,8 @@ def decode_kernel_name(n_blocks, safe=True):
     """the decoder instantiation launch_decompress (kernels.hip) picks by batch size: lanes per block, SAFE, PIPE, STAGE"""
     s = "true" if safe else "false"
     if n_blocks >= 40960:
-        return "decode_kernel<4, %s, false, true>" % s
-    return "decode_kernel<%d, %s, true, false>" % (8 if n_blocks >= 8192 else 16, s)
+        return "decode_kernel<4, %s, 0, true>" % s
+    return "decode_kernel<%d, %s, 2, false>" % (8 if n_blocks >= 8192 else 16, s)   # (2: the deep interior loop, csrc/lz4_decode_deep.h)
 
 
 def cpu_entry(fn):

@@ -937,7 +937,7 @@ int lz4hip_set_option(const char* name, int value) {
     return LZ4HIP_OK;
   }
   if (name && strcmp(name, "decode_pipe") == 0) {
-    if (value < -1 || value > 1) return fail(LZ4HIP_E_ARG, "decode_pipe must be -1, 0 or 1");
+    if (value < -1 || value > 2) return fail(LZ4HIP_E_ARG, "decode_pipe must be -1, 0, 1 or 2");
     g_decode_pipe = value;
     return LZ4HIP_OK;
   }

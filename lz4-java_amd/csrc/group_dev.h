@@ -159,6 +159,45 @@ struct GroupDev {
     }
   }
 
+  // ---- backend of the deep interior loop (lz4_decode_deep.h): the block's window of the compressed stream in an LDS ring of
+  // kStream bytes, refilled in 256-byte pieces (each lane CB bytes), its first 16 bytes repeated behind the end so that no read
+  // wraps; whole 64-byte steps loaded / stored by all lanes of the group. ----
+#ifndef LZ4HIP_KSTREAM
+#define LZ4HIP_KSTREAM 1024   /* stream bytes per block in LDS (power of two, >= 1024) */
+#endif
+  static constexpr uint32_t kStream = LZ4HIP_KSTREAM;
+  static constexpr uint32_t kStreamLds = kStream + 16u;
+  static constexpr uint32_t kPiece = 256u;
+  static constexpr uint32_t CB = kPiece / GL < 4u ? 4u : kPiece / GL;   // bytes of a piece per lane (the deep loop runs with GL <= 16)
+  struct PieceRegs { uint32_t w[CB / 4]; };
+  typedef Chunk<LB / 4> LChunk;
+  uint8_t* srb = nullptr;
+  __device__ __forceinline__ void sr_begin(uint8_t* lds) { srb = lds; }
+  __device__ __forceinline__ PieceRegs sr_fetch(const uint8_t* src, uint32_t pos) const {   // pos: multiple of 256; the whole piece is readable
+    PieceRegs r;
+    __builtin_memcpy(&r, src + pos + l * CB, CB);
+    return r;
+  }
+  __device__ __forceinline__ void sr_put(uint32_t pos, const PieceRegs& r) {
+    const uint32_t q = (pos & (kStream - 1u)) + l * CB;
+    __builtin_memcpy(srb + q, &r, CB);
+    if (q < 16u) __builtin_memcpy(srb + kStream + q, &r, CB < 16u ? CB : 16u);
+  }
+  __device__ __forceinline__ uint32_t sr_ld32(uint32_t p) const { uint32_t v; __builtin_memcpy(&v, srb + (p & (kStream - 1u)), 4); return v; }
+  __device__ __forceinline__ uint64_t sr_ld64(uint32_t p) const { uint64_t v; __builtin_memcpy(&v, srb + (p & (kStream - 1u)), 8); return v; }
+  __device__ __forceinline__ Chunk<LB / 4> sr_step(uint32_t p) const {   // this lane's LB bytes of the 64 stream bytes at p
+    Chunk<LB / 4> v;
+    __builtin_memcpy(&v, srb + ((p + l * LB) & (kStream - 1u)), LB);
+    return v;
+  }
+  __device__ __forceinline__ Chunk<LB / 4> step_load(const uint8_t* m) const {   // this lane's LB bytes of the 64 bytes at m
+    Chunk<LB / 4> v;
+    const vecLB t = LZ4HIP_MATCH_LOAD((const vecLB*)(m + l * LB));
+    __builtin_memcpy(&v, &t, LB);
+    return v;
+  }
+  __device__ __forceinline__ void step_store(uint8_t* d, const Chunk<LB / 4>& v) const { store_out(d + l * LB, v); }
+
   // dst[op+i] = dst[op-offset+i] for i in [0,len), byte-forward (overlap replicates the pattern)
   __device__ __forceinline__ void copy_match(uint8_t* dst, uint32_t op, uint32_t offset, uint32_t len, bool wild) const {
     uint8_t* d = dst + op;

@@ -528,31 +528,38 @@ int launch_container_blocks(int kind, int block_checksum, int hc_level, const ui
 // ------------------------------------------------------------------------------------------------
 // decode
 // ------------------------------------------------------------------------------------------------
-template <int GL, bool SAFE, bool PIPE, bool STAGE>
+template <int GL, bool SAFE, int PIPE, bool STAGE>
 __global__ __launch_bounds__(256) void decode_kernel(BatchArgs a) {
-  // STAGE: one staging buffer per block of the workgroup (group_dev.h st_*): 256/GL x 576 bytes
-  __shared__ __attribute__((aligned(16))) uint8_t stage_mem[STAGE ? (256 / GL) * GroupDev<GL>::kStage : 16];
+  // STAGE: one staging buffer per block of the workgroup (group_dev.h st_*): 256/GL x 576 bytes; PIPE 2: the block's window of
+  // the compressed stream (group_dev.h sr_*): 256/GL x (kStream + 16) bytes
+  constexpr uint32_t kPer = PIPE == 2 ? GroupDev<GL>::kStreamLds : GroupDev<GL>::kStage;
+  __shared__ __attribute__((aligned(16))) uint8_t stage_mem[(STAGE || PIPE == 2) ? (256 / GL) * kPer : 16];
   const uint32_t gid = (blockIdx.x * 256u + threadIdx.x) / GL;
   if (gid >= a.n) return;  // a whole group leaves together
   GroupDev<GL> g;
-  uint8_t* stage = STAGE ? stage_mem + (threadIdx.x / GL) * GroupDev<GL>::kStage : nullptr;
+  uint8_t* stage = (STAGE || PIPE == 2) ? stage_mem + (threadIdx.x / GL) * kPer : nullptr;
   const int r = decode_block<GroupDev<GL>, SAFE, PIPE, STAGE>(g, a.src + a.src_off[gid], a.src_len[gid], a.dst + a.dst_off[gid], a.dst_cap[gid], stage);
   if (g.l == 0) a.out[gid] = r;
 }
 
 template <int GL>
-static int launch_decode_gl(const BatchArgs& a, bool safe, bool pipe, bool stage, hipStream_t st) {
+static int launch_decode_gl(const BatchArgs& a, bool safe, int pipe, bool stage, hipStream_t st) {
   const uint32_t per_wg = 256u / GL;
   const uint32_t grid = (a.n + per_wg - 1u) / per_wg;
   if (stage) {   // (staging belongs to the plain loop)
-    if (safe) hipLaunchKernelGGL((decode_kernel<GL, true, false, true>), dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((decode_kernel<GL, false, false, true>), dim3(grid), dim3(256), 0, st, a);
+    if (safe) hipLaunchKernelGGL((decode_kernel<GL, true, 0, true>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((decode_kernel<GL, false, 0, true>), dim3(grid), dim3(256), 0, st, a);
+  } else if (pipe == 2 && GL <= 16) {   // (the deep loop works in 64-byte steps: groups of up to 16 lanes)
+    if constexpr (GL <= 16) {
+      if (safe) hipLaunchKernelGGL((decode_kernel<GL, true, 2, false>), dim3(grid), dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((decode_kernel<GL, false, 2, false>), dim3(grid), dim3(256), 0, st, a);
+    }
   } else if (safe) {
-    if (pipe) hipLaunchKernelGGL((decode_kernel<GL, true, true, false>), dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((decode_kernel<GL, true, false, false>), dim3(grid), dim3(256), 0, st, a);
+    if (pipe) hipLaunchKernelGGL((decode_kernel<GL, true, 1, false>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((decode_kernel<GL, true, 0, false>), dim3(grid), dim3(256), 0, st, a);
   } else {
-    if (pipe) hipLaunchKernelGGL((decode_kernel<GL, false, true, false>), dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((decode_kernel<GL, false, false, false>), dim3(grid), dim3(256), 0, st, a);
+    if (pipe) hipLaunchKernelGGL((decode_kernel<GL, false, 1, false>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((decode_kernel<GL, false, 0, false>), dim3(grid), dim3(256), 0, st, a);
   }
   return (int)hipGetLastError();
 }
@@ -569,7 +576,9 @@ int launch_decompress(const BatchArgs& a, bool safe, int lanes_per_block, int pi
   //                    every wavefront has to make progress on its own.
   const bool auto_lanes = lanes_per_block == 0;
   if (auto_lanes) lanes_per_block = a.n >= 40960u ? 4 : (a.n >= 8192u ? 8 : 16);
-  const bool p = pipe < 0 ? (a.n < 40960u && lanes_per_block >= 8) : pipe != 0;
+  // the pipelined loop of the smaller batches is the DEEP one (lz4_decode_deep.h) for groups of up to 16 lanes: 16384 x 4 MiB
+  // blocks 571 -> 742 GB/s, 16384 x 64 KiB App. F 442 -> 503, text 104 -> 126, 4096 x 4 MiB 185 -> 216
+  const int p = pipe < 0 ? ((a.n < 40960u && lanes_per_block >= 8) ? (lanes_per_block <= 16 ? 2 : 1) : 0) : pipe;
   // staging (whole-line output through LDS) pays where the batch is bandwidth-bound: App. F 65536 blocks 487 -> 680 GB/s
   // (text 106 -> 111); below that the pipelined loop wins (16384 blocks: 424 vs 289 staged vs 304 plain; 32768: 545 vs 447;
   // 49152: 508 vs 597)

@@ -36,17 +36,20 @@
 #ifndef LZ4HIP_DECODE_REENTER
 #define LZ4HIP_DECODE_REENTER 1   // 0: the interior loop is entered once per block (round 1 behaviour; developer A/B builds)
 #endif
+#include "lz4_decode_deep.h"
 namespace lz4hip {
 
 // SAFE: LZ4_decompress_safe(src, dst, src_size, out_size) -> decoded size or negative.
 // !SAFE: LZ4_decompress_fast(src, dst, out_size) -> bytes consumed or negative; `src_size` is then
 //        the readable capacity of the source slot and is never exceeded (liblz4 itself trusts the
 //        stream blindly; results on valid streams are identical).
-// PIPE: pipelined interior loop (below).  Pays when a wavefront has to make progress on its own (few, large blocks);
-//       with the GPU full of blocks the plain loop is as fast.
+// PIPE: 1 = pipelined interior loop (below).  Pays when a wavefront has to make progress on its own (few, large blocks);
+//       with the GPU full of blocks the plain loop is as fast.  2 = the deep loop of lz4_decode_deep.h (stream staged in LDS at
+//       `stage`, Grp::kStreamLds bytes for this block; three match sources of the block in flight); the last 2 KB of the stream
+//       are left to loop 1.
 // STAGE: the interior loop writes through an LDS staging buffer (`stage`, Grp::kStage bytes for this block) and output leaves
 //        it as whole 128-byte lines (group_dev.h st_*).
-template <class Grp, bool SAFE, bool PIPE = false, bool STAGE = false>
+template <class Grp, bool SAFE, int PIPE = 0, bool STAGE = false>
 LZ4HIP_DEV int decode_block(Grp& g, const uint8_t* src, int src_size, uint8_t* dst, int out_size, uint8_t* stage = nullptr) {
   int ip = 0, op = 0;
   const int iend = src_size, oend = out_size;  // iend: real end (SAFE) / read bound (!SAFE)
@@ -71,7 +74,11 @@ LZ4HIP_DEV int decode_block(Grp& g, const uint8_t* src, int src_size, uint8_t* d
     // sequence start, to the exact tier-1 code below, which re-decodes that sequence with all checks. ----
     // The 8 bytes fetched at the offset position also hold the NEXT sequence's token (and its first length byte), so the
     // steady state costs two dependent loads per sequence: {offset word + literals} and {match source}.
-    if (PIPE && ip <= iend - 306 && op <= oend - 606) {
+    if constexpr (PIPE == 2) {
+      if (ip + 2048 <= iend && ip <= iend - 306 && op <= oend - 606)
+        if (decode_deep_loop(g, src, iend, dst, oend, ip, op, stage)) goto interior;
+    }
+    if ((PIPE == 1 || (PIPE == 2 && ip + 2048 > iend)) && ip <= iend - 306 && op <= oend - 606) {   // (2: only the tail of the stream)
       // ---- the same loop, software-pipelined.  A wavefront's memory operations retire in order, so a wait for a load also
       // waits for every OLDER store.  Here (a) the next sequence's offset word is requested as soon as this sequence's header
       // is parsed, (b) a "simple" sequence (literals and match take one step each, match source entirely before the

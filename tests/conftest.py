@@ -95,3 +95,54 @@ def rnd_inputs(O, corpus, seed, count, max_n=70000):
             v = O.gen_block(n, rng.randrange(1000), litmax=rng.choice([2, 4, 38, 200]), win=rng.choice([4, 8, 64, 300, 4096, 65535]))
         out.append(v)
     return out
+
+
+def deep_decoder_cases(ref, O, corpus, rng, lz4_seq):
+    """streams long enough for the decoder's deep interior loop (it needs 2 KB of stream ahead): compressed real and synthetic
+    blocks, hand-assembled streams mixing one-step sequences with long literal runs, long matches, offsets shorter than a step and
+    offsets that reach into the sequences still waiting in a slot; then the same streams corrupted, truncated, with wrong
+    capacities.  -> (valid [(stream, size)], all cases [(stream, capacity)]); used by the CPU simulator test and the GPU test"""
+    valid = []
+    for v in (corpus["book1[:200000]"][:70000], corpus["geo[:65536]"], corpus["pic[:65536]"], O.gen_block(65536, 1), O.gen_block(300000, 2, win=4096),
+              O.gen_block(65536, 3, litmax=4, win=64), O.gen_block(100000, 4, litmax=70, win=300), bytes(50000) + rng.randbytes(3000) + bytes(40000),
+              (b"abcdefghijklmnopqrstuvwxyz" * 3 + rng.randbytes(11)) * 900):
+        valid.append((ref.compress_fast(v), len(v)))
+    for trial in range(12):   # hand-assembled: every kind of sequence next to every other
+        c, n = bytearray(), 0
+        for _ in range(rng.randrange(300, 900)):
+            kind = rng.random()
+            if kind < 0.70: lit, ml = rng.randrange(0, 65), rng.randrange(4, 65)
+            elif kind < 0.80: lit, ml = rng.randrange(65, 600), rng.randrange(4, 65)
+            elif kind < 0.90: lit, ml = rng.randrange(0, 40), rng.randrange(65, 1200)
+            else: lit, ml = rng.randrange(0, 20), rng.randrange(4, 30)
+            hi = n + lit
+            if hi == 0: lit, hi = 1, 1
+            off = rng.choice([rng.randrange(1, min(hi, 64) + 1), rng.randrange(1, min(hi, 300) + 1), rng.randrange(1, min(hi, 65535) + 1)])
+            c += lz4_seq(lit, ml, off, rng); n += lit + ml
+        last = rng.randrange(5, 40)
+        c += bytes([last << 4 if last < 15 else 0xF0]) + (bytes([last - 15]) if last >= 15 else b"") + rng.randbytes(last); n += last
+        valid.append((bytes(c), n))
+    cases = [(c, n) for c, n in valid]
+    for c, n in valid:   # malformed: flipped bytes, truncation, wrong capacities
+        for _ in range(3):
+            b = bytearray(c)
+            for _ in range(rng.randrange(1, 4)):
+                b[rng.randrange(len(b))] = rng.randrange(256)
+            cases.append((bytes(b), n))
+        cases.append((c[:rng.randrange(len(c) // 2, len(c))], n))
+        cases.append((c, n - rng.randrange(1, 700)))
+        cases.append((c, n + rng.randrange(1, 100)))
+    return valid, cases
+
+
+def lz4_seq(lit, ml, off, rng):
+    """one LZ4 sequence: `lit` random literals, then a match of `ml` >= 4 bytes at distance `off` (hand-assembled)"""
+    def ext(v):
+        out = bytearray()
+        while v >= 255:
+            out.append(255); v -= 255
+        out.append(v)
+        return bytes(out)
+    tok = (min(lit, 15) << 4) | min(ml - 4, 15)
+    s = bytes([tok]) + (ext(lit - 15) if lit >= 15 else b"") + rng.randbytes(lit) + bytes([off & 255, off >> 8])
+    return s + (ext(ml - 4 - 15) if ml - 4 >= 15 else b"")

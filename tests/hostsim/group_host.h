@@ -142,6 +142,49 @@ struct GroupHost {
     }
   }
 
+  // ---- backend of the deep interior loop (lz4_decode_deep.h; group_dev.h sr_* / step_*): the stream ring in "LDS" (an index
+  // outside it counts as oob), whole 64-byte steps by all lanes -- every call is one instruction: all lanes' loads, then all stores
+  static constexpr uint32_t kStream = 1024u, kStreamLds = kStream + 16u, kPiece = 256u;
+  struct LChunk { uint8_t b[64][16]; };
+  struct PieceRegs { uint8_t b[64][64]; };
+  uint8_t sr_mem[kStreamLds];
+  bool lds_ok(uint32_t idx, uint32_t k) { if (idx + k > kStreamLds) { oob = true; return false; } return true; }
+  void sr_begin(uint8_t*) { memset(sr_mem, 0xEE, sizeof sr_mem); }
+  uint32_t cb() const { return kPiece / GL < 4u ? 4u : kPiece / GL; }
+  PieceRegs sr_fetch(const uint8_t* s, uint32_t pos) {
+    PieceRegs r; memset(&r, 0, sizeof r);
+    const uint32_t CB = cb();
+    for (int l = 0; l < GL; l++) if (rd_ok(s + pos + l * CB, CB)) memcpy(r.b[l], s + pos + l * CB, CB);
+    return r;
+  }
+  void sr_put(uint32_t pos, const PieceRegs& r) {
+    const uint32_t CB = cb();
+    for (int l = 0; l < GL; l++) {
+      const uint32_t q = (pos & (kStream - 1u)) + l * CB;
+      if (lds_ok(q, CB)) memcpy(sr_mem + q, r.b[l], CB);
+      if (q < 16u) { const uint32_t k = CB < 16u ? CB : 16u; if (lds_ok(kStream + q, k)) memcpy(sr_mem + kStream + q, r.b[l], k); }
+    }
+  }
+  uint32_t sr_ld32(uint32_t p) { uint32_t v = 0; const uint32_t q = p & (kStream - 1u); if (lds_ok(q, 4)) memcpy(&v, sr_mem + q, 4); return v; }
+  static inline uint64_t deep_trips = 0;   // (the test asserts that the deep loop really ran)
+  uint64_t sr_ld64(uint32_t p) { deep_trips++; uint64_t v = 0; const uint32_t q = p & (kStream - 1u); if (lds_ok(q, 8)) memcpy(&v, sr_mem + q, 8); return v; }
+  LChunk sr_step(uint32_t p) {
+    LChunk v; memset(&v, 0, sizeof v);
+    const uint32_t LB = lb();
+    for (int l = 0; l < GL; l++) { const uint32_t q = (p + l * LB) & (kStream - 1u); if (lds_ok(q, LB)) memcpy(v.b[l], sr_mem + q, LB); }
+    return v;
+  }
+  LChunk step_load(const uint8_t* m) {
+    LChunk v; memset(&v, 0, sizeof v);
+    const uint32_t LB = lb();
+    for (int l = 0; l < GL; l++) if (rd_ok(m + l * LB, LB)) memcpy(v.b[l], m + l * LB, LB);
+    return v;
+  }
+  void step_store(uint8_t* d, const LChunk& v) {
+    const uint32_t LB = lb();
+    for (int l = 0; l < GL; l++) if (wr_ok(d + l * LB, LB)) memcpy(d + l * LB, v.b[l], LB);
+  }
+
   void copy_match(uint8_t* dst, uint32_t op, uint32_t offset, uint32_t len, bool wild) {
     uint8_t* d = dst + op;
     const uint8_t* m = d - offset;

@@ -166,18 +166,23 @@ int sim_compress_fast_ms(const uint8_t* src, int n, uint8_t* dst, int cap, uint6
   return (int)r;
 }
 
+unsigned long long sim_deep_trips() { return hostsim::GroupHost::deep_trips; }   // offset words the deep decoder loop has parsed so far
+
 // safe != 0: (src_size = compressed length) -> decoded size; safe == 0: (src_size = readable
 // capacity) -> bytes consumed.  `gl` = lanes per group (4..64).  -1000000 = out-of-slot access.
 int sim_decompress(const uint8_t* src, int src_size, uint8_t* dst, int out_size, int safe, int gl) {
   const bool pipe = (gl & 0x100) != 0;   // bit 8 of gl: the pipelined interior loop
   const bool stage = (gl & 0x200) != 0;  // bit 9: output staging
+  const bool deep = (gl & 0x400) != 0;   // bit 10: the deep interior loop (lz4_decode_deep.h; groups of up to 16 lanes)
   gl &= 0xFF;
   hostsim::GroupHost g(gl, src, src_size, dst, out_size);
   int r;
-  if (stage) r = safe ? lz4hip::decode_block<hostsim::GroupHost, true, false, true>(g, src, src_size, dst, out_size, g.stg_buf)
-                      : lz4hip::decode_block<hostsim::GroupHost, false, false, true>(g, src, src_size, dst, out_size, g.stg_buf);
-  else if (pipe) r = safe ? lz4hip::decode_block<hostsim::GroupHost, true, true>(g, src, src_size, dst, out_size)
-                     : lz4hip::decode_block<hostsim::GroupHost, false, true>(g, src, src_size, dst, out_size);
+  if (deep) r = safe ? lz4hip::decode_block<hostsim::GroupHost, true, 2>(g, src, src_size, dst, out_size, g.stg_buf)
+                     : lz4hip::decode_block<hostsim::GroupHost, false, 2>(g, src, src_size, dst, out_size, g.stg_buf);
+  else if (stage) r = safe ? lz4hip::decode_block<hostsim::GroupHost, true, 0, true>(g, src, src_size, dst, out_size, g.stg_buf)
+                      : lz4hip::decode_block<hostsim::GroupHost, false, 0, true>(g, src, src_size, dst, out_size, g.stg_buf);
+  else if (pipe) r = safe ? lz4hip::decode_block<hostsim::GroupHost, true, 1>(g, src, src_size, dst, out_size)
+                     : lz4hip::decode_block<hostsim::GroupHost, false, 1>(g, src, src_size, dst, out_size);
   else r = safe ? lz4hip::decode_block<hostsim::GroupHost, true>(g, src, src_size, dst, out_size)
                 : lz4hip::decode_block<hostsim::GroupHost, false>(g, src, src_size, dst, out_size);
   if (g.oob) return -1000000;

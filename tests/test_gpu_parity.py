@@ -126,7 +126,8 @@ def test_decode_fuzz_bit_exact(amd, ref, O, corpus):
             c, cap = bytearray(rng.randbytes(rng.randrange(1, 40))), rng.randrange(0, 200)
         streams.append(bytes(c)); caps.append(cap)
     # pipe: the pipelined interior loop; stage: output staging in LDS (plain loop only)
-    for lanes, pipe, stage in ((0, -1, -1), (4, 0, 0), (4, 1, 0), (8, 1, 0), (16, 0, 0), (64, 0, 0), (64, 1, 0), (4, 0, 1), (8, 0, 1), (32, 0, 1), (64, 0, 1)):
+    for lanes, pipe, stage in ((0, -1, -1), (4, 0, 0), (4, 1, 0), (8, 1, 0), (16, 0, 0), (64, 0, 0), (64, 1, 0), (4, 0, 1), (8, 0, 1), (32, 0, 1), (64, 0, 1),
+                               (4, 2, 0), (8, 2, 0), (16, 2, 0)):   # pipe 2: the deep interior loop (lz4_decode_deep.h)
         amd.set_option("decode_lanes", lanes)
         amd.set_option("decode_pipe", pipe)
         amd.set_option("decode_stage", stage)
@@ -275,7 +276,7 @@ def test_decode_variants_at_odd_offsets(amd, ref, corpus):
         pos += rng.choice([1, 3, 9, 13, 127, 129])
         dst_off.append(pos); pos += len(b)
     total = pos + 77
-    for lanes, pipe, stage in ((4, 0, 1), (8, 0, 1), (16, 0, 1), (64, 0, 1), (4, 0, 0), (8, 1, 0), (16, 1, 0)):
+    for lanes, pipe, stage in ((4, 0, 1), (8, 0, 1), (16, 0, 1), (64, 0, 1), (4, 0, 0), (8, 1, 0), (16, 1, 0), (4, 2, 0), (8, 2, 0), (16, 2, 0)):
         amd.set_option("decode_lanes", lanes); amd.set_option("decode_pipe", pipe); amd.set_option("decode_stage", stage)
         dst = bytearray(b"\xC3" * total)
         out = amd.LZ4HIPBatch.decompressSafe(bytes(src), so, [len(c) for c in comp], dst, dst_off, [len(b) for b in blocks])
@@ -285,6 +286,27 @@ def test_decode_variants_at_odd_offsets(amd, ref, corpus):
             expect[o:o + len(b)] = b
         assert dst == expect, (lanes, pipe, stage)
     amd.set_option("decode_lanes", 0); amd.set_option("decode_pipe", -1); amd.set_option("decode_stage", -1)
+
+
+def test_deep_decoder_loop_long_streams(amd, ref, O, corpus):
+    """the decoder's deep interior loop (csrc/lz4_decode_deep.h; decode_pipe 2) on streams long enough for it to run -- compressed real
+    and synthetic blocks, hand-assembled mixes of every kind of sequence, and the same streams corrupted / truncated / with wrong
+    capacities: return codes and bytes of the safe decoder against the reference library, groups of 4 / 8 / 16 lanes (the CPU suite
+    runs the same cases in the lane simulator: tests/test_hostsim.py::test_deep_decoder_loop)"""
+    from conftest import deep_decoder_cases, lz4_seq
+    rng = random.Random(4242)
+    valid, cases = deep_decoder_cases(ref, O, corpus, rng, lz4_seq)
+    streams = [c for c, _ in cases]
+    caps = [cap for _, cap in cases]
+    want = [ref.decompress_safe_raw(c, cap) for c, cap in cases]
+    try:
+        for lanes in (4, 8, 16):
+            amd.set_option("decode_lanes", lanes); amd.set_option("decode_pipe", 2); amd.set_option("decode_stage", 0)
+            res = gpu_decode_safe_many(amd, streams, caps)
+            for k, ((r, d), (er, ed)) in enumerate(zip(res, want)):
+                assert r == er and (er < 0 or d[:er] == ed[:er]), (lanes, k, len(streams[k]), caps[k], r, er)
+    finally:
+        amd.set_option("decode_lanes", 0); amd.set_option("decode_pipe", -1); amd.set_option("decode_stage", -1)
 
 
 def test_concurrent_callers(amd, ref, corpus):

@@ -91,7 +91,8 @@ def test_cfg3_reference_compressed_4MiB_blocks_every_decoder_variant(amd, ref, O
     cl = torch.tensor([len(s) for s in streams], dtype=torch.int32, device=dev)
     back = torch.empty(n * blk, dtype=torch.uint8, device=dev)
     try:
-        for lanes, pipe, stage in ((0, -1, -1), (4, 0, 0), (4, 1, 0), (8, 1, 0), (16, 0, 0), (16, 1, 0), (32, 1, 0), (64, 0, 0), (64, 1, 0), (4, 0, 1), (8, 0, 1), (16, 0, 1), (64, 0, 1)):
+        for lanes, pipe, stage in ((0, -1, -1), (4, 0, 0), (4, 1, 0), (8, 1, 0), (16, 0, 0), (16, 1, 0), (32, 1, 0), (64, 0, 0), (64, 1, 0), (4, 0, 1), (8, 0, 1), (16, 0, 1), (64, 0, 1),
+                                   (4, 2, 0), (8, 2, 0), (16, 2, 0)):
             amd.set_option("decode_lanes", lanes); amd.set_option("decode_pipe", pipe); amd.set_option("decode_stage", stage)
             back.zero_()
             amd.DeviceBatch.decompress_safe(dcomp, co, cl, back, B["so"], B["sl"], B["dlen"])

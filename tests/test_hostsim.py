@@ -249,6 +249,8 @@ def test_decode_core_fuzz(sim, ref, O, corpus):
             c, cap = bytearray(rng.randbytes(rng.randrange(1, 40))), rng.randrange(0, 200)
         c = bytes(c)
         gl = rng.choice([4, 8, 16, 32, 64]) | rng.choice([0, 0x100, 0x200])   # bit 8: the pipelined interior loop, bit 9: output staging
+        if rng.random() < 0.25:
+            gl = rng.choice([4, 8, 16]) | 0x400                                  # bit 10: the deep interior loop
         r2, d2 = ref.decompress_safe_raw(c, cap)
         r1, d1 = sim_decode(sim, c, cap, 1, gl)
         assert r1 == r2 and (r2 < 0 or d1[:r2] == d2[:r2]), ("safe", mode, gl, len(v), cap, r1, r2)
@@ -302,10 +304,34 @@ def test_staged_decoder_flush_past_position(sim, ref):
             assert r == n and d == want, (trial, gl, r)
 
 
+def test_deep_decoder_loop(sim, ref, O, corpus):
+    """The deep interior loop (csrc/lz4_decode_deep.h: stream staged in an LDS ring, three match sources in flight, whole-step
+    unconditional loads / stores) in the lock-step simulator, groups of 4 / 8 / 16 lanes: real and synthetic blocks whose streams
+    are long enough for the loop to run (it needs 2 KB of stream ahead), hand-assembled streams that mix one-step sequences with
+    long literal runs, long matches, offsets shorter than a step and offsets that reach into the sequences still waiting in a
+    slot -- and the same streams corrupted / truncated: return codes and bytes against the reference library (safe) and the C
+    restatement's bounded fast decoder.  Every access outside the block's slots or the ring counts as a failure."""
+    rng = random.Random(4242)
+    from conftest import deep_decoder_cases
+    valid, cases = deep_decoder_cases(ref, O, corpus, rng, _lz4_seq)
+    sim.sim_deep_trips.restype = C.c_ulonglong
+    trips0 = sim.sim_deep_trips()
+    for k, (c, cap) in enumerate(cases):
+        want_r, want = ref.decompress_safe_raw(c, cap)
+        for gl in ((4, 8, 16) if k < len(valid) else (rng.choice([4, 8, 16]),)):
+            r, d = sim_decode(sim, c, cap, 1, gl | 0x400)
+            assert r == want_r and (want_r < 0 or d[:want_r] == want[:want_r]), ("safe", k, gl, len(c), cap, r, want_r)
+            scap = len(c) + rng.choice([0, 0, 5, 64])
+            r3, d3 = O.decompress_fast_bounded(c, scap, cap)
+            r4, d4 = sim_decode(sim, c + bytes(scap - len(c)), cap, 0, gl | 0x400, src_size=scap)
+            assert r3 == r4 and (r3 < 0 or d3[:cap] == d4[:cap]), ("fast", k, gl, len(c), cap, scap, r3, r4)
+    assert sim.sim_deep_trips() - trips0 > 500000   # (the loop under test did the work)
+
+
 def test_decode_core_malformed_vectors(sim, golden):
     for v in golden["malformed"]:
         vec = bytes.fromhex(v["hex"])
-        for gl in (4, 16, 64, 8 | 0x100, 64 | 0x100, 4 | 0x200, 16 | 0x200):
+        for gl in (4, 16, 64, 8 | 0x100, 64 | 0x100, 4 | 0x200, 16 | 0x200, 8 | 0x400):
             r, d = sim_decode(sim, vec, v["safe_cap"], 1, gl)
             assert r == v["safe_ret"]
             if r >= 0:

@@ -4,7 +4,7 @@ usage: traffic_json.py <passes dir> <blocks_per_gpu> <block_bytes> <source tag>"
 import glob, hashlib, json, os, sqlite3, sys
 d, n, blk, tag = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
 vals = {}
-full = {}   # every lz4hip kernel by its full (template) name: "decode_kernel<8, true, true, false>", ...
+full = {}   # every lz4hip kernel by its full (template) name: "decode_kernel<8, true, 2, false>", ...
 def norm(k):
     k = k.split("(")[0].replace("void ", "").replace("lz4hip::", "").strip()
     return k
@@ -19,14 +19,14 @@ for db in glob.glob(os.path.join(d, "*", "pmc_results.db")):
     # blocks; the 4-lane staged safe decoder: headline and book1) are represented by their FIRST launches in dispatch order -- the
     # warm-up and timed steps of the headline (tools/traffic_passes.sh runs --warmup 1 --steps 2: three launches).  The others
     # have one workload: MEDIAN over their dispatches.
-    HEADLINE_FIRST = ("compress_fast_v2w_cu_kernel", "compress_fast_ms_cu_kernel", "decode_kernel<4, true, false, true>")
+    HEADLINE_FIRST = ("compress_fast_v2w_cu_kernel", "compress_fast_ms_cu_kernel", "decode_kernel<4, true, 0, true>")
     for (k, c), vs in rows.items():
         if any(h in k for h in HEADLINE_FIRST):
             vs = vs[:3]
         vs = sorted(vs)
         v = vs[len(vs) // 2] if len(vs) % 2 else 0.5 * (vs[len(vs) // 2 - 1] + vs[len(vs) // 2])
         full.setdefault(norm(k), {})[c] = v
-        if "decode_kernel" in k and "decode_kernel<4, true, false, true>" not in k:
+        if "decode_kernel" in k and "decode_kernel<4, true, 0, true>" not in k:
             continue   # the legacy "decode_kernel" key below is the headline launch (65536 x 64 KiB: 4 lanes, safe, staged) only
         key = None
         for name in ("compress_fast_v2w_cu_kernel", "compress_fast_v2_cu_kernel", "compress_fast_cu_kernel", "compress_fast_ms_cu_kernel", "decode_kernel", "hc_parse_kernel", "hc_build_kernel", "xxh_multi_kernel"):
