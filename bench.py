@@ -99,7 +99,9 @@ def decode_kernel_name(n_blocks, safe=True):
     s = "true" if safe else "false"
     if n_blocks >= 40960:
         return "decode_kernel<4, %s, 0, true>" % s
-    return "decode_kernel<%d, %s, 2, false>" % (8 if n_blocks >= 8192 else 16, s)   # (2: the deep interior loop, csrc/lz4_decode_deep.h)
+    if n_blocks <= 20480:
+        return "decode_deep_kernel<%d, %s>" % (8 if n_blocks >= 8192 else 16, s)   # the deep interior loop, csrc/lz4_decode_deep.h
+    return "decode_kernel<8, %s, 1, false>" % s
 
 
 def cpu_entry(fn):

@@ -542,6 +542,21 @@ __global__ __launch_bounds__(256) void decode_kernel(BatchArgs a) {
   if (g.l == 0) a.out[gid] = r;
 }
 
+// the deep loop's kernel: the same body with an occupancy request (LZ4HIP_DEEP_WGS workgroups of 256 threads per CU)
+#ifndef LZ4HIP_DEEP_WGS
+#define LZ4HIP_DEEP_WGS 2
+#endif
+template <int GL, bool SAFE>
+__global__ __launch_bounds__(256, LZ4HIP_DEEP_WGS) void decode_deep_kernel(BatchArgs a) {
+  __shared__ __attribute__((aligned(16))) uint8_t stage_mem[(256 / GL) * GroupDev<GL>::kStreamLds];
+  const uint32_t gid = (blockIdx.x * 256u + threadIdx.x) / GL;
+  if (gid >= a.n) return;
+  GroupDev<GL> g;
+  const int r = decode_block<GroupDev<GL>, SAFE, 2, false>(g, a.src + a.src_off[gid], a.src_len[gid], a.dst + a.dst_off[gid], a.dst_cap[gid],
+                                                           stage_mem + (threadIdx.x / GL) * GroupDev<GL>::kStreamLds);
+  if (g.l == 0) a.out[gid] = r;
+}
+
 template <int GL>
 static int launch_decode_gl(const BatchArgs& a, bool safe, int pipe, bool stage, hipStream_t st) {
   const uint32_t per_wg = 256u / GL;
@@ -551,8 +566,8 @@ static int launch_decode_gl(const BatchArgs& a, bool safe, int pipe, bool stage,
     else hipLaunchKernelGGL((decode_kernel<GL, false, 0, true>), dim3(grid), dim3(256), 0, st, a);
   } else if (pipe == 2 && GL <= 16) {   // (the deep loop works in 64-byte steps: groups of up to 16 lanes)
     if constexpr (GL <= 16) {
-      if (safe) hipLaunchKernelGGL((decode_kernel<GL, true, 2, false>), dim3(grid), dim3(256), 0, st, a);
-      else hipLaunchKernelGGL((decode_kernel<GL, false, 2, false>), dim3(grid), dim3(256), 0, st, a);
+      if (safe) hipLaunchKernelGGL((decode_deep_kernel<GL, true>), dim3(grid), dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((decode_deep_kernel<GL, false>), dim3(grid), dim3(256), 0, st, a);
     }
   } else if (safe) {
     if (pipe) hipLaunchKernelGGL((decode_kernel<GL, true, 1, false>), dim3(grid), dim3(256), 0, st, a);
@@ -576,9 +591,11 @@ int launch_decompress(const BatchArgs& a, bool safe, int lanes_per_block, int pi
   //                    every wavefront has to make progress on its own.
   const bool auto_lanes = lanes_per_block == 0;
   if (auto_lanes) lanes_per_block = a.n >= 40960u ? 4 : (a.n >= 8192u ? 8 : 16);
-  // the pipelined loop of the smaller batches is the DEEP one (lz4_decode_deep.h) for groups of up to 16 lanes: 16384 x 4 MiB
-  // blocks 571 -> 742 GB/s, 16384 x 64 KiB App. F 442 -> 503, text 104 -> 126, 4096 x 4 MiB 185 -> 216
-  const int p = pipe < 0 ? ((a.n < 40960u && lanes_per_block >= 8) ? (lanes_per_block <= 16 ? 2 : 1) : 0) : pipe;
+  // up to 20480 blocks the pipelined loop is the DEEP one (lz4_decode_deep.h; groups of up to 16 lanes): 16384 x 4 MiB blocks 571 ->
+  // 738 GB/s; 64 KiB blocks, two-trip / deep: App. F 8192 blocks 264 / 362, 16384 438 / 504, 24576 534 / 488, 32768 531 / 467;
+  // text 8192 blocks 65 / 115, 16384 105 / 125, 24576 122 / 113 (beyond ~20000 blocks the unstaged output's write traffic binds
+  // and the leaner loop has nothing to win; tools/deep_matrix.sh)
+  const int p = pipe < 0 ? ((a.n < 40960u && lanes_per_block >= 8) ? ((lanes_per_block <= 16 && a.n <= 20480u) ? 2 : 1) : 0) : pipe;
   // staging (whole-line output through LDS) pays where the batch is bandwidth-bound: App. F 65536 blocks 487 -> 680 GB/s
   // (text 106 -> 111); below that the pipelined loop wins (16384 blocks: 424 vs 289 staged vs 304 plain; 32768: 545 vs 447;
   // 49152: 508 vs 597)

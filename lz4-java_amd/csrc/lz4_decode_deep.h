@@ -36,13 +36,27 @@ LZ4HIP_DEV bool decode_deep_loop(Grp& g, const uint8_t* src, const int iend, uin
   // slots: literals (v) and match source (u) of a sequence that starts at output position sop; lit = its literal length
   LChunk v0 = LChunk(), u0 = LChunk(), v1 = LChunk(), u1 = LChunk(), v2 = LChunk(), u2 = LChunk(), v3 = LChunk(), u3 = LChunk();
   uint32_t sop0 = op, sop1 = op, sop2 = op, sop3 = op, lit0 = 0, lit1 = 0, lit2 = 0, lit3 = 0;
+  LChunk v4 = LChunk(), u4 = LChunk(), v5 = LChunk(), u5 = LChunk();   // (LZ4HIP_DEEP_SLOTS == 6)
+  uint32_t sop4 = op, sop5 = op, lit4 = 0, lit5 = 0;
+  (void)v4; (void)u4; (void)v5; (void)u5; (void)sop4; (void)sop5; (void)lit4; (void)lit5;
   typename Grp::PieceRegs rf = g.sr_fetch(src, fetched - PC);
   uint32_t rf_pos = fetched - PC;
   uint32_t t4 = g.sr_ld32(ip);
 
 #define LZ4HIP_RETIRE(k) do { g.step_store(dst + sop##k, v##k); g.step_store(dst + sop##k + lit##k, u##k); } while (0)
-  // one trip: fills slot c, stores slot a (the oldest: a, b, d are the slots of the three trips before, oldest first)
-#define LZ4HIP_TRIP(c, a, b, d, REFILL)                                                                                        \
+#ifndef LZ4HIP_DEEP_SLOTS
+#define LZ4HIP_DEEP_SLOTS 4   /* slots of the pipeline: 4 (three match sources in flight) or 6 (five) */
+#endif
+#if LZ4HIP_DEEP_SLOTS == 6
+#define LZ4HIP_REST(b, d, e, f, OP) OP(b); OP(d); OP(e); OP(f)
+#define LZ4HIP_TRIP(c, a, b, d, e, f, REFILL) LZ4HIP_TRIP_(c, a, LZ4HIP_REST(b, d, e, f, LZ4HIP_RETIRE), LZ4HIP_REST(b, d, e, f, LZ4HIP_AIM), REFILL)
+#else
+#define LZ4HIP_REST(b, d, OP) OP(b); OP(d)
+#define LZ4HIP_TRIP(c, a, b, d, REFILL) LZ4HIP_TRIP_(c, a, LZ4HIP_REST(b, d, LZ4HIP_RETIRE), LZ4HIP_REST(b, d, LZ4HIP_AIM), REFILL)
+#endif
+#define LZ4HIP_AIM(k) do { sop##k = aim; lit##k = 0u; } while (0)
+  // one trip: fills slot c, stores slot a (the oldest of the slots filled by the trips before; RETIRE_REST / AIM_REST: the others, oldest first)
+#define LZ4HIP_TRIP_(c, a, RETIRE_REST, AIM_REST, REFILL)                                                                      \
   {                                                                                                                            \
     uint32_t lit = (t4 >> 4) & 15u, ml = t4 & 15u;                                                                             \
     const uint32_t e1 = (t4 >> 8) & 255u;                                                                                      \
@@ -58,10 +72,10 @@ LZ4HIP_DEV bool decode_deep_loop(Grp& g, const uint8_t* src, const int iend, uin
     const uint32_t adv = hdr + lit + (m15 ? 3u : 2u);                                                                          \
     const uint32_t mpos = op + lit - off;            /* where the match copies from */                                         \
     if ((l15 & (e1 == 255u)) | (m15 & (e2 == 255u)) | (off > op + lit)) {   /* not for this loop (nothing of it done) */       \
-      LZ4HIP_RETIRE(a); LZ4HIP_RETIRE(b); LZ4HIP_RETIRE(d); break; }                                                           \
+      LZ4HIP_RETIRE(a); RETIRE_REST; break; }                                                                                  \
     if (LZ4HIP_UNLIKELY((lit > STEP) | (ml > STEP) | (mpos + ml > sop##a))) {                                                   \
       /* the slots first: the source reaches into bytes that wait in one, or this sequence is copied the wide way */          \
-      LZ4HIP_RETIRE(a); LZ4HIP_RETIRE(b); LZ4HIP_RETIRE(d);                                                                    \
+      LZ4HIP_RETIRE(a); RETIRE_REST;                                                                                           \
       const bool simple = (lit <= STEP) & (ml <= STEP) & (mpos + ml <= op);                                                    \
       uint32_t aim = op;                                                                                                       \
       if (!simple) {                                                                                                           \
@@ -69,16 +83,16 @@ LZ4HIP_DEV bool decode_deep_loop(Grp& g, const uint8_t* src, const int iend, uin
         g.copy_match_wide(dst, op + lit, off, ml);                                                                             \
         aim = op + lit + ml;                         /* (empty slots aim behind what has just been written) */                \
       }                                                                                                                        \
-      sop##a = sop##b = sop##d = aim; lit##a = lit##b = lit##d = 0u;                                                           \
+      LZ4HIP_AIM(a); AIM_REST;                                                                                                 \
       if (!simple) {                                                                                                           \
-        sop##c = aim; lit##c = 0u; op = aim; ip += adv; t4 = nxt;                                                              \
+        LZ4HIP_AIM(c); op = aim; ip += adv; t4 = nxt;                                                                          \
         if (fetched != avail) { g.sr_put(rf_pos, rf); avail = rf_pos + PC; }   /* (a piece on its way lands before the rotation restarts) */ \
         if (!((ip <= ilim) & (op <= olim) & (ip + 288u <= avail))) break;                                                      \
         continue;                                                                                                              \
       }                                                                                                                        \
     }                                                                                                                          \
     if (REFILL == 1) {   /* the next piece of the stream (the last one again when the ring has no room or the stream ends) */ \
-      const bool room = (fetched + PC <= (uint32_t)iend) & (fetched + PC <= (ip & ~(PC - 1u)) + KS);                    \
+      const bool room = (fetched + PC <= (uint32_t)iend) & (fetched + PC <= (ip & ~(PC - 1u)) + KS);                           \
       rf_pos = room ? fetched : fetched - PC;                                                                                  \
       rf = g.sr_fetch(src, rf_pos);                                                                                            \
       fetched = rf_pos + PC;                                                                                                   \
@@ -89,16 +103,28 @@ LZ4HIP_DEV bool decode_deep_loop(Grp& g, const uint8_t* src, const int iend, uin
     LZ4HIP_RETIRE(a);                                                                                                          \
     if (REFILL == 2) { g.sr_put(rf_pos, rf); avail = rf_pos + PC; }                                                            \
     op += lit + ml; ip += adv; t4 = nxt;                                                                                       \
-    if (!((ip <= ilim) & (op <= olim) & (ip + 288u <= avail))) { LZ4HIP_RETIRE(b); LZ4HIP_RETIRE(d); LZ4HIP_RETIRE(c); break; }  \
+    if (!((ip <= ilim) & (op <= olim) & (ip + 288u <= avail))) { RETIRE_REST; LZ4HIP_RETIRE(c); break; }                       \
   }
   for (;;) {
+#if LZ4HIP_DEEP_SLOTS == 6
+    LZ4HIP_TRIP(0, 1, 2, 3, 4, 5, 1)
+    LZ4HIP_TRIP(1, 2, 3, 4, 5, 0, 0)
+    LZ4HIP_TRIP(2, 3, 4, 5, 0, 1, 0)
+    LZ4HIP_TRIP(3, 4, 5, 0, 1, 2, 0)
+    LZ4HIP_TRIP(4, 5, 0, 1, 2, 3, 0)
+    LZ4HIP_TRIP(5, 0, 1, 2, 3, 4, 2)
+#else
     LZ4HIP_TRIP(0, 1, 2, 3, 1)
     LZ4HIP_TRIP(1, 2, 3, 0, 0)
     LZ4HIP_TRIP(2, 3, 0, 1, 0)
     LZ4HIP_TRIP(3, 0, 1, 2, 2)
+#endif
   }
   // (every way out of a trip has stored what was waiting, oldest first)
 #undef LZ4HIP_TRIP
+#undef LZ4HIP_TRIP_
+#undef LZ4HIP_REST
+#undef LZ4HIP_AIM
 #undef LZ4HIP_RETIRE
   ip_io = (int)ip; op_io = (int)op;
   return (ip <= ilim) & (op <= olim) & (ip + 288u > avail);   // true: left for want of stream bytes in the ring -- come again

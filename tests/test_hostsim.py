@@ -18,7 +18,7 @@ def load_sim():
     d = os.path.join(ROOT, "tests", "hostsim")
     so = os.path.join(d, "libhostsim.so")
     srcs = [os.path.join(d, f) for f in ("hostsim.cpp", "wave_host.h", "group_host.h")] + \
-           [os.path.join(ROOT, "lz4-java_amd", "csrc", f) for f in ("lz4_fast_core.h", "lz4_fast_ms_core.h", "lz4_fast_v2_core.h", "lz4_decode_core.h", "lz4_hc_core.h")]
+           [os.path.join(ROOT, "lz4-java_amd", "csrc", f) for f in ("lz4_fast_core.h", "lz4_fast_ms_core.h", "lz4_fast_v2_core.h", "lz4_decode_core.h", "lz4_decode_deep.h", "lz4_hc_core.h")]
     srcs.append(os.path.join(ROOT, "lz4-java_amd", "csrc", "mail_ring.h"))
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", so, os.path.join(d, "hostsim.cpp")])

@@ -1,12 +1,10 @@
 #!/bin/bash
-# usage (GPU box): tools/ab_deep.sh   -- the deep decoder loop (decode_pipe 2) against the defaults: 4 MiB blocks, text, App. F 64 KiB
+# usage (GPU box): tools/ab_deep.sh <variant ...>   -- decoder defaults of the built library and of variant libraries: 4 MiB blocks, text, App. F
 cd $GRAFT_REPO_ROOT
-N3=${N3:-16384}
-echo -n "cfg3 $N3 default:      "; timeout 200 python tools/gpu_cfg3.py $N3 2 0 2>&1 | tail -1
-for L in ${LANES:-4 8 16}; do echo -n "cfg3 $N3 deep lanes $L: "; DP=2 DS=0 timeout 200 python tools/gpu_cfg3.py $N3 2 $L 2>&1 | tail -1; done
-for data in book1 synth; do
-  for n in 16384 65536; do
-    echo -n "$data $n default:        "; timeout 200 python tools/gpu_one.py $n 2 0 $data 2>&1 | tail -1
-    for L in ${LANES:-4 8 16}; do echo -n "$data $n deep lanes $L:   "; DP=2 DS=0 timeout 200 python tools/gpu_one.py $n 2 $L $data 2>&1 | tail -1; done
-  done
+cp lz4-java_amd/liblz4hip.so /tmp/base.so
+for v in base "$@"; do
+  if [ $v != base ]; then cp lz4-java_amd/variants/$v.so lz4-java_amd/liblz4hip.so; fi
+  for n in 4096 16384; do echo -n "$v cfg3 $n: "; timeout 200 python tools/gpu_cfg3.py $n 2 0 2>&1 | tail -1; done
+  for data in book1 synth; do for n in 4096 16384 32768; do echo -n "$v $data $n: "; timeout 200 python tools/gpu_one.py $n 2 0 $data 2>&1 | tail -1; done; done
 done
+cp /tmp/base.so lz4-java_amd/liblz4hip.so
