@@ -44,6 +44,16 @@ LZ4HIP_DEV bool decode_deep_loop(Grp& g, const uint8_t* src, const int iend, uin
   uint32_t t4 = g.sr_ld32(ip);
 
 #define LZ4HIP_RETIRE(k) do { g.step_store(dst + sop##k, v##k); g.step_store(dst + sop##k + lit##k, u##k); } while (0)
+#ifndef LZ4HIP_DEEP_COND_REFILL
+#define LZ4HIP_DEEP_COND_REFILL 1   /* 1: no request when the ring has no room (0: the last piece is requested again -- every trip the same operations; measured: configs[2] 740 -> 765 GB/s, 16384 x 64 KiB text 128 -> 148 with 1) */
+#endif
+#if LZ4HIP_DEEP_COND_REFILL
+#define LZ4HIP_REFILL_FETCH if ((fetched + PC <= (uint32_t)iend) & (fetched + PC <= (ip & ~(PC - 1u)) + KS)) { rf_pos = fetched; rf = g.sr_fetch(src, rf_pos); fetched = rf_pos + PC; }
+#define LZ4HIP_REFILL_PUT if (fetched != avail) { g.sr_put(rf_pos, rf); avail = rf_pos + PC; }
+#else
+#define LZ4HIP_REFILL_FETCH { const bool room = (fetched + PC <= (uint32_t)iend) & (fetched + PC <= (ip & ~(PC - 1u)) + KS); rf_pos = room ? fetched : fetched - PC; rf = g.sr_fetch(src, rf_pos); fetched = rf_pos + PC; }
+#define LZ4HIP_REFILL_PUT { g.sr_put(rf_pos, rf); avail = rf_pos + PC; }
+#endif
 #ifndef LZ4HIP_DEEP_SLOTS
 #define LZ4HIP_DEEP_SLOTS 4   /* slots of the pipeline: 4 (three match sources in flight) or 6 (five) */
 #endif
@@ -91,17 +101,14 @@ LZ4HIP_DEV bool decode_deep_loop(Grp& g, const uint8_t* src, const int iend, uin
         continue;                                                                                                              \
       }                                                                                                                        \
     }                                                                                                                          \
-    if (REFILL == 1) {   /* the next piece of the stream (the last one again when the ring has no room or the stream ends) */ \
-      const bool room = (fetched + PC <= (uint32_t)iend) & (fetched + PC <= (ip & ~(PC - 1u)) + KS);                           \
-      rf_pos = room ? fetched : fetched - PC;                                                                                  \
-      rf = g.sr_fetch(src, rf_pos);                                                                                            \
-      fetched = rf_pos + PC;                                                                                                   \
+    if (REFILL == 1) {   /* the next piece of the stream, when the ring has room for it and the stream has it */              \
+      LZ4HIP_REFILL_FETCH                                                                                                      \
     }                                                                                                                          \
     v##c = g.sr_step(ip + hdr);                                                                                                \
     u##c = g.step_load(dst + mpos);                                                                                            \
     sop##c = op; lit##c = lit;                                                                                                 \
     LZ4HIP_RETIRE(a);                                                                                                          \
-    if (REFILL == 2) { g.sr_put(rf_pos, rf); avail = rf_pos + PC; }                                                            \
+    if (REFILL == 2) { LZ4HIP_REFILL_PUT }                                                                                     \
     op += lit + ml; ip += adv; t4 = nxt;                                                                                       \
     if (!((ip <= ilim) & (op <= olim) & (ip + 288u <= avail))) { RETIRE_REST; LZ4HIP_RETIRE(c); break; }                       \
   }
@@ -121,6 +128,8 @@ LZ4HIP_DEV bool decode_deep_loop(Grp& g, const uint8_t* src, const int iend, uin
 #endif
   }
   // (every way out of a trip has stored what was waiting, oldest first)
+#undef LZ4HIP_REFILL_FETCH
+#undef LZ4HIP_REFILL_PUT
 #undef LZ4HIP_TRIP
 #undef LZ4HIP_TRIP_
 #undef LZ4HIP_REST
