@@ -99,9 +99,7 @@ def decode_kernel_name(n_blocks, safe=True):
     s = "true" if safe else "false"
     if n_blocks >= 40960:
         return "decode_kernel<4, %s, 0, true>" % s
-    if n_blocks <= 20480:
-        return "decode_deep_kernel<%d, %s>" % (8 if n_blocks >= 8192 else 16, s)   # the deep interior loop, csrc/lz4_decode_deep.h
-    return "decode_kernel<8, %s, 1, false>" % s
+    return "decode_deep_kernel<8, %s>" % s   # the deep interior loop, csrc/lz4_decode_deep.h
 
 
 def cpu_entry(fn):

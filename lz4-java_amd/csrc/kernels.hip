@@ -582,20 +582,17 @@ static int launch_decode_gl(const BatchArgs& a, bool safe, int pipe, bool stage,
 int launch_decompress(const BatchArgs& a, bool safe, int lanes_per_block, int pipe, int stage, void* stream) {
   if (a.n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  // Defaults by batch size (tools/decode_matrix.sh; App. F / text / 4 MiB blocks):
+  // Defaults by batch size (tools/decode_matrix.sh, tools/deep_matrix.sh; App. F / text / 4 MiB blocks):
   //   >= 40960 blocks: 4 lanes x 16 bytes per block (16 blocks per wavefront), plain loop with output staging -- the GPU is
-  //                    full, long-sequence data is bandwidth-bound (pipelined or not: 512 vs 519 GB/s) and short-sequence data
-  //                    issue-bound (text: the pipelined loop costs 25 % there);
-  //   >= 8192 blocks:  8 lanes, pipelined loop (App. F 301 -> 422 GB/s at 16384 blocks; text 77 -> 73);
-  //   fewer:           16 lanes, pipelined loop (App. F 90 -> 138 GB/s at 4096 blocks, 4096 x 4 MiB 131 -> 179, text 25 -> 27):
-  //                    every wavefront has to make progress on its own.
+  //                    full, long-sequence data is bandwidth-bound and short-sequence data issue-bound;
+  //   fewer:           8 lanes, the deep loop (lz4_decode_deep.h).  Against the two-trip pipelined loop it replaced as the
+  //                    default (GB/s of output): 16384 x 4 MiB 571 -> 794-821, 4096 x 4 MiB 185 (16 lanes) -> 282; 64 KiB App. F
+  //                    blocks 2048: 70 -> 111, 8192: 264 -> 403, 16384: 438 -> 590, 24576: 538 -> 584, 32768: 551 -> 546, 40000: 542 ->
+  //                    616; text 2048: 17 -> 34, 8192: 65 -> 125, 16384: 105 -> 153, 32768: 127 -> 133.  (16 lanes, the old choice
+  //                    below 8192 blocks, are slower than 8 with this loop: 4096 blocks 182 vs 215.)
   const bool auto_lanes = lanes_per_block == 0;
-  if (auto_lanes) lanes_per_block = a.n >= 40960u ? 4 : (a.n >= 8192u ? 8 : 16);
-  // up to 20480 blocks the pipelined loop is the DEEP one (lz4_decode_deep.h; groups of up to 16 lanes): 16384 x 4 MiB blocks 571 ->
-  // 738 GB/s; 64 KiB blocks, two-trip / deep: App. F 8192 blocks 264 / 362, 16384 438 / 504, 24576 534 / 488, 32768 531 / 467;
-  // text 8192 blocks 65 / 115, 16384 105 / 125, 24576 122 / 113 (beyond ~20000 blocks the unstaged output's write traffic binds
-  // and the leaner loop has nothing to win; tools/deep_matrix.sh)
-  const int p = pipe < 0 ? ((a.n < 40960u && lanes_per_block >= 8) ? ((lanes_per_block <= 16 && a.n <= 20480u) ? 2 : 1) : 0) : pipe;
+  if (auto_lanes) lanes_per_block = a.n >= 40960u ? 4 : 8;
+  const int p = pipe < 0 ? ((a.n < 40960u && lanes_per_block >= 8) ? (lanes_per_block <= 16 ? 2 : 1) : 0) : pipe;
   // staging (whole-line output through LDS) pays where the batch is bandwidth-bound: App. F 65536 blocks 487 -> 680 GB/s
   // (text 106 -> 111); below that the pipelined loop wins (16384 blocks: 424 vs 289 staged vs 304 plain; 32768: 545 vs 447;
   // 49152: 508 vs 597)

@@ -5,8 +5,10 @@
 //  * the compressed stream of the block is staged in an LDS ring (Grp::sr_*), so the token parse is a chain of LDS reads -- a
 //    wavefront's VECTOR memory operations return in order, and a parse that read the stream from memory waited for every older
 //    match-source load as well (one sequence per memory latency and block);
-//  * four slots hold the sequences whose match source is on its way; a trip fills one and stores the one filled three trips
-//    earlier -- three match sources of a block in flight, the only wait of a trip is for a load that is three trips old;
+//  * slots hold the sequences whose match source is on its way; a trip fills one and stores the oldest, in sequence order, so the
+//    wait of a trip is for a load that was requested a trip (or more) earlier.  Two slots are the default: with the trip this lean
+//    the deeper queues measured slower (LZ4HIP_DEEP_SLOTS 2 / 3 / 4 / 6: 821 / 791 / 762 / 524 GB/s on 16384 x 4 MiB blocks) -- more
+//    sequences wait, more match sources reach into them, and every slot is code;
 //  * everything a trip does in memory is unconditional and whole-step: all lanes of the group load and store their part of 64
 //    bytes whatever the lengths; what a step writes past its length is put right by the stores that follow (slots are stored in
 //    sequence order), slots that hold no sequence are aimed at bytes that are written again later.  No per-lane predicates, no
@@ -34,6 +36,7 @@ LZ4HIP_DEV bool decode_deep_loop(Grp& g, const uint8_t* src, const int iend, uin
   while (avail < ip + 768u) { g.sr_put(avail, g.sr_fetch(src, avail)); avail += PC; }   // (the caller left >= 2048 stream bytes)
   uint32_t fetched = avail;
   // slots: literals (v) and match source (u) of a sequence that starts at output position sop; lit = its literal length
+  // (six sets of registers; LZ4HIP_DEEP_SLOTS of them are used)
   LChunk v0 = LChunk(), u0 = LChunk(), v1 = LChunk(), u1 = LChunk(), v2 = LChunk(), u2 = LChunk(), v3 = LChunk(), u3 = LChunk();
   uint32_t sop0 = op, sop1 = op, sop2 = op, sop3 = op, lit0 = 0, lit1 = 0, lit2 = 0, lit3 = 0;
   LChunk v4 = LChunk(), u4 = LChunk(), v5 = LChunk(), u5 = LChunk();   // (LZ4HIP_DEEP_SLOTS == 6)
@@ -55,11 +58,16 @@ LZ4HIP_DEV bool decode_deep_loop(Grp& g, const uint8_t* src, const int iend, uin
 #define LZ4HIP_REFILL_PUT { g.sr_put(rf_pos, rf); avail = rf_pos + PC; }
 #endif
 #ifndef LZ4HIP_DEEP_SLOTS
-#define LZ4HIP_DEEP_SLOTS 4   /* slots of the pipeline: 4 (three match sources in flight) or 6 (five) */
+#define LZ4HIP_DEEP_SLOTS 2   /* slots of the pipeline: 2 (one match source of a block waits while the next is requested), 3, 4 or 6 -- measured on configs[2]: 821 / 791 / 762 / 524 GB/s: the leaner trip beats the deeper queue */
 #endif
 #if LZ4HIP_DEEP_SLOTS == 6
 #define LZ4HIP_REST(b, d, e, f, OP) OP(b); OP(d); OP(e); OP(f)
 #define LZ4HIP_TRIP(c, a, b, d, e, f, REFILL) LZ4HIP_TRIP_(c, a, LZ4HIP_REST(b, d, e, f, LZ4HIP_RETIRE), LZ4HIP_REST(b, d, e, f, LZ4HIP_AIM), REFILL)
+#elif LZ4HIP_DEEP_SLOTS == 2
+#define LZ4HIP_TRIP(c, a, REFILL) LZ4HIP_TRIP_(c, a, (void)0, (void)0, REFILL)
+#elif LZ4HIP_DEEP_SLOTS == 3
+#define LZ4HIP_REST(b, OP) OP(b)
+#define LZ4HIP_TRIP(c, a, b, REFILL) LZ4HIP_TRIP_(c, a, LZ4HIP_REST(b, LZ4HIP_RETIRE), LZ4HIP_REST(b, LZ4HIP_AIM), REFILL)
 #else
 #define LZ4HIP_REST(b, d, OP) OP(b); OP(d)
 #define LZ4HIP_TRIP(c, a, b, d, REFILL) LZ4HIP_TRIP_(c, a, LZ4HIP_REST(b, d, LZ4HIP_RETIRE), LZ4HIP_REST(b, d, LZ4HIP_AIM), REFILL)
@@ -120,6 +128,13 @@ LZ4HIP_DEV bool decode_deep_loop(Grp& g, const uint8_t* src, const int iend, uin
     LZ4HIP_TRIP(3, 4, 5, 0, 1, 2, 0)
     LZ4HIP_TRIP(4, 5, 0, 1, 2, 3, 0)
     LZ4HIP_TRIP(5, 0, 1, 2, 3, 4, 2)
+#elif LZ4HIP_DEEP_SLOTS == 2
+    LZ4HIP_TRIP(0, 1, 1)
+    LZ4HIP_TRIP(1, 0, 2)
+#elif LZ4HIP_DEEP_SLOTS == 3
+    LZ4HIP_TRIP(0, 1, 2, 1)
+    LZ4HIP_TRIP(1, 2, 0, 0)
+    LZ4HIP_TRIP(2, 0, 1, 2)
 #else
     LZ4HIP_TRIP(0, 1, 2, 3, 1)
     LZ4HIP_TRIP(1, 2, 3, 0, 0)
