@@ -300,12 +300,19 @@ void par_blocks(uint32_t i0, uint32_t i1, size_t bytes, F f) {  // f(i) for i in
   static const int copy_threads = env_int("LZ4HIP_HOST_COPY_THREADS", COPY_THREADS, 1, 128);
   const int T = (bytes < (4u << 20) || n < 2) ? 1 : (int)std::min<uint32_t>((uint32_t)copy_threads, n);
   if (T == 1) { for (uint32_t i = i0; i < i1; i++) f(i); return; }
-  std::vector<std::thread> th;
+  // (a helper that cannot be had -- thread or memory exhaustion -- is no error: its share is done right here; nothing is thrown
+  // with threads running, which would end the process from a finisher thread)
+  std::thread th[128];
+  int made = 0;
   for (int t = 0; t < T; t++) {
     const uint32_t a = i0 + (uint32_t)((uint64_t)n * t / T), b = i0 + (uint32_t)((uint64_t)n * (t + 1) / T);
-    th.emplace_back([=] { for (uint32_t i = a; i < b; i++) f(i); });
+    bool started = false;
+    if (t + 1 < T) {   // (the last share is the caller's own)
+      try { th[made] = std::thread([=] { for (uint32_t i = a; i < b; i++) f(i); }); made++; started = true; } catch (...) {}
+    }
+    if (!started) for (uint32_t i = a; i < b; i++) f(i);
   }
-  for (auto& x : th) x.join();
+  for (int t = 0; t < made; t++) th[t].join();
 }
 
 // one device's share [b0, b1) of a host batch.  Three stages run side by side on three buffer sets: the calling thread PACKS chunk
@@ -388,7 +395,10 @@ int host_shard(Op op, int level, int ord, const uint8_t* src, const uint64_t* sr
     ChunkSlot& s = pair->slot[k];
     f.rc = LZ4HIP_OK;
     try {
-      f.th = std::thread([&finish, &s, &f] { f.rc = finish(s, f); });
+      f.th = std::thread([&finish, &s, &f] {
+        try { f.rc = finish(s, f); }
+        catch (...) { f.rc = LZ4HIP_E_NOMEM; f.err = "host staging: out of memory or threads while handing a chunk back"; }
+      });
       f.live = true;
     } catch (...) {   // no thread to be had: this chunk is finished on the calling thread
       f.rc = finish(s, f);
