@@ -60,7 +60,8 @@ int lz4hip_version(void);
 /* tuning knobs (not part of the reference API): "decode_lanes" = lanes of a wavefront sharing one
  * block in the decoder (0 = default by batch size, 4/8/16/32/64); "decode_pipe" = 2 / 1 / 0 / -1 (default by batch size): the
  * software-pipelined interior loops of the decoder (faster when the batch is too small to fill the GPU; 2 = the deep loop: the
- * compressed stream staged in LDS, three match sources of a block in flight; 1 = the two-trip loop); "decode_stage" =
+ * compressed stream staged in LDS, two slots -- the match source of one sequence on its way while the next sequence is parsed and
+ * requested; 1 = the two-trip loop); "decode_stage" =
  * 1 / 0 / -1 (default by batch size): the decoder's interior loop writes through an LDS staging buffer so that output
  * reaches memory as whole 128-byte lines (faster when the batch is bandwidth-bound); "compress_core" = 5 (default: adaptive two-pass -- blocks of long
  * sequences are finished by the lean core (lz4_fast_v2_core.h), whose parked hits a partner wavefront writes out, blocks of

@@ -315,7 +315,10 @@ void par_blocks(uint32_t i0, uint32_t i1, size_t bytes, F f) {  // f(i) for i in
   for (int t = 0; t < made; t++) th[t].join();
 }
 
-// one device's share [b0, b1) of a host batch.  Three stages run side by side on three buffer sets: the calling thread PACKS chunk
+// one device's share [b0, b1) of a host batch.  Three stages run side by side on LZ4HIP_HOST_SETS rotating buffer sets (default 6,
+// each a pinned pair of 64 MiB of source + the destination capacity of its chunk, allocated on first use and kept in the per-device
+// pool -- up to ~1 GiB of pinned host memory per cached pair at the defaults; LZ4HIP_HOST_SETS=2 / LZ4HIP_HOST_CHUNK_MB lower it):
+// the calling thread PACKS chunk
 // c + 1 into pinned memory and enqueues it, the GPU works on chunk c (its H2D, kernels and D2H on the set's own stream), and a
 // finisher thread per chunk waits for chunk c - 1 and hands its bytes to the caller's slots.  (Rounds 1-2 did pack, the
 // synchronous D2H of the packed bytes and the unpack one after the other on the calling thread: 44 ms per GiB, twice what the
@@ -418,7 +421,7 @@ int host_shard(Op op, int level, int ord, const uint8_t* src, const uint64_t* sr
   while (i < b1 && rc == LZ4HIP_OK) {
     ChunkSlot& s = pair->slot[k];
     double t0 = now();
-    if ((rc = reap(k)) != LZ4HIP_OK) break;   // the chunk that used this buffer set three rounds ago
+    if ((rc = reap(k)) != LZ4HIP_OK) break;   // the chunk that used this buffer set SETS rounds ago
     t_reap += now() - t0; t0 = now();
     // the next chunk: blocks [i, j)
     uint32_t j = i;
@@ -727,12 +730,28 @@ int single(Op op, const uint8_t* src, int src_len, uint8_t* dst, int dst_cap, in
 // ---- device-side container assembly (kernels.hip launch_container_blocks) ------------------------------------------------------
 namespace {
 struct ContainerPlan { size_t cws, hcws, qwords, total; uint32_t n; };
-ContainerPlan container_plan(uint64_t n_bytes, uint32_t block_size, int hc_lv) {
+// the largest CU count of any visible device: what a workspace must be sized for when the device is not known yet
+uint32_t max_cu_count() {
+  static std::atomic<uint32_t> cached{0};
+  uint32_t v = cached.load(std::memory_order_relaxed);
+  if (v) return v;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+  for (int d = 0; d < n; d++) {
+    int c = 0;
+    if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, d) == hipSuccess && (uint32_t)c > v) v = (uint32_t)c;
+  }
+  if (!v) v = 256;
+  cached.store(v, std::memory_order_relaxed);
+  return v;
+}
+// cus: the CU count the launch will use (cu_count() under the DeviceGuard of the launch device) or max_cu_count() for a query
+ContainerPlan container_plan(uint64_t n_bytes, uint32_t block_size, int hc_lv, uint32_t cus) {
   ContainerPlan p{};
   p.n = (uint32_t)((n_bytes + block_size - 1u) / block_size);
   p.cws = (lz4hip::container_ws_bytes(n_bytes, block_size) + 255u) & ~(size_t)255u;
   p.hcws = hc_lv > 0 ? ((lz4hip::hc_ws_bytes(n_bytes, p.n, hc_lv) + 255u) & ~(size_t)255u) : 0u;
-  p.qwords = 3u + (size_t)p.n + lz4hip::compress_fast_v2w_scratch_words(cu_count());
+  p.qwords = 3u + (size_t)p.n + lz4hip::compress_fast_v2w_scratch_words(cus);
   p.total = p.cws + p.hcws + p.qwords * sizeof(uint32_t) + 256u;
   return p;
 }
@@ -753,7 +772,7 @@ extern "C" {
 size_t lz4hip_container_workspace_bytes(uint64_t n_bytes, uint32_t block_size, int level) {
   int lv = 0;
   if (ensure_init() || block_size < 64u || (level != 0 && hc_level(level, &lv))) return 0;
-  return container_plan(n_bytes, block_size, lv).total;
+  return container_plan(n_bytes, block_size, lv, max_cu_count()).total;   // (enough for whichever device the launch names)
 }
 int lz4hip_container_blocks_dev(int kind, int flags, int level, const uint8_t* src, uint64_t n_bytes, uint32_t block_size, uint8_t* dst, uint64_t dst_cap,
                                 uint64_t* total_dev, void* ws, size_t ws_bytes, int device, void* stream) {
@@ -762,11 +781,11 @@ int lz4hip_container_blocks_dev(int kind, int flags, int level, const uint8_t* s
   int lv;
   if ((rc = container_args(kind, n_bytes, block_size, level, &lv)) != 0) return rc;
   if ((n_bytes && !src) || !dst || !total_dev || !ws) return fail(LZ4HIP_E_ARG, "null pointer argument");
-  const ContainerPlan p = container_plan(n_bytes, block_size, lv);
-  if (ws_bytes < p.total) return fail(LZ4HIP_E_ARG, "container workspace too small (lz4hip_container_workspace_bytes)");
   int ord;
   if (ordinal(device, &ord)) return fail(LZ4HIP_E_ARG, "bad device index");
-  DeviceGuard g(ord);
+  DeviceGuard g(ord);   // (before the plan: its ring words are a function of the LAUNCH device's CU count)
+  const ContainerPlan p = container_plan(n_bytes, block_size, lv, cu_count());
+  if (ws_bytes < p.total) return fail(LZ4HIP_E_ARG, "container workspace too small (lz4hip_container_workspace_bytes)");
   uint8_t* w = (uint8_t*)(((uintptr_t)ws + 255u) & ~(uintptr_t)255u);
   const int e = lz4hip::launch_container_blocks(kind, flags & 1, lv, src, n_bytes, block_size, dst, dst_cap, (unsigned long long*)total_dev, w,
                                                 p.hcws ? w + p.cws : nullptr, (uint32_t*)(w + p.cws + p.hcws),
@@ -787,7 +806,7 @@ int lz4hip_container_blocks(int kind, int flags, int level, const uint8_t* src, 
   int ord;
   if (ordinal(0, &ord)) return fail(LZ4HIP_E_NO_DEVICE, "no device");
   DeviceGuard g(ord);
-  const ContainerPlan p = container_plan(n_bytes, block_size, lv);
+  const ContainerPlan p = container_plan(n_bytes, block_size, lv, cu_count());
   const uint64_t worst = n_bytes + (uint64_t)p.n * (kind == 0 ? 8u : 21u);
   hipStream_t st = nullptr;
   uint8_t *d_src = nullptr, *d_dst = nullptr, *d_ws = nullptr;

@@ -435,7 +435,7 @@ __global__ __launch_bounds__(1024) void container_scan_kernel(int kind, int bloc
   if (t == 1023u) *total = part[1023];
 }
 // header + payload of every block (one workgroup per block); hashes: kind 1 only (XXH32 of the ORIGINAL blocks, seed 0x9747b28c)
-__global__ __launch_bounds__(256) void container_copy_kernel(int kind, uint32_t level_nibble, const uint8_t* src, const uint64_t* src_off, const int32_t* src_len,
+__global__ __launch_bounds__(256) void container_copy_kernel(int kind, int block_checksum, uint32_t level_nibble, const uint8_t* src, const uint64_t* src_off, const int32_t* src_len,
                                                              const uint8_t* slots, const uint64_t* slot_off, const int32_t* stored, const uint64_t* hdr_off,
                                                              const uint32_t* hashes, uint8_t* dst, uint64_t dst_cap, uint64_t* pay_off, int32_t* pay_len) {
   const uint32_t b = blockIdx.x;
@@ -444,8 +444,12 @@ __global__ __launch_bounds__(256) void container_copy_kernel(int kind, uint32_t 
   const uint32_t len = (uint32_t)(st & 0x7FFFFFFF);
   const uint32_t hl = kind == 0 ? 4u : 21u;
   const uint64_t ho = hdr_off[b];
-  if (threadIdx.x == 0) { pay_off[b] = ho + hl; pay_len[b] = (int32_t)len; }
-  if (ho + hl + len + (kind == 0 ? 4u : 0u) > dst_cap) return;   // (the host checks *total against the capacity before it reads anything)
+  // a block that does not fit [0, dst_cap) is skipped whole -- header, payload and (frame blocks with block checksums) the 4 bytes
+  // behind the payload, exactly the bytes container_scan_kernel counted for it -- and its payload length is recorded as 0 so that
+  // the checksum pass that follows never reads dst beyond dst_cap (the caller compares *total with the capacity before it uses dst)
+  const bool fits = ho + hl + len + ((kind == 0 && block_checksum) ? 4u : 0u) <= dst_cap;
+  if (threadIdx.x == 0) { pay_off[b] = fits ? ho + hl : 0ull; pay_len[b] = fits ? (int32_t)len : 0; }
+  if (!fits) return;
   uint8_t* h = dst + ho;
   if (threadIdx.x < hl) {
     uint8_t v;
@@ -479,6 +483,7 @@ __global__ __launch_bounds__(256) void container_copy_kernel(int kind, uint32_t 
 __global__ void container_put_hashes_kernel(uint32_t n, const uint64_t* pay_off, const int32_t* pay_len, const uint32_t* hashes, uint8_t* dst, uint64_t dst_cap) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
+  if (pay_off[i] == 0ull) return;   // (a block container_copy_kernel skipped: payloads start behind a header, never at 0)
   const uint64_t o = pay_off[i] + (uint64_t)pay_len[i];
   if (o + 4u > dst_cap) return;
   const uint32_t h = hashes[i];
@@ -516,7 +521,7 @@ int launch_container_blocks(int kind, int block_checksum, int hc_level, const ui
   hipLaunchKernelGGL(container_scan_kernel, dim3(1), dim3(1024), 0, st, kind, block_checksum, n, (const int32_t*)src_len, (const int32_t*)clen, stored, hdr_off, total);
   uint32_t nib = 0;   // LZ4BlockOutputStream.compressionLevel (:57-69): max(0, ceil(log2(blockSize)) - 10)
   if (kind == 1) { uint32_t cl = 32u - (uint32_t)__builtin_clz(block_size - 1u); if (cl < 10u) cl = 10u; nib = cl - 10u; }
-  hipLaunchKernelGGL(container_copy_kernel, dim3(n), dim3(256), 0, st, kind, nib, src, (const uint64_t*)src_off, (const int32_t*)src_len, (const uint8_t*)slots,
+  hipLaunchKernelGGL(container_copy_kernel, dim3(n), dim3(256), 0, st, kind, block_checksum, nib, src, (const uint64_t*)src_off, (const int32_t*)src_len, (const uint8_t*)slots,
                      (const uint64_t*)slot_off, (const int32_t*)stored, (const uint64_t*)hdr_off, (const uint32_t*)hashes, dst, dst_cap, pay_off, pay_len);
   if (kind == 0 && block_checksum) {
     if ((e = launch_xxh32(dst, pay_off, pay_len, 0u, hashes, n, stream)) != 0) return e;

@@ -45,7 +45,7 @@ namespace lz4hip {
 //        stream blindly; results on valid streams are identical).
 // PIPE: 1 = pipelined interior loop (below).  Pays when a wavefront has to make progress on its own (few, large blocks);
 //       with the GPU full of blocks the plain loop is as fast.  2 = the deep loop of lz4_decode_deep.h (stream staged in LDS at
-//       `stage`, Grp::kStreamLds bytes for this block; three match sources of the block in flight); the last 2 KB of the stream
+//       `stage`, Grp::kStreamLds bytes for this block; two slots: one match source of the block waits while the next is requested); the last 2 KB of the stream
 //       are left to loop 1.
 // STAGE: the interior loop writes through an LDS staging buffer (`stage`, Grp::kStage bytes for this block) and output leaves
 //        it as whole 128-byte lines (group_dev.h st_*).

@@ -34,6 +34,11 @@
 #ifndef LZ4HIP_V2_ASM
 #define LZ4HIP_V2_ASM 1
 #endif
+// The loop below is gfx950 machine code (register numbers, wait counters and instruction forms of that ISA): the library is built for
+// that one target (lz4-java_amd/build.sh), and a device pass for anything else must not get as far as assembling it.
+#if LZ4HIP_V2_ASM && defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "lz4_fast_v2_asm.h is hand-scheduled gfx950 ISA: build with --offload-arch=gfx950 (or -DLZ4HIP_V2_ASM=0 for the compiler-generated lean loop)"
+#endif
 
 #ifndef LZ4HIP_ASM_DBG
 #define LZ4HIP_ASM_DBG 0

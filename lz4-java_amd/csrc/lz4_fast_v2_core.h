@@ -330,6 +330,9 @@ struct FastV2 {
 #endif
           // (the loop requests the rows of the NEXT hit before it has compared the next position with its limit: that hit lies
           // up to 191 bytes behind the limit it is given, so it gets one that much earlier; the C++ steps do the rest)
+          // (the loop sets exec itself and leaves it at all ones: it must be entered by a whole wavefront -- finder wavefronts are
+          // whole by construction, kernels.hip launches 64 x k threads and no caller sits inside a divergent region)
+          if (__builtin_amdgcn_read_exec() != ~0ull) __builtin_trap();
           const uint32_t code = lean_asm_run(ip, prev_hpos, pf_end, out.cnt, prev_fa, out.p_ms, out.p_ml, out.p_off,
                                              lim >= 192u ? lim - 192u : 0u, src,
                                              (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)w.lds, n, aprof);

@@ -52,7 +52,10 @@ class HIPEngine:
         """round 3: the container bytes of a batch of blocks are laid out on the device behind the compress launch (raw fallback,
         size scan, headers, payload compaction, checksums) -- no host pass between compress and the copy back.  Engines without
         this method (the CPU suite's oracle-backed one) make the writers assemble on the host, byte for byte the same."""
-        return LZ4HIPBatch.containerBlocks(kind, data, blockSize, blockChecksum, 0 if self.hcLevel is None else self.hcLevel)
+        # (the C ABI reads level 0 as "fast"; an HC engine built with a level < 1 means lz4-java's default HC level, as
+        # LZ4Factory.highCompressor(level) does (LZ4Factory.java:263-270: level < 1 -> 9) and as the host-assembly path behaves)
+        lv = 0 if self.hcLevel is None else (9 if self.hcLevel < 1 else self.hcLevel)
+        return LZ4HIPBatch.containerBlocks(kind, data, blockSize, blockChecksum, lv)
 
     @staticmethod
     def newStreamingHash32(seed):

@@ -14,10 +14,20 @@
  * instead: XXH32 and XXH64 (seed 0x9747b28c) of every block (src/jni/net_jpountz_xxhash_XXHashJNI.c:54,164; row a6), and the
  * line reports xxh32_GBps / xxh64_GBps.  With CPU_BENCH_FILE=<path> the blocks are slices of that file (offset (i * 7919) mod
  * (length - block size): the real-text leg of bench.py) instead of generated ones.  Every rate is reported twice: best of <reps> and (..._median) the median over them.
+ *
+ * Timing discipline (round 4): a PERSISTENT pool of <threads> workers, each pinned to one of the CPUs the process may run on,
+ * created once before anything is timed; every buffer is first touched by the worker that owns its blocks (generation, warm-up
+ * passes); a timed repetition starts and ends at a barrier the main thread takes part in and consists of as many whole passes over
+ * the sample as it takes to last CPU_BENCH_MIN_MS (default 300) milliseconds, so a repetition never measures thread start-up or a
+ * single 10 ms burst.  Inside a repetition a worker walks its own contiguous share of the blocks pass after pass and, when it has
+ * finished all of them, takes blocks from the shares of workers that are behind (one atomic ticket per block), so one descheduled
+ * worker does not set the time.  The line reports "passes" (per repetition) and "min_ms".
  */
 #define _GNU_SOURCE
 #include <dlfcn.h>
 #include <pthread.h>
+#include <sched.h>
+#include <stdatomic.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -53,35 +63,81 @@ static int cmp_d(const void* a, const void* b) { double x = *(const double*)a, y
 static double median(double* v, int n) { qsort(v, (size_t)n, sizeof(double), cmp_d); return n & 1 ? v[n / 2] : 0.5 * (v[n / 2 - 1] + v[n / 2]); }
 static double now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 
-static void* worker(void* arg) {
-  long t = (long)arg;
-  int b0 = (int)((long long)n_blocks * t / n_threads), b1 = (int)((long long)n_blocks * (t + 1) / n_threads);
-  for (int i = b0; i < b1; i++) {
-    uint8_t* s = src + (size_t)i * block_size; uint8_t* c = comp + (size_t)i * bound; uint8_t* d = back + (size_t)i * block_size;
-    int r;
-    switch (phase) {
-      case 0: if (file_buf) memcpy(s, file_buf + ((uint64_t)(first_idx + i) * 7919u) % (uint64_t)(file_len - block_size), (size_t)block_size);
-              else gen(s, block_size, 0x4C5A3447ull, first_idx + (uint64_t)i, litmax, win);
-              break;
-      case 1: r = hc_level ? r_hc((const char*)s, (char*)c, block_size, bound, hc_level)
-                           : (is_ref ? r_c((const char*)s, (char*)c, block_size, bound) : p_c(s, block_size, c, bound));
-              clen[i] = r; if (r <= 0) bad = 1; break;
-      case 2: r = is_ref ? r_ds((const char*)c, (char*)d, clen[i], block_size) : p_ds(c, clen[i], d, block_size); if (r != block_size) bad = 1; break;
-      case 3: r = is_ref ? r_df((const char*)c, (char*)d, block_size) : p_df(c, d, block_size); if (r != clen[i]) bad = 1; break;
-      case 4: hsum[t] += x32(s, (size_t)block_size, 0x9747b28cu); break;
-      case 5: hsum[t] += x64(s, (size_t)block_size, 0x9747b28cull); break;
-    }
+static void do_block(int ph, long t, int i) {
+  uint8_t* s = src + (size_t)i * block_size; uint8_t* c = comp ? comp + (size_t)i * bound : NULL; uint8_t* d = back ? back + (size_t)i * block_size : NULL;
+  int r;
+  switch (ph) {
+    case 0: if (file_buf) memcpy(s, file_buf + ((uint64_t)(first_idx + i) * 7919u) % (uint64_t)(file_len - block_size), (size_t)block_size);
+            else gen(s, block_size, 0x4C5A3447ull, first_idx + (uint64_t)i, litmax, win);
+            break;
+    case 1: r = hc_level ? r_hc((const char*)s, (char*)c, block_size, bound, hc_level)
+                         : (is_ref ? r_c((const char*)s, (char*)c, block_size, bound) : p_c(s, block_size, c, bound));
+            clen[i] = r; if (r <= 0) bad = 1; break;
+    case 2: r = is_ref ? r_ds((const char*)c, (char*)d, clen[i], block_size) : p_ds(c, clen[i], d, block_size); if (r != block_size) bad = 1; break;
+    case 3: r = is_ref ? r_df((const char*)c, (char*)d, block_size) : p_df(c, d, block_size); if (r != clen[i]) bad = 1; break;
+    case 4: hsum[t] += x32(s, (size_t)block_size, 0x9747b28cu); break;
+    case 5: hsum[t] += x64(s, (size_t)block_size, 0x9747b28cull); break;
   }
-  return NULL;
 }
 
-static double run_phase(int ph) {
-  pthread_t th[256];
-  phase = ph;
+/* the pool: workers wait at `gate`, run the repetition main has set up (phase, passes), meet main again at `gate` */
+static pthread_barrier_t gate;
+static int n_passes, quit;
+static struct Share { _Atomic long next; long total; int b0, len; char pad[40]; } share[256];   /* tickets: pass * len + (block - b0) */
+static int cpus[1024], n_cpus;
+
+static void run_share(int ph, long t, int v) {   /* blocks of worker v's share, taken ticket by ticket */
+  struct Share* s = &share[v];
+  if (!s->len) return;
+  for (;;) {
+    long k = atomic_fetch_add_explicit(&s->next, 1, memory_order_relaxed);
+    if (k >= s->total) return;
+    do_block(ph, t, s->b0 + (int)(k % s->len));
+  }
+}
+static void* worker(void* arg) {
+  long t = (long)arg;
+  if (n_cpus) { cpu_set_t set; CPU_ZERO(&set); CPU_SET(cpus[t % n_cpus], &set); (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set); }
+  for (;;) {
+    pthread_barrier_wait(&gate);
+    if (quit) return NULL;
+    run_share(phase, t, (int)t);
+    /* phase 0 (generation = first touch) stays with the owner; the timed phases help whoever is behind */
+    if (phase) for (int d = 1; d < n_threads; d++) run_share(phase, t, (int)((t + d) % n_threads));
+    pthread_barrier_wait(&gate);
+  }
+}
+static pthread_t pool[256];
+static void pool_start(void) {
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof set, &set) == 0)
+    for (int c = 0; c < CPU_SETSIZE && n_cpus < 1024; c++) if (CPU_ISSET(c, &set)) cpus[n_cpus++] = c;
+  pthread_barrier_init(&gate, NULL, (unsigned)n_threads + 1u);
+  for (long t = 0; t < n_threads; t++) pthread_create(&pool[t], NULL, worker, (void*)t);
+}
+static void pool_stop(void) {
+  quit = 1;
+  pthread_barrier_wait(&gate);
+  for (int t = 0; t < n_threads; t++) pthread_join(pool[t], NULL);
+}
+/* one repetition: `passes` whole passes of phase ph over the sample, seconds PER PASS */
+static double run_phase_n(int ph, int passes) {
+  phase = ph; n_passes = passes;
+  for (int t = 0; t < n_threads; t++) {
+    int b0 = (int)((long long)n_blocks * t / n_threads), b1 = (int)((long long)n_blocks * (t + 1) / n_threads);
+    share[t].b0 = b0; share[t].len = b1 - b0; share[t].total = (long)(b1 - b0) * passes;
+    atomic_store_explicit(&share[t].next, 0, memory_order_relaxed);
+  }
   double t0 = now();
-  for (long t = 0; t < n_threads; t++) pthread_create(&th[t], NULL, worker, (void*)t);
-  for (int t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
-  return now() - t0;
+  pthread_barrier_wait(&gate);
+  pthread_barrier_wait(&gate);
+  return (now() - t0) / passes;
+}
+static double run_phase(int ph) { return run_phase_n(ph, 1); }
+static double min_ms = 300.0;
+static int passes_for(double one_pass_s) {   /* whole passes a repetition needs to last min_ms */
+  int k = (int)(min_ms * 1e-3 / (one_pass_s > 1e-6 ? one_pass_s : 1e-6)) + 1;
+  return k < 1 ? 1 : (k > 100000 ? 100000 : k);
 }
 
 int main(int argc, char** argv) {
@@ -107,6 +163,8 @@ int main(int argc, char** argv) {
     if (!p_c || !p_ds || !p_df) { fprintf(stderr, "missing lz4o_* symbols\n"); return 4; }
   }
   bound = block_size + block_size / 255 + 16;
+  if (n_threads < 1) n_threads = 1;
+  if (getenv("CPU_BENCH_MIN_MS")) min_ms = atof(getenv("CPU_BENCH_MIN_MS"));
   if (getenv("CPU_BENCH_FILE")) {
     FILE* f = fopen(getenv("CPU_BENCH_FILE"), "rb");
     if (!f) { fprintf(stderr, "cannot open CPU_BENCH_FILE\n"); return 6; }
@@ -120,28 +178,37 @@ int main(int argc, char** argv) {
     if (!x32 || !x64) { fprintf(stderr, "missing XXH32/XXH64 symbols\n"); return 4; }
     src = malloc((size_t)n_blocks * block_size); hsum = calloc(256, sizeof(uint64_t));
     if (!src || !hsum) { fprintf(stderr, "malloc\n"); return 5; }
+    pool_start();
     run_phase(0);
     double b32 = 1e30, b64 = 1e30, t32[64], t64[64];
     if (reps > 64) reps = 64;
     run_phase(4);
-    for (int r = 0; r < reps; r++) { double t = run_phase(4); t32[r] = t; if (t < b32) b32 = t; t = run_phase(5); t64[r] = t; if (t < b64) b64 = t; }
+    const int k32 = passes_for(run_phase(4)), k64 = passes_for(run_phase(5));
+    memset(hsum, 0, 256 * sizeof(uint64_t));
+    run_phase(4); run_phase(5);   /* the check value: every hash exactly once */
     uint64_t chk = 0; for (int i = 0; i < 256; i++) chk += hsum[i];
+    for (int r = 0; r < reps; r++) { double t = run_phase_n(4, k32); t32[r] = t; if (t < b32) b32 = t; t = run_phase_n(5, k64); t64[r] = t; if (t < b64) b64 = t; }
+    pool_stop();
     double bytes = (double)n_blocks * block_size;
     printf("{\"kind\": \"%s\", \"threads\": %d, \"n_blocks\": %d, \"block_size\": %d, \"check\": %llu, \"xxh32_GBps\": %.4f, \"xxh64_GBps\": %.4f, "
-           "\"xxh32_GBps_median\": %.4f, \"xxh64_GBps_median\": %.4f}\n",
+           "\"xxh32_GBps_median\": %.4f, \"xxh64_GBps_median\": %.4f, \"passes\": [%d, %d], \"min_ms\": %.0f, \"pinned_cpus\": %d}\n",
            argv[1], n_threads, n_blocks, block_size, (unsigned long long)chk, bytes / b32 / 1e9, bytes / b64 / 1e9,
-           bytes / median(t32, reps) / 1e9, bytes / median(t64, reps) / 1e9);
+           bytes / median(t32, reps) / 1e9, bytes / median(t64, reps) / 1e9, k32, k64, min_ms, n_cpus);
     return 0;
   }
   src = malloc((size_t)n_blocks * block_size); comp = malloc((size_t)n_blocks * bound); back = malloc((size_t)n_blocks * block_size);
   clen = malloc(sizeof(int) * n_blocks);
   if (!src || !comp || !back || !clen) { fprintf(stderr, "malloc\n"); return 5; }
+  pool_start();
   run_phase(0);
   double best[4] = {0, 1e30, 1e30, 1e30}, all[4][64];
   if (reps > 64) reps = 64;
-  run_phase(1); run_phase(2);  /* warm-up */
+  run_phase(1); run_phase(2); run_phase(3);  /* warm-up = first touch of comp / back by the owners */
+  int k[4] = {1, 1, 1, 1};
+  for (int ph = 1; ph <= 3; ph++) k[ph] = passes_for(run_phase(ph));
   for (int r = 0; r < reps; r++)
-    for (int ph = 1; ph <= 3; ph++) { double t = run_phase(ph); all[ph][r] = t; if (t < best[ph]) best[ph] = t; }
+    for (int ph = 1; ph <= 3; ph++) { double t = run_phase_n(ph, k[ph]); all[ph][r] = t; if (t < best[ph]) best[ph] = t; }
+  pool_stop();
   double med[4] = {0, median(all[1], reps), median(all[2], reps), median(all[3], reps)};
   if (memcmp(src, back, (size_t)n_blocks * block_size) != 0) bad = 1;
   long long csum = 0; for (int i = 0; i < n_blocks; i++) csum += clen[i];
@@ -149,9 +216,10 @@ int main(int argc, char** argv) {
   if (hc_level) printf("{\"hc_level\": %d, ", hc_level); else printf("{");
   printf("\"kind\": \"%s\", \"threads\": %d, \"n_blocks\": %d, \"block_size\": %d, \"ratio\": %.4f, \"ok\": %s, "
          "\"compress_GBps\": %.4f, \"decompress_safe_GBps\": %.4f, \"decompress_fast_GBps\": %.4f, \"roundtrip_GBps\": %.4f, "
-         "\"compress_GBps_median\": %.4f, \"decompress_safe_GBps_median\": %.4f, \"decompress_fast_GBps_median\": %.4f, \"roundtrip_GBps_median\": %.4f}\n",
+         "\"compress_GBps_median\": %.4f, \"decompress_safe_GBps_median\": %.4f, \"decompress_fast_GBps_median\": %.4f, \"roundtrip_GBps_median\": %.4f, "
+         "\"passes\": [%d, %d, %d], \"min_ms\": %.0f, \"pinned_cpus\": %d}\n",
          argv[1], n_threads, n_blocks, block_size, bytes / (double)csum, bad ? "false" : "true",
          bytes / best[1] / 1e9, bytes / best[2] / 1e9, bytes / best[3] / 1e9, bytes / (best[1] + best[2]) / 1e9,
-         bytes / med[1] / 1e9, bytes / med[2] / 1e9, bytes / med[3] / 1e9, bytes / (med[1] + med[2]) / 1e9);
+         bytes / med[1] / 1e9, bytes / med[2] / 1e9, bytes / med[3] / 1e9, bytes / (med[1] + med[2]) / 1e9, k[1], k[2], k[3], min_ms, n_cpus);
   return bad ? 1 : 0;
 }

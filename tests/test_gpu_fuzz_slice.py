@@ -1,0 +1,30 @@
+"""A bounded slice of the volume campaigns in the driver-run suite (-m gpu): the hand-scheduled finder loop (csrc/lz4_fast_v2_asm.h)
+is ISA and has no CPU simulator -- its one real bug (tests/golden/regress/r03_binary_alphabet_*.bin) was found by tools/gpu_fuzz.py
+at volume, not by the suite.  These run the same scripts with fixed seeds that differ from every other test's: every compress core
+with full and tight capacities, every decoder variant, HC levels on subsets (gpu_fuzz.py); long valid and damaged streams through the
+deep / windowed decoder loops at 4 / 8 / 16 lanes (gpu_fuzz_deep.py).  Everything is compared with the reference library."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOOLS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+
+
+def run(script, *args):
+    r = subprocess.run([sys.executable, os.path.join(TOOLS, script)] + [str(a) for a in args], capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
+    return r.stdout
+
+
+@pytest.mark.parametrize("seed", [31337, 424242])
+def test_gpu_fuzz_slice(seed):
+    out = run("gpu_fuzz.py", 2500, seed)
+    assert "core 3: 2500 inputs bit-exact" in out and "decode safe/fast" in out
+
+
+def test_gpu_fuzz_deep_slice():
+    out = run("gpu_fuzz_deep.py", 400, 2026)
+    assert "deep fuzz ok" in out

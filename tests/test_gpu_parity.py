@@ -29,12 +29,25 @@ def gpu_compress_many(amd, blocks, caps):
     return [(r, bytes(dst[o:o + max(r, 0)])) for r, o in zip(out, do)]
 
 
+GUARD = 41   # bytes of 0xA5 in front of, between and behind the destination slots of gpu_decode_safe_many
+
+
 def gpu_decode_safe_many(amd, streams, caps):
-    src, so, sl, dst, do = pack(streams, caps)
-    for i in range(len(dst)):
-        pass
-    dst[:] = b"\xA5" * len(dst)
+    """safe-decodes a batch whose destination slots are separated by GUARD bytes of 0xA5 and asserts that NOTHING outside the slots
+    was written -- valid or malformed stream, whatever the interior loop (the deep and staged loops store whole steps / whole lines
+    unconditionally: a malformed stream must not carry one across its slot's end)"""
+    src = b"".join(streams)
+    so, sl, do, p, q = [], [], [], 0, GUARD
+    for b, c in zip(streams, caps):
+        so.append(p); sl.append(len(b)); do.append(q)
+        p += len(b); q += c + GUARD
+    dst = bytearray(b"\xA5" * q)
     out = amd.LZ4HIPBatch.decompressSafe(src, so, sl, dst, do, list(caps))
+    guard = b"\xA5" * GUARD
+    assert bytes(dst[:GUARD]) == guard, "bytes in front of the first slot were written"
+    for k, (o, c) in enumerate(zip(do, caps)):
+        assert bytes(dst[o + c:o + c + GUARD]) == guard, ("bytes behind slot %d (capacity %d, stream of %d bytes, result %d) were written"
+                                                          % (k, c, sl[k], out[k]))
     return [(r, bytes(dst[o:o + c])) for r, o, c in zip(out, do, caps)]
 
 

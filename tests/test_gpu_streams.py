@@ -168,3 +168,37 @@ def test_device_assembled_containers_equal_host_assembled(S, amd, O, corpus, ref
     amd.DeviceBatch.container_blocks(0, src, 65536, d, total, block_checksum=True)
     torch.cuda.synchronize()
     assert int(total.item()) == len(want) and d[:len(want)].cpu().numpy().tobytes() == want
+
+
+def test_device_container_exact_capacity_and_too_small(amd, O, corpus):
+    """lz4hip_container_blocks_dev with a destination of EXACTLY the container's size (round-3 advisor finding: without block
+    checksums the copy kernel's capacity guard counted 4 bytes the scan had not, and silently dropped the last block of an exactly
+    sized buffer), and with one that is too small: *total says so, nothing beyond dst_cap is written, and the checksum pass that
+    follows never reads payloads of skipped blocks beyond the capacity."""
+    import random
+    import torch
+    rng = random.Random(9)
+    dev0 = torch.device("cuda:0")
+    incompressible = rng.randbytes(3 * 65536 + 1000)          # stored raw: n_bytes + 4 n
+    mixed = corpus["book1[:200000]"][:150000] + rng.randbytes(70000)
+    for v in (incompressible, mixed):
+        for kind in (0, 1):
+            for chk in ((False, True) if kind == 0 else (False,)):
+                want = amd.LZ4HIPBatch.containerBlocks(kind, v, 65536, chk)
+                src = torch.frombuffer(bytearray(v), dtype=torch.uint8).to(dev0)
+                total = torch.zeros(1, dtype=torch.int64, device=dev0)
+                # exact capacity (a guard region behind it lives in the same tensor so that an overrun is seen, not faulted)
+                buf = torch.full((len(want) + 256,), 0xA5, dtype=torch.uint8, device=dev0)
+                amd.DeviceBatch.container_blocks(kind, src, 65536, buf[:len(want)], total, block_checksum=chk)
+                torch.cuda.synchronize()
+                assert int(total.item()) == len(want), (kind, chk)
+                assert buf[:len(want)].cpu().numpy().tobytes() == want, (kind, chk, "exactly sized destination")
+                assert bool((buf[len(want):] == 0xA5).all()), (kind, chk, "bytes beyond dst_cap written")
+                # too small by 1 .. a block: total reports the need, the guard stays intact
+                for short in (1, 3, 4, 700, 70000):
+                    cap = max(0, len(want) - short)
+                    buf.fill_(0xA5)
+                    amd.DeviceBatch.container_blocks(kind, src, 65536, buf[:cap], total, block_checksum=chk)
+                    torch.cuda.synchronize()
+                    assert int(total.item()) == len(want) > cap
+                    assert bool((buf[cap:] == 0xA5).all()), (kind, chk, short, "bytes beyond dst_cap written")
