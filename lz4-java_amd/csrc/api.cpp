@@ -71,7 +71,8 @@ enum Op { OP_COMPRESS_FAST, OP_DECODE_SAFE, OP_DECODE_FAST, OP_COMPRESS_HC };
 // never undefined behaviour; every launch reads each knob once
 std::atomic<int> g_decode_lanes{0};   // "decode_lanes"; 0 = kernel default
 std::atomic<int> g_decode_stage{-1};  // "decode_stage": 1 = LDS output staging in the plain loop
-std::atomic<int> g_decode_pipe{-1};   // "decode_pipe": 1/0 = pipelined interior loop on/off, -1 = kernel default
+std::atomic<int> g_decode_pipe{-1};   // "decode_pipe": 3 = ring loop, 2 = deep loop, 1/0 = pipelined interior loop on/off, -1 = kernel default
+std::atomic<int> g_decode_ring{0};    // "decode_ring": bytes of the ring loop's output ring (0 = default for the lane count)
 
 // lz4hip_set_option "compress_core": 5 = adaptive two-pass (default): the lean core with a writer wavefront per chain finishes
 // the blocks of long sequences, the window-parallel core the others; 3 = lean core only; 1 = window-parallel core only (the
@@ -150,7 +151,7 @@ int launch_fast(const lz4hip::BatchArgs& a, hipStream_t st) {
 }
 
 int launch_decode(const lz4hip::BatchArgs& a, bool safe, hipStream_t st) {
-  return lz4hip::launch_decompress(a, safe, g_decode_lanes.load(), g_decode_pipe.load(), g_decode_stage.load(), st);
+  return lz4hip::launch_decompress(a, safe, g_decode_lanes.load(), g_decode_pipe.load(), g_decode_stage.load(), g_decode_ring.load(), st);
 }
 
 int launch_op(Op op, const lz4hip::BatchArgs& a, hipStream_t st) {
@@ -966,8 +967,13 @@ int lz4hip_set_option(const char* name, int value) {
     return LZ4HIP_OK;
   }
   if (name && strcmp(name, "decode_pipe") == 0) {
-    if (value < -1 || value > 2) return fail(LZ4HIP_E_ARG, "decode_pipe must be -1, 0, 1 or 2");
+    if (value < -1 || value > 3) return fail(LZ4HIP_E_ARG, "decode_pipe must be -1, 0, 1, 2 or 3");
     g_decode_pipe = value;
+    return LZ4HIP_OK;
+  }
+  if (name && strcmp(name, "decode_ring") == 0) {
+    if (value != 0 && value != 512 && value != 1024 && value != 2048 && value != 4096) return fail(LZ4HIP_E_ARG, "decode_ring must be 0, 512, 1024, 2048 or 4096");
+    g_decode_ring = value;
     return LZ4HIP_OK;
   }
   if (name && strcmp(name, "decode_lanes") == 0) {

@@ -15,7 +15,8 @@
 #endif
 namespace lz4hip {
 
-template <int GL>
+// KW: bytes of the output ring of the ring loop (lz4_decode_ring.h; 0 = the other loops)
+template <int GL, int KW = 0>
 struct GroupDev {
   uint32_t l;  // lane index inside the group
   __device__ __forceinline__ GroupDev() : l(threadIdx.x & (GL - 1)) {}
@@ -197,6 +198,85 @@ struct GroupDev {
     return v;
   }
   __device__ __forceinline__ void step_store(uint8_t* d, const Chunk<LB / 4>& v) const { store_out(d + l * LB, v); }
+
+  // ---- backend of the ring loop (lz4_decode_ring.h): the block's window of the compressed stream AND its recent output in LDS.
+  // Layout of a block's kRingLds bytes: [stream ring kRs + 16][LB pad | output ring KW | 2 LB tail].
+  //  * stream ring: indexed by stream position, refilled in aligned 64-byte steps (one chunk per lane), first 16 bytes mirrored
+  //    behind the end so that no read wraps (per-lane masking: a lane's chunk wraps by itself);
+  //  * output ring: index of output position p = (p + dbase) & (KW - 1), dbase = dst address & 63, so that 64-byte aligned steps
+  //    of MEMORY are aligned steps of the ring (the flusher's reads and stores are aligned, a line never straddles the end).
+  //    A chunk written at ring index x is stored at t - LB with t = (x + LB) & (KW - 1), and once more KW bytes further on when
+  //    t < 2 LB: a chunk that straddles the end lands in [x - KW, ..) (the pad + the ring's first bytes) AND in [x, KW + LB) (the
+  //    ring's last bytes + the tail); a chunk inside the first LB bytes is repeated in the tail.  So a read of LB bytes at any
+  //    index finds them contiguous, and there is no wrap branch anywhere. ----
+#ifndef LZ4HIP_RING_KSTREAM
+#define LZ4HIP_RING_KSTREAM (GL <= 4 ? 256 : 512)
+#endif
+  static constexpr uint32_t kRs = LZ4HIP_RING_KSTREAM;      // stream bytes per block (power of two, >= 256)
+  static constexpr uint32_t kRing = KW ? (uint32_t)KW : 512u;
+  static constexpr uint32_t kRingLds = (kRs + 16u + kRing + 3u * LB + 15u) & ~15u;
+  uint8_t* rsb = nullptr;   // stream ring
+  uint8_t* rgb = nullptr;   // output ring, index 0 (behind the pad)
+  uint32_t dbase = 0;
+  __device__ __forceinline__ void ring_begin(uint8_t* lds, const uint8_t* dst) {
+    rsb = lds; rgb = lds + kRs + 16u + LB; dbase = (uint32_t)(uintptr_t)dst & 63u;
+  }
+  __device__ __forceinline__ static constexpr uint32_t ring_bytes() { return kRing; }
+  __device__ __forceinline__ static constexpr uint32_t ring_stream() { return kRs; }
+  __device__ __forceinline__ uint32_t ring_dbase() const { return dbase; }
+  // stream side
+  __device__ __forceinline__ LChunk rs_fetch(const uint8_t* src, uint32_t pos) const {   // pos: multiple of 64; [pos, pos + 64) is readable
+    LChunk r;
+    __builtin_memcpy(&r, src + pos + l * LB, LB);
+    return r;
+  }
+  __device__ __forceinline__ void rs_put(uint32_t pos, const LChunk& r) {
+    const uint32_t q = (pos & (kRs - 1u)) + l * LB;
+    __builtin_memcpy(rsb + q, &r, LB);
+    if (q < 16u) __builtin_memcpy(rsb + kRs + q, &r, LB);
+  }
+  __device__ __forceinline__ uint32_t rs_ld32(uint32_t p) const { uint32_t v; __builtin_memcpy(&v, rsb + (p & (kRs - 1u)), 4); return v; }
+  __device__ __forceinline__ uint64_t rs_ld64(uint32_t p) const { uint64_t v; __builtin_memcpy(&v, rsb + (p & (kRs - 1u)), 8); return v; }
+  __device__ __forceinline__ LChunk rs_step(uint32_t p) const {
+    LChunk v;
+    __builtin_memcpy(&v, rsb + ((p + l * LB) & (kRs - 1u)), LB);
+    return v;
+  }
+  // output side
+  __device__ __forceinline__ LChunk rg_read(uint32_t pos) const {   // this lane's LB bytes of the 64 output bytes at pos
+    LChunk v;
+    __builtin_memcpy(&v, rgb + ((pos + dbase + l * LB) & (kRing - 1u)), LB);
+    return v;
+  }
+  __device__ __forceinline__ void rg_write(uint32_t pos, const LChunk& v) {
+    const uint32_t t = (pos + dbase + l * LB + LB) & (kRing - 1u);
+    __builtin_memcpy((rgb - LB) + t, &v, LB);
+    if (t < 2u * LB) __builtin_memcpy((rgb - LB) + t + kRing, &v, LB);
+  }
+  __device__ __forceinline__ uint32_t rg_ld8(uint32_t pos) const { return rgb[(pos + dbase) & (kRing - 1u)]; }
+  __device__ __forceinline__ void rg_st8(uint32_t pos, uint32_t b) {
+    const uint32_t t = (pos + dbase + LB) & (kRing - 1u);
+    (rgb - LB)[t] = (uint8_t)b;
+    if (t < 2u * LB) (rgb - LB)[t + kRing] = (uint8_t)b;
+  }
+  // ring[op + i] = ring[op - offset + (i mod offset)], i in [0, len): a match that overlaps its own output, copied inside the ring
+  // (one byte per lane and round; a round reads only bytes in front of the match)
+  __device__ __forceinline__ void rg_replicate(uint32_t op, uint32_t offset, uint32_t len) {
+    const uint32_t m = op - offset;
+    uint32_t r = l < offset ? l : l % offset;
+    const uint32_t stp = GL < offset ? (uint32_t)GL : (uint32_t)GL % offset;
+    for (uint32_t i = l; i < len; i += GL) {
+      rg_st8(op + i, rg_ld8(m + r));
+      r += stp;
+      if (r >= offset) r -= offset;
+    }
+  }
+  __device__ __forceinline__ static LChunk pick(bool first, const LChunk& a, const LChunk& b) {
+    LChunk r;
+#pragma unroll
+    for (uint32_t k = 0; k < LB / 4u; k++) r.w[k] = first ? a.w[k] : b.w[k];
+    return r;
+  }
 
   // dst[op+i] = dst[op-offset+i] for i in [0,len), byte-forward (overlap replicates the pattern)
   __device__ __forceinline__ void copy_match(uint8_t* dst, uint32_t op, uint32_t offset, uint32_t len, bool wild) const {

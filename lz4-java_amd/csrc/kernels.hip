@@ -562,6 +562,29 @@ __global__ __launch_bounds__(256, LZ4HIP_DEEP_WGS) void decode_deep_kernel(Batch
   if (g.l == 0) a.out[gid] = r;
 }
 
+// the ring loop's kernel (lz4_decode_ring.h): per block a stream ring and an output ring of KW bytes in LDS.  One wavefront per
+// workgroup: the LDS a workgroup asks for is what one wavefront's 64 / GL blocks need, so the CU fills to the last wavefront
+// (KW 512, 4 lanes: 16 blocks x 832 bytes = 13 KB, 12 wavefronts per CU; KW 4096, 16 lanes: 4 x 4.6 KB, 8 per CU).
+template <int GL, int KW, bool SAFE>
+__global__ __launch_bounds__(64) void decode_ring_kernel(BatchArgs a) {
+  typedef GroupDev<GL, KW> G;
+  __shared__ __attribute__((aligned(16))) uint8_t ring_mem[(64 / GL) * G::kRingLds];
+  const uint32_t gid = (blockIdx.x * 64u + threadIdx.x) / GL;
+  if (gid >= a.n) return;
+  G g;
+  const int r = decode_block<G, SAFE, 3, false>(g, a.src + a.src_off[gid], a.src_len[gid], a.dst + a.dst_off[gid], a.dst_cap[gid],
+                                               ring_mem + (threadIdx.x / GL) * G::kRingLds);
+  if (g.l == 0) a.out[gid] = r;
+}
+template <int GL, int KW>
+static int launch_decode_ring(const BatchArgs& a, bool safe, hipStream_t st) {
+  const uint32_t per_wg = 64u / GL;
+  const uint32_t grid = (a.n + per_wg - 1u) / per_wg;
+  if (safe) hipLaunchKernelGGL((decode_ring_kernel<GL, KW, true>), dim3(grid), dim3(64), 0, st, a);
+  else hipLaunchKernelGGL((decode_ring_kernel<GL, KW, false>), dim3(grid), dim3(64), 0, st, a);
+  return (int)hipGetLastError();
+}
+
 template <int GL>
 static int launch_decode_gl(const BatchArgs& a, bool safe, int pipe, bool stage, hipStream_t st) {
   const uint32_t per_wg = 256u / GL;
@@ -584,9 +607,24 @@ static int launch_decode_gl(const BatchArgs& a, bool safe, int pipe, bool stage,
   return (int)hipGetLastError();
 }
 
-int launch_decompress(const BatchArgs& a, bool safe, int lanes_per_block, int pipe, int stage, void* stream) {
+int launch_decompress(const BatchArgs& a, bool safe, int lanes_per_block, int pipe, int stage, int ring, void* stream) {
   if (a.n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
+  if (pipe == 3) {   // the ring loop: lanes 4 / 8 / 16, output ring 512 .. 4096 bytes (0 = 512 with 4 lanes, 4096 otherwise)
+    const int gl = lanes_per_block == 0 ? 4 : lanes_per_block;
+    const int kw = ring ? ring : (gl == 4 ? 512 : 4096);
+    switch (gl * 100000 + kw) {
+      case 400512: return launch_decode_ring<4, 512>(a, safe, st);
+      case 401024: return launch_decode_ring<4, 1024>(a, safe, st);
+      case 800512: return launch_decode_ring<8, 512>(a, safe, st);
+      case 801024: return launch_decode_ring<8, 1024>(a, safe, st);
+      case 802048: return launch_decode_ring<8, 2048>(a, safe, st);
+      case 804096: return launch_decode_ring<8, 4096>(a, safe, st);
+      case 1602048: return launch_decode_ring<16, 2048>(a, safe, st);
+      case 1604096: return launch_decode_ring<16, 4096>(a, safe, st);
+      default: return (int)hipErrorInvalidValue;
+    }
+  }
   // Defaults by batch size (tools/decode_matrix.sh, tools/deep_matrix.sh; App. F / text / 4 MiB blocks):
   //   >= 40960 blocks: 4 lanes x 16 bytes per block (16 blocks per wavefront), plain loop with output staging -- the GPU is
   //                    full, long-sequence data is bandwidth-bound and short-sequence data issue-bound;

@@ -37,6 +37,7 @@
 #define LZ4HIP_DECODE_REENTER 1   // 0: the interior loop is entered once per block (round 1 behaviour; developer A/B builds)
 #endif
 #include "lz4_decode_deep.h"
+#include "lz4_decode_ring.h"
 namespace lz4hip {
 
 // SAFE: LZ4_decompress_safe(src, dst, src_size, out_size) -> decoded size or negative.
@@ -47,6 +48,8 @@ namespace lz4hip {
 //       with the GPU full of blocks the plain loop is as fast.  2 = the deep loop of lz4_decode_deep.h (stream staged in LDS at
 //       `stage`, Grp::kStreamLds bytes for this block; two slots: one match source of the block waits while the next is requested); the last 2 KB of the stream
 //       are left to loop 1.
+//       3 = the ring loop of lz4_decode_ring.h (stream AND recent output in LDS rings at `stage`, Grp::kRingLds bytes; near matches
+//       never leave the chip, far ones are pipelined through slots, output leaves as whole aligned 64-byte steps).
 // STAGE: the interior loop writes through an LDS staging buffer (`stage`, Grp::kStage bytes for this block) and output leaves
 //        it as whole 128-byte lines (group_dev.h st_*).
 template <class Grp, bool SAFE, int PIPE = 0, bool STAGE = false>
@@ -78,7 +81,11 @@ LZ4HIP_DEV int decode_block(Grp& g, const uint8_t* src, int src_size, uint8_t* d
       if (ip + 2048 <= iend && ip <= iend - 306 && op <= oend - 606)
         if (decode_deep_loop(g, src, iend, dst, oend, ip, op, stage)) goto interior;
     }
-    if ((PIPE == 1 || (PIPE == 2 && ip + 2048 > iend)) && ip <= iend - 306 && op <= oend - 606) {   // (2: only the tail of the stream)
+    if constexpr (PIPE == 3) {   // the ring loop (lz4_decode_ring.h): stream and recent output in LDS at `stage` (Grp::kRingLds bytes)
+      if (op >= 64 && ip + 320 <= iend && ip <= iend - 306 && op <= oend - 606)
+        if (decode_ring_loop(g, src, iend, dst, oend, ip, op, stage)) goto interior;
+    }
+    if ((PIPE == 1 || (PIPE == 2 && ip + 2048 > iend) || (PIPE == 3 && ip + 320 > iend)) && ip <= iend - 306 && op <= oend - 606) {   // (2, 3: only the tail of the stream)
       // ---- the same loop, software-pipelined.  A wavefront's memory operations retire in order, so a wait for a load also
       // waits for every OLDER store.  Here (a) the next sequence's offset word is requested as soon as this sequence's header
       // is parsed, (b) a "simple" sequence (literals and match take one step each, match source entirely before the

@@ -185,6 +185,84 @@ struct GroupHost {
     for (int l = 0; l < GL; l++) if (wr_ok(d + l * LB, LB)) memcpy(d + l * LB, v.b[l], LB);
   }
 
+  // ---- backend of the ring loop (lz4_decode_ring.h; group_dev.h rs_* / rg_*): stream ring + output ring in "LDS" with the same
+  // layout, the same mirror rules and the same per-lane index arithmetic as the device backend; every call is one instruction (all
+  // lanes' loads, then all lanes' stores); an index outside the block's LDS bytes counts as oob.  Ring sizes are chosen per test.
+  uint32_t kRs = 256u, kRing = 512u;
+  uint8_t ring_mem[1024 + 16 + 8192 + 48 + 64];
+  uint8_t* rsb = nullptr; uint8_t* rgb = nullptr;
+  uint32_t dbase = 0;
+  static inline uint64_t ring_trips = 0, ring_entries = 0, ring_repl = 0, ring_flush = 0;   // (statistics for the tests)
+  uint32_t ring_bytes() const { return kRing; }
+  uint32_t ring_stream() const { return kRs; }
+  uint32_t ring_dbase() const { return dbase; }
+  uint32_t ring_lds() const { return kRs + 16u + kRing + 3u * lb(); }
+  bool rl_ok(const uint8_t* p, uint32_t k) { if (p < ring_mem || p + k > ring_mem + ring_lds()) { oob = true; return false; } return true; }
+  void ring_begin(uint8_t*, const uint8_t* dst) {
+    ring_entries++;
+    memset(ring_mem, 0xEE, sizeof ring_mem);
+    rsb = ring_mem; rgb = ring_mem + kRs + 16u + lb(); dbase = (uint32_t)(uintptr_t)dst & 63u;
+  }
+  LChunk rs_fetch(const uint8_t* s, uint32_t pos) {
+    LChunk r; memset(&r, 0, sizeof r);
+    const uint32_t LB = lb();
+    for (int l = 0; l < GL; l++) if (rd_ok(s + pos + l * LB, LB)) memcpy(r.b[l], s + pos + l * LB, LB);
+    return r;
+  }
+  void rs_put(uint32_t pos, const LChunk& r) {
+    const uint32_t LB = lb();
+    for (int l = 0; l < GL; l++) {
+      const uint32_t q = (pos & (kRs - 1u)) + l * LB;
+      if (rl_ok(rsb + q, LB)) memcpy(rsb + q, r.b[l], LB);
+      if (q < 16u && rl_ok(rsb + kRs + q, LB)) memcpy(rsb + kRs + q, r.b[l], LB);
+    }
+  }
+  uint32_t rs_ld32(uint32_t p) { uint32_t v = 0; const uint8_t* q = rsb + (p & (kRs - 1u)); if (rl_ok(q, 4)) memcpy(&v, q, 4); return v; }
+  uint64_t rs_ld64(uint32_t p) { ring_trips++; uint64_t v = 0; const uint8_t* q = rsb + (p & (kRs - 1u)); if (rl_ok(q, 8)) memcpy(&v, q, 8); return v; }
+  LChunk rs_step(uint32_t p) {
+    LChunk v; memset(&v, 0, sizeof v);
+    const uint32_t LB = lb();
+    for (int l = 0; l < GL; l++) { const uint8_t* q = rsb + ((p + l * LB) & (kRs - 1u)); if (rl_ok(q, LB)) memcpy(v.b[l], q, LB); }
+    return v;
+  }
+  LChunk rg_read(uint32_t pos) {
+    LChunk v; memset(&v, 0, sizeof v);
+    const uint32_t LB = lb();
+    for (int l = 0; l < GL; l++) { const uint8_t* q = rgb + ((pos + dbase + l * LB) & (kRing - 1u)); if (rl_ok(q, LB)) memcpy(v.b[l], q, LB); }
+    return v;
+  }
+  void rg_write(uint32_t pos, const LChunk& v) {
+    const uint32_t LB = lb();
+    for (int l = 0; l < GL; l++) {
+      const uint32_t t = (pos + dbase + l * LB + LB) & (kRing - 1u);
+      if (rl_ok((rgb - LB) + t, LB)) memcpy((rgb - LB) + t, v.b[l], LB);
+      if (t < 2u * LB && rl_ok((rgb - LB) + t + kRing, LB)) memcpy((rgb - LB) + t + kRing, v.b[l], LB);
+    }
+  }
+  uint32_t rg_ld8(uint32_t pos) { const uint8_t* q = rgb + ((pos + dbase) & (kRing - 1u)); return rl_ok(q, 1) ? *q : 0; }
+  void rg_st8(uint32_t pos, uint32_t b) {
+    const uint32_t LB = lb();
+    const uint32_t t = (pos + dbase + LB) & (kRing - 1u);
+    if (rl_ok((rgb - LB) + t, 1)) (rgb - LB)[t] = (uint8_t)b;
+    if (t < 2u * LB && rl_ok((rgb - LB) + t + kRing, 1)) (rgb - LB)[t + kRing] = (uint8_t)b;
+  }
+  void rg_replicate(uint32_t op, uint32_t offset, uint32_t len) {
+    ring_repl++;
+    const uint32_t m = op - offset;
+    uint32_t r[64];
+    for (int l = 0; l < GL; l++) r[l] = (uint32_t)l < offset ? (uint32_t)l : (uint32_t)l % offset;
+    const uint32_t stp = (uint32_t)GL < offset ? (uint32_t)GL : (uint32_t)GL % offset;
+    for (uint32_t base = 0; base < len; base += GL) {
+      uint8_t v[64]; bool act[64];
+      for (int l = 0; l < GL; l++) { act[l] = base + l < len; v[l] = act[l] ? (uint8_t)rg_ld8(m + r[l]) : 0; }
+      for (int l = 0; l < GL; l++) {
+        if (act[l]) rg_st8(op + base + l, v[l]);
+        r[l] += stp; if (r[l] >= offset) r[l] -= offset;
+      }
+    }
+  }
+  static LChunk pick(bool first, const LChunk& a, const LChunk& b) { return first ? a : b; }
+
   void copy_match(uint8_t* dst, uint32_t op, uint32_t offset, uint32_t len, bool wild) {
     uint8_t* d = dst + op;
     const uint8_t* m = d - offset;

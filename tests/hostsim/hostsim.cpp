@@ -166,6 +166,8 @@ int sim_compress_fast_ms(const uint8_t* src, int n, uint8_t* dst, int cap, uint6
   return (int)r;
 }
 
+void sim_ring_stats(unsigned long long* out3) { out3[0] = hostsim::GroupHost::ring_trips; out3[1] = hostsim::GroupHost::ring_entries; out3[2] = hostsim::GroupHost::ring_repl; }
+unsigned long long sim_ring_trips() { return hostsim::GroupHost::ring_trips; }   // offset words the ring loop has parsed so far
 unsigned long long sim_deep_trips() { return hostsim::GroupHost::deep_trips; }   // offset words the deep decoder loop has parsed so far
 
 // safe != 0: (src_size = compressed length) -> decoded size; safe == 0: (src_size = readable
@@ -174,10 +176,16 @@ int sim_decompress(const uint8_t* src, int src_size, uint8_t* dst, int out_size,
   const bool pipe = (gl & 0x100) != 0;   // bit 8 of gl: the pipelined interior loop
   const bool stage = (gl & 0x200) != 0;  // bit 9: output staging
   const bool deep = (gl & 0x400) != 0;   // bit 10: the deep interior loop (lz4_decode_deep.h; groups of up to 16 lanes)
+  const bool ring = (gl & 0x800) != 0;   // bit 11: the ring loop (lz4_decode_ring.h); bits 12..15: log2 of the output ring's bytes (default 512)
+  const int ring_log = (gl >> 12) & 15;
   gl &= 0xFF;
   hostsim::GroupHost g(gl, src, src_size, dst, out_size);
+  if (ring_log) g.kRing = 1u << ring_log;
+  if (ring && gl > 4) g.kRs = 512u;
   int r;
-  if (deep) r = safe ? lz4hip::decode_block<hostsim::GroupHost, true, 2>(g, src, src_size, dst, out_size, g.stg_buf)
+  if (ring) r = safe ? lz4hip::decode_block<hostsim::GroupHost, true, 3>(g, src, src_size, dst, out_size, g.stg_buf)
+                     : lz4hip::decode_block<hostsim::GroupHost, false, 3>(g, src, src_size, dst, out_size, g.stg_buf);
+  else if (deep) r = safe ? lz4hip::decode_block<hostsim::GroupHost, true, 2>(g, src, src_size, dst, out_size, g.stg_buf)
                      : lz4hip::decode_block<hostsim::GroupHost, false, 2>(g, src, src_size, dst, out_size, g.stg_buf);
   else if (stage) r = safe ? lz4hip::decode_block<hostsim::GroupHost, true, 0, true>(g, src, src_size, dst, out_size, g.stg_buf)
                       : lz4hip::decode_block<hostsim::GroupHost, false, 0, true>(g, src, src_size, dst, out_size, g.stg_buf);

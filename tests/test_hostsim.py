@@ -54,11 +54,14 @@ def sim_compress(sim, v, cap, seed=0, ms=False, v2=False, raw=False):
     return r, bytes(out[:max(r, 0)]), list(st)
 
 
-def sim_decode(sim, c, cap, safe, gl, src_size=None):
-    out = (C.c_uint8 * max(cap, 1))()
-    C.memset(out, 0xA5, max(cap, 1))
-    r = sim.sim_decompress(bytes(c), len(c) if src_size is None else src_size, out, cap, safe, gl)
-    return r, bytes(out[:cap])
+def sim_decode(sim, c, cap, safe, gl, src_size=None, shift=0):
+    """shift: the destination slot starts that many bytes into its buffer (address alignment of the slot)"""
+    out = (C.c_uint8 * (max(cap, 1) + shift))()
+    C.memset(out, 0xA5, max(cap, 1) + shift)
+    dst = (C.c_uint8 * max(cap, 1)).from_buffer(out, shift)
+    r = sim.sim_decompress(bytes(c), len(c) if src_size is None else src_size, dst, cap, safe, gl)
+    assert bytes(out[:shift]) == b"\xA5" * shift
+    return r, bytes(out[shift:shift + cap])
 
 
 def test_cores_on_issue12_blob(sim, ref):
@@ -326,6 +329,39 @@ def test_deep_decoder_loop(sim, ref, O, corpus):
             r4, d4 = sim_decode(sim, c + bytes(scap - len(c)), cap, 0, gl | 0x400, src_size=scap)
             assert r3 == r4 and (r3 < 0 or d3[:cap] == d4[:cap]), ("fast", k, gl, len(c), cap, scap, r3, r4)
     assert sim.sim_deep_trips() - trips0 > 500000   # (the loop under test did the work)
+
+
+def test_ring_decoder_loop(sim, ref, O, corpus):
+    """The ring loop (csrc/lz4_decode_ring.h: stream AND recent output in LDS rings, near matches copied inside the ring -- incl. the
+    ones that overlap their own output --, far ones pipelined through slots, output leaving as address-aligned 64-byte steps) in the
+    lock-step simulator: groups of 4 / 8 / 16 lanes, output rings of 512 / 1024 / 4096 bytes, destination slots at every kind of
+    address alignment; the long-stream cases of the deep loop's test (real and synthetic blocks, hand-assembled mixes of every kind
+    of sequence, the same streams corrupted / truncated / with wrong capacities) plus short-offset text-like data that lives in the
+    ring: return codes and bytes against the reference library (safe) and the C restatement's bounded fast decoder.  Every access
+    outside the block's slots or its LDS bytes counts as a failure."""
+    rng = random.Random(777)
+    from conftest import deep_decoder_cases
+    valid, cases = deep_decoder_cases(ref, O, corpus, rng, _lz4_seq)
+    extra = [corpus["book1[:200000]"][1000:40000], O.gen_block(50000, 7, litmax=3, win=40), O.gen_block(50000, 8, litmax=20, win=500),
+             O.gen_block(80000, 9, win=4096), bytes(rng.randrange(4) for _ in range(30000)), (rng.randbytes(37) * 3000)[:70000]]
+    for v in extra:
+        c = ref.compress_fast(v)
+        valid.append((c, len(v))); cases.insert(len(valid) - 1, (c, len(v)))
+    sim.sim_ring_trips.restype = C.c_ulonglong
+    trips0 = sim.sim_ring_trips()
+    for k, (c, cap) in enumerate(cases):
+        want_r, want = ref.decompress_safe_raw(c, cap)
+        full = k < len(valid)
+        for gl, rl in (((4, 9), (8, 12), (16, 12), (8, 9), (4, 10)) if full else ((rng.choice([4, 8, 16]), rng.choice([9, 10, 12])),)):
+            flag = gl | 0x800 | (rl << 12)
+            shift = rng.choice([0, 0, 1, 7, 16, 33, 63, 64, 100])
+            r, d = sim_decode(sim, c, cap, 1, flag, shift=shift)
+            assert r == want_r and (want_r < 0 or d[:want_r] == want[:want_r]), ("safe", k, gl, rl, shift, len(c), cap, r, want_r)
+            scap = len(c) + rng.choice([0, 0, 5, 64])
+            r3, d3 = O.decompress_fast_bounded(c, scap, cap)
+            r4, d4 = sim_decode(sim, c + bytes(scap - len(c)), cap, 0, flag, src_size=scap, shift=shift)
+            assert r3 == r4 and (r3 < 0 or d3[:cap] == d4[:cap]), ("fast", k, gl, rl, len(c), cap, scap, r3, r4)
+    assert sim.sim_ring_trips() - trips0 > 500000   # (the loop under test did the work)
 
 
 def test_decode_core_malformed_vectors(sim, golden):
