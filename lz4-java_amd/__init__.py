@@ -28,7 +28,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "liblz4hip.so")
+# (developer A/B builds: LZ4HIP_LIBRARY names another build of the SAME library, e.g. lz4-java_amd/variants/<name>.so of tools/build_variant.sh)
+_LIB_PATH = os.environ.get("LZ4HIP_LIBRARY") or os.path.join(_HERE, "liblz4hip.so")
 _u8p = C.POINTER(C.c_uint8)
 _u64p = C.POINTER(C.c_uint64)
 _i32p = C.POINTER(C.c_int32)

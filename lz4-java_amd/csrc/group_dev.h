@@ -271,6 +271,10 @@ struct GroupDev {
       if (r >= offset) r -= offset;
     }
   }
+  __device__ __forceinline__ static bool any(bool x) { return __builtin_amdgcn_ballot_w64(x) != 0ull; }   // over the wavefront's active lanes
+  // every vector memory operation issued so far is waited for HERE (the compiler's wait-count pass sees the instruction: a loop
+  // entered behind it has nothing outstanding on its entry edge, so the waits inside count only the loop's own operations)
+  __device__ __forceinline__ static void settle(uint32_t&) { __builtin_amdgcn_s_waitcnt(0x0F70); }
   __device__ __forceinline__ static LChunk pick(bool first, const LChunk& a, const LChunk& b) {
     LChunk r;
 #pragma unroll

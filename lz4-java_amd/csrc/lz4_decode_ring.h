@@ -1,5 +1,5 @@
 // lz4_decode_ring.h -- the ring loop of the block decoder (lz4_decode_core.h, PIPE == 3): an interior loop whose trip touches
-// memory only for what MUST come from memory.
+// memory only for what MUST come from memory, and has no branch in it.
 //
 // Same sequences, same bytes as the other interior loops of decode_block (LZ4_decompress_safe / _fast of liblz4 1.9.3,
 // /root/reference/src/jni/net_jpountz_lz4_LZ4JNI.c:216 / :169).  What a trip works on:
@@ -8,32 +8,40 @@
 //  * the block's RECENT OUTPUT lives in a second LDS ring of KW bytes (group_dev.h rg_*): sequences are written into the ring, in
 //    sequence order; a match whose source lies inside the ring is an LDS -> LDS copy (near match), only a source the ring no longer
 //    holds is a load from the block's output in memory (far match) -- and that load is never waited for in the trip that requests
-//    it: slots hold the sequences whose match source is on its way, a trip fills one and puts the oldest into the ring;
+//    it: slots hold the pieces whose match source is on its way, a trip fills one and puts the oldest into the ring;
 //  * output leaves the ring as whole, ADDRESS-ALIGNED 64-byte steps (the ring is indexed by address, so the flusher's LDS reads and
 //    its stores are aligned): every output byte is stored to memory exactly once, no partial line is ever written twice;
-//  * everything a trip does is unconditional and whole-step, as in the deep loop: what a step writes past its length is put right by
-//    the steps that follow (sequence order), empty slots are aimed at bytes that are written again.
+//  * the blocks of a wavefront run in lock step, so a trip costs what the slowest path through it costs: there is ONE path.  A trip
+//    emits a piece = {<= 64 literal bytes, <= 64 match bytes that do not reach into waiting or own bytes}; everything irregular is a
+//    piece of another shape, not a branch:
+//      - a match source that reaches into bytes still waiting in a slot: the block STALLS for this trip (an empty piece);
+//      - a source that reaches into the sequence's own literals: the literals alone are this trip's piece, the whole match is
+//        carried in {cm, coff} to the next trips;
+//      - a match that overlaps its own output (offset < length), or is longer than 64: the piece is min(length, offset, 64) bytes,
+//        the rest is carried in {cm, coff} and copied by the next trips -- with the offset DOUBLED after every piece that was a whole
+//        period (any multiple of the period is a period), so a run reaches 64 bytes per trip after six pieces;
+//      - the flusher behind, the stream ring short of bytes at a sequence start: stalls as well;
+//    what is left -- literal runs over 64, length runs of two or more bytes, invalid offsets, a source neither the ring nor flushed
+//    memory holds (right behind an entry only), the end of the loop's range -- FREEZES the block (it stalls until the loop is left);
+//    the wavefront leaves the loop a few trips after the first block froze, each frozen block does its one sequence through memory
+//    (or leaves for the exact code of decode_block), re-seeds its rings, and the loop is entered again.
 // With KW = 512 (4 lanes per block, 16 blocks per wavefront) this is the loop for full batches of 64 KiB blocks -- text (offsets of a
-// few hundred bytes stay on chip, the rest is pipelined) and far-match data alike (two match sources of a block in flight instead of
-// one); with KW = 4096 (8 / 16 lanes) for big blocks with a short match window (BASELINE configs[2]: four matches of five never
-// leave the chip).
-// Leaves -- with ip / op at the start of a sequence it does not take, everything before it in memory -- on: literal or match
-// lengths over 64, length runs of two or more bytes, an invalid offset, the rare source that lies neither in the ring nor in
-// flushed memory (only right behind the loop's entry), the end of the staged stream.
+// few hundred bytes stay on chip, the rest is pipelined) and far-match data alike; with KW = 4096 (8 / 16 lanes) for big blocks with a
+// short match window (BASELINE configs[2]: four matches of five never leave the chip).
 #pragma once
 #include <stdint.h>
 #ifndef LZ4HIP_UNLIKELY
 #define LZ4HIP_UNLIKELY(x) __builtin_expect(!!(x), 0)
 #endif
-#ifndef LZ4HIP_RING_SLOTS
-#define LZ4HIP_RING_SLOTS 2   /* 2: one sequence waits for its match source while the next is parsed and requested; 3: two wait */
+#ifndef LZ4HIP_RING_PATIENCE
+#define LZ4HIP_RING_PATIENCE 4   /* trips the wavefront goes on after the first block froze */
 #endif
 
 namespace lz4hip {
 
 // entry: 64 <= op (the first aligned step of the flusher lies inside the block's slot), ip + 320 <= iend (the ring's first pieces are
 // readable), ip <= iend - 306, op <= oend - 606 (the interior loops' distance from both ends).
-// returns true when it left for want of staged stream bytes only (the caller comes again).
+// returns true when the block can come again (it left only because the staged stream ran short near the end of the loop's range).
 template <class Grp>
 LZ4HIP_DEV bool decode_ring_loop(Grp& g, const uint8_t* src, const int iend, uint8_t* dst, const int oend, int& ip_io, int& op_io, uint8_t* lds) {
   typedef typename Grp::LChunk LChunk;
@@ -41,116 +49,135 @@ LZ4HIP_DEV bool decode_ring_loop(Grp& g, const uint8_t* src, const int iend, uin
   uint32_t ip = (uint32_t)ip_io, op = (uint32_t)op_io;
   const uint32_t ilim = (uint32_t)iend - 306u, olim = (uint32_t)oend - 606u;
   g.ring_begin(lds, dst);
-  // stream ring: holds [.., avail); `fetched` = end of what has been requested
-  uint32_t avail = ip & ~(STEP - 1u);
-  while (avail < ip + 192u) { g.rs_put(avail, g.rs_fetch(src, avail)); avail += STEP; }
-  uint32_t fetched = avail;
-  LChunk rf = g.rs_fetch(src, fetched - STEP);
-  uint32_t rf_pos = fetched - STEP;
-  // output ring: everything below op is in memory.  The flusher works in address-aligned steps, so the ring is given the aligned step
-  // that contains op (its bytes below op from memory); fl = first position that is not flushed, a multiple of 64 in address space
-  const uint32_t mt0 = op;                                       // memory is valid below max(fl, mt0)
-  uint32_t fl = op - ((g.ring_dbase() + op) & (STEP - 1u));
-  const uint32_t rlo = fl;                                       // the ring holds nothing below this position
-  g.rg_write(fl, g.step_load(dst + fl));
-  uint32_t hw = fl + STEP;                                       // end of everything ever written into the ring: it holds [hw - KW, hw)
-  // slots: literals v, match source from the ring (ul) / from memory (ug), nr = which of the two is the source; sop = output position
-  // of the sequence, lit = its literal length
-  LChunk v0 = LChunk(), ul0 = LChunk(), ug0 = LChunk(), v1 = LChunk(), ul1 = LChunk(), ug1 = LChunk(), v2 = LChunk(), ul2 = LChunk(), ug2 = LChunk();
-  uint32_t sop0 = op, sop1 = op, sop2 = op, lit0 = 0, lit1 = 0, lit2 = 0;
-  bool nr0 = true, nr1 = true, nr2 = true;
-  (void)v2; (void)ul2; (void)ug2; (void)sop2; (void)lit2; (void)nr2;
-  uint32_t t4 = g.rs_ld32(ip);
+  uint32_t avail, fetched, rf_pos, fl, hw, rlo, mt0;
+  uint32_t t4 = g.ld32(src + ip);      // the token word at ip
+  uint32_t cm = 0, coff = 0;           // match bytes of the sequence in front of ip that are not copied yet, and the offset they use
+  LChunk rf;
+  bool leave = false;
+  for (;;) {
+    // ---- (re-)seed the rings: everything below op is in memory ----
+    // stream ring: holds [.., avail); `fetched` = end of what has been requested
+    avail = ip & ~(STEP - 1u);
+    while (avail < ip + 192u) { g.rs_put(avail, g.rs_fetch(src, avail)); avail += STEP; }
+    fetched = avail;
+    rf = g.rs_fetch(src, fetched - STEP);
+    rf_pos = fetched - STEP;
+    // output ring: the flusher works in address-aligned steps, so the ring is given the aligned step that contains op (its bytes
+    // below op from memory); fl = first position that is not flushed, a multiple of 64 in address space
+    mt0 = op;                                              // memory is valid below max(fl, mt0)
+    fl = op - ((g.ring_dbase() + op) & (STEP - 1u));
+    rlo = fl;                                              // the ring holds nothing below this position
+    g.rg_write(fl, g.step_load(dst + fl));
+    hw = fl + STEP;                                        // end of everything ever written into the ring: it holds [hw - KW, hw)
+    // slots: literals v, match source from the ring (ul) / from memory (ug), nr = which of the two it is; sop = output position
+    // of the piece, lit = its literal length
+    LChunk v0 = LChunk(), ul0 = LChunk(), ug0 = LChunk(), v1 = LChunk(), ul1 = LChunk(), ug1 = LChunk();
+    uint32_t sop0 = op, sop1 = op, lit0 = 0, lit1 = 0;
+    bool nr0 = true, nr1 = true;
+    bool frozen = false;
+    uint32_t since = 0;                                    // trips since the first block of the wavefront froze (wave-uniform)
 
 #define LZ4HIP_RETIRE(k) do { const LChunk u_ = Grp::pick(nr##k, ul##k, ug##k); g.rg_write(sop##k, v##k); g.rg_write(sop##k + lit##k, u_); \
                               hw = sop##k + lit##k + STEP; } while (0)
-#define LZ4HIP_AIM(k) do { sop##k = aim; lit##k = 0u; } while (0)
-#define LZ4HIP_FLUSH_STEP do { g.step_store(dst + fl, g.rg_read(fl)); fl += STEP; } while (0)
-#define LZ4HIP_FLUSH_ALL do { while ((int32_t)(op - fl) > 0) LZ4HIP_FLUSH_STEP; } while (0)
 #define LZ4HIP_REFILL_FETCH if ((fetched + STEP <= (uint32_t)iend) & (fetched + STEP <= (ip & ~(STEP - 1u)) + KS)) { rf_pos = fetched; rf = g.rs_fetch(src, rf_pos); fetched = rf_pos + STEP; }
 #define LZ4HIP_REFILL_PUT if (fetched != avail) { g.rs_put(rf_pos, rf); avail = rf_pos + STEP; }
-#if LZ4HIP_RING_SLOTS == 2
-#define LZ4HIP_TRIP(c, a, REFILL) LZ4HIP_TRIP_(c, a, c, (void)0, (void)0, REFILL)
-#else
-#define LZ4HIP_TRIP(c, a, b, REFILL) LZ4HIP_TRIP_(c, a, b, LZ4HIP_RETIRE(b), LZ4HIP_AIM(b), REFILL)
-#endif
-  // one trip: fills slot c, puts slot a (the oldest) into the ring; n = the slot that is the oldest afterwards (its sequence starts
-  // where the retired bytes end: the flusher's bound); RETIRE_REST / AIM_REST: the other waiting slots, oldest first
-#define LZ4HIP_TRIP_(c, a, n, RETIRE_REST, AIM_REST, REFILL)                                                                    \
-  {                                                                                                                            \
-    uint32_t lit = (t4 >> 4) & 15u, ml = t4 & 15u;                                                                             \
-    const uint32_t e1 = (t4 >> 8) & 255u;                                                                                      \
-    const bool l15 = lit == 15u;                                                                                               \
-    lit += l15 ? e1 : 0u;                                                                                                      \
-    const uint32_t hdr = l15 ? 2u : 1u;                                                                                        \
-    const uint64_t o8 = g.rs_ld64(ip + hdr + lit);   /* (a literal run over 64 reads stale ring bytes: the trip leaves below) */ \
-    const uint32_t off = (uint32_t)o8 & 0xFFFFu;                                                                               \
-    const bool m15 = ml == 15u;                                                                                                \
-    const uint32_t e2 = (uint32_t)(o8 >> 16) & 255u;                                                                           \
-    ml += (m15 ? e2 : 0u) + 4u;                                                                                                \
-    const uint32_t nxt = (uint32_t)(o8 >> (m15 ? 24 : 16));                                                                    \
-    const uint32_t adv = hdr + lit + (m15 ? 3u : 2u);                                                                          \
-    const uint32_t mpos = op + lit - off;            /* where the match copies from */                                         \
-    bool near = (mpos >= rlo) & (mpos + KW >= hw);   /* the ring holds the source (unless it reaches into waiting bytes) */     \
-    if (LZ4HIP_UNLIKELY((l15 & (e1 == 255u)) | (m15 & (e2 == 255u)) | (off - 1u >= op + lit) | (lit > STEP) | (ml > STEP) |      \
-                        (!near & (mpos + ml > fl) & (mpos + ml > mt0)))) {   /* not for this loop (nothing of it done) */      \
-      LZ4HIP_RETIRE(a); RETIRE_REST; LZ4HIP_FLUSH_ALL; break; }                                                                \
-    if (LZ4HIP_UNLIKELY(mpos + ml > sop##a)) {                                                                                 \
-      /* the source reaches into bytes that wait in a slot, or into this sequence's own bytes: the slots first */              \
-      LZ4HIP_RETIRE(a); RETIRE_REST;                                                                                           \
-      uint32_t aim = op;                                                                                                       \
-      LZ4HIP_AIM(a); AIM_REST;                                                                                                 \
-      near = (mpos >= rlo) & (mpos + KW >= hw);                                                                                \
-      if (mpos + ml > op) {                          /* ... its own literals or its own output: copied inside the ring */     \
-        if (!near) { LZ4HIP_FLUSH_ALL; break; }      /* (a source the ring does not hold that overlaps its match: exact path) */ \
-        g.rg_write(op, g.rs_step(ip + hdr));                                                                                   \
-        g.rg_replicate(op + lit, off, ml);                                                                                     \
-        hw = op + lit + ml > op + STEP ? op + lit + ml : op + STEP;                                                            \
-        op += lit + ml; ip += adv; t4 = nxt;                                                                                   \
-        aim = op;                                                                                                              \
-        LZ4HIP_AIM(c); LZ4HIP_AIM(a); AIM_REST;                                                                                \
-        if (fetched != avail) { g.rs_put(rf_pos, rf); avail = rf_pos + STEP; }   /* (a piece on its way lands before the rotation restarts) */ \
-        while (op - fl >= STEP) LZ4HIP_FLUSH_STEP;                                                                             \
-        if (!((ip <= ilim) & (op <= olim) & (ip + 80u <= avail))) { LZ4HIP_FLUSH_ALL; break; }                                 \
-        continue;                                                                                                              \
-      }                                                                                                                        \
-    }                                                                                                                          \
-    if (REFILL == 1) { LZ4HIP_REFILL_FETCH }                                                                                   \
-    v##c = g.rs_step(ip + hdr);                                                                                                \
-    ul##c = g.rg_read(mpos);                                                                                                   \
-    ug##c = g.step_load(dst + (near ? fl : mpos));   /* (a near match loads a step it does not use: every trip the same operations) */ \
-    sop##c = op; lit##c = lit; nr##c = near;                                                                                   \
-    LZ4HIP_RETIRE(a);                                                                                                          \
-    if (sop##n - fl >= STEP) {                       /* a whole aligned step lies below the waiting sequences: to memory */     \
-      LZ4HIP_FLUSH_STEP;                                                                                                       \
-      while (LZ4HIP_UNLIKELY(sop##n - fl > KW - 256u)) LZ4HIP_FLUSH_STEP;   /* (the ring must keep room for two more sequences) */ \
-    }                                                                                                                          \
-    if (REFILL == 2) { LZ4HIP_REFILL_PUT }                                                                                     \
-    op += lit + ml; ip += adv; t4 = nxt;                                                                                       \
-    if (!((ip <= ilim) & (op <= olim) & (ip + 80u <= avail))) { RETIRE_REST; LZ4HIP_RETIRE(c); LZ4HIP_FLUSH_ALL; break; }       \
-  }
-  for (;;) {
-#if LZ4HIP_RING_SLOTS == 2
-    LZ4HIP_TRIP(0, 1, 1)
-    LZ4HIP_TRIP(1, 0, 2)
-#else
-    LZ4HIP_TRIP(0, 1, 2, 1)
-    LZ4HIP_TRIP(1, 2, 0, 2)
-    LZ4HIP_TRIP(2, 0, 1, 0)
-#endif
-  }
+    // one trip: fills slot c, puts slot a (filled by the trip before) into the ring
+#define LZ4HIP_TRIP(c, a, REFILL)                                                                                              \
+    {                                                                                                                          \
+      uint32_t lit = (t4 >> 4) & 15u, ml = t4 & 15u;                                                                           \
+      const uint32_t e1 = (t4 >> 8) & 255u;                                                                                    \
+      const bool l15 = lit == 15u;                                                                                             \
+      lit += l15 ? e1 : 0u;                                                                                                    \
+      const uint32_t hdr = l15 ? 2u : 1u;                                                                                      \
+      const uint64_t o8 = g.rs_ld64(ip + hdr + lit);   /* (a literal run over 64 reads stale ring bytes: the block freezes) */  \
+      uint32_t off = (uint32_t)o8 & 0xFFFFu;                                                                                   \
+      const bool m15 = ml == 15u;                                                                                              \
+      const uint32_t e2 = (uint32_t)(o8 >> 16) & 255u;                                                                         \
+      ml += (m15 ? e2 : 0u) + 4u;                                                                                              \
+      const uint32_t nxt = (uint32_t)(o8 >> (m15 ? 24 : 16));                                                                  \
+      const uint32_t adv = hdr + lit + (m15 ? 3u : 2u);                                                                        \
+      const bool inc = cm != 0u;                       /* the rest of a match is to be copied: no token is parsed */            \
+      const bool odd = !inc & ((l15 & (e1 == 255u)) | (m15 & (e2 == 255u)) | (off - 1u >= op + lit) | (lit > STEP) |            \
+                               !((ip <= ilim) & (op <= olim)));                                                                \
+      const bool hungry = !inc & (ip + 80u > avail);   /* the stream ring is short of this sequence: wait for the next piece */ \
+      lit = inc ? 0u : lit; ml = inc ? cm : ml; off = inc ? coff : off;                                                        \
+      const bool split = !inc & (lit != 0u) & (off < lit + ml);   /* the source reaches into the sequence's own literals */     \
+      const uint32_t cap = off < STEP ? off : STEP;                                                                            \
+      uint32_t me = ml < cap ? ml : cap;               /* a piece never reaches into its own output */                         \
+      me = split ? 0u : me;                                                                                                    \
+      const uint32_t mpos = op + lit - off;            /* where the match copies from */                                       \
+      const bool near = (mpos >= rlo) & (mpos + KW >= hw);   /* the ring holds the source (unless it reaches into waiting bytes) */ \
+      const bool lost = (me != 0u) & !near & (mpos + me > fl) & (mpos + me > mt0);   /* neither the ring nor flushed memory */  \
+      const bool fdue = sop##a - fl >= STEP;           /* a whole aligned step lies below the waiting pieces: to memory */      \
+      frozen = odd | (lost & !fdue);                   /* (while the flusher still has steps to store, a lost source may just be early) */ \
+      const bool stall = frozen | lost | hungry | ((me != 0u) & (mpos + me > sop##a)) | (sop##a - fl > KW - 384u) | (since >= LZ4HIP_RING_PATIENCE); \
+      if (REFILL == 1) { LZ4HIP_REFILL_FETCH }                                                                                 \
+      const LChunk fx = g.rg_read(fl);                                                                                         \
+      v##c = g.rs_step(ip + hdr);                                                                                              \
+      ul##c = g.rg_read(mpos);                                                                                                 \
+      ug##c = g.step_load(dst + ((near | stall) ? fl : mpos));   /* (a near match, a stalled trip load a step they do not use: every trip the same operations) */ \
+      sop##c = op; lit##c = stall ? 0u : lit; nr##c = near;   /* (a stalled trip's piece is empty: it is aimed at bytes that are written again) */ \
+      LZ4HIP_RETIRE(a);                                                                                                        \
+      if (fdue) { g.step_store(dst + fl, fx); fl += STEP; }                                                                    \
+      if (REFILL == 2) { LZ4HIP_REFILL_PUT }                                                                                   \
+      const bool tok = !stall & !inc;                  /* a token is consumed: the rest of its match, if any, travels in cm */   \
+      op += stall ? 0u : lit + me;                                                                                             \
+      ip = tok ? ip + adv : ip;                                                                                                \
+      t4 = tok ? nxt : t4;                                                                                                     \
+      cm = stall ? cm : ml - me;                                                                                               \
+      coff = stall ? coff : (me == off ? 2u * off : off);                                                                      \
+      since += (since != 0u) | g.any(frozen) ? 1u : 0u;                                                                        \
+    }
+    // (values that come from memory are made to arrive HERE: a wait at the loop's head would be a wait for everything every trip)
+    g.settle(t4);
+    // the branch-free loop; it is left by the whole wavefront behind a pair of trips in which everyone stalled (nothing waits in a
+    // slot then: the pieces of such trips are empty).  ONE exit, at the end of the pair: a second way back to the loop's head from
+    // the middle of the pair would carry the first trip's load across it, and the compiler would wait for everything at the head.
+    for (;;) {
+      const bool last = since >= LZ4HIP_RING_PATIENCE;
+      LZ4HIP_TRIP(0, 1, 1)
+      LZ4HIP_TRIP(1, 0, 2)
+      if (last) break;
+    }
 #undef LZ4HIP_TRIP
-#undef LZ4HIP_TRIP_
 #undef LZ4HIP_REFILL_FETCH
 #undef LZ4HIP_REFILL_PUT
-#undef LZ4HIP_FLUSH_ALL
-#undef LZ4HIP_FLUSH_STEP
-#undef LZ4HIP_AIM
 #undef LZ4HIP_RETIRE
-  // (every way out has put the waiting sequences into the ring, oldest first, and flushed the ring up to op -- the last step may
-  // carry ring bytes past op: positions of this block that are written again, op <= oend - 606)
+    // nothing waits in a slot (the last pieces were empty); ring and memory together hold everything below op.  Every block of
+    // the wavefront goes through memory and a re-seed here, frozen or not (the ones that only waited for another block skip the
+    // sequence step)
+    while ((int32_t)(op - fl) > 0) { g.step_store(dst + fl, g.rg_read(fl)); fl += STEP; }   // whole steps; the last one may carry ring bytes past op: positions that are written again
+    if (cm != 0u) {                       // the rest of a match whose source neither the ring nor flushed memory held: through memory
+      g.copy_match_wide(dst, op, coff, cm);
+      op += cm; cm = 0u;
+    } else if (frozen) {
+      // one sequence through memory, with the plain interior loop's rules (lz4_decode_core.h): lengths with at most one extension
+      // byte, a valid offset, far from both ends; anything else -- and the end of the loop's range -- is for the caller
+      uint32_t lit = (t4 >> 4) & 15u, ml = t4 & 15u;
+      const uint32_t e1 = (t4 >> 8) & 255u;
+      const bool l15 = lit == 15u;
+      lit += l15 ? e1 : 0u;
+      const uint32_t hdr = l15 ? 2u : 1u;
+      if ((l15 & (e1 == 255u)) | !((ip <= ilim) & (op <= olim))) leave = true;
+      else {
+        const uint64_t o8 = g.ld64(src + ip + hdr + lit);
+        const uint32_t off = (uint32_t)o8 & 0xFFFFu;
+        const bool m15 = ml == 15u;
+        const uint32_t e2 = (uint32_t)(o8 >> 16) & 255u;
+        ml += (m15 ? e2 : 0u) + 4u;
+        if ((m15 & (e2 == 255u)) | (off - 1u >= op + lit)) leave = true;
+        else {
+          g.copy_lits_wide(dst + op, src + ip + hdr, lit);
+          g.copy_match_wide(dst, op + lit, off, ml);
+          op += lit + ml; ip += hdr + lit + (m15 ? 3u : 2u);
+          t4 = g.ld32(src + ip);
+        }
+      }
+    }
+    if (leave | !((ip <= ilim) & (op <= olim) & (ip + 320u <= (uint32_t)iend))) break;
+  }
   ip_io = (int)ip; op_io = (int)op;
-  return (ip <= ilim) & (op <= olim) & (ip + 80u > avail) & (ip + 320u <= (uint32_t)iend);
+  return !leave & (ip <= ilim) & (op <= olim) & (ip + 320u <= (uint32_t)iend);
 }
 
 }  // namespace lz4hip

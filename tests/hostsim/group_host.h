@@ -261,6 +261,8 @@ struct GroupHost {
       }
     }
   }
+  static bool any(bool x) { return x; }   // (the simulated "wavefront" is this one group)
+  static void settle(uint32_t&) {}
   static LChunk pick(bool first, const LChunk& a, const LChunk& b) { return first ? a : b; }
 
   void copy_match(uint8_t* dst, uint32_t op, uint32_t offset, uint32_t len, bool wild) {

@@ -254,6 +254,8 @@ def test_decode_core_fuzz(sim, ref, O, corpus):
         gl = rng.choice([4, 8, 16, 32, 64]) | rng.choice([0, 0x100, 0x200])   # bit 8: the pipelined interior loop, bit 9: output staging
         if rng.random() < 0.25:
             gl = rng.choice([4, 8, 16]) | 0x400                                  # bit 10: the deep interior loop
+        elif rng.random() < 0.33:
+            gl = rng.choice([4, 8, 16]) | 0x800 | (rng.choice([9, 10, 11, 12]) << 12)   # bit 11: the ring loop; bits 12..15: log2 of its output ring
         r2, d2 = ref.decompress_safe_raw(c, cap)
         r1, d1 = sim_decode(sim, c, cap, 1, gl)
         assert r1 == r2 and (r2 < 0 or d1[:r2] == d2[:r2]), ("safe", mode, gl, len(v), cap, r1, r2)
