@@ -960,6 +960,12 @@ int lz4hip_device_count(void) {
   return (int)g_devs.size();
 }
 
+#ifdef LZ4HIP_RING_DBG
+}  // extern "C"
+namespace lz4hip { int ring_stats_fetch(unsigned long long* out8); }
+extern "C" {
+__attribute__((visibility("default"))) int lz4hip_dbg_ring_stats(unsigned long long* out8) { return lz4hip::ring_stats_fetch(out8); }
+#endif
 int lz4hip_set_option(const char* name, int value) {
   if (name && strcmp(name, "decode_stage") == 0) {
     if (value < -1 || value > 1) return fail(LZ4HIP_E_ARG, "decode_stage must be -1, 0 or 1");

@@ -14,6 +14,9 @@
 #define LZ4HIP_MATCH_LOAD(p) (*(p))
 #endif
 namespace lz4hip {
+#ifdef LZ4HIP_RING_DBG
+__device__ unsigned long long g_ring_stat[8];   // developer build: trips, stalled trips, frozen trips, (re-)seeds, trips spent waiting for another block, loop entries
+#endif
 
 // KW: bytes of the output ring of the ring loop (lz4_decode_ring.h; 0 = the other loops)
 template <int GL, int KW = 0>
@@ -224,53 +227,98 @@ struct GroupDev {
   __device__ __forceinline__ static constexpr uint32_t ring_bytes() { return kRing; }
   __device__ __forceinline__ static constexpr uint32_t ring_stream() { return kRs; }
   __device__ __forceinline__ uint32_t ring_dbase() const { return dbase; }
+  // Every LDS access below is NATURALLY ALIGNED, and what the bytes' real position asks for is done in registers.  Measured
+  // (tools/ubench/lds_unaligned.hip, lds_masked.hip; profiles/r04_lds_alignment.txt): an LDS instruction whose lanes are not aligned to
+  // the access width (b32: 4, b64: 8, b128: 16) is served ONE LANE PER CYCLE -- 64 LDS cycles for a wavefront's unaligned read or
+  // write against 2..8 for an aligned one, ~45 with twelve wavefronts per CU contending; with sixteen wavefronts that alone is more
+  // than a thousand cycles per trip and instruction.  So: reads fetch whole dwords (LB / 4 + 1 of them from the dword below the
+  // position) and funnel them with v_alignbyte; writes store the step as aligned dwords by lanes 1.. of the group (each lane's chunk
+  // moved up by the position's byte offset: one dword from the lane below, v_perm for the rest) and only lane 0 -- whose chunk would
+  // need the ring's old bytes in front of the position -- stores its LB bytes where they belong (4 .. 16 unaligned lanes per
+  // wavefront: 4 .. 16 cycles).  A step written at position w covers [w, w + 64 - (w & 3)): pieces are at most 60 bytes long.
+  __device__ __forceinline__ static const uint32_t* dwp(const uint8_t* p) { return (const uint32_t*)__builtin_assume_aligned(p, 4); }
+  __device__ __forceinline__ static uint32_t* dwp(uint8_t* p) { return (uint32_t*)__builtin_assume_aligned(p, 4); }
+  // LB bytes at byte offset s (0..3) of the LB / 4 + 1 dwords d[]
+  __device__ __forceinline__ static LChunk funnel(const uint32_t* d, uint32_t s) {
+    LChunk v;
+#pragma unroll
+    for (uint32_t k = 0; k < LB / 4u; k++) v.w[k] = __builtin_amdgcn_alignbyte(d[k + 1], d[k], s);
+    return v;
+  }
   // stream side
   __device__ __forceinline__ LChunk rs_fetch(const uint8_t* src, uint32_t pos) const {   // pos: multiple of 64; [pos, pos + 64) is readable
     LChunk r;
     __builtin_memcpy(&r, src + pos + l * LB, LB);
     return r;
   }
-  __device__ __forceinline__ void rs_put(uint32_t pos, const LChunk& r) {
+  __device__ __forceinline__ void rs_put(uint32_t pos, const LChunk& r) {   // (aligned: pos is a multiple of 64, the lane's chunk of LB)
     const uint32_t q = (pos & (kRs - 1u)) + l * LB;
-    __builtin_memcpy(rsb + q, &r, LB);
-    if (q < 16u) __builtin_memcpy(rsb + kRs + q, &r, LB);
+    __builtin_memcpy(__builtin_assume_aligned(rsb + q, LB), &r, LB);
+    if (q < 16u) __builtin_memcpy(__builtin_assume_aligned(rsb + kRs + q, LB), &r, LB);
   }
-  __device__ __forceinline__ uint32_t rs_ld32(uint32_t p) const { uint32_t v; __builtin_memcpy(&v, rsb + (p & (kRs - 1u)), 4); return v; }
-  __device__ __forceinline__ uint64_t rs_ld64(uint32_t p) const { uint64_t v; __builtin_memcpy(&v, rsb + (p & (kRs - 1u)), 8); return v; }
-  __device__ __forceinline__ LChunk rs_step(uint32_t p) const {
-    LChunk v;
-    __builtin_memcpy(&v, rsb + ((p + l * LB) & (kRs - 1u)), LB);
-    return v;
+  __device__ __forceinline__ uint64_t rs_ld64(uint32_t p) const {   // the 8 stream bytes at p (every lane of the group the same)
+    const uint32_t* q = dwp(rsb + (p & (kRs - 1u) & ~3u));
+    const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], s = p & 3u;
+    return (uint64_t)__builtin_amdgcn_alignbyte(d1, d0, s) | ((uint64_t)__builtin_amdgcn_alignbyte(d2, d1, s) << 32);
+  }
+  __device__ __forceinline__ LChunk rs_step(uint32_t p) const {     // this lane's LB bytes of the 64 stream bytes at p
+    const uint32_t* q = dwp(rsb + ((p + l * LB) & (kRs - 1u) & ~3u));
+    uint32_t d[LB / 4u + 1u];
+#pragma unroll
+    for (uint32_t k = 0; k <= LB / 4u; k++) d[k] = q[k];
+    return funnel(d, p & 3u);
   }
   // output side
   __device__ __forceinline__ LChunk rg_read(uint32_t pos) const {   // this lane's LB bytes of the 64 output bytes at pos
+    const uint32_t x = pos + dbase + l * LB;
+    const uint32_t* q = dwp(rgb + (x & (kRing - 1u) & ~3u));
+    uint32_t d[LB / 4u + 1u];
+#pragma unroll
+    for (uint32_t k = 0; k <= LB / 4u; k++) d[k] = q[k];
+    return funnel(d, x & 3u);
+  }
+  __device__ __forceinline__ LChunk rg_read_al(uint32_t pos) const {   // the same for an aligned step (the flusher's)
     LChunk v;
-    __builtin_memcpy(&v, rgb + ((pos + dbase + l * LB) & (kRing - 1u)), LB);
+    __builtin_memcpy(&v, __builtin_assume_aligned(rgb + ((pos + dbase + l * LB) & (kRing - 1u)), LB), LB);
     return v;
   }
-  __device__ __forceinline__ void rg_write(uint32_t pos, const LChunk& v) {
-    const uint32_t t = (pos + dbase + l * LB + LB) & (kRing - 1u);
-    __builtin_memcpy((rgb - LB) + t, &v, LB);
-    if (t < 2u * LB) __builtin_memcpy((rgb - LB) + t + kRing, &v, LB);
-  }
-  __device__ __forceinline__ uint32_t rg_ld8(uint32_t pos) const { return rgb[(pos + dbase) & (kRing - 1u)]; }
-  __device__ __forceinline__ void rg_st8(uint32_t pos, uint32_t b) {
-    const uint32_t t = (pos + dbase + LB) & (kRing - 1u);
-    (rgb - LB)[t] = (uint8_t)b;
-    if (t < 2u * LB) (rgb - LB)[t + kRing] = (uint8_t)b;
-  }
-  // ring[op + i] = ring[op - offset + (i mod offset)], i in [0, len): a match that overlaps its own output, copied inside the ring
-  // (one byte per lane and round; a round reads only bytes in front of the match)
-  __device__ __forceinline__ void rg_replicate(uint32_t op, uint32_t offset, uint32_t len) {
-    const uint32_t m = op - offset;
-    uint32_t r = l < offset ? l : l % offset;
-    const uint32_t stp = GL < offset ? (uint32_t)GL : (uint32_t)GL % offset;
-    for (uint32_t i = l; i < len; i += GL) {
-      rg_st8(op + i, rg_ld8(m + r));
-      r += stp;
-      if (r >= offset) r -= offset;
+  // chunk c (LB bytes, any alignment or dword alignment -- the caller knows) to ring index x: at t - LB with t = (x + LB) & (KW - 1),
+  // and once more KW bytes on when t < 2 LB (the mirror rule above)
+  __device__ __forceinline__ void rg_put(uint32_t x, const LChunk& c, bool aligned) {
+    const uint32_t t = (x + LB) & (kRing - 1u);
+    uint8_t* a = (rgb - LB) + t;
+    if (aligned) {
+      __builtin_memcpy(__builtin_assume_aligned(a, 4), &c, LB);
+      if (t < 2u * LB) __builtin_memcpy(__builtin_assume_aligned(a + kRing, 4), &c, LB);
+    } else {
+      __builtin_memcpy(a, &c, LB);
+      if (t < 2u * LB) __builtin_memcpy(a + kRing, &c, LB);
     }
   }
+  // the 64-byte step v (lane j holds bytes [j LB, j LB + LB)) to output position pos: covers [pos, pos + 64 - s), s = ring index & 3
+  __device__ __forceinline__ void rg_write(uint32_t pos, const LChunk& v) {
+    const uint32_t w = pos + dbase, s = w & 3u;
+    // lanes 1..: the aligned chunk at (w & ~3) + l LB holds the step's bytes [l LB - s, l LB - s + LB): this lane's dwords moved up
+    // by s bytes, the lowest bytes from the top dword of the lane below
+    const uint32_t below = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.w[LB / 4u - 1u], 0x111 /* row_shr:1 */, 0xF, 0xF, false);
+    const uint32_t sel = 0x03020100u + (4u - s) * 0x01010101u;   // v_perm selector: bytes [4 - s, 8 - s) of {hi, lo}
+    LChunk m;
+#pragma unroll
+    for (uint32_t k = 0; k < LB / 4u; k++) m.w[k] = __builtin_amdgcn_perm(v.w[k], k ? v.w[k - 1u] : below, sel);
+    if (l != 0u) rg_put((w & ~3u) + l * LB, m, true);
+    else rg_put(w, v, false);   // lane 0: its bytes where they belong (the only unaligned lanes: 64 / GL per wavefront)
+  }
+#ifdef LZ4HIP_RING_DBG
+  __device__ __forceinline__ void ring_stats(uint32_t trips, uint32_t stall, uint32_t frozen, uint32_t seeds, uint32_t wait, uint32_t wtrips) const {
+    atomicAdd(&g_ring_stat[6], (unsigned long long)wtrips);
+    if (l == 0u) {
+      atomicAdd(&g_ring_stat[0], (unsigned long long)trips); atomicAdd(&g_ring_stat[1], (unsigned long long)stall);
+      atomicAdd(&g_ring_stat[2], (unsigned long long)frozen); atomicAdd(&g_ring_stat[3], (unsigned long long)seeds);
+      atomicAdd(&g_ring_stat[4], (unsigned long long)wait); atomicAdd(&g_ring_stat[5], 1ull);
+    }
+  }
+#endif
+  __device__ __forceinline__ static bool first_active() { return __builtin_amdgcn_mbcnt_hi(__builtin_amdgcn_read_exec_hi(), __builtin_amdgcn_mbcnt_lo(__builtin_amdgcn_read_exec_lo(), 0u)) == 0u; }
   __device__ __forceinline__ static bool any(bool x) { return __builtin_amdgcn_ballot_w64(x) != 0ull; }   // over the wavefront's active lanes
   // every vector memory operation issued so far is waited for HERE (the compiler's wait-count pass sees the instruction: a loop
   // entered behind it has nothing outstanding on its entry edge, so the waits inside count only the loop's own operations)

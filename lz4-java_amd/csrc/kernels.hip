@@ -607,6 +607,14 @@ static int launch_decode_gl(const BatchArgs& a, bool safe, int pipe, bool stage,
   return (int)hipGetLastError();
 }
 
+#ifdef LZ4HIP_RING_DBG
+int ring_stats_fetch(unsigned long long* out8) {   // developer build: reads and clears the ring loop's counters
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_ring_stat), sizeof z);
+  if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_ring_stat), z, sizeof z);
+  return (int)e;
+}
+#endif
 int launch_decompress(const BatchArgs& a, bool safe, int lanes_per_block, int pipe, int stage, int ring, void* stream) {
   if (a.n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;

@@ -20,8 +20,9 @@
 //      - a match that overlaps its own output (offset < length), or is longer than 64: the piece is min(length, offset, 64) bytes,
 //        the rest is carried in {cm, coff} and copied by the next trips -- with the offset DOUBLED after every piece that was a whole
 //        period (any multiple of the period is a period), so a run reaches 64 bytes per trip after six pieces;
+//      - a literal run of more than 60 bytes: 60 per trip, the rest is carried in {cl, ipl};
 //      - the flusher behind, the stream ring short of bytes at a sequence start: stalls as well;
-//    what is left -- literal runs over 64, length runs of two or more bytes, invalid offsets, a source neither the ring nor flushed
+//    what is left -- literal runs of more than ~180 bytes, length runs of two or more bytes, invalid offsets, a source neither the ring nor flushed
 //    memory holds (right behind an entry only), the end of the loop's range -- FREEZES the block (it stalls until the loop is left);
 //    the wavefront leaves the loop a few trips after the first block froze, each frozen block does its one sequence through memory
 //    (or leaves for the exact code of decode_block), re-seeds its rings, and the loop is entered again.
@@ -32,6 +33,9 @@
 #include <stdint.h>
 #ifndef LZ4HIP_UNLIKELY
 #define LZ4HIP_UNLIKELY(x) __builtin_expect(!!(x), 0)
+#endif
+#ifndef LZ4HIP_RING_SLOTS
+#define LZ4HIP_RING_SLOTS 3      /* pieces in the pipeline: a far source has LZ4HIP_RING_SLOTS - 1 trips to arrive (2, 3 or 4) */
 #endif
 #ifndef LZ4HIP_RING_PATIENCE
 #define LZ4HIP_RING_PATIENCE 4   /* trips the wavefront goes on after the first block froze */
@@ -46,15 +50,27 @@ template <class Grp>
 LZ4HIP_DEV bool decode_ring_loop(Grp& g, const uint8_t* src, const int iend, uint8_t* dst, const int oend, int& ip_io, int& op_io, uint8_t* lds) {
   typedef typename Grp::LChunk LChunk;
   const uint32_t KW = g.ring_bytes(), KS = g.ring_stream(), STEP = 64u;
+  const uint32_t PIECE = 60u;          // bytes of literals / of match a trip emits at most (a step written at an odd address covers 64 - 3)
   uint32_t ip = (uint32_t)ip_io, op = (uint32_t)op_io;
   const uint32_t ilim = (uint32_t)iend - 306u, olim = (uint32_t)oend - 606u;
   g.ring_begin(lds, dst);
-  uint32_t avail, fetched, rf_pos, fl, hw, rlo, mt0;
+  uint32_t avail, fetched, rf_pos, fl, rlo, mt0;
   uint32_t t4 = g.ld32(src + ip);      // the token word at ip
-  uint32_t cm = 0, coff = 0;           // match bytes of the sequence in front of ip that are not copied yet, and the offset they use
+  // what is left of the sequence in front of ip (its token is consumed when its first piece is emitted): cl literal bytes from stream
+  // position ipl on, then cm match bytes at offset coff
+  uint32_t cl = 0, ipl = 0, cm = 0, coff = 0;
   LChunk rf;
   bool leave = false;
+#ifdef LZ4HIP_RING_DBG   /* developer build: what the loop did (tools/ring_stats.py) */
+  uint32_t dbg_trips = 0, dbg_stall = 0, dbg_frozen = 0, dbg_seeds = 0, dbg_wait = 0, dbg_wtrips = 0;
+#define LZ4HIP_RING_COUNT(stall_, frozen_, wait_) do { dbg_trips++; dbg_wtrips += g.first_active() ? 1u : 0u; dbg_stall += (stall_); dbg_frozen += (frozen_); dbg_wait += (wait_); } while (0)
+#else
+#define LZ4HIP_RING_COUNT(stall_, frozen_, wait_) do { } while (0)
+#endif
   for (;;) {
+#ifdef LZ4HIP_RING_DBG
+    dbg_seeds++;
+#endif
     // ---- (re-)seed the rings: everything below op is in memory ----
     // stream ring: holds [.., avail); `fetched` = end of what has been requested
     avail = ip & ~(STEP - 1u);
@@ -68,22 +84,28 @@ LZ4HIP_DEV bool decode_ring_loop(Grp& g, const uint8_t* src, const int iend, uin
     fl = op - ((g.ring_dbase() + op) & (STEP - 1u));
     rlo = fl;                                              // the ring holds nothing below this position
     g.rg_write(fl, g.step_load(dst + fl));
-    hw = fl + STEP;                                        // end of everything ever written into the ring: it holds [hw - KW, hw)
-    // slots: literals v, match source from the ring (ul) / from memory (ug), nr = which of the two it is; sop = output position
-    // of the piece, lit = its literal length
-    LChunk v0 = LChunk(), ul0 = LChunk(), ug0 = LChunk(), v1 = LChunk(), ul1 = LChunk(), ug1 = LChunk();
-    uint32_t sop0 = op, sop1 = op, lit0 = 0, lit1 = 0;
-    bool nr0 = true, nr1 = true;
+    // slots: literals v and -- far matches only -- the match source from memory (ug) of a piece; sop = its output position, lit = its
+    // literal length, mp = where its match copies from, nr = the source is read from the ring (when the piece is put there)
+    LChunk v0 = LChunk(), ug0 = LChunk(), v1 = LChunk(), ug1 = LChunk(), v2 = LChunk(), ug2 = LChunk(), v3 = LChunk(), ug3 = LChunk();
+    uint32_t sop0 = op, sop1 = op, sop2 = op, sop3 = op, lit0 = 0, lit1 = 0, lit2 = 0, lit3 = 0, mp0 = op, mp1 = op, mp2 = op, mp3 = op;
+    bool nr0 = true, nr1 = true, nr2 = true, nr3 = true;
+    (void)v2; (void)ug2; (void)v3; (void)ug3; (void)sop2; (void)sop3; (void)lit2; (void)lit3; (void)mp2; (void)mp3; (void)nr2; (void)nr3;
     bool frozen = false;
     uint32_t since = 0;                                    // trips since the first block of the wavefront froze (wave-uniform)
 
-#define LZ4HIP_RETIRE(k) do { const LChunk u_ = Grp::pick(nr##k, ul##k, ug##k); g.rg_write(sop##k, v##k); g.rg_write(sop##k + lit##k, u_); \
-                              hw = sop##k + lit##k + STEP; } while (0)
-#define LZ4HIP_REFILL_FETCH if ((fetched + STEP <= (uint32_t)iend) & (fetched + STEP <= (ip & ~(STEP - 1u)) + KS)) { rf_pos = fetched; rf = g.rs_fetch(src, rf_pos); fetched = rf_pos + STEP; }
+#define LZ4HIP_REFILL_FETCH if ((fetched + STEP <= (uint32_t)iend) & (fetched + STEP <= ((cl ? ipl : ip) & ~(STEP - 1u)) + KS)) { rf_pos = fetched; rf = g.rs_fetch(src, rf_pos); fetched = rf_pos + STEP; }
 #define LZ4HIP_REFILL_PUT if (fetched != avail) { g.rs_put(rf_pos, rf); avail = rf_pos + STEP; }
-    // one trip: fills slot c, puts slot a (filled by the trip before) into the ring
+    // one trip: fills slot c, puts slot a (the oldest: filled LZ4HIP_RING_SLOTS - 1 trips ago) into the ring.
+    // Pieces go into the ring in sequence order, and a near source is read from the ring only WHEN ITS PIECE GOES IN -- behind the
+    // piece's own literals: everything in front of the match is in the ring by then, so a source may reach into waiting pieces and
+    // into its own literals at no cost, and a piece waits for nothing but a far source's load.  (The literals are written and the
+    // source is requested at the head of the trip, the match is written at its end: the LDS round trip lies under the parse.)
 #define LZ4HIP_TRIP(c, a, REFILL)                                                                                              \
     {                                                                                                                          \
+      g.rg_write(sop##a, v##a);                                                                                                \
+      const LChunk ul = g.rg_read(mp##a);                                                                                      \
+      const bool fdue = sop##a - fl >= STEP;           /* a whole aligned step lies below the waiting pieces: to memory */      \
+      const LChunk fx = g.rg_read_al(fl);                                                                                         \
       uint32_t lit = (t4 >> 4) & 15u, ml = t4 & 15u;                                                                           \
       const uint32_t e1 = (t4 >> 8) & 255u;                                                                                    \
       const bool l15 = lit == 15u;                                                                                             \
@@ -96,58 +118,74 @@ LZ4HIP_DEV bool decode_ring_loop(Grp& g, const uint8_t* src, const int iend, uin
       ml += (m15 ? e2 : 0u) + 4u;                                                                                              \
       const uint32_t nxt = (uint32_t)(o8 >> (m15 ? 24 : 16));                                                                  \
       const uint32_t adv = hdr + lit + (m15 ? 3u : 2u);                                                                        \
-      const bool inc = cm != 0u;                       /* the rest of a match is to be copied: no token is parsed */            \
-      const bool odd = !inc & ((l15 & (e1 == 255u)) | (m15 & (e2 == 255u)) | (off - 1u >= op + lit) | (lit > STEP) |            \
+      const bool inc = (cl | cm) != 0u;                /* the rest of a sequence is to be copied: no token is parsed */          \
+      const uint32_t need = hdr + lit + 8u;            /* stream bytes the parse of this sequence reads */                     \
+      const bool odd = !inc & ((l15 & (e1 == 255u)) | (m15 & (e2 == 255u)) | (off - 1u >= op + lit) | (need > KS - 72u) |        \
                                !((ip <= ilim) & (op <= olim)));                                                                \
-      const bool hungry = !inc & (ip + 80u > avail);   /* the stream ring is short of this sequence: wait for the next piece */ \
-      lit = inc ? 0u : lit; ml = inc ? cm : ml; off = inc ? coff : off;                                                        \
-      const bool split = !inc & (lit != 0u) & (off < lit + ml);   /* the source reaches into the sequence's own literals */     \
-      const uint32_t cap = off < STEP ? off : STEP;                                                                            \
-      uint32_t me = ml < cap ? ml : cap;               /* a piece never reaches into its own output */                         \
-      me = split ? 0u : me;                                                                                                    \
-      const uint32_t mpos = op + lit - off;            /* where the match copies from */                                       \
-      const bool near = (mpos >= rlo) & (mpos + KW >= hw);   /* the ring holds the source (unless it reaches into waiting bytes) */ \
-      const bool lost = (me != 0u) & !near & (mpos + me > fl) & (mpos + me > mt0);   /* neither the ring nor flushed memory */  \
-      const bool fdue = sop##a - fl >= STEP;           /* a whole aligned step lies below the waiting pieces: to memory */      \
-      frozen = odd | (lost & !fdue);                   /* (while the flusher still has steps to store, a lost source may just be early) */ \
-      const bool stall = frozen | lost | hungry | ((me != 0u) & (mpos + me > sop##a)) | (sop##a - fl > KW - 384u) | (since >= LZ4HIP_RING_PATIENCE); \
+      const bool hungry = !inc & (ip + (need < 80u ? 80u : need) > avail);   /* the stream ring is short of this sequence: wait for the next piece */ \
+      lit = inc ? cl : lit; ml = inc ? cm : ml; off = inc ? coff : off;                                                        \
+      const uint32_t lpos = inc ? ipl : ip + hdr;      /* where the literals are read from */                                  \
+      const uint32_t le = lit < PIECE ? lit : PIECE;   /* this trip's literals; its match bytes only once the literals are done */ \
+      const uint32_t cap = off < PIECE ? off : PIECE;                                                                          \
+      const uint32_t me = (le == lit) ? (ml < cap ? ml : cap) : 0u;   /* a piece never reaches into its own match bytes */      \
+      const uint32_t mpos = op + le - off;             /* where the match copies from */                                       \
+      const bool near = (mpos >= rlo) & (mpos + KW >= op + 2u * STEP);   /* the ring will still hold the source when this piece goes in */ \
+      const bool lost = (me != 0u) & !near & (mpos + me > fl) & (mpos + me > mt0);   /* ... nor does flushed memory hold it (yet) */         \
+      frozen = odd | (lost & !fdue & (sop##a == op));  /* (a lost source may just be early while pieces wait or the flusher has steps to store) */ \
+      const bool stall = odd | lost | hungry | (op - fl > KW - 320u) | (since >= LZ4HIP_RING_PATIENCE);                         \
+      LZ4HIP_RING_COUNT(stall, frozen, !frozen & (since >= LZ4HIP_RING_PATIENCE));                                           \
       if (REFILL == 1) { LZ4HIP_REFILL_FETCH }                                                                                 \
-      const LChunk fx = g.rg_read(fl);                                                                                         \
-      v##c = g.rs_step(ip + hdr);                                                                                              \
-      ul##c = g.rg_read(mpos);                                                                                                 \
-      ug##c = g.step_load(dst + ((near | stall) ? fl : mpos));   /* (a near match, a stalled trip load a step they do not use: every trip the same operations) */ \
-      sop##c = op; lit##c = stall ? 0u : lit; nr##c = near;   /* (a stalled trip's piece is empty: it is aimed at bytes that are written again) */ \
-      LZ4HIP_RETIRE(a);                                                                                                        \
+      v##c = g.rs_step(lpos);                                                                                                  \
+      /* (a near or empty piece loads the step that was flushed last and does not use it: every trip issues the same operations,   \
+         so the compiler can count how many a wait may leave outstanding) */                                                   \
+      const bool nomem = near | stall | (me == 0u);    /* nothing is needed from memory */                                    \
+      ug##c = g.step_load(dst + (nomem ? (fl < STEP ? STEP : fl) - STEP : mpos));                                     \
+      sop##c = op; lit##c = stall ? 0u : le; mp##c = mpos; nr##c = nomem;   /* (a stalled trip's piece is empty: it is aimed at bytes that are written again) */ \
       if (fdue) { g.step_store(dst + fl, fx); fl += STEP; }                                                                    \
       if (REFILL == 2) { LZ4HIP_REFILL_PUT }                                                                                   \
       const bool tok = !stall & !inc;                  /* a token is consumed: the rest of its match, if any, travels in cm */   \
-      op += stall ? 0u : lit + me;                                                                                             \
+      op += stall ? 0u : le + me;                                                                                              \
       ip = tok ? ip + adv : ip;                                                                                                \
       t4 = tok ? nxt : t4;                                                                                                     \
+      cl = stall ? cl : lit - le;                                                                                              \
+      ipl = stall ? ipl : lpos + le;                                                                                           \
       cm = stall ? cm : ml - me;                                                                                               \
       coff = stall ? coff : (me == off ? 2u * off : off);                                                                      \
       since += (since != 0u) | g.any(frozen) ? 1u : 0u;                                                                        \
+      g.rg_write(sop##a + lit##a, Grp::pick(nr##a, ul, ug##a));                                                                \
     }
     // (values that come from memory are made to arrive HERE: a wait at the loop's head would be a wait for everything every trip)
     g.settle(t4);
-    // the branch-free loop; it is left by the whole wavefront behind a pair of trips in which everyone stalled (nothing waits in a
-    // slot then: the pieces of such trips are empty).  ONE exit, at the end of the pair: a second way back to the loop's head from
-    // the middle of the pair would carry the first trip's load across it, and the compiler would wait for everything at the head.
+    // the branch-free loop; it is left by the whole wavefront behind a round of trips in which everyone stalled (nothing waits in a
+    // slot then: the pieces of such trips are empty).  ONE exit, at the end of the round: a second way back to the loop's head from
+    // the middle of it would carry a trip's load across the head, and the compiler would wait for everything there.
     for (;;) {
       const bool last = since >= LZ4HIP_RING_PATIENCE;
+#if LZ4HIP_RING_SLOTS == 2
       LZ4HIP_TRIP(0, 1, 1)
       LZ4HIP_TRIP(1, 0, 2)
+#elif LZ4HIP_RING_SLOTS == 3
+      LZ4HIP_TRIP(0, 1, 1)
+      LZ4HIP_TRIP(1, 2, 2)
+      LZ4HIP_TRIP(2, 0, 0)
+#else
+      LZ4HIP_TRIP(0, 1, 1)
+      LZ4HIP_TRIP(1, 2, 2)
+      LZ4HIP_TRIP(2, 3, 1)
+      LZ4HIP_TRIP(3, 0, 2)
+#endif
       if (last) break;
     }
 #undef LZ4HIP_TRIP
 #undef LZ4HIP_REFILL_FETCH
 #undef LZ4HIP_REFILL_PUT
-#undef LZ4HIP_RETIRE
     // nothing waits in a slot (the last pieces were empty); ring and memory together hold everything below op.  Every block of
     // the wavefront goes through memory and a re-seed here, frozen or not (the ones that only waited for another block skip the
     // sequence step)
-    while ((int32_t)(op - fl) > 0) { g.step_store(dst + fl, g.rg_read(fl)); fl += STEP; }   // whole steps; the last one may carry ring bytes past op: positions that are written again
-    if (cm != 0u) {                       // the rest of a match whose source neither the ring nor flushed memory held: through memory
+    while ((int32_t)(op - fl) > 0) { g.step_store(dst + fl, g.rg_read_al(fl)); fl += STEP; }   // whole steps; the last one may carry ring bytes past op: positions that are written again
+    if ((cl | cm) != 0u) {                // the rest of a sequence that was under way: through memory
+      g.copy_lits_wide(dst + op, src + ipl, cl);
+      op += cl; cl = 0u;
       g.copy_match_wide(dst, op, coff, cm);
       op += cm; cm = 0u;
     } else if (frozen) {
@@ -176,6 +214,10 @@ LZ4HIP_DEV bool decode_ring_loop(Grp& g, const uint8_t* src, const int iend, uin
     }
     if (leave | !((ip <= ilim) & (op <= olim) & (ip + 320u <= (uint32_t)iend))) break;
   }
+#ifdef LZ4HIP_RING_DBG
+  g.ring_stats(dbg_trips, dbg_stall, dbg_frozen, dbg_seeds, dbg_wait, dbg_wtrips);
+#endif
+#undef LZ4HIP_RING_COUNT
   ip_io = (int)ip; op_io = (int)op;
   return !leave & (ip <= ilim) & (op <= olim) & (ip + 320u <= (uint32_t)iend);
 }

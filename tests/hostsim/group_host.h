@@ -231,35 +231,24 @@ struct GroupHost {
     for (int l = 0; l < GL; l++) { const uint8_t* q = rgb + ((pos + dbase + l * LB) & (kRing - 1u)); if (rl_ok(q, LB)) memcpy(v.b[l], q, LB); }
     return v;
   }
+  LChunk rg_read_al(uint32_t pos) { if ((pos + dbase) & 63u) oob = true; return rg_read(pos); }   // (the flusher's steps are aligned)
+  // one chunk of LB bytes to ring index x with the device backend's mirror rule
+  void rg_put(uint32_t x, const uint8_t* c) {
+    const uint32_t LB = lb();
+    const uint32_t t = (x + LB) & (kRing - 1u);
+    if (rl_ok((rgb - LB) + t, LB)) memcpy((rgb - LB) + t, c, LB);
+    if (t < 2u * LB && rl_ok((rgb - LB) + t + kRing, LB)) memcpy((rgb - LB) + t + kRing, c, LB);
+  }
+  // the device backend stores a step as ALIGNED chunks (lanes 1..: the step's bytes [l LB - s, l LB - s + LB) at the dword-aligned
+  // index below) plus lane 0's own bytes at the position: it covers [pos, pos + 64 - s), s = ring index & 3 -- exactly that here
   void rg_write(uint32_t pos, const LChunk& v) {
     const uint32_t LB = lb();
-    for (int l = 0; l < GL; l++) {
-      const uint32_t t = (pos + dbase + l * LB + LB) & (kRing - 1u);
-      if (rl_ok((rgb - LB) + t, LB)) memcpy((rgb - LB) + t, v.b[l], LB);
-      if (t < 2u * LB && rl_ok((rgb - LB) + t + kRing, LB)) memcpy((rgb - LB) + t + kRing, v.b[l], LB);
-    }
-  }
-  uint32_t rg_ld8(uint32_t pos) { const uint8_t* q = rgb + ((pos + dbase) & (kRing - 1u)); return rl_ok(q, 1) ? *q : 0; }
-  void rg_st8(uint32_t pos, uint32_t b) {
-    const uint32_t LB = lb();
-    const uint32_t t = (pos + dbase + LB) & (kRing - 1u);
-    if (rl_ok((rgb - LB) + t, 1)) (rgb - LB)[t] = (uint8_t)b;
-    if (t < 2u * LB && rl_ok((rgb - LB) + t + kRing, 1)) (rgb - LB)[t + kRing] = (uint8_t)b;
-  }
-  void rg_replicate(uint32_t op, uint32_t offset, uint32_t len) {
-    ring_repl++;
-    const uint32_t m = op - offset;
-    uint32_t r[64];
-    for (int l = 0; l < GL; l++) r[l] = (uint32_t)l < offset ? (uint32_t)l : (uint32_t)l % offset;
-    const uint32_t stp = (uint32_t)GL < offset ? (uint32_t)GL : (uint32_t)GL % offset;
-    for (uint32_t base = 0; base < len; base += GL) {
-      uint8_t v[64]; bool act[64];
-      for (int l = 0; l < GL; l++) { act[l] = base + l < len; v[l] = act[l] ? (uint8_t)rg_ld8(m + r[l]) : 0; }
-      for (int l = 0; l < GL; l++) {
-        if (act[l]) rg_st8(op + base + l, v[l]);
-        r[l] += stp; if (r[l] >= offset) r[l] -= offset;
-      }
-    }
+    const uint32_t w = pos + dbase, s = w & 3u;
+    uint8_t flat[64 + 16];
+    for (int l = 0; l < GL; l++) memcpy(flat + 4 + l * LB, v.b[l], LB);
+    memset(flat, 0xDD, 4);   // (what lane 1 gets "from the lane below" never reaches the ring: lane 0's own store covers those bytes)
+    rg_put(w, flat + 4);     // lane 0
+    for (int l = 1; l < GL; l++) rg_put((w & ~3u) + l * LB, flat + 4 + l * LB - s);
   }
   static bool any(bool x) { return x; }   // (the simulated "wavefront" is this one group)
   static void settle(uint32_t&) {}
