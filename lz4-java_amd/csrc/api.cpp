@@ -151,7 +151,12 @@ int launch_fast(const lz4hip::BatchArgs& a, hipStream_t st) {
 }
 
 int launch_decode(const lz4hip::BatchArgs& a, bool safe, hipStream_t st) {
-  return lz4hip::launch_decompress(a, safe, g_decode_lanes.load(), g_decode_pipe.load(), g_decode_stage.load(), g_decode_ring.load(), st);
+  // (a word of scratch for the device-side choice between the deep and the ring loop: only batches of 8192 .. 40959 blocks use it)
+  uint32_t* route = nullptr;
+  if (a.n >= 8192u && a.n < 40960u && hipMallocAsync((void**)&route, sizeof(uint32_t), st) != hipSuccess) route = nullptr;
+  const int e = lz4hip::launch_decompress(a, safe, g_decode_lanes.load(), g_decode_pipe.load(), g_decode_stage.load(), g_decode_ring.load(), st, route);
+  if (route) (void)hipFreeAsync(route, st);
+  return e;
 }
 
 int launch_op(Op op, const lz4hip::BatchArgs& a, hipStream_t st) {
@@ -978,12 +983,12 @@ int lz4hip_set_option(const char* name, int value) {
     return LZ4HIP_OK;
   }
   if (name && strcmp(name, "decode_ring") == 0) {
-    if (value != 0 && value != 512 && value != 1024 && value != 2048 && value != 4096) return fail(LZ4HIP_E_ARG, "decode_ring must be 0, 512, 1024, 2048 or 4096");
+    if (value != 0 && value != 256 && value != 512 && value != 1024 && value != 2048 && value != 4096) return fail(LZ4HIP_E_ARG, "decode_ring must be 0, 256, 512, 1024, 2048 or 4096");
     g_decode_ring = value;
     return LZ4HIP_OK;
   }
   if (name && strcmp(name, "decode_lanes") == 0) {
-    if (value != 0 && value != 4 && value != 8 && value != 16 && value != 32 && value != 64) return fail(LZ4HIP_E_ARG, "decode_lanes must be 0,4,8,16,32,64");
+    if (value != 0 && value != 1 && value != 4 && value != 8 && value != 16 && value != 32 && value != 64) return fail(LZ4HIP_E_ARG, "decode_lanes must be 0,1 (ring loop only),4,8,16,32,64");
     g_decode_lanes = value;
     return LZ4HIP_OK;
   }

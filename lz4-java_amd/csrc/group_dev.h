@@ -45,7 +45,7 @@ struct GroupDev {
   // Wide variants for the decoder's interior loop (>= 300 bytes of slack on every side): each lane moves
   // LB = 64/GL bytes per step, so a step always covers 64 bytes whatever the group size -- smaller groups put more
   // blocks behind every instruction of the (issue-bound) loop.  May touch up to LB-1 bytes past len.
-  static constexpr uint32_t LB = 64u / GL < 4u ? 4u : 64u / GL;
+  static constexpr uint32_t LB = GL == 1 ? 16u : (64u / GL < 4u ? 4u : 64u / GL);   // (GL == 1: the ring loop's lane-per-block form, 16-byte steps)
   template <int N> struct Chunk { uint32_t w[N]; };
   typedef uint32_t vecLB __attribute__((ext_vector_type(LB / 4), aligned(1)));
   __device__ __forceinline__ static void store_out(uint8_t* p, const Chunk<LB / 4>& v) {
@@ -187,11 +187,25 @@ struct GroupDev {
     __builtin_memcpy(srb + q, &r, CB);
     if (q < 16u) __builtin_memcpy(srb + kStream + q, &r, CB < 16u ? CB : 16u);
   }
-  __device__ __forceinline__ uint32_t sr_ld32(uint32_t p) const { uint32_t v; __builtin_memcpy(&v, srb + (p & (kStream - 1u)), 4); return v; }
-  __device__ __forceinline__ uint64_t sr_ld64(uint32_t p) const { uint64_t v; __builtin_memcpy(&v, srb + (p & (kStream - 1u)), 8); return v; }
+  // (round 4: the reads below fetch whole ALIGNED dwords and funnel them -- an LDS instruction whose lanes are not aligned to its
+  // width is served one lane per cycle, 64 cycles for a wavefront instead of 2..8: tools/ubench/lds_unaligned.hip)
+  __device__ __forceinline__ uint32_t sr_ld32(uint32_t p) const {
+    const uint32_t* q = (const uint32_t*)__builtin_assume_aligned(srb + (p & (kStream - 1u) & ~3u), 4);
+    return __builtin_amdgcn_alignbyte(q[1], q[0], p & 3u);
+  }
+  __device__ __forceinline__ uint64_t sr_ld64(uint32_t p) const {
+    const uint32_t* q = (const uint32_t*)__builtin_assume_aligned(srb + (p & (kStream - 1u) & ~3u), 4);
+    const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], s = p & 3u;
+    return (uint64_t)__builtin_amdgcn_alignbyte(d1, d0, s) | ((uint64_t)__builtin_amdgcn_alignbyte(d2, d1, s) << 32);
+  }
   __device__ __forceinline__ Chunk<LB / 4> sr_step(uint32_t p) const {   // this lane's LB bytes of the 64 stream bytes at p
+    const uint32_t* q = (const uint32_t*)__builtin_assume_aligned(srb + ((p + l * LB) & (kStream - 1u) & ~3u), 4);
+    uint32_t d[LB / 4u + 1u];
+#pragma unroll
+    for (uint32_t k = 0; k <= LB / 4u; k++) d[k] = q[k];
     Chunk<LB / 4> v;
-    __builtin_memcpy(&v, srb + ((p + l * LB) & (kStream - 1u)), LB);
+#pragma unroll
+    for (uint32_t k = 0; k < LB / 4u; k++) v.w[k] = __builtin_amdgcn_alignbyte(d[k + 1], d[k], p & 3u);
     return v;
   }
   __device__ __forceinline__ Chunk<LB / 4> step_load(const uint8_t* m) const {   // this lane's LB bytes of the 64 bytes at m
@@ -201,9 +215,13 @@ struct GroupDev {
     return v;
   }
   __device__ __forceinline__ void step_store(uint8_t* d, const Chunk<LB / 4>& v) const { store_out(d + l * LB, v); }
+  // the same, but lanes whose LB bytes lie at or beyond `len` read from `idle` (a step that is cached) instead
+  __device__ __forceinline__ Chunk<LB / 4> step_load_upto(const uint8_t* m, uint32_t len, const uint8_t* idle) const {
+    return step_load(l * LB < len ? m : idle);
+  }
 
   // ---- backend of the ring loop (lz4_decode_ring.h): the block's window of the compressed stream AND its recent output in LDS.
-  // Layout of a block's kRingLds bytes: [stream ring kRs + 16][LB pad | output ring KW | 2 LB tail].
+  // Layout of a block's kRingLds bytes: [stream ring kRs + max(16, LB)][LB pad | output ring KW | 2 LB tail].
   //  * stream ring: indexed by stream position, refilled in aligned 64-byte steps (one chunk per lane), first 16 bytes mirrored
   //    behind the end so that no read wraps (per-lane masking: a lane's chunk wraps by itself);
   //  * output ring: index of output position p = (p + dbase) & (KW - 1), dbase = dst address & 63, so that 64-byte aligned steps
@@ -213,18 +231,24 @@ struct GroupDev {
   //    ring's last bytes + the tail); a chunk inside the first LB bytes is repeated in the tail.  So a read of LB bytes at any
   //    index finds them contiguous, and there is no wrap branch anywhere. ----
 #ifndef LZ4HIP_RING_KSTREAM
-#define LZ4HIP_RING_KSTREAM (GL <= 4 ? 256 : 512)
+#define LZ4HIP_RING_KSTREAM 256
 #endif
   static constexpr uint32_t kRs = LZ4HIP_RING_KSTREAM;      // stream bytes per block (power of two, >= 256)
   static constexpr uint32_t kRing = KW ? (uint32_t)KW : 512u;
-  static constexpr uint32_t kRingLds = (kRs + 16u + kRing + 3u * LB + 15u) & ~15u;
+  static constexpr uint32_t kRsTail = LB < 16u ? 16u : LB;   // stream bytes repeated behind the ring's end (a lane reads LB + 4 from a masked index)
+  static constexpr uint32_t WB = GL == 1 ? LB + 4u : LB;     // bytes a lane stores at once (GL == 1: the window of five aligned dwords around its 16 bytes)
+  static constexpr uint32_t kPad = GL == 1 ? 32u : LB;           // bytes in front of the ring's index 0 (a straddling store's lower copy; 16-byte aligned ring)
+  static constexpr uint32_t kRingLds0 = (kRs + kRsTail + kPad + kRing + 2u * WB + 15u) & ~15u;
+  static constexpr uint32_t kRingLds = kRingLds0 + (((kRingLds0 >> 4) & 1u) ? 0u : 16u);   // an odd number of 16-byte units: the blocks of a wavefront start in different banks
   uint8_t* rsb = nullptr;   // stream ring
   uint8_t* rgb = nullptr;   // output ring, index 0 (behind the pad)
   uint32_t dbase = 0;
   __device__ __forceinline__ void ring_begin(uint8_t* lds, const uint8_t* dst) {
-    rsb = lds; rgb = lds + kRs + 16u + LB; dbase = (uint32_t)(uintptr_t)dst & 63u;
+    rsb = lds; rgb = lds + kRs + kRsTail + kPad; dbase = (uint32_t)(uintptr_t)dst & 63u;
   }
   __device__ __forceinline__ static constexpr uint32_t ring_bytes() { return kRing; }
+  __device__ __forceinline__ static constexpr uint32_t ring_step() { return GL * LB; }                       // bytes of a step: 64, or 16 with a lane per block
+  __device__ __forceinline__ static constexpr uint32_t ring_piece() { return GL == 1 ? 16u : GL * LB - 4u; }   // bytes of literals / of match a trip emits at most
   __device__ __forceinline__ static constexpr uint32_t ring_stream() { return kRs; }
   __device__ __forceinline__ uint32_t ring_dbase() const { return dbase; }
   // Every LDS access below is NATURALLY ALIGNED, and what the bytes' real position asks for is done in registers.  Measured
@@ -253,8 +277,8 @@ struct GroupDev {
   }
   __device__ __forceinline__ void rs_put(uint32_t pos, const LChunk& r) {   // (aligned: pos is a multiple of 64, the lane's chunk of LB)
     const uint32_t q = (pos & (kRs - 1u)) + l * LB;
-    __builtin_memcpy(__builtin_assume_aligned(rsb + q, LB), &r, LB);
-    if (q < 16u) __builtin_memcpy(__builtin_assume_aligned(rsb + kRs + q, LB), &r, LB);
+    __builtin_memcpy(__builtin_assume_aligned(rsb + q, LB < 16u ? LB : 16u), &r, LB);
+    if (q < kRsTail) __builtin_memcpy(__builtin_assume_aligned(rsb + kRs + q, LB < 16u ? LB : 16u), &r, LB);
   }
   __device__ __forceinline__ uint64_t rs_ld64(uint32_t p) const {   // the 8 stream bytes at p (every lane of the group the same)
     const uint32_t* q = dwp(rsb + (p & (kRs - 1u) & ~3u));
@@ -279,7 +303,7 @@ struct GroupDev {
   }
   __device__ __forceinline__ LChunk rg_read_al(uint32_t pos) const {   // the same for an aligned step (the flusher's)
     LChunk v;
-    __builtin_memcpy(&v, __builtin_assume_aligned(rgb + ((pos + dbase + l * LB) & (kRing - 1u)), LB), LB);
+    __builtin_memcpy(&v, __builtin_assume_aligned(rgb + ((pos + dbase + l * LB) & (kRing - 1u)), LB < 16u ? LB : 16u), LB);
     return v;
   }
   // chunk c (LB bytes, any alignment or dword alignment -- the caller knows) to ring index x: at t - LB with t = (x + LB) & (KW - 1),
@@ -295,29 +319,47 @@ struct GroupDev {
       if (t < 2u * LB) __builtin_memcpy(a + kRing, &c, LB);
     }
   }
+  // GL == 1: the lane keeps the five aligned dwords it stored last (cw, at ring position cbase).  Output is written in order, so the
+  // bytes in front of the next position are always in that window: the next store is again five ALIGNED dwords, its first one made
+  // of the window's bytes below the position and the new bytes -- no lane of the wavefront ever stores unaligned.
+  uint32_t cw[5] = {0, 0, 0, 0, 0};
+  uint32_t cbase = 0;
   // the 64-byte step v (lane j holds bytes [j LB, j LB + LB)) to output position pos: covers [pos, pos + 64 - s), s = ring index & 3
+  // (GL == 1: the lane's 16 bytes, all of them)
   __device__ __forceinline__ void rg_write(uint32_t pos, const LChunk& v) {
     const uint32_t w = pos + dbase, s = w & 3u;
-    // lanes 1..: the aligned chunk at (w & ~3) + l LB holds the step's bytes [l LB - s, l LB - s + LB): this lane's dwords moved up
-    // by s bytes, the lowest bytes from the top dword of the lane below
-    const uint32_t below = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.w[LB / 4u - 1u], 0x111 /* row_shr:1 */, 0xF, 0xF, false);
     const uint32_t sel = 0x03020100u + (4u - s) * 0x01010101u;   // v_perm selector: bytes [4 - s, 8 - s) of {hi, lo}
-    LChunk m;
+    if constexpr (GL == 1) {
+      const uint32_t k = ((w & ~3u) - cbase) >> 2;               // the window dword that holds the bytes below the position (0..4)
+      const uint32_t c = k == 0u ? cw[0] : k == 1u ? cw[1] : k == 2u ? cw[2] : k == 3u ? cw[3] : cw[4];
+      // first dword: bytes [0, s) of c, then bytes [0, 4 - s) of the new data
+      const uint32_t sel0 = 0x03020100u + ((0x04040404u - s * 0x01010101u) & (0xFFFFFFFFu << (8u * s)));
+      cw[0] = __builtin_amdgcn_perm(v.w[0], c, sel0);
+      cw[1] = __builtin_amdgcn_perm(v.w[1], v.w[0], sel);
+      cw[2] = __builtin_amdgcn_perm(v.w[2], v.w[1], sel);
+      cw[3] = __builtin_amdgcn_perm(v.w[3], v.w[2], sel);
+      cw[4] = __builtin_amdgcn_perm(v.w[3], v.w[3], sel);        // (its upper bytes are bytes that are written again)
+      cbase = w & ~3u;
+      const uint32_t t = (cbase + WB) & (kRing - 1u);
+      uint32_t* a = dwp((rgb - WB) + t);
+      a[0] = cw[0]; a[1] = cw[1]; a[2] = cw[2]; a[3] = cw[3]; a[4] = cw[4];
+      if (t < 2u * WB) { uint32_t* b = dwp((rgb - WB) + t + kRing); b[0] = cw[0]; b[1] = cw[1]; b[2] = cw[2]; b[3] = cw[3]; b[4] = cw[4]; }
+    } else {
+      // lanes 1..: the aligned chunk at (w & ~3) + l LB holds the step's bytes [l LB - s, l LB - s + LB): this lane's dwords moved
+      // up by s bytes, the lowest bytes from the top dword of the lane below
+      const uint32_t below = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.w[LB / 4u - 1u], 0x111 /* row_shr:1 */, 0xF, 0xF, false);
+      LChunk m;
 #pragma unroll
-    for (uint32_t k = 0; k < LB / 4u; k++) m.w[k] = __builtin_amdgcn_perm(v.w[k], k ? v.w[k - 1u] : below, sel);
-    if (l != 0u) rg_put((w & ~3u) + l * LB, m, true);
-    else rg_put(w, v, false);   // lane 0: its bytes where they belong (the only unaligned lanes: 64 / GL per wavefront)
-  }
-#ifdef LZ4HIP_RING_DBG
-  __device__ __forceinline__ void ring_stats(uint32_t trips, uint32_t stall, uint32_t frozen, uint32_t seeds, uint32_t wait, uint32_t wtrips) const {
-    atomicAdd(&g_ring_stat[6], (unsigned long long)wtrips);
-    if (l == 0u) {
-      atomicAdd(&g_ring_stat[0], (unsigned long long)trips); atomicAdd(&g_ring_stat[1], (unsigned long long)stall);
-      atomicAdd(&g_ring_stat[2], (unsigned long long)frozen); atomicAdd(&g_ring_stat[3], (unsigned long long)seeds);
-      atomicAdd(&g_ring_stat[4], (unsigned long long)wait); atomicAdd(&g_ring_stat[5], 1ull);
+      for (uint32_t k = 0; k < LB / 4u; k++) m.w[k] = __builtin_amdgcn_perm(v.w[k], k ? v.w[k - 1u] : below, sel);
+      if (l != 0u) rg_put((w & ~3u) + l * LB, m, true);
+      else rg_put(w, v, false);   // lane 0: its bytes where they belong (the only unaligned lanes: 64 / GL per wavefront)
     }
   }
-#endif
+  // (re-)seed: the aligned step at pos (from memory) is the ring's first content
+  __device__ __forceinline__ void rg_seed(uint32_t pos, const LChunk& v) {
+    if constexpr (GL == 1) { cbase = (pos + dbase) & ~3u; cw[0] = cw[1] = cw[2] = cw[3] = cw[4] = 0u; }
+    rg_write(pos, v);
+  }
   __device__ __forceinline__ static bool first_active() { return __builtin_amdgcn_mbcnt_hi(__builtin_amdgcn_read_exec_hi(), __builtin_amdgcn_mbcnt_lo(__builtin_amdgcn_read_exec_lo(), 0u)) == 0u; }
   __device__ __forceinline__ static bool any(bool x) { return __builtin_amdgcn_ballot_w64(x) != 0ull; }   // over the wavefront's active lanes
   // every vector memory operation issued so far is waited for HERE (the compiler's wait-count pass sees the instruction: a loop

@@ -46,7 +46,9 @@ int launch_container_blocks(int kind, int block_checksum, int hc_level, const ui
 // pipe: 1 = pipelined interior loop (lz4_decode_core.h PIPE), 0 = plain, -1 = default for the batch size
 // stage: 1 = the plain interior loop writes through LDS staging (whole-line output), 0 / -1 = off
 // pipe 3: the ring loop (lz4_decode_ring.h); ring = bytes of its output ring (512 / 1024 / 2048 / 4096; 0 = default for the lanes)
-int launch_decompress(const BatchArgs& a, bool safe, int lanes_per_block, int pipe, int stage, int ring, void* stream);
+// route_word: one device uint32_t of scratch (or nullptr): with every knob at its default, batches of 8192 .. 40959 blocks are routed
+// between the deep loop and the ring loop on the device by the blocks' compressed sizes (decode_route_kernel)
+int launch_decompress(const BatchArgs& a, bool safe, int lanes_per_block, int pipe, int stage, int ring, void* stream, uint32_t* route_word = nullptr);
 int launch_xxh32(const uint8_t* buf, const uint64_t* off, const int32_t* len, uint32_t seed, uint32_t* out, uint32_t n, void* stream);
 int launch_xxh64(const uint8_t* buf, const uint64_t* off, const int32_t* len, uint64_t seed, uint64_t* out, uint32_t n, void* stream);
 // streaming xxhash: `rec` = device record of xxh_stream_rec_bytes() bytes (the digest so far sits at xxh_stream_digest_offset());

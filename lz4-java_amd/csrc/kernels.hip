@@ -552,7 +552,8 @@ __global__ __launch_bounds__(256) void decode_kernel(BatchArgs a) {
 #define LZ4HIP_DEEP_WGS 2
 #endif
 template <int GL, bool SAFE>
-__global__ __launch_bounds__(256, LZ4HIP_DEEP_WGS) void decode_deep_kernel(BatchArgs a) {
+__global__ __launch_bounds__(256, LZ4HIP_DEEP_WGS) void decode_deep_kernel(BatchArgs a, const uint32_t* route, uint32_t want) {
+  if (route && *route != want) return;   // (the launch was routed to another decoder: launch_decompress)
   __shared__ __attribute__((aligned(16))) uint8_t stage_mem[(256 / GL) * GroupDev<GL>::kStreamLds];
   const uint32_t gid = (blockIdx.x * 256u + threadIdx.x) / GL;
   if (gid >= a.n) return;
@@ -566,7 +567,8 @@ __global__ __launch_bounds__(256, LZ4HIP_DEEP_WGS) void decode_deep_kernel(Batch
 // workgroup: the LDS a workgroup asks for is what one wavefront's 64 / GL blocks need, so the CU fills to the last wavefront
 // (KW 512, 4 lanes: 16 blocks x 832 bytes = 13 KB, 12 wavefronts per CU; KW 4096, 16 lanes: 4 x 4.6 KB, 8 per CU).
 template <int GL, int KW, bool SAFE>
-__global__ __launch_bounds__(64) void decode_ring_kernel(BatchArgs a) {
+__global__ __launch_bounds__(64) void decode_ring_kernel(BatchArgs a, const uint32_t* route, uint32_t want) {
+  if (route && *route != want) return;   // (the launch was routed to another decoder: launch_decompress)
   typedef GroupDev<GL, KW> G;
   __shared__ __attribute__((aligned(16))) uint8_t ring_mem[(64 / GL) * G::kRingLds];
   const uint32_t gid = (blockIdx.x * 64u + threadIdx.x) / GL;
@@ -577,16 +579,27 @@ __global__ __launch_bounds__(64) void decode_ring_kernel(BatchArgs a) {
   if (g.l == 0) a.out[gid] = r;
 }
 template <int GL, int KW>
-static int launch_decode_ring(const BatchArgs& a, bool safe, hipStream_t st) {
+static int launch_decode_ring(const BatchArgs& a, bool safe, hipStream_t st, const uint32_t* route = nullptr, uint32_t want = 0) {
   const uint32_t per_wg = 64u / GL;
   const uint32_t grid = (a.n + per_wg - 1u) / per_wg;
-  if (safe) hipLaunchKernelGGL((decode_ring_kernel<GL, KW, true>), dim3(grid), dim3(64), 0, st, a);
-  else hipLaunchKernelGGL((decode_ring_kernel<GL, KW, false>), dim3(grid), dim3(64), 0, st, a);
+  if (safe) hipLaunchKernelGGL((decode_ring_kernel<GL, KW, true>), dim3(grid), dim3(64), 0, st, a, route, want);
+  else hipLaunchKernelGGL((decode_ring_kernel<GL, KW, false>), dim3(grid), dim3(64), 0, st, a, route, want);
   return (int)hipGetLastError();
+}
+// Which decoder a mid-sized batch gets is decided ON THE DEVICE from the blocks' compressed sizes (the launch is asynchronous and
+// its arguments live in device memory): *route = 1 when a sample of the blocks averages at least `big` compressed bytes -- big
+// blocks with (typically) a short match window, where the ring loop with a 2 KiB output ring wins (BASELINE configs[2]: 847 vs 808-835
+// GB/s, and a fabric traffic of 2.x instead of 3.75x the algorithmic bytes) -- else 0: the deep loop (64 KiB-class blocks: the ring
+// loop loses there below 40960 blocks, 70 vs 103 GB/s on text).  Both kernels are launched; the one that is not meant returns at once.
+__global__ __launch_bounds__(64) void decode_route_kernel(const int32_t* src_len, uint32_t n, uint32_t big, uint32_t* route) {
+  const uint32_t step = n > 64u ? n / 64u : 1u, i = threadIdx.x * step;
+  uint32_t v = (i < n && src_len[i] > 0) ? (uint32_t)src_len[i] : 0u, c = i < n ? 1u : 0u;
+  for (int d = 32; d >= 1; d >>= 1) { v += (uint32_t)__shfl_xor((int)v, d, 64); c += (uint32_t)__shfl_xor((int)c, d, 64); }
+  if (threadIdx.x == 0) *route = (c && v / c >= big) ? 1u : 0u;
 }
 
 template <int GL>
-static int launch_decode_gl(const BatchArgs& a, bool safe, int pipe, bool stage, hipStream_t st) {
+static int launch_decode_gl(const BatchArgs& a, bool safe, int pipe, bool stage, hipStream_t st, const uint32_t* route = nullptr) {
   const uint32_t per_wg = 256u / GL;
   const uint32_t grid = (a.n + per_wg - 1u) / per_wg;
   if (stage) {   // (staging belongs to the plain loop)
@@ -594,8 +607,8 @@ static int launch_decode_gl(const BatchArgs& a, bool safe, int pipe, bool stage,
     else hipLaunchKernelGGL((decode_kernel<GL, false, 0, true>), dim3(grid), dim3(256), 0, st, a);
   } else if (pipe == 2 && GL <= 16) {   // (the deep loop works in 64-byte steps: groups of up to 16 lanes)
     if constexpr (GL <= 16) {
-      if (safe) hipLaunchKernelGGL((decode_deep_kernel<GL, true>), dim3(grid), dim3(256), 0, st, a);
-      else hipLaunchKernelGGL((decode_deep_kernel<GL, false>), dim3(grid), dim3(256), 0, st, a);
+      if (safe) hipLaunchKernelGGL((decode_deep_kernel<GL, true>), dim3(grid), dim3(256), 0, st, a, route, 0u);
+      else hipLaunchKernelGGL((decode_deep_kernel<GL, false>), dim3(grid), dim3(256), 0, st, a, route, 0u);
     }
   } else if (safe) {
     if (pipe) hipLaunchKernelGGL((decode_kernel<GL, true, 1, false>), dim3(grid), dim3(256), 0, st, a);
@@ -615,15 +628,18 @@ int ring_stats_fetch(unsigned long long* out8) {   // developer build: reads and
   return (int)e;
 }
 #endif
-int launch_decompress(const BatchArgs& a, bool safe, int lanes_per_block, int pipe, int stage, int ring, void* stream) {
+int launch_decompress(const BatchArgs& a, bool safe, int lanes_per_block, int pipe, int stage, int ring, void* stream, uint32_t* route_word) {
   if (a.n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   if (pipe == 3) {   // the ring loop: lanes 4 / 8 / 16, output ring 512 .. 4096 bytes (0 = 512 with 4 lanes, 4096 otherwise)
     const int gl = lanes_per_block == 0 ? 4 : lanes_per_block;
-    const int kw = ring ? ring : (gl == 4 ? 512 : 4096);
+    const int kw = ring ? ring : (gl == 1 ? 256 : gl == 4 ? 512 : 4096);
     switch (gl * 100000 + kw) {
+      case 100256: return launch_decode_ring<1, 256>(a, safe, st);   // a lane per block: 64 blocks per wavefront, 16-byte steps
+      case 100512: return launch_decode_ring<1, 512>(a, safe, st);
       case 400512: return launch_decode_ring<4, 512>(a, safe, st);
       case 401024: return launch_decode_ring<4, 1024>(a, safe, st);
+      case 402048: return launch_decode_ring<4, 2048>(a, safe, st);
       case 800512: return launch_decode_ring<8, 512>(a, safe, st);
       case 801024: return launch_decode_ring<8, 1024>(a, safe, st);
       case 802048: return launch_decode_ring<8, 2048>(a, safe, st);
@@ -648,6 +664,13 @@ int launch_decompress(const BatchArgs& a, bool safe, int lanes_per_block, int pi
   // (text 106 -> 111); below that the pipelined loop wins (16384 blocks: 424 vs 289 staged vs 304 plain; 32768: 545 vs 447;
   // 49152: 508 vs 597)
   const bool sg = !p && (stage < 0 ? a.n >= 40960u : stage != 0);
+  if (auto_lanes && pipe < 0 && stage < 0 && route_word && a.n >= 8192u && a.n < 40960u) {
+    // every default in place and a batch that fills the GPU about once: deep loop or ring loop, decided from the blocks' sizes
+    hipLaunchKernelGGL(decode_route_kernel, dim3(1), dim3(64), 0, st, a.src_len, a.n, 512u << 10, route_word);
+    int e = launch_decode_gl<8>(a, safe, 2, false, st, route_word);
+    if (e == 0) e = launch_decode_ring<4, 2048>(a, safe, st, route_word, 1u);
+    return e;
+  }
   switch (lanes_per_block) {
     case 4: return launch_decode_gl<4>(a, safe, p, sg, st);
     case 16: return launch_decode_gl<16>(a, safe, p, sg, st);

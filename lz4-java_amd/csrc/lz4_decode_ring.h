@@ -35,7 +35,7 @@
 #define LZ4HIP_UNLIKELY(x) __builtin_expect(!!(x), 0)
 #endif
 #ifndef LZ4HIP_RING_SLOTS
-#define LZ4HIP_RING_SLOTS 3      /* pieces in the pipeline: a far source has LZ4HIP_RING_SLOTS - 1 trips to arrive (2, 3 or 4) */
+#define LZ4HIP_RING_SLOTS 4      /* pieces in the pipeline: a far source has LZ4HIP_RING_SLOTS - 1 trips to arrive (2, 3, 4, 6 or 8; measured on 16384 x 4 MiB: 765 / 845 / 850 GB/s with 3 / 4 / 6) */
 #endif
 #ifndef LZ4HIP_RING_PATIENCE
 #define LZ4HIP_RING_PATIENCE 4   /* trips the wavefront goes on after the first block froze */
@@ -49,8 +49,9 @@ namespace lz4hip {
 template <class Grp>
 LZ4HIP_DEV bool decode_ring_loop(Grp& g, const uint8_t* src, const int iend, uint8_t* dst, const int oend, int& ip_io, int& op_io, uint8_t* lds) {
   typedef typename Grp::LChunk LChunk;
-  const uint32_t KW = g.ring_bytes(), KS = g.ring_stream(), STEP = 64u;
-  const uint32_t PIECE = 60u;          // bytes of literals / of match a trip emits at most (a step written at an odd address covers 64 - 3)
+  const uint32_t KW = g.ring_bytes(), KS = g.ring_stream();
+  const uint32_t STEP = g.ring_step();     // bytes of a step: what the block's lanes move at once, the flusher's and the refill's unit (64; 16 with a lane per block)
+  const uint32_t PIECE = g.ring_piece();   // bytes of literals / of match a trip emits at most (60: a 64-byte step written at an odd address covers 64 - 3; 16)
   uint32_t ip = (uint32_t)ip_io, op = (uint32_t)op_io;
   const uint32_t ilim = (uint32_t)iend - 306u, olim = (uint32_t)oend - 606u;
   g.ring_begin(lds, dst);
@@ -83,13 +84,18 @@ LZ4HIP_DEV bool decode_ring_loop(Grp& g, const uint8_t* src, const int iend, uin
     mt0 = op;                                              // memory is valid below max(fl, mt0)
     fl = op - ((g.ring_dbase() + op) & (STEP - 1u));
     rlo = fl;                                              // the ring holds nothing below this position
-    g.rg_write(fl, g.step_load(dst + fl));
+    g.rg_seed(fl, g.step_load(dst + fl));
     // slots: literals v and -- far matches only -- the match source from memory (ug) of a piece; sop = its output position, lit = its
     // literal length, mp = where its match copies from, nr = the source is read from the ring (when the piece is put there)
     LChunk v0 = LChunk(), ug0 = LChunk(), v1 = LChunk(), ug1 = LChunk(), v2 = LChunk(), ug2 = LChunk(), v3 = LChunk(), ug3 = LChunk();
-    uint32_t sop0 = op, sop1 = op, sop2 = op, sop3 = op, lit0 = 0, lit1 = 0, lit2 = 0, lit3 = 0, mp0 = op, mp1 = op, mp2 = op, mp3 = op;
-    bool nr0 = true, nr1 = true, nr2 = true, nr3 = true;
+    LChunk v4 = LChunk(), ug4 = LChunk(), v5 = LChunk(), ug5 = LChunk(), v6 = LChunk(), ug6 = LChunk(), v7 = LChunk(), ug7 = LChunk();
+    uint32_t sop0 = op, sop1 = op, sop2 = op, sop3 = op, sop4 = op, sop5 = op, sop6 = op, sop7 = op;
+    uint32_t lit0 = 0, lit1 = 0, lit2 = 0, lit3 = 0, lit4 = 0, lit5 = 0, lit6 = 0, lit7 = 0;
+    uint32_t mp0 = op, mp1 = op, mp2 = op, mp3 = op, mp4 = op, mp5 = op, mp6 = op, mp7 = op;
+    bool nr0 = true, nr1 = true, nr2 = true, nr3 = true, nr4 = true, nr5 = true, nr6 = true, nr7 = true;
     (void)v2; (void)ug2; (void)v3; (void)ug3; (void)sop2; (void)sop3; (void)lit2; (void)lit3; (void)mp2; (void)mp3; (void)nr2; (void)nr3;
+    (void)v4; (void)ug4; (void)v5; (void)ug5; (void)sop4; (void)sop5; (void)lit4; (void)lit5; (void)mp4; (void)mp5; (void)nr4; (void)nr5;
+    (void)v6; (void)ug6; (void)v7; (void)ug7; (void)sop6; (void)sop7; (void)lit6; (void)lit7; (void)mp6; (void)mp7; (void)nr6; (void)nr7;
     bool frozen = false;
     uint32_t since = 0;                                    // trips since the first block of the wavefront froze (wave-uniform)
 
@@ -132,14 +138,18 @@ LZ4HIP_DEV bool decode_ring_loop(Grp& g, const uint8_t* src, const int iend, uin
       const bool near = (mpos >= rlo) & (mpos + KW >= op + 2u * STEP);   /* the ring will still hold the source when this piece goes in */ \
       const bool lost = (me != 0u) & !near & (mpos + me > fl) & (mpos + me > mt0);   /* ... nor does flushed memory hold it (yet) */         \
       frozen = odd | (lost & !fdue & (sop##a == op));  /* (a lost source may just be early while pieces wait or the flusher has steps to store) */ \
-      const bool stall = odd | lost | hungry | (op - fl > KW - 320u) | (since >= LZ4HIP_RING_PATIENCE);                         \
+      const bool stall = odd | lost | hungry | (op - fl > KW - 5u * STEP) | (since >= LZ4HIP_RING_PATIENCE);                         \
       LZ4HIP_RING_COUNT(stall, frozen, !frozen & (since >= LZ4HIP_RING_PATIENCE));                                           \
-      if (REFILL == 1) { LZ4HIP_REFILL_FETCH }                                                                                 \
+      if (REFILL == 1) { LZ4HIP_REFILL_FETCH }         /* (a request in one trip, its bytes into the ring in the next: every conditional   \
+                                                          memory operation makes the compiler's wait counts more careful) */     \
       v##c = g.rs_step(lpos);                                                                                                  \
       /* (a near or empty piece loads the step that was flushed last and does not use it: every trip issues the same operations,   \
          so the compiler can count how many a wait may leave outstanding) */                                                   \
       const bool nomem = near | stall | (me == 0u);    /* nothing is needed from memory */                                    \
-      ug##c = g.step_load(dst + (nomem ? (fl < STEP ? STEP : fl) - STEP : mpos));                                     \
+      /* (only the lanes that hold bytes of the match ask memory for them -- every request is a 128-byte line on its way through   \
+         the fabric, and the launch is bound by how many of those the memory system serves; the others, like a near or empty       \
+         piece, load the step that was flushed last: every trip issues the same operations) */                                   \
+      ug##c = g.step_load_upto(dst + mpos, nomem ? 0u : me, dst + ((fl < STEP ? STEP : fl) - STEP));                             \
       sop##c = op; lit##c = stall ? 0u : le; mp##c = mpos; nr##c = nomem;   /* (a stalled trip's piece is empty: it is aimed at bytes that are written again) */ \
       if (fdue) { g.step_store(dst + fl, fx); fl += STEP; }                                                                    \
       if (REFILL == 2) { LZ4HIP_REFILL_PUT }                                                                                   \
@@ -168,11 +178,15 @@ LZ4HIP_DEV bool decode_ring_loop(Grp& g, const uint8_t* src, const int iend, uin
       LZ4HIP_TRIP(0, 1, 1)
       LZ4HIP_TRIP(1, 2, 2)
       LZ4HIP_TRIP(2, 0, 0)
-#else
+#elif LZ4HIP_RING_SLOTS == 4
       LZ4HIP_TRIP(0, 1, 1)
       LZ4HIP_TRIP(1, 2, 2)
       LZ4HIP_TRIP(2, 3, 1)
       LZ4HIP_TRIP(3, 0, 2)
+#elif LZ4HIP_RING_SLOTS == 6
+      LZ4HIP_TRIP(0, 1, 1) LZ4HIP_TRIP(1, 2, 2) LZ4HIP_TRIP(2, 3, 1) LZ4HIP_TRIP(3, 4, 2) LZ4HIP_TRIP(4, 5, 1) LZ4HIP_TRIP(5, 0, 2)
+#else
+      LZ4HIP_TRIP(0, 1, 1) LZ4HIP_TRIP(1, 2, 2) LZ4HIP_TRIP(2, 3, 1) LZ4HIP_TRIP(3, 4, 2) LZ4HIP_TRIP(4, 5, 1) LZ4HIP_TRIP(5, 6, 2) LZ4HIP_TRIP(6, 7, 1) LZ4HIP_TRIP(7, 0, 2)
 #endif
       if (last) break;
     }

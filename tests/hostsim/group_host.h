@@ -46,20 +46,20 @@ struct GroupHost {
 
   // wide variants (interior loop): LB = 64/GL bytes per lane and step, lock-step loads then stores
   void copy_lits_wide(uint8_t* d, const uint8_t* s, uint32_t len) {
-    const uint32_t LB = 64u / GL < 4u ? 4u : 64u / GL;
+    const uint32_t LB = lb();
     for (uint32_t base = 0; base < len; base += LB * GL) {
-      uint8_t v[64][16]; bool act[64];
+      uint8_t v[64][32]; bool act[64];
       for (int l = 0; l < GL; l++) { uint32_t i = base + LB * l; act[l] = i < len; if (act[l] && rd_ok(s + i, LB)) memcpy(v[l], s + i, LB); }
       for (int l = 0; l < GL; l++) { uint32_t i = base + LB * l; if (act[l] && wr_ok(d + i, LB)) memcpy(d + i, v[l], LB); }
     }
   }
   void copy_match_wide(uint8_t* dst, uint32_t op, uint32_t offset, uint32_t len) {
-    const uint32_t LB = 64u / GL < 4u ? 4u : 64u / GL;
+    const uint32_t LB = lb();
     if (offset >= LB * GL) {
       uint8_t* d = dst + op;
       const uint8_t* m = d - offset;
       for (uint32_t base = 0; base < len; base += LB * GL) {
-        uint8_t v[64][16]; bool act[64];
+        uint8_t v[64][32]; bool act[64];
         for (int l = 0; l < GL; l++) { uint32_t i = base + LB * l; act[l] = i < len; if (act[l] && rd_ok(m + i, LB)) memcpy(v[l], m + i, LB); }
         for (int l = 0; l < GL; l++) { uint32_t i = base + LB * l; if (act[l] && wr_ok(d + i, LB)) memcpy(d + i, v[l], LB); }
       }
@@ -69,9 +69,9 @@ struct GroupHost {
   }
 
   // split sequence copy of the pipelined interior loop (group_dev.h seq_load / seq_store), lock-step per call
-  struct SeqRegs { uint8_t v[64][16], u[64][16]; };
+  struct SeqRegs { uint8_t v[64][32], u[64][32]; };
   uint32_t step() const { return lb() * (uint32_t)GL; }
-  uint32_t lb() const { return 64u / GL < 4u ? 4u : 64u / GL; }
+  uint32_t lb() const { return GL == 1 ? 16u : (64u / GL < 4u ? 4u : 64u / GL); }   // (GL == 1: the ring loop's lane-per-block form)
   uint32_t slack() const { return lb(); }
   void seq_load(SeqRegs& r, const uint8_t* s, uint32_t lit, const uint8_t* m, uint32_t len) {
     const uint32_t LB = lb();
@@ -102,7 +102,7 @@ struct GroupHost {
     for (uint32_t base = 0; base < nb; base += LB * GL)
       for (int l = 0; l < GL; l++) { const uint32_t o = base + LB * l; if (o < nb && st_ok(o, LB) && wr_ok(dst + fl + o, LB)) memcpy(dst + fl + o, stg + o, LB); }
     for (uint32_t base = 0; base < rem; base += LB * GL) {
-      uint8_t v[64][16]; bool act[64];
+      uint8_t v[64][32]; bool act[64];
       for (int l = 0; l < GL; l++) { const uint32_t o = base + LB * l; act[l] = o < rem && st_ok(nb + o, LB); if (act[l]) memcpy(v[l], stg + nb + o, LB); }
       for (int l = 0; l < GL; l++) { const uint32_t o = base + LB * l; if (act[l]) memcpy(stg + o, v[l], LB); }
     }
@@ -120,7 +120,7 @@ struct GroupHost {
     const uint32_t LB = lb();
     for (uint32_t base = 0; base < len; base += LB * GL) {
       if (op + base - fl + LB * GL + LB > kStage) st_flush_lines(dst, op + base);
-      uint8_t v[64][16]; bool act[64];
+      uint8_t v[64][32]; bool act[64];
       for (int l = 0; l < GL; l++) { const uint32_t i = base + LB * l; act[l] = i < len && rd_ok(s + i, LB); if (act[l]) memcpy(v[l], s + i, LB); }
       for (int l = 0; l < GL; l++) { const uint32_t i = base + LB * l; if (act[l] && st_ok(op + i - fl, LB)) memcpy(stg + (op + i - fl), v[l], LB); }
     }
@@ -130,7 +130,7 @@ struct GroupHost {
     const uint8_t* m = dst + op - offset;
     for (uint32_t base = 0; base < len; base += LB * GL) {
       if (op + base - fl + LB * GL + LB > kStage) st_flush_lines(dst, op + base);
-      uint8_t v[64][16]; bool act[64];
+      uint8_t v[64][32]; bool act[64];
       for (int l = 0; l < GL; l++) {
         const uint32_t i = base + LB * l;
         act[l] = i < len;
@@ -145,7 +145,7 @@ struct GroupHost {
   // ---- backend of the deep interior loop (lz4_decode_deep.h; group_dev.h sr_* / step_*): the stream ring in "LDS" (an index
   // outside it counts as oob), whole 64-byte steps by all lanes -- every call is one instruction: all lanes' loads, then all stores
   static constexpr uint32_t kStream = 1024u, kStreamLds = kStream + 16u, kPiece = 256u;
-  struct LChunk { uint8_t b[64][16]; };
+  struct LChunk { uint8_t b[64][32]; };
   struct PieceRegs { uint8_t b[64][64]; };
   uint8_t sr_mem[kStreamLds];
   bool lds_ok(uint32_t idx, uint32_t k) { if (idx + k > kStreamLds) { oob = true; return false; } return true; }
@@ -180,6 +180,12 @@ struct GroupHost {
     for (int l = 0; l < GL; l++) if (rd_ok(m + l * LB, LB)) memcpy(v.b[l], m + l * LB, LB);
     return v;
   }
+  LChunk step_load_upto(const uint8_t* m, uint32_t len, const uint8_t* idle) {
+    LChunk v; memset(&v, 0, sizeof v);
+    const uint32_t LB = lb();
+    for (int l = 0; l < GL; l++) { const uint8_t* p = ((uint32_t)l * LB < len ? m : idle) + l * LB; if (rd_ok(p, LB)) memcpy(v.b[l], p, LB); }
+    return v;
+  }
   void step_store(uint8_t* d, const LChunk& v) {
     const uint32_t LB = lb();
     for (int l = 0; l < GL; l++) if (wr_ok(d + l * LB, LB)) memcpy(d + l * LB, v.b[l], LB);
@@ -189,19 +195,23 @@ struct GroupHost {
   // layout, the same mirror rules and the same per-lane index arithmetic as the device backend; every call is one instruction (all
   // lanes' loads, then all lanes' stores); an index outside the block's LDS bytes counts as oob.  Ring sizes are chosen per test.
   uint32_t kRs = 256u, kRing = 512u;
-  uint8_t ring_mem[1024 + 16 + 8192 + 48 + 64];
+  uint8_t ring_mem[1024 + 32 + 8192 + 96 + 64];
   uint8_t* rsb = nullptr; uint8_t* rgb = nullptr;
   uint32_t dbase = 0;
   static inline uint64_t ring_trips = 0, ring_entries = 0, ring_repl = 0, ring_flush = 0;   // (statistics for the tests)
   uint32_t ring_bytes() const { return kRing; }
+  uint32_t ring_step() const { return lb() * (uint32_t)GL; }
+  uint32_t ring_piece() const { return GL == 1 ? 16u : lb() * (uint32_t)GL - 4u; }
+  void rg_seed(uint32_t pos, const LChunk& v) { rg_write(pos, v); }
   uint32_t ring_stream() const { return kRs; }
   uint32_t ring_dbase() const { return dbase; }
-  uint32_t ring_lds() const { return kRs + 16u + kRing + 3u * lb(); }
+  uint32_t rs_tail() const { return lb() < 16u ? 16u : lb(); }
+  uint32_t ring_lds() const { return kRs + rs_tail() + kRing + 3u * lb() + (GL == 1 ? 32u : 0u); }
   bool rl_ok(const uint8_t* p, uint32_t k) { if (p < ring_mem || p + k > ring_mem + ring_lds()) { oob = true; return false; } return true; }
   void ring_begin(uint8_t*, const uint8_t* dst) {
     ring_entries++;
     memset(ring_mem, 0xEE, sizeof ring_mem);
-    rsb = ring_mem; rgb = ring_mem + kRs + 16u + lb(); dbase = (uint32_t)(uintptr_t)dst & 63u;
+    rsb = ring_mem; rgb = ring_mem + kRs + rs_tail() + (GL == 1 ? 32u : lb()); dbase = (uint32_t)(uintptr_t)dst & 63u;
   }
   LChunk rs_fetch(const uint8_t* s, uint32_t pos) {
     LChunk r; memset(&r, 0, sizeof r);
@@ -214,7 +224,7 @@ struct GroupHost {
     for (int l = 0; l < GL; l++) {
       const uint32_t q = (pos & (kRs - 1u)) + l * LB;
       if (rl_ok(rsb + q, LB)) memcpy(rsb + q, r.b[l], LB);
-      if (q < 16u && rl_ok(rsb + kRs + q, LB)) memcpy(rsb + kRs + q, r.b[l], LB);
+      if (q < rs_tail() && rl_ok(rsb + kRs + q, LB)) memcpy(rsb + kRs + q, r.b[l], LB);
     }
   }
   uint32_t rs_ld32(uint32_t p) { uint32_t v = 0; const uint8_t* q = rsb + (p & (kRs - 1u)); if (rl_ok(q, 4)) memcpy(&v, q, 4); return v; }
@@ -231,7 +241,7 @@ struct GroupHost {
     for (int l = 0; l < GL; l++) { const uint8_t* q = rgb + ((pos + dbase + l * LB) & (kRing - 1u)); if (rl_ok(q, LB)) memcpy(v.b[l], q, LB); }
     return v;
   }
-  LChunk rg_read_al(uint32_t pos) { if ((pos + dbase) & 63u) oob = true; return rg_read(pos); }   // (the flusher's steps are aligned)
+  LChunk rg_read_al(uint32_t pos) { if ((pos + dbase) & (ring_step() - 1u)) oob = true; return rg_read(pos); }   // (the flusher's steps are aligned)
   // one chunk of LB bytes to ring index x with the device backend's mirror rule
   void rg_put(uint32_t x, const uint8_t* c) {
     const uint32_t LB = lb();
@@ -244,6 +254,14 @@ struct GroupHost {
   void rg_write(uint32_t pos, const LChunk& v) {
     const uint32_t LB = lb();
     const uint32_t w = pos + dbase, s = w & 3u;
+    if (GL == 1) {   // the device backend's window store puts exactly the lane's 16 bytes at the position (and keeps what lies below)
+      for (uint32_t i = 0; i < 16u; i++) {
+        const uint32_t x = (w + i) & (kRing - 1u);
+        if (rl_ok(rgb + x, 1)) rgb[x] = v.b[0][i];
+        if (x < 32u && rl_ok(rgb + kRing + x, 1)) rgb[kRing + x] = v.b[0][i];
+      }
+      return;
+    }
     uint8_t flat[64 + 16];
     for (int l = 0; l < GL; l++) memcpy(flat + 4 + l * LB, v.b[l], LB);
     memset(flat, 0xDD, 4);   // (what lane 1 gets "from the lane below" never reaches the ring: lane 0's own store covers those bytes)

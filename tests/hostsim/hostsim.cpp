@@ -181,7 +181,6 @@ int sim_decompress(const uint8_t* src, int src_size, uint8_t* dst, int out_size,
   gl &= 0xFF;
   hostsim::GroupHost g(gl, src, src_size, dst, out_size);
   if (ring_log) g.kRing = 1u << ring_log;
-  if (ring && gl > 4) g.kRs = 512u;
   int r;
   if (ring) r = safe ? lz4hip::decode_block<hostsim::GroupHost, true, 3>(g, src, src_size, dst, out_size, g.stg_buf)
                      : lz4hip::decode_block<hostsim::GroupHost, false, 3>(g, src, src_size, dst, out_size, g.stg_buf);

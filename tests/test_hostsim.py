@@ -255,7 +255,8 @@ def test_decode_core_fuzz(sim, ref, O, corpus):
         if rng.random() < 0.25:
             gl = rng.choice([4, 8, 16]) | 0x400                                  # bit 10: the deep interior loop
         elif rng.random() < 0.33:
-            gl = rng.choice([4, 8, 16]) | 0x800 | (rng.choice([9, 10, 11, 12]) << 12)   # bit 11: the ring loop; bits 12..15: log2 of its output ring
+            gl = rng.choice([1, 4, 8, 16])
+            gl |= 0x800 | (rng.choice([8, 9, 10] if gl == 1 else [9, 10, 11, 12]) << 12)   # (the output ring holds at least eight steps)   # bit 11: the ring loop; bits 12..15: log2 of its output ring
         r2, d2 = ref.decompress_safe_raw(c, cap)
         r1, d1 = sim_decode(sim, c, cap, 1, gl)
         assert r1 == r2 and (r2 < 0 or d1[:r2] == d2[:r2]), ("safe", mode, gl, len(v), cap, r1, r2)
@@ -354,7 +355,7 @@ def test_ring_decoder_loop(sim, ref, O, corpus):
     for k, (c, cap) in enumerate(cases):
         want_r, want = ref.decompress_safe_raw(c, cap)
         full = k < len(valid)
-        for gl, rl in (((4, 9), (8, 12), (16, 12), (8, 9), (4, 10)) if full else ((rng.choice([4, 8, 16]), rng.choice([9, 10, 12])),)):
+        for gl, rl in (((4, 9), (8, 12), (16, 12), (8, 9), (4, 10), (1, 8), (1, 9)) if full else ((rng.choice([1, 4, 8, 16]), rng.choice([9, 10, 12])),)):
             flag = gl | 0x800 | (rl << 12)
             shift = rng.choice([0, 0, 1, 7, 16, 33, 63, 64, 100])
             r, d = sim_decode(sim, c, cap, 1, flag, shift=shift)
