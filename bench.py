@@ -94,11 +94,14 @@ def cpu_bench(args, env=None):
     return r
 
 
-def decode_kernel_name(n_blocks, safe=True):
-    """the decoder instantiation launch_decompress (kernels.hip) picks by batch size: lanes per block, SAFE, PIPE, STAGE"""
+def decode_kernel_name(n_blocks, safe=True, big_blocks=False):
+    """the decoder instantiation launch_decompress (kernels.hip) picks: by batch size, and -- batches of 12288 .. 40959 blocks -- on the
+    device by the blocks' compressed sizes (decode_route_kernel: blocks of >= 512 KiB go to the ring loop, csrc/lz4_decode_ring.h)"""
     s = "true" if safe else "false"
     if n_blocks >= 40960:
         return "decode_kernel<4, %s, 0, true>" % s
+    if 12288 <= n_blocks < 40960 and big_blocks:
+        return "decode_ring_kernel<4, 2048, %s>" % s
     return "decode_deep_kernel<8, %s>" % s   # the deep interior loop, csrc/lz4_decode_deep.h
 
 
@@ -414,8 +417,8 @@ def main():
         extra["configs2_decode_4MiB"] = {"workload": "%d x 4 MiB blocks per GPU in one launch (BASELINE configs[2]: 16384 blocks in all, sharded over the ranks), "
                                                      "App.F win 4096, LZ4_decompress_safe of fast-compressed blocks, ratio %.3f" % (n3, n3 * b3 / cs3),
                                          "value": round(world * float(n3) * b3 / wall / 1e9, 3), "unit": "GB/s", "verified": ok3,
-                                         "roofline": roof(decode_kernel_name(n3), float(n3) * b3 + cs3, tk,
-                                                          kernel_traffic(tr, world, decode_kernel_name(n3)) if n3 == (tr.get("configs2_blocks") or 16384) else None)}
+                                         "roofline": roof(decode_kernel_name(n3, True, True), float(n3) * b3 + cs3, tk,
+                                                          kernel_traffic(tr, world, decode_kernel_name(n3, True, True)) if n3 == (tr.get("configs2_blocks") or 16384) else None)}
         ok = ok and ok3
         if want_cpu:
             def f3():

@@ -196,6 +196,31 @@ int lz4hip_container_blocks(int kind, int flags, int level, const uint8_t* src, 
 int lz4hip_container_blocks_dev(int kind, int flags, int level, const uint8_t* src, uint64_t n_bytes, uint32_t block_size,
                                 uint8_t* dst, uint64_t dst_cap, uint64_t* total_dev, void* ws, size_t ws_bytes, int device, void* stream);
 
+/* Device-side container READ path (round 4; replaces the per-block loops of LZ4FrameInputStream.readBlock,
+ * src/java/net/jpountz/lz4/LZ4FrameInputStream.java:258-322, and LZ4BlockInputStream.refill, LZ4BlockInputStream.java:191-264, for a
+ * whole run of blocks that lies in DEVICE memory): the size words (kind 0: LZ4 Frame body, starting at the first block's size word;
+ * flags & 1 = a block checksum follows every payload; max_block = the frame's block maximum size) or the 21-byte headers (kind 1:
+ * lz4-java's "LZ4Block" stream) of body[0, body_bytes) are walked on the device, frame block checksums verified where the payloads
+ * lie, compressed blocks decoded (LZ4_decompress_safe into max_block bytes / LZ4_decompress_fast into the header's original length,
+ * whose return value must be the header's compressed length), raw blocks copied, LZ4Block checksums verified on the decoded bytes --
+ * all asynchronous on `stream`.  Block k decodes to dst + k * slot_bytes (slot_bytes >= max_block for frames; n_max slots);
+ * sizes_dev[k] = its decoded size; info_dev[0..4] = { blocks delivered, bytes of body consumed by them (+ the end mark / empty
+ * block when it was reached), stop reason, decoded bytes of the delivered blocks, liblz4's code when a decode failed }.
+ * Stop reasons follow the readers' own order of checks per block; the first block that fails ends the run:
+ *   0 end mark (frame) / empty block (LZ4Block) reached     1 body ended at a block boundary     7 all n_max slots used, more follows
+ *   2 body ended inside a block ("Stream ended prematurely")   3 frame: "Block size %s exceeded max"  (or a slot too small)
+ *   4 frame: block checksum mismatch     5 frame: the block does not decode (LZ4Exception)     6 LZ4Block: "Stream is corrupted"
+ * ws = device scratch of lz4hip_container_decode_workspace_bytes(n_max) bytes.                                               */
+size_t lz4hip_container_decode_workspace_bytes(uint32_t n_max);
+int lz4hip_container_decode_dev(int kind, int flags, const uint8_t* body, uint64_t body_bytes, uint32_t max_block, uint8_t* dst,
+                                uint64_t slot_bytes, uint32_t n_max, int32_t* sizes_dev, uint64_t* info_dev, void* ws, size_t ws_bytes,
+                                int device, void* stream);
+/* the same with host pointers: H2D of the container bytes, the device path, D2H of the delivered blocks BACK TO BACK into dst
+ * (max_block: frame block maximum / an upper bound of the LZ4Block original lengths, e.g. 1 << (10 + level nibble)); sizes[n_max],
+ * info[5] as above */
+int lz4hip_container_decode(int kind, int flags, const uint8_t* body, uint64_t body_bytes, uint32_t max_block, uint32_t n_max,
+                            uint8_t* dst, uint64_t dst_cap, int32_t* sizes, uint64_t* info);
+
 /* ---- workload helper (not part of the reference API) ------------------------------------------
  * Fills n_blocks slots of `block_len` bytes at dst + i*stride with the SURVEY.md App. F synthetic
  * blocks idx = first_idx + i (deterministic, seed-addressed).  Device pointer, async on stream.

@@ -76,6 +76,10 @@ C_ABI = {
     "lz4hip_container_blocks": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, _u64p]),
     "lz4hip_container_blocks_dev": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p,
                                               C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+    "lz4hip_container_decode_workspace_bytes": (C.c_size_t, [C.c_uint32]),
+    "lz4hip_container_decode_dev": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+    "lz4hip_container_decode": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "lz4hip_gen_blocks_dev": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
                                         C.c_uint32, C.c_int, C.c_void_p]),
 }
@@ -577,6 +581,25 @@ class LZ4HIPBatch:
         out = C.c_uint64(0)
         _chk(lib().lz4hip_container_blocks(kind, 1 if blockChecksum else 0, level, sp, len(data), blockSize, dp, cap, C.byref(out)))
         return bytes(dst[:out.value])
+
+    # stop reasons of containerDecode (include/lz4hip.h)
+    CR_END, CR_MORE, CR_TRUNCATED, CR_BLOCK_TOO_BIG, CR_BLOCK_CHECKSUM, CR_DECODE, CR_CORRUPT, CR_SLOTS = range(8)
+
+    @staticmethod
+    def containerDecode(kind, body, maxBlock, nMax, blockChecksum=False):
+        """the READ path of the container formats on the device: the data blocks of an LZ4 Frame body / of an LZ4Block stream in `body`
+        are walked, verified and decoded there (LZ4FrameInputStream.readBlock / LZ4BlockInputStream.refill for a run of blocks)
+        -> (decoded bytes of the delivered blocks, [their sizes], bytes of body consumed, stop reason, liblz4 code of a failed decode)"""
+        dst = bytearray(max(maxBlock * nMax, 1))
+        sizes = (C.c_int32 * nMax)()
+        info = (C.c_uint64 * 5)()
+        sp, sk = _ro_ptr(body)
+        dp, dk = _rw_ptr(dst)
+        _chk(lib().lz4hip_container_decode(kind, 1 if blockChecksum else 0, sp, len(body), maxBlock, nMax, dp, len(dst), sizes, info))
+        n_ok, consumed, why, total, code = (int(info[i]) for i in range(5))
+        if code >= 1 << 63:
+            code -= 1 << 64
+        return bytes(dst[:total]), [int(sizes[i]) for i in range(n_ok)], consumed, why, code
 
     @classmethod
     def decompressSafe(cls, src, srcOff, srcLen, dst, dstOff, dstCap):

@@ -151,9 +151,9 @@ int launch_fast(const lz4hip::BatchArgs& a, hipStream_t st) {
 }
 
 int launch_decode(const lz4hip::BatchArgs& a, bool safe, hipStream_t st) {
-  // (a word of scratch for the device-side choice between the deep and the ring loop: only batches of 8192 .. 40959 blocks use it)
+  // (a word of scratch for the device-side choice between the deep and the ring loop: only batches of 12288 .. 40959 blocks use it)
   uint32_t* route = nullptr;
-  if (a.n >= 8192u && a.n < 40960u && hipMallocAsync((void**)&route, sizeof(uint32_t), st) != hipSuccess) route = nullptr;
+  if (a.n >= 12288u && a.n < 40960u && hipMallocAsync((void**)&route, sizeof(uint32_t), st) != hipSuccess) route = nullptr;
   const int e = lz4hip::launch_decompress(a, safe, g_decode_lanes.load(), g_decode_pipe.load(), g_decode_stage.load(), g_decode_ring.load(), st, route);
   if (route) (void)hipFreeAsync(route, st);
   return e;
@@ -844,6 +844,85 @@ int lz4hip_container_blocks(int kind, int flags, int level, const uint8_t* src, 
   if (total && (he = hipMemcpyAsync(dst, d_dst, total, hipMemcpyDeviceToHost, st)) != hipSuccess) return done(fail(LZ4HIP_E_HIP, "D2H", he));
   if ((he = hipStreamSynchronize(st)) != hipSuccess) return done(fail(LZ4HIP_E_HIP, "hipStreamSynchronize", he));
   *out_bytes = total;
+  return done(LZ4HIP_OK);
+}
+size_t lz4hip_container_decode_workspace_bytes(uint32_t n_max) { return lz4hip::container_read_ws_bytes(n_max) + 256u; }
+int lz4hip_container_decode_dev(int kind, int flags, const uint8_t* body, uint64_t body_bytes, uint32_t max_block, uint8_t* dst, uint64_t slot_bytes,
+                                uint32_t n_max, int32_t* sizes_dev, uint64_t* info_dev, void* ws, size_t ws_bytes, int device, void* stream) {
+  int rc = ensure_init();
+  if (rc) return fail(rc, "no HIP device: liblz4hip has no CPU fallback");
+  if (kind != 0 && kind != 1) return fail(LZ4HIP_E_ARG, "container kind must be 0 (LZ4 Frame blocks) or 1 (LZ4Block blocks)");
+  if ((body_bytes && !body) || !dst || !sizes_dev || !info_dev || !ws) return fail(LZ4HIP_E_ARG, "null pointer argument");
+  if (n_max == 0 || n_max > 0x7FFFFFFFu) return fail(LZ4HIP_E_ARG, "n_max must be 1 .. 2^31 - 1");
+  if (slot_bytes == 0 || slot_bytes > 0x7FFFFFFFull || (kind == 0 && (max_block == 0 || slot_bytes < max_block)))
+    return fail(LZ4HIP_E_ARG, "slot_bytes must be 1 .. 2^31 - 1 and, for frame blocks, at least the frame's block maximum size");
+  if (ws_bytes < lz4hip_container_decode_workspace_bytes(n_max)) return fail(LZ4HIP_E_ARG, "workspace too small (lz4hip_container_decode_workspace_bytes)");
+  int ord;
+  if (ordinal(device, &ord)) return fail(LZ4HIP_E_ARG, "bad device index");
+  DeviceGuard g(ord);
+  uint8_t* w = (uint8_t*)(((uintptr_t)ws + 255u) & ~(uintptr_t)255u);
+  const int e = lz4hip::launch_container_read(kind, flags & 1, body, body_bytes, max_block, dst, slot_bytes, n_max, sizes_dev,
+                                              (unsigned long long*)info_dev, w, stream);
+  if (e) return fail(LZ4HIP_E_HIP, "kernel launch", (hipError_t)e);
+  return LZ4HIP_OK;
+}
+// host pointers: H2D of the container bytes, the device path above, D2H of the delivered blocks back to back into dst
+int lz4hip_container_decode(int kind, int flags, const uint8_t* body, uint64_t body_bytes, uint32_t max_block, uint32_t n_max, uint8_t* dst,
+                            uint64_t dst_cap, int32_t* sizes, uint64_t* info) {
+  int rc = ensure_init();
+  if (rc) return fail(rc, "no HIP device: liblz4hip has no CPU fallback");
+  if ((body_bytes && !body) || !sizes || !info || (dst_cap && !dst)) return fail(LZ4HIP_E_ARG, "null pointer argument");
+  if (n_max == 0 || max_block == 0 || max_block > 0x7FFFFFFFu) return fail(LZ4HIP_E_ARG, "n_max and max_block must be positive");
+  for (int i = 0; i < 5; i++) info[i] = 0;
+  int ord;
+  if (ordinal(0, &ord)) return fail(LZ4HIP_E_NO_DEVICE, "no device");
+  DeviceGuard g(ord);
+  const size_t wsb = lz4hip_container_decode_workspace_bytes(n_max);
+  const uint64_t slot = ((uint64_t)max_block + 63u) & ~63ull;
+  hipStream_t st = nullptr;
+  uint8_t *d_body = nullptr, *d_dst = nullptr, *d_ws = nullptr;
+  int32_t* d_sizes = nullptr;
+  uint64_t* d_info = nullptr;
+  hipError_t he = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+  auto done = [&](int r) {
+    if (d_body) (void)hipFreeAsync(d_body, st);
+    if (d_dst) (void)hipFreeAsync(d_dst, st);
+    if (d_ws) (void)hipFreeAsync(d_ws, st);
+    if (d_sizes) (void)hipFreeAsync(d_sizes, st);
+    if (d_info) (void)hipFreeAsync(d_info, st);
+    if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    return r;
+  };
+  if (he != hipSuccess) return fail(LZ4HIP_E_HIP, "hipStreamCreate", he);
+  if ((he = hipMallocAsync((void**)&d_body, body_bytes ? body_bytes : 1, st)) != hipSuccess || (he = hipMallocAsync((void**)&d_dst, slot * n_max, st)) != hipSuccess ||
+      (he = hipMallocAsync((void**)&d_ws, wsb, st)) != hipSuccess || (he = hipMallocAsync((void**)&d_sizes, sizeof(int32_t) * (size_t)n_max, st)) != hipSuccess ||
+      (he = hipMallocAsync((void**)&d_info, 5 * sizeof(uint64_t), st)) != hipSuccess)
+    return done(fail(he == hipErrorOutOfMemory ? LZ4HIP_E_NOMEM : LZ4HIP_E_HIP, "device allocation", he));
+  if (body_bytes && (he = hipMemcpyAsync(d_body, body, body_bytes, hipMemcpyHostToDevice, st)) != hipSuccess) return done(fail(LZ4HIP_E_HIP, "H2D", he));
+  uint8_t* w = (uint8_t*)(((uintptr_t)d_ws + 255u) & ~(uintptr_t)255u);
+  const int e = lz4hip::launch_container_read(kind, flags & 1, d_body, body_bytes, max_block, d_dst, slot, n_max, d_sizes, (unsigned long long*)d_info, w, st);
+  if (e) return done(fail(LZ4HIP_E_HIP, "kernel launch", (hipError_t)e));
+  if ((he = hipMemcpyAsync(info, d_info, 5 * sizeof(uint64_t), hipMemcpyDeviceToHost, st)) != hipSuccess ||
+      (he = hipMemcpyAsync(sizes, d_sizes, sizeof(int32_t) * (size_t)n_max, hipMemcpyDeviceToHost, st)) != hipSuccess ||
+      (he = hipStreamSynchronize(st)) != hipSuccess)
+    return done(fail(LZ4HIP_E_HIP, "container result", he));
+  const uint64_t n_ok = info[0];
+  if (info[3] > dst_cap) return done(fail(LZ4HIP_E_ARG, "destination too small for the decoded blocks"));
+  // runs of full slots go back in one copy each (the usual case: every block but the last is a whole block)
+  uint64_t o = 0;
+  for (uint64_t k = 0; k < n_ok;) {
+    uint64_t j = k;
+    while (j < n_ok && (uint64_t)sizes[j] == slot) j++;
+    if (j > k) {
+      if ((he = hipMemcpyAsync(dst + o, d_dst + k * slot, (j - k) * slot, hipMemcpyDeviceToHost, st)) != hipSuccess) return done(fail(LZ4HIP_E_HIP, "D2H", he));
+      o += (j - k) * slot; k = j;
+    } else {
+      const uint64_t sz = sizes[k] > 0 ? (uint64_t)sizes[k] : 0;
+      if (sz && (he = hipMemcpyAsync(dst + o, d_dst + k * slot, sz, hipMemcpyDeviceToHost, st)) != hipSuccess) return done(fail(LZ4HIP_E_HIP, "D2H", he));
+      o += sz; k++;
+    }
+  }
+  if ((he = hipStreamSynchronize(st)) != hipSuccess) return done(fail(LZ4HIP_E_HIP, "hipStreamSynchronize", he));
   return done(LZ4HIP_OK);
 }
 #if defined(__GNUC__)

@@ -42,11 +42,18 @@ int launch_pack(const BatchArgs& a, uint64_t* poff, uint8_t* pack, void* stream)
 size_t container_ws_bytes(uint64_t n_bytes, uint32_t block_size);
 int launch_container_blocks(int kind, int block_checksum, int hc_level, const uint8_t* src, uint64_t n_bytes, uint32_t block_size, uint8_t* dst, uint64_t dst_cap,
                             unsigned long long* total, void* ws, void* hc_ws, uint32_t* q_scratch, uint32_t dense64, uint32_t n_cus, int core, void* stream);
+// Device-side container READ path (kernels.hip): the data blocks of an LZ4 Frame body (kind 0; block_checksum: a XXH32 word behind
+// each payload) or of an LZ4Block stream (kind 1) in body[0, body_bytes) are walked, verified and decoded; block k decodes to
+// dst + k * slot_bytes, sizes[k] = its decoded size, info[0..4] = {blocks delivered, body bytes consumed, stop reason, decoded bytes,
+// liblz4 code of a failed decode}; ws = container_read_ws_bytes(n_max) bytes of device scratch
+size_t container_read_ws_bytes(uint32_t n_max);
+int launch_container_read(int kind, int block_checksum, const uint8_t* body, uint64_t body_bytes, uint32_t max_block, uint8_t* dst, uint64_t slot_bytes,
+                          uint32_t n_max, int32_t* sizes, unsigned long long* info, void* ws, void* stream);
 // lanes_per_block: lanes of a wavefront that share one block in the decoder (4..64); 0 = default
 // pipe: 1 = pipelined interior loop (lz4_decode_core.h PIPE), 0 = plain, -1 = default for the batch size
 // stage: 1 = the plain interior loop writes through LDS staging (whole-line output), 0 / -1 = off
 // pipe 3: the ring loop (lz4_decode_ring.h); ring = bytes of its output ring (512 / 1024 / 2048 / 4096; 0 = default for the lanes)
-// route_word: one device uint32_t of scratch (or nullptr): with every knob at its default, batches of 8192 .. 40959 blocks are routed
+// route_word: one device uint32_t of scratch (or nullptr): with every knob at its default, batches of 12288 .. 40959 blocks are routed
 // between the deep loop and the ring loop on the device by the blocks' compressed sizes (decode_route_kernel)
 int launch_decompress(const BatchArgs& a, bool safe, int lanes_per_block, int pipe, int stage, int ring, void* stream, uint32_t* route_word = nullptr);
 int launch_xxh32(const uint8_t* buf, const uint64_t* off, const int32_t* len, uint32_t seed, uint32_t* out, uint32_t n, void* stream);

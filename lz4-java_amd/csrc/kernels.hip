@@ -531,6 +531,174 @@ int launch_container_blocks(int kind, int block_checksum, int hc_level, const ui
 }
 
 // ------------------------------------------------------------------------------------------------
+// Device-side container READ path: the data blocks of an LZ4 Frame body
+// (LZ4FrameInputStream.readBlock, /root/reference/src/java/net/jpountz/lz4/LZ4FrameInputStream.java:258-322) or of an lz4-java
+// "LZ4Block" stream (LZ4BlockInputStream.refill, LZ4BlockInputStream.java:191-264) that lie in device memory are walked, verified and
+// decoded on the launch stream: (1) one wavefront walks the size words / 21-byte headers (a serial chain: every header's position
+// follows from the one before) into the batch arrays, applying the readers' header rules in their order; (2) frame block checksums
+// (XXH32, seed 0, of the STORED payload) are hashed where the payloads lie; (3) compressed blocks are decoded -- LZ4_decompress_safe
+// into a slot of the frame's block maximum, or, for LZ4Block, the fast decoder into originalLen bytes, whose return value must be the
+// header's compressed length --, raw blocks copied; (4) LZ4Block checksums (XXH32 of the DECODED bytes, seed 0x9747b28c, low 28 bits)
+// are hashed where the blocks now lie; (5) one pass finds the first block that fails, in the readers' order of checks per block
+// (frame: size > max, premature end, checksum, decode; LZ4Block: header rules, premature end, decode / consumed length, checksum),
+// and reports {blocks delivered, body bytes consumed, why it stopped, decoded bytes}.  Block k decodes to dst + k * slot_bytes.
+// Stop reasons (info[2]):
+enum { CR_END = 0, CR_MORE = 1, CR_TRUNCATED = 2, CR_BLOCK_TOO_BIG = 3, CR_BLOCK_CHECKSUM = 4, CR_DECODE = 5, CR_CORRUPT = 6, CR_SLOTS = 7 };
+//   CR_END        the end mark (frame) / the empty block (LZ4Block) was reached: consumed includes it
+//   CR_MORE       the body ended exactly at a block boundary      CR_SLOTS  n_max blocks are delivered, more follow
+//   CR_TRUNCATED  the body ended inside a header, a payload or a checksum ("Stream ended prematurely")
+//   CR_BLOCK_TOO_BIG / CR_BLOCK_CHECKSUM / CR_DECODE (info[4] = liblz4's negative code)   frame errors, LZ4FrameInputStream.java:284-311
+//   CR_CORRUPT    LZ4Block "Stream is corrupted" (every rule of LZ4BlockInputStream.java:200-259)
+// ------------------------------------------------------------------------------------------------
+struct ContainerRead {   // arrays of n_max entries in the workspace
+  uint64_t* src_off; int32_t* src_len; uint64_t* dst_off; int32_t* dst_cap; int32_t* out;   // the decode batch
+  uint64_t* pay_off; int32_t* pay_len;      // stored payloads (frame checksums are taken over these)
+  uint64_t* end_off;                         // body offset behind block k (incl. its checksum word)
+  uint32_t* stored;                          // stored checksum (frame) / check field (LZ4Block)
+  uint32_t* hashes;                          // computed
+  int32_t* meta;                             // bit 0: raw block; bits 8..: LZ4Block originalLen is in dst_cap
+  uint32_t* walk;                            // [0] blocks walked, [1] stop reason of the walk, [2..3] body offset where it stopped
+};
+__device__ __forceinline__ uint32_t rd32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+__global__ __launch_bounds__(64) void container_walk_kernel(int kind, int block_checksum, const uint8_t* body, uint64_t body_bytes, uint32_t max_block,
+                                                            uint64_t slot_bytes, uint32_t n_max, ContainerRead c) {
+  // every entry gets a value (the decode launch covers all n_max slots): blocks that are not walked decode nothing
+  for (uint32_t i = threadIdx.x; i < n_max; i += 64u) { c.src_off[i] = 0; c.src_len[i] = 0; c.dst_off[i] = (uint64_t)i * slot_bytes; c.dst_cap[i] = 0; c.out[i] = 0;
+                                                        c.pay_off[i] = 0; c.pay_len[i] = 0; c.end_off[i] = 0; c.stored[i] = 0; c.hashes[i] = 0; c.meta[i] = 0; }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  uint64_t p = 0;
+  uint32_t k = 0, why = CR_SLOTS;
+  while (k < n_max) {
+    if (p == body_bytes) { why = CR_MORE; break; }
+    if (kind == 0) {
+      if (p + 4u > body_bytes) { why = CR_TRUNCATED; break; }
+      const uint32_t word = rd32(body + p);
+      const uint32_t size = word & 0x7FFFFFFFu;
+      if (size == 0u) { p += 4u; why = CR_END; break; }                       // LZ4FrameInputStream.java:264-276 (the caller reads what follows)
+      if (size > max_block) { why = CR_BLOCK_TOO_BIG; break; }                 // :284-286
+      const uint64_t need = 4ull + size + (block_checksum ? 4u : 0u);
+      if (p + need > body_bytes) { why = CR_TRUNCATED; break; }                // :289-295 PREMATURE_EOS
+      const bool raw = (word & 0x80000000u) != 0u;
+      c.pay_off[k] = p + 4u; c.pay_len[k] = (int32_t)size;
+      c.src_off[k] = p + 4u; c.src_len[k] = raw ? 0 : (int32_t)size;
+      c.dst_cap[k] = raw ? 0 : (int32_t)(max_block < slot_bytes ? max_block : (uint32_t)slot_bytes);
+      c.meta[k] = raw ? 1 : 0;
+      if (raw && size > slot_bytes) { why = CR_BLOCK_TOO_BIG; break; }
+      if (block_checksum) c.stored[k] = rd32(body + p + 4u + size);
+      p += need;
+      c.end_off[k] = p;
+      k++;
+    } else {
+      if (p + 21u > body_bytes) { why = CR_TRUNCATED; break; }                 // LZ4BlockInputStream.java:192-199
+      const uint8_t* h = body + p;
+      const char* magic = "LZ4Block";
+      bool bad = false;
+      for (int i = 0; i < 8; i++) bad |= h[i] != (uint8_t)magic[i];           // :200-204
+      const uint32_t token = h[8], method = token & 0xF0u, level = 10u + (token & 0x0Fu);
+      bad |= method != 0x10u && method != 0x20u;                               // :208-210
+      const int32_t clen = (int32_t)rd32(h + 9), olen = (int32_t)rd32(h + 13);
+      const uint32_t check = rd32(h + 17);
+      bad |= olen > (int32_t)(1u << level) || olen < 0 || clen < 0 || (olen == 0 && clen != 0) || (olen != 0 && clen == 0) ||
+             (method == 0x10u && olen != clen);                                // :215-222
+      if (bad) { why = CR_CORRUPT; break; }
+      if (olen == 0) {                                                         // :223-233: the empty block
+        if (check != 0u) { why = CR_CORRUPT; break; }
+        p += 21u; why = CR_END; break;
+      }
+      if ((uint64_t)olen > slot_bytes) { why = CR_BLOCK_TOO_BIG; break; }      // (the caller's slots are too small: not a stream error)
+      if (p + 21u + (uint64_t)clen > body_bytes) { why = CR_TRUNCATED; break; }
+      const bool raw = method == 0x10u;
+      c.pay_off[k] = p + 21u; c.pay_len[k] = clen;
+      c.src_off[k] = p + 21u; c.src_len[k] = raw ? 0 : clen;                   // (fast decoder: src_len = readable bytes of the slot)
+      c.dst_cap[k] = raw ? 0 : olen;
+      c.meta[k] = (raw ? 1 : 0) | (olen << 1);
+      c.stored[k] = check;
+      p += 21u + (uint64_t)clen;
+      c.end_off[k] = p;
+      k++;
+    }
+  }
+  c.walk[0] = k; c.walk[1] = why; c.walk[2] = (uint32_t)p; c.walk[3] = (uint32_t)(p >> 32);
+}
+// raw blocks: payload -> slot (one workgroup per block); also the length array of the LZ4Block checksum pass
+__global__ __launch_bounds__(256) void container_raw_kernel(int kind, const uint8_t* body, uint8_t* dst, ContainerRead c, int32_t* hash_len) {
+  const uint32_t b = blockIdx.x;
+  if (b >= c.walk[0]) { if (threadIdx.x == 0) hash_len[b] = 0; return; }
+  const bool raw = (c.meta[b] & 1) != 0;
+  const uint32_t len = (uint32_t)c.pay_len[b];
+  if (threadIdx.x == 0) hash_len[b] = kind == 1 ? (raw ? (int32_t)len : (c.meta[b] >> 1)) : 0;
+  if (!raw) return;
+  const uint8_t* s = body + c.pay_off[b];
+  uint8_t* d = dst + c.dst_off[b];
+  const uint32_t body16 = len & ~15u;
+  for (uint32_t i = threadIdx.x * 16u; i < body16; i += 256u * 16u) { uint4 v; __builtin_memcpy(&v, s + i, 16); __builtin_memcpy(d + i, &v, 16); }
+  const uint32_t i = body16 + threadIdx.x;
+  if (i < len) d[i] = s[i];
+  if (threadIdx.x == 0) c.out[b] = (int32_t)len;
+}
+// the first block that fails, in stream order, with the readers' order of checks inside a block
+__global__ __launch_bounds__(1024) void container_verdict_kernel(int kind, int block_checksum, ContainerRead c, int32_t* sizes, unsigned long long* info) {
+  __shared__ uint32_t first_bad;
+  __shared__ unsigned long long total;
+  if (threadIdx.x == 0) { first_bad = 0xFFFFFFFFu; total = 0; }
+  __syncthreads();
+  const uint32_t n = c.walk[0];
+  for (uint32_t b = threadIdx.x; b < n; b += 1024u) {
+    const bool raw = (c.meta[b] & 1) != 0;
+    bool bad;
+    if (kind == 0) bad = (block_checksum && c.hashes[b] != c.stored[b]) || (!raw && c.out[b] < 0);
+    else bad = (!raw && c.out[b] != c.pay_len[b]) || ((c.hashes[b] & 0x0FFFFFFFu) != c.stored[b]);   // consumed == compressedLen, then the check
+    if (bad) atomicMin(&first_bad, b);
+  }
+  __syncthreads();
+  const uint32_t nok = first_bad < n ? first_bad : n;
+  for (uint32_t b = threadIdx.x; b < n; b += 1024u) {
+    const bool raw = (c.meta[b] & 1) != 0;
+    const int32_t sz = kind == 0 ? c.out[b] : (raw ? c.pay_len[b] : (c.meta[b] >> 1));
+    sizes[b] = sz;
+    if (b < nok) atomicAdd(&total, (unsigned long long)(sz > 0 ? sz : 0));
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t why = c.walk[1];
+    long long code = 0;
+    if (nok < n) {
+      const bool raw = (c.meta[nok] & 1) != 0;
+      if (kind == 0) { if (block_checksum && c.hashes[nok] != c.stored[nok]) why = CR_BLOCK_CHECKSUM; else { why = CR_DECODE; code = c.out[nok]; } }
+      else { why = CR_CORRUPT; (void)raw; }
+    }
+    info[0] = nok;
+    info[1] = nok < n ? (nok ? c.end_off[nok - 1u] : 0ull) : ((unsigned long long)c.walk[2] | ((unsigned long long)c.walk[3] << 32));
+    info[2] = why;
+    info[3] = total;
+    info[4] = (unsigned long long)code;
+  }
+}
+size_t container_read_ws_bytes(uint32_t n_max) { return (size_t)n_max * (4u * 8u + 8u * 4u) + 64u; }
+int launch_container_read(int kind, int block_checksum, const uint8_t* body, uint64_t body_bytes, uint32_t max_block, uint8_t* dst, uint64_t slot_bytes,
+                          uint32_t n_max, int32_t* sizes, unsigned long long* info, void* ws, void* stream) {
+  if (n_max == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  uint8_t* p = (uint8_t*)ws;
+  ContainerRead c;
+  c.src_off = (uint64_t*)p; c.dst_off = c.src_off + n_max; c.pay_off = c.dst_off + n_max; c.end_off = c.pay_off + n_max;
+  c.src_len = (int32_t*)(c.end_off + n_max); c.dst_cap = c.src_len + n_max; c.out = c.dst_cap + n_max; c.pay_len = c.out + n_max;
+  c.stored = (uint32_t*)(c.pay_len + n_max); c.hashes = c.stored + n_max; c.meta = (int32_t*)(c.hashes + n_max);
+  int32_t* hash_len = c.meta + n_max;
+  c.walk = (uint32_t*)(hash_len + n_max);
+  hipLaunchKernelGGL(container_walk_kernel, dim3(1), dim3(64), 0, st, kind, block_checksum, body, body_bytes, max_block, slot_bytes, n_max, c);
+  int e;
+  if (kind == 0 && block_checksum && (e = launch_xxh32(body, c.pay_off, c.pay_len, 0u, c.hashes, n_max, stream)) != 0) return e;
+  BatchArgs a{body, c.src_off, c.src_len, dst, c.dst_off, c.dst_cap, c.out, n_max};
+  if ((e = launch_decompress(a, kind == 0, 0, -1, -1, 0, stream, nullptr)) != 0) return e;
+  hipLaunchKernelGGL(container_raw_kernel, dim3(n_max), dim3(256), 0, st, kind, body, dst, c, hash_len);
+  if (kind == 1 && (e = launch_xxh32(dst, c.dst_off, hash_len, 0x9747b28cu, c.hashes, n_max, stream)) != 0) return e;
+  hipLaunchKernelGGL(container_verdict_kernel, dim3(1), dim3(1024), 0, st, kind, block_checksum, c, sizes, info);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // decode
 // ------------------------------------------------------------------------------------------------
 template <int GL, bool SAFE, int PIPE, bool STAGE>
@@ -664,8 +832,9 @@ int launch_decompress(const BatchArgs& a, bool safe, int lanes_per_block, int pi
   // (text 106 -> 111); below that the pipelined loop wins (16384 blocks: 424 vs 289 staged vs 304 plain; 32768: 545 vs 447;
   // 49152: 508 vs 597)
   const bool sg = !p && (stage < 0 ? a.n >= 40960u : stage != 0);
-  if (auto_lanes && pipe < 0 && stage < 0 && route_word && a.n >= 8192u && a.n < 40960u) {
-    // every default in place and a batch that fills the GPU about once: deep loop or ring loop, decided from the blocks' sizes
+  if (auto_lanes && pipe < 0 && stage < 0 && route_word && a.n >= 12288u && a.n < 40960u) {
+    // every default in place and a batch that fills the GPU with the ring loop's 16 blocks per wavefront (8192 x 4 MiB: 422 vs 544
+    // GB/s for the deep loop; 16384: 847 vs 815): deep loop or ring loop, decided from the blocks' sizes
     hipLaunchKernelGGL(decode_route_kernel, dim3(1), dim3(64), 0, st, a.src_len, a.n, 512u << 10, route_word);
     int e = launch_decode_gl<8>(a, safe, 2, false, st, route_word);
     if (e == 0) e = launch_decode_ring<4, 2048>(a, safe, st, route_word, 1u);

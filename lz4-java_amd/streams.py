@@ -57,6 +57,11 @@ class HIPEngine:
         lv = 0 if self.hcLevel is None else (9 if self.hcLevel < 1 else self.hcLevel)
         return LZ4HIPBatch.containerBlocks(kind, data, blockSize, blockChecksum, lv)
 
+    def containerDecode(self, kind, body, maxBlock, nMax, blockChecksum=False):
+        """round 4: the READ side on the device -- size words / 21-byte headers walked, block checksums verified, blocks decoded or
+        copied there (lz4hip_container_decode); engines without this method make the readers walk the headers on the host"""
+        return LZ4HIPBatch.containerDecode(kind, body, maxBlock, nMax, blockChecksum)
+
     @staticmethod
     def newStreamingHash32(seed):
         """content checksum state (LZ4FrameOutputStream.java:116: `XXHashFactory...newStreamingHash32(0)`)"""
@@ -288,9 +293,15 @@ class _Reader:
 
     def __init__(self, inp):
         self.inp = inp
+        self.back = b""      # bytes handed back by the device read path (container bytes it did not consume)
+
+    def unread(self, b):
+        self.back = bytes(b) + self.back
 
     def read_upto(self, n):
         parts, got = [], 0
+        if self.back:
+            parts.append(self.back[:n]); got = len(parts[0]); self.back = self.back[got:]
         while got < n:
             c = self.inp.read(n - got)
             if not c:
@@ -313,8 +324,9 @@ class LZ4FrameInputStream(io.RawIOBase):
     blocks decoded in one safe-decompress launch.  A defect in block k surfaces when the reader reaches
     block k, after the bytes of blocks < k have been delivered, as in the reference."""
 
-    def __init__(self, inp, readSingleFrame=False, engine=None, batchBlocks=64):
+    def __init__(self, inp, readSingleFrame=False, engine=None, batchBlocks=64, hostWalk=False):
         super().__init__()
+        self.hostWalk = hostWalk   # True: headers walked and checksums compared on the host around the batch launches (rounds 1-3)
         self.r = _Reader(inp)
         self.engine = engine or HIPEngine()
         self.readSingleFrame = readSingleFrame
@@ -372,8 +384,56 @@ class LZ4FrameInputStream(io.RawIOBase):
         self.frame_finished = False
 
     # -- block level ----------------------------------------------------------------------------
+    def _readBlocksDevice(self):
+        """the same on the device (engine.containerDecode): one chunk of container bytes goes over, the decoded blocks and a stop
+        reason come back; what the device did not consume is handed back to the reader.  Same checks in the same order, same
+        messages; a defect in block k surfaces after the bytes of the blocks before it."""
+        B = LZ4HIPBatch
+        block_checksum = self.flg.isEnabled(FLG.Bits.BLOCK_CHECKSUM)
+        want = self.batchBlocks * (self.maxBlockSize + 8) + 4
+        chunk = self.r.read_upto(want)
+        at_eof = len(chunk) < want
+        decoded, sizes, consumed, why, code = self.engine.containerDecode(B.FRAME_BLOCKS, chunk, self.maxBlockSize, self.batchBlocks, block_checksum)
+        rest = chunk[consumed:]
+        if decoded:
+            first = len(self.ready)
+            self.ready += decoded
+            self.totalContentSize += len(decoded)
+            if self.content is not None:  # one update per batch of decoded blocks
+                self.content.update(self.ready, first, len(decoded))
+        self.r.unread(rest)
+        if why == B.CR_END:
+            self._endMark()
+        elif why == B.CR_BLOCK_TOO_BIG:
+            self.r.read_upto(4)
+            self.pending_exc = IOException("Block size %s exceeded max: %s" % (_U32.unpack(rest[:4])[0] & ~LZ4_FRAME_INCOMPRESSIBLE_MASK & 0xFFFFFFFF, self.maxBlockSize))
+        elif why == B.CR_BLOCK_CHECKSUM:
+            self.pending_exc = IOException(BLOCK_HASH_MISMATCH)
+        elif why == B.CR_DECODE:  # LZ4JNISafeDecompressor.java:39-41, wrapped in IOException (:307-311)
+            self.pending_exc = IOException(LZ4Exception("Error decoding offset %d of input buffer" % (-code)))
+        elif why in (B.CR_TRUNCATED, B.CR_MORE) and at_eof:
+            self.r.read_upto(len(rest))
+            self.pending_exc = IOException(PREMATURE_EOS)
+        # (CR_MORE / CR_SLOTS / a chunk that ended inside a block: the next call goes on from the bytes handed back)
+
+    def _endMark(self):
+        """behind the end mark (LZ4FrameInputStream.java:264-276): content checksum, content size"""
+        try:
+            if self.flg.isEnabled(FLG.Bits.CONTENT_CHECKSUM):
+                stored = _U32.unpack(self.r.read_fully(4))[0]
+                if stored != self.content.getValue():
+                    raise IOException("Content checksum mismatch")
+            if self.flg.isEnabled(FLG.Bits.CONTENT_SIZE) and self.expectedContentSize != self.totalContentSize:
+                raise IOException("Size check mismatch")
+        except IOException as e:
+            self.pending_exc = e
+            return
+        self.frame_finished = True
+
     def _readBlocks(self):
         """LZ4FrameInputStream.readBlock (:258-322) for up to batchBlocks blocks"""
+        if not self.hostWalk and hasattr(self.engine, "containerDecode"):
+            return self._readBlocksDevice()
         blocks = []  # (compressed?, payload, stored checksum | None)
         end_mark = False
         exc = None
@@ -436,17 +496,7 @@ class LZ4FrameInputStream(io.RawIOBase):
             self.pending_exc = exc
             return
         if end_mark:
-            try:
-                if self.flg.isEnabled(FLG.Bits.CONTENT_CHECKSUM):
-                    stored = _U32.unpack(self.r.read_fully(4))[0]
-                    if stored != self.content.getValue():
-                        raise IOException("Content checksum mismatch")
-                if self.flg.isEnabled(FLG.Bits.CONTENT_SIZE) and self.expectedContentSize != self.totalContentSize:
-                    raise IOException("Size check mismatch")
-            except IOException as e:
-                self.pending_exc = e
-                return
-            self.frame_finished = True
+            self._endMark()
 
     def _fill(self):
         """False at end of stream"""
@@ -645,8 +695,9 @@ class LZ4BlockInputStream(io.RawIOBase):
 
     CORRUPTED = "Stream is corrupted"
 
-    def __init__(self, inp, stopOnEmptyBlock=True, engine=None, batchBlocks=256, checksum=None):
+    def __init__(self, inp, stopOnEmptyBlock=True, engine=None, batchBlocks=256, checksum=None, hostWalk=False):
         super().__init__()
+        self.hostWalk = hostWalk   # True: headers walked and checksums compared on the host around the batch launches (rounds 1-3)
         self.checksum = checksum   # None: the default XXH32 (batched); else a Checksum-like object (LZ4BlockInputStream.java:71-76)
         self.r = _Reader(inp)
         self.engine = engine or HIPEngine()
@@ -659,7 +710,43 @@ class LZ4BlockInputStream(io.RawIOBase):
     def readable(self):
         return True
 
+    def _refillDevice(self):
+        """LZ4BlockInputStream.refill for a run of blocks on the device (engine.containerDecode): headers walked with the reference's
+        rules, LZ4 blocks through the fast decoder (its return value must be the header's compressed length), raw ones copied, the
+        checksums of the decoded bytes compared -- every defect is "Stream is corrupted", delivered after the blocks before it.
+        False: this run is for the host path (a block bigger than the first header announced)."""
+        B = LZ4HIPBatch
+        head = self.r.read_upto(HEADER_LENGTH)
+        self.r.unread(head)
+        if len(head) < HEADER_LENGTH or head[:MAGIC_LENGTH] != BLOCK_MAGIC:
+            return False   # (the host path produces the reference's exception / end of stream)
+        maxBlock = 1 << (COMPRESSION_LEVEL_BASE + (head[MAGIC_LENGTH] & 0x0F))
+        want = self.batchBlocks * (maxBlock + HEADER_LENGTH) + HEADER_LENGTH
+        chunk = self.r.read_upto(want)
+        at_eof = len(chunk) < want
+        decoded, sizes, consumed, why, code = self.engine.containerDecode(B.LZ4BLOCK_BLOCKS, chunk, maxBlock, self.batchBlocks, False)
+        if why == B.CR_BLOCK_TOO_BIG:
+            self.r.unread(chunk)
+            return False
+        rest = chunk[consumed:]
+        self.ready += decoded
+        self.r.unread(rest)
+        if why == B.CR_END:
+            if self.stopOnEmptyBlock:
+                self.finished = True
+        elif why == B.CR_CORRUPT:
+            self.pending_exc = IOException(self.CORRUPTED)
+        elif why in (B.CR_TRUNCATED, B.CR_MORE) and at_eof:
+            self.r.read_upto(len(rest))
+            if len(rest) < HEADER_LENGTH and not self.stopOnEmptyBlock:
+                self.finished = True                      # (:192-199: the stream may end at -- or inside -- a header)
+            else:
+                self.pending_exc = EOFException(PREMATURE_EOS)
+        return True
+
     def _refill(self):  # LZ4BlockInputStream.java:191-264, for up to batchBlocks blocks
+        if self.checksum is None and not self.hostWalk and hasattr(self.engine, "containerDecode") and self._refillDevice():
+            return
         blocks = []  # (method, payload, originalLen, check)
         exc = None
         finished = False

@@ -202,3 +202,94 @@ def test_device_container_exact_capacity_and_too_small(amd, O, corpus):
                     torch.cuda.synchronize()
                     assert int(total.item()) == len(want) > cap
                     assert bool((buf[cap:] == 0xA5).all()), (kind, chk, short, "bytes beyond dst_cap written")
+
+
+def test_device_read_path_equals_host_walk(S, amd, O, corpus, ref):
+    """SURVEY.md 8(f) f1 / f2, READ side: frames and LZ4Block streams whose headers are walked, checksums verified and blocks decoded ON
+    THE DEVICE (lz4hip_container_decode{,_dev}) deliver the same bytes and raise the same exception, at the same point of the stream,
+    as the readers that walk the headers on the host around the batch launches (hostWalk=True; the other cases of this file pin
+    those to the reference's readers) -- intact streams of every shape and the same streams damaged at every kind of place:
+    size words, payload bytes, block / content checksums, headers' magic / token / lengths / check, truncation anywhere."""
+    import random
+    rng = random.Random(404)
+    book = corpus["book1[:200000]"]
+    inputs = [b"", b"x", rng.randbytes(70000), book[:150000], O.gen_block(300000, 21, win=4096),
+              rng.randbytes(65536) + book[:65536] + bytes(65536) + rng.randbytes(100)]
+    eng = S.HIPEngine()
+
+    def drain(stream):
+        got = bytearray()
+        try:
+            while True:
+                b = stream.read(50000)
+                if not b:
+                    return bytes(got), None
+                got += b
+        except Exception as e:  # noqa: BLE001 -- the exception's type and text are what is compared
+            return bytes(got), (type(e).__name__, str(e))
+
+    def both(make):
+        a, b = drain(make(False)), drain(make(True))
+        assert a == b, (a[1], b[1], len(a[0]), len(b[0]))
+        return a
+
+    streams = []
+    for v in inputs:
+        for bs, bits in ((S.BLOCKSIZE.SIZE_64KB, (S.FLG.Bits.BLOCK_INDEPENDENCE,)),
+                         (S.BLOCKSIZE.SIZE_64KB, (S.FLG.Bits.BLOCK_INDEPENDENCE, S.FLG.Bits.BLOCK_CHECKSUM, S.FLG.Bits.CONTENT_CHECKSUM)),
+                         (S.BLOCKSIZE.SIZE_256KB, (S.FLG.Bits.BLOCK_INDEPENDENCE, S.FLG.Bits.CONTENT_SIZE))):
+            o = io.BytesIO()
+            w = S.LZ4FrameOutputStream(o, bs, len(v) if S.FLG.Bits.CONTENT_SIZE in bits else -1, *bits, engine=eng, batchBlocks=5)
+            w.write(v); w.close()
+            streams.append(("frame", o.getvalue(), v))
+        for block in (64, 1000, 65536):
+            o = io.BytesIO()
+            w = S.LZ4BlockOutputStream(o, block, engine=eng, batchBlocks=7)
+            w.write(v); w.close()
+            streams.append(("block", o.getvalue(), v))
+    n_err = 0
+    for kind, data, v in streams:
+        def make(hw, d=data, k=kind, bb=3):
+            return (S.LZ4FrameInputStream(io.BytesIO(d), engine=eng, batchBlocks=bb, hostWalk=hw) if k == "frame"
+                    else S.LZ4BlockInputStream(io.BytesIO(d), engine=eng, batchBlocks=bb, hostWalk=hw))
+        got, exc = both(make)
+        assert exc is None and got == v
+        for _ in range(6 if len(data) > 40 else 2):   # damage: a flipped byte anywhere, or a cut
+            d = bytearray(data)
+            if rng.random() < 0.3 and len(d) > 1:
+                d = d[:rng.randrange(1, len(d))]
+            else:
+                d[rng.randrange(len(d))] ^= 1 << rng.randrange(8)
+            r = both(lambda hw, d=bytes(d), k=kind: make(hw, d, k, rng.choice([1, 2, 64])) if False else make(hw, d, k))
+            n_err += r[1] is not None
+    assert n_err > 50
+    # stopOnEmptyBlock = False: the reader goes on behind an empty block
+    o = io.BytesIO()
+    for part in (book[:3000], b"", book[3000:9000]):
+        w = S.LZ4BlockOutputStream(o, 1000, engine=eng); w.write(part); w.finish()
+    cat = o.getvalue()
+    a = both(lambda hw: S.LZ4BlockInputStream(io.BytesIO(cat), stopOnEmptyBlock=False, engine=eng, batchBlocks=4, hostWalk=hw))
+    assert a == (book[:9000], None)
+    # the device-pointer entry itself: a frame body in device memory
+    import ctypes as C
+    import torch
+    o = io.BytesIO()
+    w = S.LZ4FrameOutputStream(o, S.BLOCKSIZE.SIZE_64KB, -1, S.FLG.Bits.BLOCK_INDEPENDENCE, S.FLG.Bits.BLOCK_CHECKSUM, engine=eng)
+    w.write(book[:150000] + rng.randbytes(66000)); w.close()
+    body = o.getvalue()[7:]   # magic, FLG, BD, HC: 7 bytes
+    dev0 = torch.device("cuda:0")
+    t = torch.frombuffer(bytearray(body), dtype=torch.uint8).to(dev0)
+    n_max = 8
+    dst = torch.zeros(n_max * 65536, dtype=torch.uint8, device=dev0)
+    sizes = torch.zeros(n_max, dtype=torch.int32, device=dev0)
+    info = torch.zeros(5, dtype=torch.int64, device=dev0)
+    wsb = amd.lib().lz4hip_container_decode_workspace_bytes(n_max)
+    ws = torch.zeros(wsb, dtype=torch.uint8, device=dev0)
+    rc = amd.lib().lz4hip_container_decode_dev(0, 1, t.data_ptr(), len(body), 65536, dst.data_ptr(), 65536, n_max, sizes.data_ptr(), info.data_ptr(),
+                                               ws.data_ptr(), wsb, 0, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert rc == 0
+    n_ok, consumed, why, total = (int(x) for x in info[:4].cpu())
+    assert (n_ok, why, total, consumed) == (4, 0, 216000, len(body))
+    out = b"".join(dst[k * 65536:k * 65536 + int(sizes[k])].cpu().numpy().tobytes() for k in range(n_ok))
+    assert out[:150000] == book[:150000] and len(out) == 216000
