@@ -328,6 +328,31 @@ def main():
                                      "unit": "GB/s", "verified": okc, "bytes_out": tot}
         ok = ok and okc
 
+        # ---- device-resident container decode (READ side): the frame body just assembled is walked (size words),
+        # decoded and its blocks' sizes checked on the device (lz4hip_container_decode_dev); the walk is a serial chain of one
+        # dependent load per block ----
+        import ctypes as C
+        L = amd.lib()
+        wsb = L.lz4hip_container_decode_workspace_bytes(n)
+        ws_t = torch.empty(wsb, dtype=u8, device=dev)
+        sizes_t = torch.zeros(n, dtype=i32, device=dev)
+        info_t = torch.zeros(5, dtype=i64, device=dev)
+        back.zero_()
+
+        def frame_read():
+            rc = L.lz4hip_container_decode_dev(0, 0, comp.data_ptr(), tot, blk, back.data_ptr(), blk, n, sizes_t.data_ptr(), info_t.data_ptr(),
+                                               ws_t.data_ptr(), wsb, dev.index or 0, torch.cuda.current_stream().cuda_stream)
+            assert rc == 0, L.lz4hip_last_error()
+        wr, tkr = timed(frame_read, 2)
+        inf = [int(x) for x in info_t.cpu()]
+        okr = all_ok(inf[0] == n and inf[1] == tot and inf[2] == 1 and inf[3] == n * blk and bool(torch.equal(back, src)))
+        extra["frame_read_dev"] = {"workload": "the frame body above (%d blocks) -> walked, decoded and checked on the device (lz4hip_container_decode_dev); "
+                                               "stop reason 1 = the body ended at a block boundary" % n,
+                                   "value": round(world * nbytes / wr / 1e9, 3), "unit": "GB/s", "verified": okr, "ms": round(tkr * 1e3, 3),
+                                   "note": "the size-word walk is one dependent load per block on one lane: it bounds this leg for small blocks"}
+        ok = ok and okr
+        del ws_t, sizes_t, info_t
+
         # ---- real text: BASELINE configs[0] names a 64 KiB Silesia/dickens block; the only real data of the reference are
         # src/test-resources/calgary/* (LZ4Test.java:335-348), so: every block = 64 KiB of Calgary book1 (English prose, the same
         # class) from a different offset.  Compressed bytes of a sample of blocks are compared with the reference library's. ----

@@ -619,6 +619,7 @@ __global__ __launch_bounds__(64) void container_walk_kernel(int kind, int block_
       k++;
     }
   }
+  if (k == n_max && p == body_bytes) why = CR_MORE;   // (every slot used and nothing left: not "more follows")
   c.walk[0] = k; c.walk[1] = why; c.walk[2] = (uint32_t)p; c.walk[3] = (uint32_t)(p >> 32);
 }
 // raw blocks: payload -> slot (one workgroup per block); also the length array of the LZ4Block checksum pass
