@@ -313,10 +313,14 @@ struct GroupDev {
     uint8_t* a = (rgb - LB) + t;
     if (aligned) {
       __builtin_memcpy(__builtin_assume_aligned(a, 4), &c, LB);
+#ifndef LZ4HIP_RING_PROBE_NOMIRROR   /* developer timing probe, NOT bit-exact: what the mirror stores' tests cost */
       if (t < 2u * LB) __builtin_memcpy(__builtin_assume_aligned(a + kRing, 4), &c, LB);
+#endif
     } else {
       __builtin_memcpy(a, &c, LB);
+#ifndef LZ4HIP_RING_PROBE_NOMIRROR
       if (t < 2u * LB) __builtin_memcpy(a + kRing, &c, LB);
+#endif
     }
   }
   // GL == 1: the lane keeps the five aligned dwords it stored last (cw, at ring position cbase).  Output is written in order, so the
@@ -346,13 +350,22 @@ struct GroupDev {
       if (t < 2u * WB) { uint32_t* b = dwp((rgb - WB) + t + kRing); b[0] = cw[0]; b[1] = cw[1]; b[2] = cw[2]; b[3] = cw[3]; b[4] = cw[4]; }
     } else {
       // lanes 1..: the aligned chunk at (w & ~3) + l LB holds the step's bytes [l LB - s, l LB - s + LB): this lane's dwords moved
-      // up by s bytes, the lowest bytes from the top dword of the lane below
+      // up by s bytes, the lowest bytes from the top dword of the lane below; lane 0: its bytes where they belong (the only
+      // unaligned lanes: 64 / GL per wavefront).  ONE index computation and ONE mirror test serve both kinds of lanes (a probe
+      // build without the mirror stores -- ten instructions and two conditional stores fewer per trip -- ran 10 % faster).
       const uint32_t below = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.w[LB / 4u - 1u], 0x111 /* row_shr:1 */, 0xF, 0xF, false);
       LChunk m;
 #pragma unroll
       for (uint32_t k = 0; k < LB / 4u; k++) m.w[k] = __builtin_amdgcn_perm(v.w[k], k ? v.w[k - 1u] : below, sel);
-      if (l != 0u) rg_put((w & ~3u) + l * LB, m, true);
-      else rg_put(w, v, false);   // lane 0: its bytes where they belong (the only unaligned lanes: 64 / GL per wavefront)
+      const bool l0 = l == 0u;
+      const uint32_t t = ((l0 ? w : (w & ~3u) + l * LB) + LB) & (kRing - 1u);
+      uint8_t* a = (rgb - LB) + t;
+      if (l0) __builtin_memcpy(a, &v, LB); else __builtin_memcpy(__builtin_assume_aligned(a, 4), &m, LB);
+#ifndef LZ4HIP_RING_PROBE_NOMIRROR   /* developer timing probe, NOT bit-exact */
+      if (__builtin_expect(t < 2u * LB, 0)) {
+        if (l0) __builtin_memcpy(a + kRing, &v, LB); else __builtin_memcpy(__builtin_assume_aligned(a + kRing, 4), &m, LB);
+      }
+#endif
     }
   }
   // (re-)seed: the aligned step at pos (from memory) is the ring's first content
