@@ -215,6 +215,7 @@ struct GroupDev {
     return v;
   }
   __device__ __forceinline__ void step_store(uint8_t* d, const Chunk<LB / 4>& v) const { store_out(d + l * LB, v); }
+  __device__ __forceinline__ uint32_t lane_bytes() const { return l * LB; }   // this lane's offset inside a step
   // the same, but lanes whose LB bytes lie at or beyond `len` read from `idle` (a step that is cached) instead
   __device__ __forceinline__ Chunk<LB / 4> step_load_upto(const uint8_t* m, uint32_t len, const uint8_t* idle) const {
     return step_load(l * LB < len ? m : idle);

@@ -113,7 +113,7 @@ LZ4HIP_DEV bool decode_deep_loop(Grp& g, const uint8_t* src, const int iend, uin
       LZ4HIP_REFILL_FETCH                                                                                                      \
     }                                                                                                                          \
     v##c = g.sr_step(ip + hdr);                                                                                                \
-    u##c = g.step_load(dst + mpos);                                                                                            \
+    u##c = g.step_load_upto(dst + mpos, ml, dst + mpos - g.lane_bytes());   /* (lanes beyond the match re-read its first bytes: no line of their own) */ \
     sop##c = op; lit##c = lit;                                                                                                 \
     LZ4HIP_RETIRE(a);                                                                                                          \
     if (REFILL == 2) { LZ4HIP_REFILL_PUT }                                                                                     \

@@ -180,6 +180,7 @@ struct GroupHost {
     for (int l = 0; l < GL; l++) if (rd_ok(m + l * LB, LB)) memcpy(v.b[l], m + l * LB, LB);
     return v;
   }
+  uint32_t lane_bytes() const { return 0; }   // (the simulator's idle lanes read the step's own first chunk: see step_load_upto)
   LChunk step_load_upto(const uint8_t* m, uint32_t len, const uint8_t* idle) {
     LChunk v; memset(&v, 0, sizeof v);
     const uint32_t LB = lb();
