@@ -40,8 +40,11 @@ def pack(blocks, caps):
         so.append(p); sl.append(len(b)); do.append(q); p += len(b); q += c
     return src, so, sl, bytearray(max(q, 1)), do
 src, so, sl, dst, do = pack(streams, caps)
-for lanes in (4, 8, 16):
-    amd.set_option("decode_lanes", lanes); amd.set_option("decode_pipe", 2); amd.set_option("decode_stage", 0)
+# FUZZ_PIPE=3 [FUZZ_RING=<bytes>]: the ring loop (lz4_decode_ring.h) instead of the deep loop; lanes 1 / 4 / 8 / 16
+pipe = int(os.environ.get("FUZZ_PIPE", "2")); ring = int(os.environ.get("FUZZ_RING", "0"))
+for lanes in ((4, 8, 16) if pipe == 2 else (1, 4, 8, 16)):
+    amd.set_option("decode_lanes", lanes); amd.set_option("decode_pipe", pipe); amd.set_option("decode_stage", 0)
+    amd.set_option("decode_ring", ring if lanes != 1 or ring in (0, 256, 512) else 256)
     out = amd.LZ4HIPBatch.decompressSafe(src, so, sl, dst, do, caps)
     bad = 0
     for k, (r, (er, ed)) in enumerate(zip(out, want)):
