@@ -107,7 +107,7 @@ def decode_kernel_name(n_blocks, safe=True, big_blocks=False):
 
 def spread(r, *keys):
     """best-of-N / median-of-N of the named rates of a cpu_bench line (1.0 = every repetition the same; the harness repeats whole
-    passes for >= 300 ms per repetition on a persistent pinned thread pool, oracle/cpu_bench.c)"""
+    passes for >= CPU_BENCH_MIN_MS (300; headline 1000) per repetition on a persistent pinned thread pool, oracle/cpu_bench.c)"""
     return {k: round(r[k] / r[k + "_median"], 3) for k in keys if r.get(k + "_median")}
 
 
@@ -549,7 +549,7 @@ def main():
         if want_cpu:
             def f1():
                 sample = min(n, 64 * cores)
-                r = cpu_bench([sample, blk, cores, 5, 0, args.litmax, args.win])
+                r = cpu_bench([sample, blk, cores, 5, 0, args.litmax, args.win], {"CPU_BENCH_MIN_MS": "1000"})
                 r1 = cpu_bench([min(n, 256), blk, 1, 3, 0, args.litmax, args.win])     # one host thread: the per-core figure
                 return {"value": round(r["roundtrip_GBps"], 3), "median": round(r["roundtrip_GBps_median"], 3), "unit": "GB/s", "cores": cores, "kind": r["_kind"],
                         "sample": "%d x %d B blocks (same generator/seed), %d pinned threads of a persistent pool, best (and median) of 5 repetitions of >= %d ms "

@@ -85,6 +85,10 @@ static pthread_barrier_t gate;
 static int n_passes, quit;
 static struct Share { _Atomic long next; long total; int b0, len; char pad[40]; } share[256];   /* tickets: pass * len + (block - b0) */
 static int cpus[1024], n_cpus;
+/* one worker per block at a time: with stealing, a late ticket of pass p and a ticket of pass p + 1 can name the same block, and two
+   decoders writing one output (wild copies run past the match end before the next sequence overwrites them) would read each other's
+   scratch bytes */
+static _Atomic unsigned char* busy;
 
 static void run_share(int ph, long t, int v) {   /* blocks of worker v's share, taken ticket by ticket */
   struct Share* s = &share[v];
@@ -92,7 +96,10 @@ static void run_share(int ph, long t, int v) {   /* blocks of worker v's share, 
   for (;;) {
     long k = atomic_fetch_add_explicit(&s->next, 1, memory_order_relaxed);
     if (k >= s->total) return;
-    do_block(ph, t, s->b0 + (int)(k % s->len));
+    const int b = s->b0 + (int)(k % s->len);
+    while (atomic_exchange_explicit(&busy[b], 1, memory_order_acquire)) __builtin_ia32_pause();
+    do_block(ph, t, b);
+    atomic_store_explicit(&busy[b], 0, memory_order_release);
   }
 }
 static void* worker(void* arg) {
@@ -112,6 +119,8 @@ static void pool_start(void) {
   cpu_set_t set;
   if (sched_getaffinity(0, sizeof set, &set) == 0)
     for (int c = 0; c < CPU_SETSIZE && n_cpus < 1024; c++) if (CPU_ISSET(c, &set)) cpus[n_cpus++] = c;
+  busy = calloc((size_t)n_blocks, 1);
+  if (!busy) { fprintf(stderr, "malloc\n"); exit(5); }
   pthread_barrier_init(&gate, NULL, (unsigned)n_threads + 1u);
   for (long t = 0; t < n_threads; t++) pthread_create(&pool[t], NULL, worker, (void*)t);
 }

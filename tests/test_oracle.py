@@ -131,3 +131,23 @@ def test_fast_decoder_contract_vectors(O):
         assert r == e["ret"]
         if r >= 0:
             assert hashlib.sha256(d[:e["dst_len"]]).hexdigest() == e["sha256"]
+
+
+def test_cpu_bench_harness_one_block_per_thread():
+    """oracle/cpu_bench (the CPU leg of bench.py): with as many threads as blocks every share is ONE block, repeated passes and
+    stealing make several workers ask for the same block, and the harness must still hand a block to one worker at a time
+    (two decoders on one output buffer read each other's wild-copy scratch).  Port library only: runs without oracle/_ref."""
+    import json
+    import subprocess
+    odir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    exe = os.path.join(odir, "cpu_bench_test")
+    subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-o", exe, os.path.join(odir, "cpu_bench.c"), "-ldl", "-lpthread"])
+    try:
+        port = os.path.join(odir, "liblz4oracle.so")
+        for n, blk in ((4, 65536), (3, 1 << 20)):
+            out = subprocess.check_output([exe, "port", port, port, str(n), str(blk), str(n), "2", "0", "38", "4096"],
+                                          env=dict(os.environ, CPU_BENCH_MIN_MS="60"), timeout=120)
+            r = json.loads(out)
+            assert r["ok"] is True and r["n_blocks"] == n and min(r["passes"]) >= 2
+    finally:
+        os.remove(exe)
