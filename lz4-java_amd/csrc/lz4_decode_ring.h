@@ -161,7 +161,7 @@ LZ4HIP_DEV bool decode_ring_loop(Grp& g, const uint8_t* src, const int iend, uin
       ipl = stall ? ipl : lpos + le;                                                                                           \
       cm = stall ? cm : ml - me;                                                                                               \
       coff = stall ? coff : (me == off ? 2u * off : off);                                                                      \
-      since += (since != 0u) | g.any(frozen) ? 1u : 0u;                                                                        \
+      since += ((since != 0u) | g.any(frozen)) ? 1u : 0u;                                                                        \
       g.rg_write(sop##a + lit##a, Grp::pick(nr##a, ul, ug##a));                                                                \
     }
     // (values that come from memory are made to arrive HERE: a wait at the loop's head would be a wait for everything every trip)

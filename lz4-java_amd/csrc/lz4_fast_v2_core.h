@@ -21,6 +21,7 @@
 #include "lz4_fast_core.h"
 #if defined(__HIPCC__)
 #include "lz4_fast_v2_asm.h"
+#include "lz4_fast_v2_asm32.h"
 #endif
 
 #ifndef LZ4HIP_V2_PROBE
@@ -344,6 +345,20 @@ struct FastV2 {
           }
 #endif
           (void)code;
+          if (out.cnt == 64u) { out.batch(); continue; }
+          if (ip > lim) break;
+        }
+      }
+#ifndef LZ4HIP_V2_ASM32
+#define LZ4HIP_V2_ASM32 1   /* 0: byU32 blocks keep the compiler-generated lean loop (developer A/B) */
+#endif
+      // byU32 blocks: the same loop with 64-bit table entries and the 5-byte hash (lz4_fast_v2_asm32.h)
+      if constexpr (!U16 && LZ4HIP_V2_ASM32 && !LZ4HIP_V2_ASM_PROF && W::kAsmLean && OUT::kAsmPark) {
+        if (!st) {
+          if (__builtin_amdgcn_read_exec() != ~0ull) __builtin_trap();
+          (void)lean_asm_run32(ip, prev_hpos, pf_end, out.cnt, prev_fa, out.p_ms, out.p_ml, out.p_off,
+                               lim >= 192u ? lim - 192u : 0u, src,
+                               (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)w.lds, n);
           if (out.cnt == 64u) { out.batch(); continue; }
           if (ip > lim) break;
         }
