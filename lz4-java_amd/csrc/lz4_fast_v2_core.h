@@ -321,6 +321,17 @@ struct FastV2 {
     uint32_t prev_hpos = 0x80000000u;   // (no row yet: ip - prev_hpos is huge)
     while (ip <= lim && !out.bail) {
 #if defined(__HIP_DEVICE_COMPILE__) && LZ4HIP_V2_ASM
+#ifndef LZ4HIP_V2_ROWLOAD
+#define LZ4HIP_V2_ROWLOAD 1   /* 0: without a row the first step after an exact-path sequence is a C++ step (developer A/B) */
+#endif
+      // The hand-scheduled loop cuts its windows out of the row at the previous hit.  After a sequence of the exact path there is
+      // none: fetch the 256 bytes at ip - 2 (one round trip) instead of spending a whole compiler-generated step on getting one.
+      if constexpr (LZ4HIP_V2_ROWLOAD && W::kAsmLean && OUT::kAsmPark) {
+        if (!st && ip - prev_hpos > (U16 ? 127u : 126u) && ip >= 2u && out.cnt < 63u) {
+          prev_hpos = ip - 2u;
+          prev_fa = w.ldu32(src, j4 + prev_hpos);
+        }
+      }
       // The common steps run in the hand-scheduled loop of lz4_fast_v2_asm.h; it comes back when 64 hits are parked, at the loop
       // limit, or in front of a step it does not handle -- nothing of that step is left in the table, and the C++ step below
       // takes it from the same state with every rule.
