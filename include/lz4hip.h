@@ -68,7 +68,9 @@ int lz4hip_version(void);
  * reaches memory as whole 128-byte lines (faster when the batch is bandwidth-bound); "compress_core" = 5 (default: adaptive two-pass -- blocks of long
  * sequences are finished by the lean core (lz4_fast_v2_core.h), whose parked hits a partner wavefront writes out, blocks of
  * short sequences by the window-parallel core), 3 (lean core only) or 1 (window-parallel core only);
- * "compress_switch" = routing threshold of the adaptive schemes in bytes per sequence (default 16).  The knobs are
+ * "compress_switch" = routing threshold of the adaptive schemes in bytes per sequence (default 16); "compress_pack" = 1 (default) / 0:
+ * blocks of 65547 bytes .. 4 MiB are compressed with 32-bit table entries on eight match-finder chains per CU instead of five
+ * (0: every block on the five-chain kernel).  The knobs are
  * process-wide atomics read once per launch; every setting produces the same bytes.                                       */
 int lz4hip_set_option(const char* name, int value);
 

@@ -1076,6 +1076,11 @@ int lz4hip_set_option(const char* name, int value) {
     g_compress_core = value;
     return LZ4HIP_OK;
   }
+  if (name && strcmp(name, "compress_pack") == 0) {
+    if (value != 0 && value != 1) return fail(LZ4HIP_E_ARG, "compress_pack must be 0 or 1");
+    lz4hip::set_compress_pack(value);
+    return LZ4HIP_OK;
+  }
   if (name && strcmp(name, "compress_switch") == 0) {
     if (value < 0 || value > 1024) return fail(LZ4HIP_E_ARG, "compress_switch must be 0..1024");
     g_compress_switch = value;

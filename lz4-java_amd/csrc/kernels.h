@@ -24,6 +24,8 @@ struct BatchArgs {
 // `mail`: compress_fast_v2w_scratch_words(n_cus) words of device scratch (the finder/writer rings)
 size_t compress_fast_v2w_scratch_words(uint32_t n_cus);
 int launch_compress_fast_v2w(const BatchArgs& a, uint32_t* q, uint32_t* routed, uint32_t dense64, uint32_t n_cus, uint32_t* mail, void* stream);
+// 1 (default): blocks of 65547 bytes .. 4 MiB run on ten pairs per CU with compact table entries (compress_fast_v2wp_cu_kernel); 0: five pairs for all
+void set_compress_pack(int v);
 int launch_compress_fast_ms(const BatchArgs& a, uint32_t* q, const uint32_t* routed, bool first, uint32_t n_cus, void* stream);
 #ifdef LZ4HIP_DEV_TOOLS
 int launch_compress_fast_prof(const BatchArgs& a, uint64_t* prof, int core, void* stream);  // developer build only (tools/build_variant.sh dev -DLZ4HIP_DEV_TOOLS)

@@ -19,6 +19,8 @@
 //   gen_blocks_kernel    : SURVEY.md App. F workload generator (setup only, never timed).
 // No MFMA anywhere: this is byte shuffling, not a contraction.
 #include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -115,8 +117,27 @@ __device__ __forceinline__ void mail_writer(const BatchArgs& a, uint32_t* slots,
   mail_writer_t<WaveDev, MailDev>(w, a, slots, ctr);
 }
 
+// Control words of a fast-compress launch (the first words of its `mail` scratch): which blocks go to which kernel.
+//   A block of 65547 bytes .. 4 MiB can use the compact table entries of lz4_fast_core.h (PK: {position 22 bits, fingerprint 10 bits},
+//   16 KB per table), and a CU then holds TEN finder / writer pairs instead of five: compress_fast_v2wp_cu_kernel takes those blocks,
+//   compress_fast_v2w_cu_kernel everything else.  The lengths live in device memory, so both kernels are always launched and decide
+//   from these counts on the device; the one without work returns at once (~10 us per launch).
+enum : uint32_t { CTL_PK = 0, CTL_OTHER = 1, CTL_DRAW_PK = 2, CTL_WORDS = 64 };
+constexpr int32_t PK_MAX_N = 1 << 22;
+__device__ __forceinline__ bool pk_block(int32_t n, int32_t cap) { return n >= 65547 && n <= PK_MAX_N && cap >= 0; }
+__global__ __launch_bounds__(256) void compress_classify_kernel(const int32_t* src_len, const int32_t* dst_cap, uint32_t n, uint32_t* ctl) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  const bool in = i < n;
+  const bool pk = in && pk_block(src_len[i], dst_cap[i]);
+  const uint32_t c_pk = (uint32_t)__builtin_popcountll(__ballot(pk)), c_ot = (uint32_t)__builtin_popcountll(__ballot(in && !pk));
+  if (__lane_id() == 0) {
+    if (c_pk) atomicAdd(ctl + CTL_PK, c_pk);
+    if (c_ot) atomicAdd(ctl + CTL_OTHER, c_ot);
+  }
+}
+
 // ---- the default: the five LDS pairs alone ----
-__global__ __launch_bounds__(64 * 2 * WAVES_PER_CU) void compress_fast_v2w_cu_kernel(BatchArgs a, uint32_t* q, uint32_t* routed, uint32_t dense64, uint32_t* mail_ctr, uint32_t* mail_slots) {
+__global__ __launch_bounds__(64 * 2 * WAVES_PER_CU) void compress_fast_v2w_cu_kernel(BatchArgs a, uint32_t* q, uint32_t* routed, uint32_t dense64, uint32_t* mail_ctr, uint32_t* mail_slots, const uint32_t* ctl) {
   __shared__ __attribute__((aligned(16))) uint64_t tables[WAVES_PER_CU][LZ4HIP_TABLE_U64];
   const uint32_t wv = threadIdx.x >> 6;
   const uint32_t pair = blockIdx.x * WAVES_PER_CU + (wv < WAVES_PER_CU ? wv : wv - WAVES_PER_CU);
@@ -129,10 +150,18 @@ __global__ __launch_bounds__(64 * 2 * WAVES_PER_CU) void compress_fast_v2w_cu_ke
   uint64_t* table = tables[wv];
   WaveDev w(table);
   uint32_t head = 0, tail_seen = 0;
+  // (ctl: the ten-pair kernel ran before this one and took the blocks it can take)
+  const bool pk_taken = ctl != nullptr && __builtin_amdgcn_readfirstlane(ctl[CTL_PK]) != 0u;
+  if (pk_taken && __builtin_amdgcn_readfirstlane(ctl[CTL_OTHER]) == 0u) {
+    MailOut<WaveDev> out(w, slots, ctr, head);
+    out.post(MAIL_EXIT, 0u, 0u);
+    return;
+  }
   for (;;) {
     uint32_t b = 0;
     if (__lane_id() == 0) b = atomicAdd(q, 1u);
     b = __builtin_amdgcn_readfirstlane(b);
+    if (b < a.n && pk_taken && pk_block(uniform_i32(a.src_len[b]), uniform_i32(a.dst_cap[b]))) continue;
     MailOut<WaveDev> out(w, slots, ctr, head);
     out.tail_seen = tail_seen;
     if (b >= a.n) { out.post(MAIL_EXIT, 0u, 0u); return; }
@@ -146,7 +175,7 @@ __global__ __launch_bounds__(64 * 2 * WAVES_PER_CU) void compress_fast_v2w_cu_ke
         FastV2<WaveDev, MailOut<WaveDev>> c(w, out, s, (uint32_t)n);
         (void)c.run();
       } else {
-        FastV2<WaveDev, MailOut<WaveDev>, false> c(w, out, s, (uint32_t)n);   // byU32 blocks: the lean loop in C++ + the exact core
+        FastV2<WaveDev, MailOut<WaveDev>, false> c(w, out, s, (uint32_t)n);   // byU32 blocks (64-bit entries: any size)
         (void)c.run();
       }
       if (out.bail) {
@@ -160,21 +189,94 @@ __global__ __launch_bounds__(64 * 2 * WAVES_PER_CU) void compress_fast_v2w_cu_ke
     WaveDev::sync();  // the table is reused
   }
 }
-// scratch words the two-wave kernel needs after the three queue words: counters of every pair, then (256-word aligned) the rings
+
+// ---- byU32 blocks of at most 4 MiB (the largest block of the LZ4 Frame format, the default of the reference's
+// LZ4FrameOutputStream): compact entries, 16 KB per table.  Measured on 8192 x 4 MiB (profiles/r04_compress_study.txt): throughput is
+// linear in the chains a CU holds -- 3 / 5 / 6 / 8 chains: 74 / 115 / 134 / 177 GB/s -- and workgroups that SHARE a CU get 128 KB of its
+// LDS between them, not 160 (2 x 80 KB, 3 x 48 KB and 5 x 32 KB all leave one workgroup waiting; a single workgroup does get 160 KB).
+// So: four pairs per workgroup (64 KB, eight wavefronts = two per SIMD), two workgroups per CU = EIGHT chains per CU, against five
+// with 32 KB tables.  (Ten would take one workgroup of more than 1024 threads, or writers shared between finders.)
+#ifndef LZ4HIP_PK_PAIRS
+#define LZ4HIP_PK_PAIRS 4
+#endif
+#ifndef LZ4HIP_PK_WGS
+#define LZ4HIP_PK_WGS 2
+#endif
+#ifndef LZ4HIP_PK_WAVES_PER_SIMD
+#define LZ4HIP_PK_WAVES_PER_SIMD 4
+#endif
+constexpr uint32_t PK_PAIRS = LZ4HIP_PK_PAIRS;
+constexpr uint32_t PK_WGS_PER_CU = LZ4HIP_PK_WGS;
+__global__ __launch_bounds__(64 * 2 * PK_PAIRS, LZ4HIP_PK_WAVES_PER_SIMD) void compress_fast_v2wp_cu_kernel(BatchArgs a, uint32_t* ctl, uint32_t* q, uint32_t* routed, uint32_t dense64, uint32_t* mail_ctr, uint32_t* mail_slots) {
+  __shared__ __attribute__((aligned(16))) uint32_t tables[PK_PAIRS][4096];
+  if (__builtin_amdgcn_readfirstlane(ctl[CTL_PK]) == 0u) return;   // (every wavefront: no such block in this batch)
+  const uint32_t wv = threadIdx.x >> 6;
+  const uint32_t pair = blockIdx.x * PK_PAIRS + (wv < PK_PAIRS ? wv : wv - PK_PAIRS);
+  uint32_t* ctr = mail_ctr + 2u * pair;
+  uint32_t* slots = mail_slots + (size_t)pair * (MAIL_RING * MAIL_SLOT_WORDS);
+  if (wv >= PK_PAIRS) { mail_writer(a, slots, ctr); return; }
+  __builtin_amdgcn_s_setprio(3);
+  WaveDev w((uint64_t*)tables[wv]);
+  uint32_t head = 0, tail_seen = 0;
+  for (;;) {
+    uint32_t b = 0;
+    if (__lane_id() == 0) b = atomicAdd(ctl + CTL_DRAW_PK, 1u);
+    b = __builtin_amdgcn_readfirstlane(b);
+    if (b < a.n && !pk_block(uniform_i32(a.src_len[b]), uniform_i32(a.dst_cap[b]))) continue;
+    MailOut<WaveDev> out(w, slots, ctr, head);
+    out.tail_seen = tail_seen;
+    if (b >= a.n) { out.post(MAIL_EXIT, 0u, 0u); return; }
+    out.b = b;
+    const int32_t n = uniform_i32(a.src_len[b]);
+    const uint8_t* s = uniform_ptr(a.src + a.src_off[b]);
+    out.dense64 = routed ? dense64 : 0u;
+    {
+      FastV2<WaveDev, MailOut<WaveDev>, false, true> c(w, out, s, (uint32_t)n);
+      (void)c.run();
+    }
+    if (out.bail) {
+      out.post(MAIL_ABORT, 0u, 0u);
+      if (__lane_id() == 0) routed[atomicAdd(q + 1, 1u)] = b;
+    }
+    head = out.head; tail_seen = out.tail_seen;
+    WaveDev::sync();  // the table is reused
+  }
+}
+// scratch words the two-wave kernels need after the three queue words: the control words, the counters of every pair (ten per CU
+// at most), then (1024-byte aligned) the rings
+static int g_compress_pack = 1;   // "compress_pack": 0 = every block on the five-pair kernel (developer A/B)
+void set_compress_pack(int v) { g_compress_pack = v; }
 size_t compress_fast_v2w_scratch_words(uint32_t n_cus) {
-  const size_t pairs = (size_t)n_cus * WAVES_PER_CU;
-  return 2u * pairs + 256u + pairs * (MAIL_RING * MAIL_SLOT_WORDS);
+  const size_t pairs = (size_t)n_cus * (PK_PAIRS * PK_WGS_PER_CU > WAVES_PER_CU ? PK_PAIRS * PK_WGS_PER_CU : WAVES_PER_CU);
+  return CTL_WORDS + 2u * pairs + 256u + pairs * (MAIL_RING * MAIL_SLOT_WORDS);
 }
 int launch_compress_fast_v2w(const BatchArgs& a, uint32_t* q, uint32_t* routed, uint32_t dense64, uint32_t n_cus, uint32_t* mail, void* stream) {
   if (a.n == 0) return 0;
-  const size_t pairs = (size_t)n_cus * WAVES_PER_CU;
-  hipError_t e = hipMemsetAsync(q, 0, 3 * sizeof(uint32_t), (hipStream_t)stream);
+  hipStream_t st = (hipStream_t)stream;
+  const bool pack = g_compress_pack != 0;
+  const size_t pairs_max = (size_t)n_cus * (PK_PAIRS * PK_WGS_PER_CU > WAVES_PER_CU ? PK_PAIRS * PK_WGS_PER_CU : WAVES_PER_CU);
+  uint32_t* ctl = mail;
+  uint32_t* ctr = mail + CTL_WORDS;
+  uint32_t* slots = (uint32_t*)(((uintptr_t)(ctr + 2u * pairs_max) + 1023u) & ~(uintptr_t)1023u);
+  hipError_t e = hipMemsetAsync(q, 0, 3 * sizeof(uint32_t), st);
   if (e != hipSuccess) return (int)e;
-  e = hipMemsetAsync(mail, 0, 2u * pairs * sizeof(uint32_t), (hipStream_t)stream);
+  e = hipMemsetAsync(mail, 0, (CTL_WORDS + 2u * pairs_max) * sizeof(uint32_t), st);
   if (e != hipSuccess) return (int)e;
-  uint32_t* slots = (uint32_t*)(((uintptr_t)(mail + 2u * pairs) + 1023u) & ~(uintptr_t)1023u);
+  if (pack) {
+    if (getenv("LZ4HIP_OCC_DEBUG")) {
+      int nb = -1;
+      hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, compress_fast_v2wp_cu_kernel, 64 * 2 * PK_PAIRS, 0);
+      fprintf(stderr, "[lz4hip] compress_fast_v2wp_cu_kernel: %d workgroups per CU (%s)\n", nb, hipGetErrorString(oe));
+    }
+    hipLaunchKernelGGL(compress_classify_kernel, dim3((a.n + 255u) / 256u), dim3(256), 0, st, a.src_len, a.dst_cap, a.n, ctl);
+    const uint32_t want = (a.n + PK_PAIRS - 1u) / PK_PAIRS, most = n_cus * PK_WGS_PER_CU;
+    hipLaunchKernelGGL(compress_fast_v2wp_cu_kernel, dim3(want < most ? want : most), dim3(64 * 2 * PK_PAIRS), 0, st, a, ctl, q, routed, dense64, ctr, slots);
+    e = hipMemsetAsync(ctr, 0, 2u * pairs_max * sizeof(uint32_t), st);   // the rings start empty again
+    if (e != hipSuccess) return (int)e;
+  }
   const uint32_t wgs = (a.n + WAVES_PER_CU - 1u) / WAVES_PER_CU;
-  hipLaunchKernelGGL(compress_fast_v2w_cu_kernel, dim3(wgs < n_cus ? wgs : n_cus), dim3(64 * 2 * WAVES_PER_CU), 0, (hipStream_t)stream, a, q, routed, dense64, mail, slots);
+  hipLaunchKernelGGL(compress_fast_v2w_cu_kernel, dim3(wgs < n_cus ? wgs : n_cus), dim3(64 * 2 * WAVES_PER_CU), 0, st, a, q, routed, dense64, ctr, slots,
+                     pack ? (const uint32_t*)ctl : (const uint32_t*)nullptr);
   return (int)hipGetLastError();
 }
 

@@ -222,15 +222,23 @@ struct DirectOut {
 // flag / mask of a packed literal length (lz4_fast_ms_core.h): bit 29 = liblz4's _next_match path (no literal-capacity check)
 constexpr uint32_t SEQ_NOCHECK = 1u << 29, SEQ_LIT_MASK = (1u << 29) - 1u;
 
-template <class W, bool U16, class Out = DirectOut<W>>
+// PK (byU32 blocks of at most 4 MiB only -- the largest block of the LZ4 Frame format and its default in the reference's
+// LZ4FrameOutputStream): the 4096 entries are 32 bits, {position (22 bits), fingerprint (10 bits)}, 16 KB instead of 32 -- twice the
+// match-finder chains per CU (kernels.hip, compress_fast_v2w8_cu_kernel).  A narrower fingerprint only means more tentative hits that
+// their candidate bytes rule out; what is accepted and what the table holds are liblz4's at any width.
+template <class W, bool U16, class Out = DirectOut<W>, bool PK = false>
 struct FastCore {
+  static_assert(!(U16 && PK), "compact entries are a byU32 layout");
+  static constexpr bool S32 = U16 || PK;           // entries are 32 bits
+  static constexpr uint32_t kPackMaxN = 1u << 22;  // PK: positions have 22 bits
   using VU = typename W::VU;
   using VU64 = typename W::VU64;
   using VB = typename W::VB;
-  using E = typename W::template Entry<U16>::S;   // scalar table entry (uint32_t / uint64_t)
-  using VE = typename W::template Entry<U16>::V;  // per-lane table entry
+  using E = typename W::template Entry<S32>::S;   // scalar table entry (uint32_t / uint64_t)
+  using VE = typename W::template Entry<S32>::V;  // per-lane table entry
   static constexpr int HLOG = U16 ? LZ4HIP_PROBE_HLOG : 12;
-  static constexpr int PSHIFT = U16 ? 16 : 32;
+  static constexpr int PSHIFT = U16 ? 16 : (PK ? 10 : 32);
+  static constexpr uint32_t FPM = PK ? 0x3FFu : 0xFFFFu;   // fingerprint bits of an entry
   static constexpr uint32_t MAXD = 65535u;
 #ifndef LZ4HIP_SPEC_LANES
 #define LZ4HIP_SPEC_LANES 16
@@ -259,16 +267,21 @@ struct FastCore {
 
   // ---- table entry helpers ---------------------------------------------------------------
   LZ4HIP_DEV static VE mk_entry(VU pos, VU fp) {
-    if constexpr (U16) return (pos << 16) | fp;
+    if constexpr (S32) return (pos << PSHIFT) | fp;
     else return (W::u64(pos) << 32) | W::u64(fp);
   }
   LZ4HIP_DEV static VU e_pos(VE e) {
-    if constexpr (U16) return e >> 16;
+    if constexpr (S32) return e >> PSHIFT;
     else return W::lo32(e >> 32);
   }
   LZ4HIP_DEV static VU e_fp(VE e) {
-    if constexpr (U16) return e & 0xFFFFu;
+    if constexpr (S32) return e & FPM;
     else return W::lo32(e) & 0xFFFFu;
+  }
+  // byU32 fingerprint of the four bytes x (byU16 entries take theirs out of the bucket product)
+  LZ4HIP_DEV static VU fp32(VU x) {
+    if constexpr (PK) return ((x * 2654435761u) >> 16) & FPM;
+    else return (x * 2654435761u) >> 16;
   }
   LZ4HIP_DEV static uint32_t se_pos(E e) { return (uint32_t)(e >> PSHIFT); }
 
@@ -359,9 +372,9 @@ struct FastCore {
     {
       const uint32_t x0 = w.sld32(src, 0);
       if constexpr (U16) fp0 = ((x0 * 2654435761u) >> 3) & LZ4HIP_FP_MASK;
-      else fp0 = (x0 * 2654435761u) >> 16;
+      else fp0 = ((x0 * 2654435761u) >> 16) & FPM;
     }
-    w.template lds_fill<U16>(1u << HLOG, (E)fp0);
+    w.template lds_fill<S32>(1u << HLOG, (E)fp0);
     w.sync();
     if (dense64 == 0u) return loop<0>(false, 1u, 0u, 0u);
     // density probe: a second copy of the loop counts the first 96 sequences, so the main loop stays untouched
@@ -405,11 +418,11 @@ struct FastCore {
       } else {
         x32 = W::lo32(sp_x64);
         h = W::lo32(((sp_x64 << 24) * 889523592379ull) >> (64 - HLOG));
-        fp = (x32 * 2654435761u) >> 16;
+        fp = fp32(x32);
       }
       LZ4HIP_PHASE(0, w.bcast(h, 0));   // t[0]: input window arrived + hash
       // ---- [2] table lookup, tentative hits, commit ----
-      const VE e = w.template lds_rdu<U16>(h);
+      const VE e = w.template lds_rdu<S32>(h);
       const VE newe = mk_entry(pos, fp);
       // (ballots of plain compares are free -- the compare already writes the lane mask; the masks are combined on the scalar side)
       uint64_t tmask = w.ballot(e_fp(e) == fp) & probem;
@@ -421,13 +434,13 @@ struct FastCore {
       bool have_hit = ncommit == k0 + 1u;   // == (k0 < kinv), as a 32-bit equality (the 64-bit ctz results have no scalar "<")
       uint64_t inm = ncommit >= 64u ? ~0ull : ((1ull << ncommit) - 1ull);  // lanes that commit their insert
       LZ4HIP_PHASE(1, ncommit);          // t[1]: table read + ballots
-      const VE old = w.template lds_max<U16>(h, newe, w.lanes(inm));
+      const VE old = w.template lds_max<S32>(h, newe, w.lanes(inm));
 
       // ---- [3] speculative candidate fetch: verify + forward + backward extension in ONE round trip.
       // Branch-free: without a tentative hit the loads still go out (lane 0's slot vs position 0, L1 hits). ----
       const uint32_t kk = have_hit ? k0 : 0u;
       uint32_t hpos = w.bcast(pos, (int)kk);
-      uint32_t mpos = se_pos(w.template bcast_e<U16>(e, (int)kk));
+      uint32_t mpos = se_pos(w.template bcast_e<S32>(e, (int)kk));
       bool hit_post = post && k0 == 1u;
       uint32_t maxback = (!have_hit || hit_post) ? 0u : ((hpos - anchor) < mpos ? (hpos - anchor) : mpos);
       // (only the first kSpecLanes lanes take part -- 8 bytes each: the candidate side is a random re-read of the block and
@@ -460,7 +473,7 @@ struct FastCore {
       if (LZ4HIP_UNLIKELY(det != 0)) {
         if (st) st->slow_steps++;
         const VB inrange = w.lanes(inm);
-        w.template lds_wr<U16>(h, e, inrange);
+        w.template lds_wr<S32>(h, e, inrange);
         w.sync();
         VE se = e;  // candidate each lane sees under sequential semantics
         uint64_t pendm = det;
@@ -472,7 +485,7 @@ struct FastCore {
           const VU64 lower = w.lanemask_lt() & VU64(gm);
           const VB has = grp & (lower != VU64(0));
           const VU srcl = VU(63u) - W::clz64(lower);
-          const VE pe = w.template shfl_e<U16>(newe, srcl);
+          const VE pe = w.template shfl_e<S32>(newe, srcl);
           se = W::select(has, pe, se);
           pendm &= ~gm;
         }
@@ -488,10 +501,10 @@ struct FastCore {
           have_hit = false;  // the tentative lane (if any) no longer matches under the sequential candidates
         }
         inm = ncommit >= 64u ? ~0ull : ((1ull << ncommit) - 1ull);
-        (void)w.template lds_max<U16>(h, newe, w.lanes(inm));
+        (void)w.template lds_max<S32>(h, newe, w.lanes(inm));
         if (have_hit) {
           hpos = w.bcast(pos, (int)k0);
-          mpos = se_pos(w.template bcast_e<U16>(se, (int)k0));
+          mpos = se_pos(w.template bcast_e<S32>(se, (int)k0));
           if (!had || hpos != hpos_old || mpos != mpos_old) {  // the speculation fetched the wrong candidate
             hit_post = post && k0 == 1u;
             maxback = hit_post ? 0u : ((hpos - anchor) < mpos ? (hpos - anchor) : mpos);

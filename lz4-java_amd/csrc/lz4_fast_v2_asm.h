@@ -87,11 +87,11 @@ __device__ unsigned long long g_asm_prof[16];
 // (a speculative commit is undone from the saved entries) -- so the C++ step can always continue.
 //
 // registers of the block (fixed, declared as clobbers):
-//   v100 shift  v101 permute address  v102..v105 row words / window words / hash products
-//   group A: v106 LDS address  v107 entry  v108 new entry  v109 candidate position      group B: v110 .. v113 likewise
-//   v114/v115 values the atomics returned   v116..v119 saved {address, entry} of both groups (undo of the commit in flight)
-//   v120 row at the hit  v121 row at the candidate  v122 forward length per lane  v123 address scratch  v124..v127 source touch
-//   v128/v129 fingerprints  v130 slot positions
+//   v48 shift  v49 permute address  v50..v53 row words / window words / hash products
+//   group A: v54 LDS address  v55 entry  v56 new entry  v57 candidate position      group B: v58 .. v61 likewise
+//   v62/v63 values the atomics returned   v64..v67 saved {address, entry} of both groups (undo of the commit in flight)
+//   v68 row at the hit  v69 row at the candidate  v70 forward length per lane  v71 address scratch  v72..v75 source touch
+//   v76/v77 fingerprints  v78 slot positions
 //   s70 position of slot 0   s71 hit slot   s72/s73 hit and candidate position of the hit in flight   s74 its length
 //   s75..s77 scratch (s76: first slot of the window)   s[78:79]/s[80:81] tentative slots A/B   s[82:83]/s[84:85] committing slots
 //   s[86:89] scratch masks   s90 effective loop limit (0: leave at the next clean point)   s91 a validated hit waits to be parked
@@ -102,38 +102,38 @@ __device__ unsigned long long g_asm_prof[16];
 #define LZ4HIP_TICK0 "  s_memtime s[92:93]\n  s_waitcnt lgkmcnt(0)\n"
 #define LZ4HIP_TICK(acc) "  s_memtime s[96:97]\n  s_waitcnt lgkmcnt(0)\n  s_sub_u32 s98, s96, s92\n  s_add_u32 %[" acc "], %[" acc "], s98\n  s_mov_b32 s92, s96\n"
 #endif
-// the 128 lookups: s75 = byte offset of slot 0 in the row %[pfa], s70 = position of slot 0.  Part 1 requests the row words;
+// the 128 lookups: sreg = byte offset of slot 0 in the row %[pfa], s70 = position of slot 0.  Part 1 requests the row words;
 // part 2 (after the wait that also brings the commit's results back) hashes them and reads the table
-#define LZ4HIP_BUILD_E1 \
-      "  v_add_u32 v100, s75, %[lane]\n" \
-      "  v_and_b32 v101, -4, v100\n" \
-      "  v_and_b32 v100, 3, v100\n" \
-      "  ds_bpermute_b32 v102, v101, %[pfa]\n" \
-      "  ds_bpermute_b32 v103, v101, %[pfa] offset:4\n" \
-      "  ds_bpermute_b32 v104, v101, %[pfa] offset:64\n" \
-      "  ds_bpermute_b32 v105, v101, %[pfa] offset:68\n" \
-      "  v_add_u32 v130, s70, %[lane]\n"
+#define LZ4HIP_BUILD_E1(sreg) \
+      "  v_add_u32 v48, " sreg ", %[lane]\n" \
+      "  v_and_b32 v49, -4, v48\n" \
+      "  v_and_b32 v48, 3, v48\n" \
+      "  ds_bpermute_b32 v50, v49, %[pfa]\n" \
+      "  ds_bpermute_b32 v51, v49, %[pfa] offset:4\n" \
+      "  ds_bpermute_b32 v52, v49, %[pfa] offset:64\n" \
+      "  ds_bpermute_b32 v53, v49, %[pfa] offset:68\n" \
+      "  v_add_u32 v78, s70, %[lane]\n"
 #define LZ4HIP_BUILD_E2 \
-      "  v_alignbyte_b32 v102, v103, v102, v100\n" \
-      "  v_alignbyte_b32 v104, v105, v104, v100\n" \
-      "  v_mul_lo_u32 v103, v102, %[kmul]\n" \
-      "  v_mul_lo_u32 v105, v104, %[kmul]\n" \
-      "  v_lshrrev_b32 v106, 19, v103\n" \
-      "  v_lshrrev_b32 v110, 19, v105\n" \
-      "  v_lshl_add_u32 v106, v106, 2, %[tbl]\n" \
-      "  v_lshl_add_u32 v110, v110, 2, %[tbl]\n" \
-      "  ds_read_b32 v107, v106\n" \
-      "  ds_read_b32 v111, v110\n" \
-      "  v_bfe_u32 v128, v103, 3, 16\n" \
-      "  v_bfe_u32 v129, v105, 3, 16\n" \
-      "  v_lshl_or_b32 v108, v130, 16, v128\n" \
-      "  v_add_u32 v130, 64, v130\n" \
-      "  v_lshl_or_b32 v112, v130, 16, v129\n" \
+      "  v_alignbyte_b32 v50, v51, v50, v48\n" \
+      "  v_alignbyte_b32 v52, v53, v52, v48\n" \
+      "  v_mul_lo_u32 v51, v50, %[kmul]\n" \
+      "  v_mul_lo_u32 v53, v52, %[kmul]\n" \
+      "  v_lshrrev_b32 v54, 19, v51\n" \
+      "  v_lshrrev_b32 v58, 19, v53\n" \
+      "  v_lshl_add_u32 v54, v54, 2, %[tbl]\n" \
+      "  v_lshl_add_u32 v58, v58, 2, %[tbl]\n" \
+      "  ds_read_b32 v55, v54\n" \
+      "  ds_read_b32 v59, v58\n" \
+      "  v_bfe_u32 v76, v51, 3, 16\n" \
+      "  v_bfe_u32 v77, v53, 3, 16\n" \
+      "  v_lshl_or_b32 v56, v78, 16, v76\n" \
+      "  v_add_u32 v78, 64, v78\n" \
+      "  v_lshl_or_b32 v60, v78, 16, v77\n" \
       "  s_waitcnt lgkmcnt(0)\n" \
-      "  v_cmp_eq_u32_sdwa s[78:79], v107, v128 src0_sel:WORD_0 src1_sel:DWORD\n" \
-      "  v_cmp_eq_u32_sdwa s[80:81], v111, v129 src0_sel:WORD_0 src1_sel:DWORD\n" \
-      "  v_lshrrev_b32 v109, 16, v107\n" \
-      "  v_lshrrev_b32 v113, 16, v111\n"
+      "  v_cmp_eq_u32_sdwa s[78:79], v55, v76 src0_sel:WORD_0 src1_sel:DWORD\n" \
+      "  v_cmp_eq_u32_sdwa s[80:81], v59, v77 src0_sel:WORD_0 src1_sel:DWORD\n" \
+      "  v_lshrrev_b32 v57, 16, v55\n" \
+      "  v_lshrrev_b32 v61, 16, v59\n"
 // first tentative slot of the window whose first probe slot is s75 (its insert-only slot is s76 = s75 - 2): slot -> s71,
 // candidate position -> s77, hit position -> s75, rows requested; `nohit` = label for "no tentative slot among the 63 probes"
 #define LZ4HIP_SELECT(tag, nohit) \
@@ -141,13 +141,13 @@ __device__ unsigned long long g_asm_prof[16];
       "  s_and_b64 s[88:89], s[86:87], s[78:79]\n" \
       "  s_cbranch_scc0 L_selB" tag "_%=\n" \
       "  s_ff1_i32_b64 s71, s[88:89]\n" \
-      "  v_readlane_b32 s77, v109, s71\n" \
+      "  v_readlane_b32 s77, v57, s71\n" \
       "L_req" tag "_%=:\n" \
       "  s_add_u32 s75, s70, s71\n" \
-      "  v_add_u32 v123, s77, %[j4]\n" \
-      "  global_load_dword v121, v123, %[src]\n" \
-      "  v_add_u32 v123, s75, %[j4]\n" \
-      "  global_load_dword v120, v123, %[src]\n"
+      "  v_add_u32 v71, s77, %[j4]\n" \
+      "  global_load_dword v69, v71, %[src]\n" \
+      "  v_add_u32 v71, s75, %[j4]\n" \
+      "  global_load_dword v68, v71, %[src]\n"
 #define LZ4HIP_SELECT_B(tag, nohit) \
       "L_selB" tag "_%=:\n" \
       "  s_sub_u32 s77, 62, s76\n" \
@@ -155,7 +155,7 @@ __device__ unsigned long long g_asm_prof[16];
       "  s_and_b64 s[88:89], s[88:89], s[80:81]\n" \
       "  s_cbranch_scc0 " nohit "_%=\n" \
       "  s_ff1_i32_b64 s71, s[88:89]\n" \
-      "  v_readlane_b32 s77, v113, s71\n" \
+      "  v_readlane_b32 s77, v61, s71\n" \
       "  s_add_u32 s71, s71, 64\n" \
       "  s_branch L_req" tag "_%=\n"
 #define LZ4HIP_PARK \
@@ -177,224 +177,15 @@ __device__ __forceinline__ uint32_t lean_asm_run(uint32_t& ip, uint32_t& php, ui
   const uint32_t j4 = lane * 4u, j16 = lane * 16u;
   const uint32_t kmul = 2654435761u, ntop = n - 16u;
   asm volatile(
-      // ---- entry: post-match state at ip, the row %[pfa] holds the block's bytes from php on
-      "  s_cmp_gt_u32 %[ip], %[lim]\n"
-      "  s_cbranch_scc1 L_x1_%=\n"
-      "  s_cmp_eq_u32 %[pc], 63\n"
-      "  s_cbranch_scc1 L_x2_%=\n"
-      "  s_sub_u32 s75, %[ip], %[php]\n"
-      "  s_add_u32 s75, s75, -2\n"
-      "  s_cmpk_gt_u32 s75, 125\n"
-      "  s_cbranch_scc1 L_x2_%=\n"
-      "  s_lshr_b64 s[94:95], -1, 1\n"
-      "  s_add_u32 s70, %[ip], -2\n"
-      "  s_mov_b32 s91, 0\n"
-#if LZ4HIP_ASM_DBG & 2
-      "  s_mov_b32 s90, 0\n"
-#else
-      "  s_mov_b32 s90, %[lim]\n"
-#endif
-      LZ4HIP_BUILD_E1
-      "  s_waitcnt lgkmcnt(0)\n"
-      LZ4HIP_BUILD_E2
-      "  s_mov_b32 s76, 0\n"
-      "  s_mov_b32 s75, 2\n"
-      LZ4HIP_TICK0
-      LZ4HIP_SELECT("p", "L_x2")
-      "  s_branch L_commit_%=\n"
-      LZ4HIP_SELECT_B("p", "L_x2")
-      // ---- top of the loop: the rows of the hit at s72 (candidate s73) arrive
-      "L_arrive_%=:\n"
-      LZ4HIP_TICK("t1")
-#if LZ4HIP_V2_PF
-      "  s_waitcnt vmcnt(2)\n"
-#else
-      "  s_waitcnt vmcnt(0)\n"
-#endif
-      LZ4HIP_TICK("t2")
-      "L_arrived_%=:\n"
-      "  v_xor_b32 v122, v120, v121\n"
-      "  v_cmp_ne_u32_e32 vcc, 0, v122\n"
-      "  v_ffbl_b32 v122, v122\n"
-      "  v_lshrrev_b32 v122, 3, v122\n"
-      "  v_lshl_add_u32 v122, %[lane], 2, v122\n"
-      "  v_mov_b32 %[pfa], v120\n"            // the row at the hit: the next windows are cut from it (before v120 is requested again)
-      "  s_ff1_i32_b64 s75, vcc\n"
-      "  v_readlane_b32 s74, v122, s75\n"     // forward length
-      "  s_add_u32 s76, s74, -4\n"
-      "  s_add_u32 s75, s74, -2\n"
-      LZ4HIP_SELECT("l", "L_nohit")
-      // what has to hold for the hit at s72 before anything of the next window is committed: it differs from its candidate
-      // within 256 bytes, is 4 .. 65 bytes long (the next window lies among the 128 slots), and the loop goes on
-      "  s_cbranch_vccz L_f1_%=\n"
-      "  s_cmpk_gt_u32 s76, 61\n"
-      "  s_cbranch_scc1 L_odd_%=\n"
-      "  s_add_u32 %[ip], s72, s74\n"
-      "  s_cmp_gt_u32 %[ip], s90\n"
-      "  s_cbranch_scc1 L_clean_%=\n"
-      "  s_mov_b32 %[php], s72\n"
-      // ---- in the shadow of the request: the window's slots up to the hit slot s71 commit their inserts
-      "L_commit_%=:\n"
-      LZ4HIP_TICK("t0")
-      "  s_lshl_b64 s[82:83], 1, s76\n"
-      "  s_or_b64 s[82:83], s[82:83], s[86:87]\n"
-      "  s_lshl_b64 s[88:89], -2, s71\n"
-      "  s_cmp_lt_u32 s71, 64\n"
-      "  s_cbranch_scc0 L_maskB_%=\n"
-      "  s_andn2_b64 s[82:83], s[82:83], s[88:89]\n"
-      "  s_mov_b64 s[84:85], 0\n"
-      "L_masked_%=:\n"
-      "  s_mov_b64 exec, s[82:83]\n"
-      "  ds_max_rtn_u32 v114, v106, v108\n"
-      "  s_mov_b64 exec, s[84:85]\n"
-      "  ds_max_rtn_u32 v115, v110, v112\n"
-      "  s_mov_b64 exec, -1\n"
-      // the next 128 lookups are cut from the row at php, slot 0 = (new hit) + 2; their row words are requested first, the
-      // bookkeeping runs while they (and the commit's results) are on their way
-      "  s_sub_u32 s86, s75, %[php]\n"
-      "  s_add_u32 s70, s75, 2\n"
-      "  s_add_u32 s86, s86, 2\n"
-      "  v_add_u32 v100, s86, %[lane]\n"
-      "  v_and_b32 v101, -4, v100\n"
-      "  v_and_b32 v100, 3, v100\n"
-      "  ds_bpermute_b32 v102, v101, %[pfa]\n"
-      "  ds_bpermute_b32 v103, v101, %[pfa] offset:4\n"
-      "  ds_bpermute_b32 v104, v101, %[pfa] offset:64\n"
-      "  ds_bpermute_b32 v105, v101, %[pfa] offset:68\n"
-      "  v_add_u32 v130, s70, %[lane]\n"
-      "  s_cmpk_gt_u32 s86, 125\n"
-      "  s_cselect_b32 s90, 0, s90\n"          // the row does not reach: leave at the next clean point
-      // the hit validated above is parked: {position, forward length, offset}
-      "  s_cmp_eq_u32 s91, 0\n"
-      "  s_cbranch_scc1 L_nopark_%=\n"
-      LZ4HIP_PARK
-      "  s_cmp_eq_u32 %[pc], 63\n"
-      "  s_cselect_b32 s90, 0, s90\n"          // the parked registers will be full: leave at the next clean point
-      "L_nopark_%=:\n"
-      "  s_mov_b32 s91, 1\n"
-      "  s_mov_b32 s72, s75\n"
-      "  s_mov_b32 s73, s77\n"
-      "  v_mov_b32 v116, v106\n"
-      "  v_mov_b32 v118, v110\n"
-      "  s_waitcnt lgkmcnt(0)\n"
-      // a slot that got back another slot's entry: two committing slots share a bucket
-      "  v_cmp_ne_u32_e64 s[86:87], v114, v107\n"
-      "  v_cmp_ne_u32_e64 s[88:89], v115, v111\n"
-      "  s_and_b64 s[86:87], s[86:87], s[82:83]\n"
-      "  s_and_b64 s[88:89], s[88:89], s[84:85]\n"
-      "  s_or_b64 vcc, s[86:87], s[88:89]\n"
-      "  s_cbranch_scc1 L_coll_%=\n"
-      "L_cont_%=:\n"
-      "  v_mov_b32 v117, v107\n"
-      "  v_mov_b32 v119, v111\n"
-      LZ4HIP_BUILD_E2
-#if LZ4HIP_V2_PF
-      // (A/B) the candidate lines of every tentative slot among the 128: the next hit's candidate is one of them
-      "  s_mov_b64 exec, s[78:79]\n"
-      "  global_load_dword v131, v109, %[src]\n"
-      "  s_mov_b64 exec, s[80:81]\n"
-      "  global_load_dword v132, v113, %[src]\n"
-      "  s_mov_b64 exec, -1\n"
-#endif
-      "  s_add_u32 s75, s72, 1024\n"
-      "  s_cmp_gt_u32 s75, %[pfe]\n"
-      "  s_cbranch_scc0 L_arrive_%=\n"
-      // the source is touched 1 KB ahead of the parse (one 1 KB wave load per 1 KB of progress; nobody waits for it: it is
-      // older than the next rows)
-      "  s_cmp_ge_u32 %[pfe], %[n]\n"
-      "  s_cbranch_scc1 L_touched_%=\n"
-      "  v_add_u32 v123, %[pfe], %[j16]\n"
-      "  v_min_u32 v123, %[ntop], v123\n"
-      "  global_load_dwordx4 v[124:127], v123, %[src]\n"
-      "  s_add_u32 %[pfe], %[pfe], 1024\n"
-#if LZ4HIP_V2_PF
-      "  s_waitcnt vmcnt(3)\n"
-#else
-      "  s_waitcnt vmcnt(1)\n"
-#endif
-      "  s_branch L_arrived_%=\n"
-      "L_touched_%=:\n"
-      "  s_add_u32 %[pfe], %[pfe], 1024\n"
-      "  s_branch L_arrive_%=\n"
-      LZ4HIP_SELECT_B("l", "L_nohit")
-      "L_maskB_%=:\n"                          // the hit slot is in group B: all window slots of A commit, B's up to the hit
-      "  s_sub_u32 s86, 62, s76\n"
-      "  s_lshr_b64 s[84:85], s[94:95], s86\n"
-      "  s_andn2_b64 s[84:85], s[84:85], s[88:89]\n"
-      "  s_branch L_masked_%=\n"
-      // ---- clean exits: the hit in s72..s74 is validated and not parked yet; nothing of the next window is committed
-      "L_nohit_%=:\n"                           // no tentative slot among the next window's 63 probes
-      "  s_cbranch_vccz L_f1_%=\n"
-      "  s_cmpk_gt_u32 s76, 61\n"
-      "  s_cbranch_scc1 L_odd_%=\n"
-      "L_long_%=:\n"
-      "  s_add_u32 %[ip], s72, s74\n"
-      "L_clean_%=:\n"
-      "  s_mov_b32 %[php], s72\n"
-      LZ4HIP_PARK
-      "  s_cmp_gt_u32 %[ip], %[lim]\n"
-      "  s_cselect_b32 %[code], 1, 2\n"
-      "  s_branch L_out_%=\n"
-      "L_odd_%=:\n"
-      "  s_cmp_lt_u32 s74, 4\n"
-      "  s_cbranch_scc0 L_long_%=\n"           // a match of more than 65 bytes: the next window is not among the 128 slots
-      // the hit's candidate differs within its first four bytes, or is equal for 256: its commit is undone from the saved entries
-      "L_f1_%=:\n"
-      "  s_brev_b32 %[php], 1\n"               // (the row in %[pfa] starts at that hit, possibly at ip itself: no row for the C++ step)
-      "  s_mov_b64 exec, s[82:83]\n"
-      "  ds_write_b32 v116, v117\n"
-      "  s_mov_b64 exec, s[84:85]\n"
-      "  ds_write_b32 v118, v119\n"
-      "  s_mov_b64 exec, -1\n"
-      "  s_branch L_x2_%=\n"
-      // Two committing slots share a bucket (a slot got back another slot's entry).  The rule of the C++ step: with exactly ONE
-      // such slot, the foreign entry's fingerprint different from that slot's own, and the bucket not the hit slot's, liblz4 --
-      // inserting position by position -- would not have decided differently (the slot's old entry was no hit and neither is
-      // the foreign one) and the atomic max has left the bucket as liblz4 leaves it: carry on.  Everything else is undone and
-      // left to the C++ step.
-      "L_coll_%=:\n"
-#if LZ4HIP_ASM_DBG & 1
-      "  s_branch L_undo_%=\n"
-#endif
-      "  s_bcnt1_i32_b64 s75, vcc\n"
-      "  s_cmp_eq_u32 s75, 1\n"
-      "  s_cbranch_scc0 L_undo_%=\n"
-      "  s_cmp_eq_u64 s[86:87], 0\n"
-      "  s_cbranch_scc1 L_collB_%=\n"
-      "  s_ff1_i32_b64 s75, s[86:87]\n"
-      "  v_readlane_b32 s76, v114, s75\n"
-      "  v_readlane_b32 s77, v128, s75\n"
-      "  v_readlane_b32 s75, v106, s75\n"
-      "  s_branch L_coll2_%=\n"
-      "L_collB_%=:\n"
-      "  s_ff1_i32_b64 s75, s[88:89]\n"
-      "  v_readlane_b32 s76, v115, s75\n"
-      "  v_readlane_b32 s77, v129, s75\n"
-      "  v_readlane_b32 s75, v110, s75\n"
-      "L_coll2_%=:\n"
-      "  s_and_b32 s76, s76, 0xffff\n"
-      "  s_cmp_eq_u32 s76, s77\n"
-      "  s_cbranch_scc1 L_undo_%=\n"
-      "  v_readlane_b32 s76, v106, s71\n"
-      "  v_readlane_b32 s77, v110, s71\n"
-      "  s_cmp_lt_u32 s71, 64\n"
-      "  s_cselect_b32 s76, s76, s77\n"
-      "  s_cmp_eq_u32 s75, s76\n"
-      "  s_cbranch_scc0 L_cont_%=\n"
-      "L_undo_%=:\n"
-      "  s_mov_b64 exec, s[82:83]\n"
-      "  ds_write_b32 v106, v107\n"
-      "  s_mov_b64 exec, s[84:85]\n"
-      "  ds_write_b32 v110, v111\n"
-      "  s_mov_b64 exec, -1\n"
-      "L_x2_%=:\n"
-      LZ4HIP_COUNT("c1")
-      "  s_mov_b32 %[code], 2\n"
-      "  s_branch L_out_%=\n"
-      "L_x1_%=:\n"
-      "  s_mov_b32 %[code], 1\n"
-      "L_out_%=:\n"
-      "  s_waitcnt vmcnt(0) lgkmcnt(0)\n"
+#define LZ4HIP_LEAN_E1(sreg) LZ4HIP_BUILD_E1(sreg)
+#define LZ4HIP_LEAN_E2 LZ4HIP_BUILD_E2
+#define LZ4HIP_LEAN_ROWLIM "125"
+#define LZ4HIP_LEAN_FPMASK "0xffff"
+#include "lz4_fast_v2_asm_body.inc"
+#undef LZ4HIP_LEAN_E1
+#undef LZ4HIP_LEAN_E2
+#undef LZ4HIP_LEAN_ROWLIM
+#undef LZ4HIP_LEAN_FPMASK
       : [ip] "+s"(ip), [php] "+s"(php), [pfe] "+s"(pfe), [pc] "+s"(pc), [pfa] "+v"(pfa), [pms] "+v"(pms), [pml] "+v"(pml),
         [pof] "+v"(pof), [code] "=&s"(code)
 #if LZ4HIP_V2_ASM_PROF
@@ -402,9 +193,9 @@ __device__ __forceinline__ uint32_t lean_asm_run(uint32_t& ip, uint32_t& php, ui
 #endif
       : [lim] "s"(lim), [src] "s"(src), [tbl] "v"(tbl), [n] "s"(n), [ntop] "s"(ntop), [kmul] "s"(kmul), [lane] "v"(lane), [j4] "v"(j4),
         [j16] "v"(j16)
-      : "memory", "vcc", "scc", "m0", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111",
-        "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126",
-        "v127", "v128", "v129", "v130", "v131", "v132", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82",
+      : "memory", "vcc", "scc", "m0", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59",
+        "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74",
+        "v75", "v76", "v77", "v78", "v79", "v80", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82",
         "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s94", "s95"
 #if LZ4HIP_V2_ASM_PROF
         , "s92", "s93", "s96", "s97", "s98"

@@ -245,12 +245,14 @@ struct ParkOutRaw : ParkOut<W> {
 // U16 = true: blocks < 65547 bytes (liblz4's byU16 table, 4-byte hash); false: larger blocks (byU32: 4096 entries of
 // {position, fingerprint} in 64 bits, 5-byte hash, candidates more than 65535 bytes back are no hits) -- round 3: the LZ4 Frame
 // default block size is 4 MiB (LZ4FrameOutputStream.java:169-171), until then those blocks ran on the one-sequence core alone.
-template <class W, class OUT = ParkOut<W>, bool U16 = true>
+// PK: the compact byU32 entries of FastCore (blocks of at most 4 MiB).
+template <class W, class OUT = ParkOut<W>, bool U16 = true, bool PK = false>
 struct FastV2 {
   using VU = typename W::VU;
   using VU64 = typename W::VU64;
   using VB = typename W::VB;
-  using Gen = FastCore<W, U16, OUT>;
+  using Gen = FastCore<W, U16, OUT, PK>;
+  static constexpr bool S32 = Gen::S32;
   using VE = typename Gen::VE;
   using E = typename Gen::E;
   static constexpr uint32_t kFwdBytes = 256u;                       // forward compare of the lean step: 64 lanes x 4 bytes
@@ -270,7 +272,7 @@ struct FastV2 {
       const uint32_t x0 = w.sld32(src, 0);
       // every bucket: {pos 0, fp(bytes at 0)}
       if constexpr (U16) w.template lds_fill<true>(1u << Gen::HLOG, (((x0 * 2654435761u) >> 3) & LZ4HIP_FP_MASK));
-      else w.template lds_fill<false>(1u << Gen::HLOG, (E)((x0 * 2654435761u) >> 16));
+      else w.template lds_fill<S32>(1u << Gen::HLOG, (E)(((x0 * 2654435761u) >> 16) & Gen::FPM));
       w.sync();
     }
     Gen gen(w, out, src, n, st);
@@ -367,6 +369,11 @@ struct FastV2 {
       if constexpr (!U16 && LZ4HIP_V2_ASM32 && !LZ4HIP_V2_ASM_PROF && W::kAsmLean && OUT::kAsmPark) {
         if (!st) {
           if (__builtin_amdgcn_read_exec() != ~0ull) __builtin_trap();
+          if constexpr (PK)
+            (void)lean_asm_run32p(ip, prev_hpos, pf_end, out.cnt, prev_fa, out.p_ms, out.p_ml, out.p_off,
+                                  lim >= 192u ? lim - 192u : 0u, src,
+                                  (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)w.lds, n);
+          else
           (void)lean_asm_run32(ip, prev_hpos, pf_end, out.cnt, prev_fa, out.p_ms, out.p_ml, out.p_off,
                                lim >= 192u ? lim - 192u : 0u, src,
                                (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)w.lds, n);
@@ -405,10 +412,10 @@ struct FastV2 {
       } else {
         const VU64 x64 = W::u64(x32) | (W::u64(x32b) << 32);
         h = W::lo32(((x64 << 24) * 889523592379ull) >> (64 - Gen::HLOG));
-        fp = (x32 * 2654435761u) >> 16;
+        fp = Gen::fp32(x32);
       }
       LZ4HIP_PHASE2(0, w.bcast(h, 0));     // t[0]: window load + hash
-      const VE e = w.template lds_rdu<U16>(h);
+      const VE e = w.template lds_rdu<S32>(h);
       const VE newe = Gen::mk_entry(pos, fp);
       uint64_t tmask = w.ballot(Gen::e_fp(e) == fp) & ~1ull;
       if constexpr (!U16) tmask &= w.ballot(Gen::e_pos(e) + Gen::MAXD >= pos);   // (byU32: a candidate more than 65535 bytes back is no hit)
@@ -442,9 +449,9 @@ struct FastV2 {
         k0 = (uint32_t)ctz64(tm);
         upto = (2ull << k0) - 1ull;                               // lanes 0..k0
         const uint64_t inm = upto & ~((1ull << lo) - 1ull);       // lanes lo..k0 commit now
-        const VE old = w.template lds_max<U16>(h, newe, w.lanes(inm));
+        const VE old = w.template lds_max<S32>(h, newe, w.lanes(inm));
         hpos = ip + k0 - 1u;
-        mpos = Gen::se_pos(w.template bcast_e<U16>(e, (int)k0));
+        mpos = Gen::se_pos(w.template bcast_e<S32>(e, (int)k0));
         // candidate fetch: forward 64 x 4 bytes from both positions; backward (policies that extend backwards here): lane l
         // (1..k0-1) holds src[ip+l-1] in its window word and needs src[mpos-k0+l] -- one contiguous byte load
         // (32 or 16 lanes instead of 64 -- fewer candidate lines per fetch -- measured no different: 59.2 / 59.2 / 59.1 GB/s)
@@ -501,7 +508,7 @@ struct FastV2 {
         }
         // undo everything this step committed, exact path
         if (st) l_slow++;
-        w.template lds_wr<U16>(h, e, w.lanes(upto));
+        w.template lds_wr<S32>(h, e, w.lanes(upto));
         w.sync();
         fail = true;
         break;

@@ -131,6 +131,22 @@ int sim_compress_fast_v2raw(const uint8_t* src, int n, uint8_t* dst, int cap, ui
   return (int)r;
 }
 
+// the same with the compact byU32 entries ({position 22 bits, fingerprint 10 bits}: blocks of 65547 bytes .. 4 MiB) -- what the
+// eight-chain kernel of such batches runs; other sizes: -3
+int sim_compress_fast_v2pk(const uint8_t* src, int n, uint8_t* dst, int cap, uint64_t* stats4, uint64_t seed) {
+  if (n < 65547 || n > (1 << 22) || cap < 0) return -3;
+  hostsim::WaveHost w;
+  if (seed) w.rng = seed;
+  w.bounds(src, (size_t)n, dst, (size_t)cap);
+  lz4hip::FastStats st{};
+  lz4hip::ParkOutRaw<hostsim::WaveHost> out(w, src, (uint32_t)n, dst, (uint32_t)cap);
+  lz4hip::FastV2<hostsim::WaveHost, lz4hip::ParkOutRaw<hostsim::WaveHost>, false, true> c(w, out, src, (uint32_t)n, &st);
+  const uint32_t r = c.run();
+  if (stats4) { stats4[0] = st.steps; stats4[1] = st.slow_steps; stats4[2] = st.false_pos; stats4[3] = st.sequences; }
+  if (w.oob) return -1000;
+  return (int)r;
+}
+
 // lean core with the density probe of the adaptive scheme: -2 = left to the window-parallel core
 int sim_compress_fast_v2_probe(const uint8_t* src, int n, uint8_t* dst, int cap, uint32_t dense64) {
   if (n < 0 || (uint32_t)n > 0x7E000000u || cap < 0) return 0;

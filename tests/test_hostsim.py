@@ -164,6 +164,33 @@ def test_compress_v2_raw_parking(sim, ref, O, corpus):
             assert r == a[0] and (r <= 0 or b == a[1]), (len(v), cap, r, a[0])
 
 
+def test_compress_v2_packed_entries(sim, ref, O, corpus):
+    """byU32 blocks of at most 4 MiB with the compact table entries of the eight-chain kernel ({position 22 bits, fingerprint 10
+    bits}, csrc/lz4_fast_core.h PK): a narrower fingerprint only adds tentative hits that the candidate bytes rule out -- same bytes
+    as the reference on synthetic / text / periodic / random blocks, copies at distances around 65535, full and tight capacities"""
+    sim.sim_compress_fast_v2pk.restype = C.c_int
+    sim.sim_compress_fast_v2pk.argtypes = [C.c_char_p, C.c_int, _u8p, C.c_int, C.POINTER(C.c_uint64), C.c_uint64]
+    rng = random.Random(44)
+    book = corpus["book1[:200000]"]
+    unit = rng.randbytes(900)
+    inputs = [O.gen_block(65547, 1), O.gen_block(200000, 2, win=4096), O.gen_block(150000, 3, litmax=4, win=64), book[:150000],
+              (book[:70000] + rng.randbytes(500)) * 2, (unit + rng.randbytes(65535 - 900)) * 3, (unit + rng.randbytes(65536 - 900)) * 2 + unit,
+              bytes(rng.randrange(2) for _ in range(30000)) * 3, rng.randbytes(70000), (rng.randbytes(41) * 2000)[:80000], O.gen_block(1 << 20, 5, win=65535)]
+    slow = 0
+    for k, v in enumerate(inputs):
+        full = ref.compress_bound(len(v))
+        er, _ = ref.compress_fast_raw(v, full)
+        for cap in (full, max(0, er + rng.choice([-1, 0, 1, -7]))):
+            a = ref.compress_fast_raw(v, cap)
+            out = (C.c_uint8 * max(cap, 1))()
+            st = (C.c_uint64 * 4)()
+            r = sim.sim_compress_fast_v2pk(bytes(v), len(v), out, cap, st, rng.getrandbits(63) | 1)
+            assert r == a[0] and (r <= 0 or bytes(out[:r]) == a[1]), (k, len(v), cap, r, a[0])
+            slow += st[1]
+    assert slow > 0
+    assert sim.sim_compress_fast_v2pk(bytes(100), 100, (C.c_uint8 * 200)(), 200, None, 0) == -3
+
+
 def test_v2_density_probe_routes_blocks(sim, ref, O, corpus):
     """the lean core leaves a block to the window-parallel core exactly when its sequences 32..95 cover fewer than dense64
     bytes (decided when 128 sequences are parked); otherwise it finishes it with the usual bytes"""

@@ -104,11 +104,12 @@ if __name__ == "__main__":
         so = torch.arange(nb, dtype=torch.int64, device=dev) * b; sl = torch.full((nb,), b, dtype=torch.int32, device=dev)
         do = torch.arange(nb, dtype=torch.int64, device=dev) * cap; dc = torch.full((nb,), cap, dtype=torch.int32, device=dev)
         res = torch.empty(nb, dtype=torch.int32, device=dev)
-        for core in (3, 5):
-            amd.set_option("compress_core", core)
+        for core, pack in ((3, 1), (5, 1), (3, 0)):
+            amd.set_option("compress_core", core); amd.set_option("compress_pack", pack)
             best = 1e9
             for _ in range(4):
                 torch.cuda.synchronize(); t = time.time()
                 amd.DeviceBatch.compress_fast(s, so, sl, c, do, dc, res)
                 torch.cuda.synchronize(); best = min(best, time.time() - t)
-            print("core %d: %d x 4 MiB (win 4096): %.2f ms, %.1f GB/s, ratio %.3f" % (core, nb, best * 1e3, nb * b / best / 1e9, nb * b / float(res.sum().item())), flush=True)
+            print("core %d pack %d: %d x 4 MiB (win 4096): %.2f ms, %.1f GB/s, ratio %.3f" % (core, pack, nb, best * 1e3, nb * b / best / 1e9, nb * b / float(res.sum().item())), flush=True)
+        amd.set_option("compress_pack", 1); amd.set_option("compress_core", 5)

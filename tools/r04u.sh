@@ -1,8 +1,9 @@
 #!/bin/bash
-# byU32 ISA loop: fuzz + timing (U32_BLOCKS x 4 MiB), optionally against the compiler-generated loop (variant build noasm32)
+# byU32 blocks: fuzz + timing (U32_BLOCKS x 4 MiB; compact entries on ten pairs per CU vs 64-bit entries on five)
 cd "$(dirname "$0")/.."; mkdir -p gpurun_out/r04u
-U32_BLOCKS=${U32_BLOCKS:-8192} timeout 1200 python tools/gpu_fuzz_u32.py ${U32_N:-1000} ${U32_SEED:-7} ${U32_MAX:-1500000} > gpurun_out/r04u/fuzz_asm.log 2>&1; echo "fuzz asm rc=$?" >> gpurun_out/r04u/fuzz_asm.log
-if [ -n "$U32_AB" ] && [ -f lz4-java_amd/variants/noasm32.so ]; then
-  U32_BLOCKS=${U32_BLOCKS:-8192} LZ4HIP_LIBRARY=$PWD/lz4-java_amd/variants/noasm32.so timeout 600 python tools/gpu_fuzz_u32.py 4 1 > gpurun_out/r04u/fuzz_c.log 2>&1; echo "rc=$?" >> gpurun_out/r04u/fuzz_c.log
-fi
-tail -6 gpurun_out/r04u/fuzz_asm.log; [ -n "$U32_AB" ] && tail -4 gpurun_out/r04u/fuzz_c.log
+{
+U32_TIMING=0 timeout 900 python tools/gpu_fuzz_u32.py ${U32_N2:-24} 11 5500000
+U32_BLOCKS=${U32_BLOCKS:-8192} timeout 1200 python tools/gpu_fuzz_u32.py ${U32_N:-600} ${U32_SEED:-8} ${U32_MAX:-1500000}
+echo "rc=$?"
+} > gpurun_out/r04u/fuzz_asm.log 2>&1
+grep -v amdgpu.ids gpurun_out/r04u/fuzz_asm.log | tail -14
