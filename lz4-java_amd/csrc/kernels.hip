@@ -194,27 +194,36 @@ __global__ __launch_bounds__(64 * 2 * WAVES_PER_CU) void compress_fast_v2w_cu_ke
 // LZ4FrameOutputStream): compact entries, 16 KB per table.  Measured on 8192 x 4 MiB (profiles/r04_compress_study.txt): throughput is
 // linear in the chains a CU holds -- 3 / 5 / 6 / 8 chains: 74 / 115 / 134 / 177 GB/s -- and workgroups that SHARE a CU get 128 KB of its
 // LDS between them, not 160 (2 x 80 KB, 3 x 48 KB and 5 x 32 KB all leave one workgroup waiting; a single workgroup does get 160 KB).
-// So: four pairs per workgroup (64 KB, eight wavefronts = two per SIMD), two workgroups per CU = EIGHT chains per CU, against five
-// with 32 KB tables.  (Ten would take one workgroup of more than 1024 threads, or writers shared between finders.)
-#ifndef LZ4HIP_PK_PAIRS
-#define LZ4HIP_PK_PAIRS 4
+// So: ONE workgroup per CU with all 160 KB = TEN tables, and since ten pairs would be 1280 threads, ten finders share SIX writers
+// (mail_ring.h mail_writer2_t: writer j takes the rings of finders j and j + 6; a writer is busy for a tenth of the time a finder
+// needs to fill a batch).  LZ4HIP_PK_FINDERS / _WRITERS / _WGS: developer builds of other shapes (4 / 4 / 2 = eight chains in pairs).
+#ifndef LZ4HIP_PK_FINDERS
+#define LZ4HIP_PK_FINDERS 10
+#endif
+#ifndef LZ4HIP_PK_WRITERS
+#define LZ4HIP_PK_WRITERS 6
 #endif
 #ifndef LZ4HIP_PK_WGS
-#define LZ4HIP_PK_WGS 2
+#define LZ4HIP_PK_WGS 1
 #endif
-#ifndef LZ4HIP_PK_WAVES_PER_SIMD
-#define LZ4HIP_PK_WAVES_PER_SIMD 4
-#endif
-constexpr uint32_t PK_PAIRS = LZ4HIP_PK_PAIRS;
+constexpr uint32_t PK_FINDERS = LZ4HIP_PK_FINDERS, PK_WRITERS = LZ4HIP_PK_WRITERS;
 constexpr uint32_t PK_WGS_PER_CU = LZ4HIP_PK_WGS;
-__global__ __launch_bounds__(64 * 2 * PK_PAIRS, LZ4HIP_PK_WAVES_PER_SIMD) void compress_fast_v2wp_cu_kernel(BatchArgs a, uint32_t* ctl, uint32_t* q, uint32_t* routed, uint32_t dense64, uint32_t* mail_ctr, uint32_t* mail_slots) {
-  __shared__ __attribute__((aligned(16))) uint32_t tables[PK_PAIRS][4096];
+static_assert(PK_WRITERS <= PK_FINDERS && PK_FINDERS <= 2 * PK_WRITERS && 64 * (PK_FINDERS + PK_WRITERS) <= 1024, "shape of the packed kernel");
+__global__ __launch_bounds__(64 * (PK_FINDERS + PK_WRITERS)) void compress_fast_v2wp_cu_kernel(BatchArgs a, uint32_t* ctl, uint32_t* q, uint32_t* routed, uint32_t dense64, uint32_t* mail_ctr, uint32_t* mail_slots) {
+  __shared__ __attribute__((aligned(16))) uint32_t tables[PK_FINDERS][4096];
   if (__builtin_amdgcn_readfirstlane(ctl[CTL_PK]) == 0u) return;   // (every wavefront: no such block in this batch)
   const uint32_t wv = threadIdx.x >> 6;
-  const uint32_t pair = blockIdx.x * PK_PAIRS + (wv < PK_PAIRS ? wv : wv - PK_PAIRS);
-  uint32_t* ctr = mail_ctr + 2u * pair;
-  uint32_t* slots = mail_slots + (size_t)pair * (MAIL_RING * MAIL_SLOT_WORDS);
-  if (wv >= PK_PAIRS) { mail_writer(a, slots, ctr); return; }
+  const uint32_t ring0 = blockIdx.x * PK_FINDERS;                   // this workgroup's rings: one per finder
+  if (wv >= PK_FINDERS) {
+    const uint32_t j = wv - PK_FINDERS, k = j + PK_WRITERS;
+    WaveDev w(nullptr);
+    mail_writer2_t<WaveDev, MailDev>(w, a, mail_slots + (size_t)(ring0 + j) * (MAIL_RING * MAIL_SLOT_WORDS), mail_ctr + 2u * (ring0 + j),
+                                     k < PK_FINDERS ? mail_slots + (size_t)(ring0 + k) * (MAIL_RING * MAIL_SLOT_WORDS) : nullptr,
+                                     k < PK_FINDERS ? mail_ctr + 2u * (ring0 + k) : nullptr);
+    return;
+  }
+  uint32_t* ctr = mail_ctr + 2u * (ring0 + wv);
+  uint32_t* slots = mail_slots + (size_t)(ring0 + wv) * (MAIL_RING * MAIL_SLOT_WORDS);
   __builtin_amdgcn_s_setprio(3);
   WaveDev w((uint64_t*)tables[wv]);
   uint32_t head = 0, tail_seen = 0;
@@ -247,14 +256,14 @@ __global__ __launch_bounds__(64 * 2 * PK_PAIRS, LZ4HIP_PK_WAVES_PER_SIMD) void c
 static int g_compress_pack = 1;   // "compress_pack": 0 = every block on the five-pair kernel (developer A/B)
 void set_compress_pack(int v) { g_compress_pack = v; }
 size_t compress_fast_v2w_scratch_words(uint32_t n_cus) {
-  const size_t pairs = (size_t)n_cus * (PK_PAIRS * PK_WGS_PER_CU > WAVES_PER_CU ? PK_PAIRS * PK_WGS_PER_CU : WAVES_PER_CU);
+  const size_t pairs = (size_t)n_cus * (PK_FINDERS * PK_WGS_PER_CU > WAVES_PER_CU ? PK_FINDERS * PK_WGS_PER_CU : WAVES_PER_CU);
   return CTL_WORDS + 2u * pairs + 256u + pairs * (MAIL_RING * MAIL_SLOT_WORDS);
 }
 int launch_compress_fast_v2w(const BatchArgs& a, uint32_t* q, uint32_t* routed, uint32_t dense64, uint32_t n_cus, uint32_t* mail, void* stream) {
   if (a.n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   const bool pack = g_compress_pack != 0;
-  const size_t pairs_max = (size_t)n_cus * (PK_PAIRS * PK_WGS_PER_CU > WAVES_PER_CU ? PK_PAIRS * PK_WGS_PER_CU : WAVES_PER_CU);
+  const size_t pairs_max = (size_t)n_cus * (PK_FINDERS * PK_WGS_PER_CU > WAVES_PER_CU ? PK_FINDERS * PK_WGS_PER_CU : WAVES_PER_CU);
   uint32_t* ctl = mail;
   uint32_t* ctr = mail + CTL_WORDS;
   uint32_t* slots = (uint32_t*)(((uintptr_t)(ctr + 2u * pairs_max) + 1023u) & ~(uintptr_t)1023u);
@@ -265,12 +274,12 @@ int launch_compress_fast_v2w(const BatchArgs& a, uint32_t* q, uint32_t* routed, 
   if (pack) {
     if (getenv("LZ4HIP_OCC_DEBUG")) {
       int nb = -1;
-      hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, compress_fast_v2wp_cu_kernel, 64 * 2 * PK_PAIRS, 0);
+      hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, compress_fast_v2wp_cu_kernel, 64 * (PK_FINDERS + PK_WRITERS), 0);
       fprintf(stderr, "[lz4hip] compress_fast_v2wp_cu_kernel: %d workgroups per CU (%s)\n", nb, hipGetErrorString(oe));
     }
     hipLaunchKernelGGL(compress_classify_kernel, dim3((a.n + 255u) / 256u), dim3(256), 0, st, a.src_len, a.dst_cap, a.n, ctl);
-    const uint32_t want = (a.n + PK_PAIRS - 1u) / PK_PAIRS, most = n_cus * PK_WGS_PER_CU;
-    hipLaunchKernelGGL(compress_fast_v2wp_cu_kernel, dim3(want < most ? want : most), dim3(64 * 2 * PK_PAIRS), 0, st, a, ctl, q, routed, dense64, ctr, slots);
+    const uint32_t want = (a.n + PK_FINDERS - 1u) / PK_FINDERS, most = n_cus * PK_WGS_PER_CU;
+    hipLaunchKernelGGL(compress_fast_v2wp_cu_kernel, dim3(want < most ? want : most), dim3(64 * (PK_FINDERS + PK_WRITERS)), 0, st, a, ctl, q, routed, dense64, ctr, slots);
     e = hipMemsetAsync(ctr, 0, 2u * pairs_max * sizeof(uint32_t), st);   // the rings start empty again
     if (e != hipSuccess) return (int)e;
   }

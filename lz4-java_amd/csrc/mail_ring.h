@@ -127,4 +127,60 @@ LZ4HIP_DEV void mail_writer_t(W& w, const A& a, uint32_t* slots, uint32_t* ctr) 
   }
 }
 
+// writer side, TWO finders per writer (the ten-chain kernel of packed byU32 blocks has ten finders and six writers in its 1024
+// threads): the rings are polled in turn, a message is handled exactly as above with the state of its ring.  A writer is busy for a
+// small fraction of the time its finders need to fill a batch, and a ring holds MAIL_RING batches, so a finder rarely waits.
+// slots1 == nullptr: one ring only.
+template <class W, class M>
+struct MailRingSide {
+  uint32_t* slots;
+  uint32_t* ctr;
+  uint32_t tail = 0, cur = 0xFFFFFFFFu, op = 0, prev_end = 0;
+  bool ok = true, alive = true;
+  template <class A>
+  LZ4HIP_DEV void serve(W& w, const A& a) {   // one message is waiting
+    using VU = typename W::VU;
+    M::acquire();
+    const uint32_t* s = slots + (tail % MAIL_RING) * MAIL_SLOT_WORDS;
+    const VU ms = W::ld_lanes(s), ml = W::ld_lanes(s + 64u), off = W::ld_lanes(s + 128u);
+    uint32_t kind, b, m, x;
+    W::ld_hdr(s + 192u, kind, b, m, x);
+    tail++;
+    M::publish(ctr + 1, tail);
+    if (kind == MAIL_EXIT) { alive = false; return; }
+    if (kind == MAIL_ABORT) { cur = 0xFFFFFFFFu; return; }
+    if (b != cur) { cur = b; op = 0; prev_end = 0; ok = true; }
+    const int32_t n = M::u32(a.src_len[b]);
+    const int32_t cap = M::u32(a.dst_cap[b]);
+    const uint8_t* sp = M::uptr(a.src + a.src_off[b]);
+    uint8_t* dp = M::uptr(a.dst + a.dst_off[b]);
+    M::block_begin(w, sp, (uint32_t)n, dp, (uint32_t)cap);
+    ParkOut<W> out(w, sp, (uint32_t)n, dp, (uint32_t)cap);
+    out.op = op; out.prev_end = prev_end; out.ok = ok;
+    if (kind == MAIL_BATCH) {
+      out.p_ms = ms; out.p_ml = ml; out.p_off = off; out.cnt = m;
+      out.resolve_raw();
+      out.flush();
+      op = out.op; prev_end = out.prev_end; ok = out.ok;
+    } else {   // MAIL_LAST
+      const uint32_t r = ok ? out.emit_last(x) : 0u;
+      M::result(a.out, b, (int32_t)r);
+      cur = 0xFFFFFFFFu;
+    }
+  }
+  LZ4HIP_DEV bool waiting(uint32_t spin) const { return alive && ((spin & 63u) ? M::peek(ctr) : M::peek_far(ctr)) != tail; }
+};
+template <class W, class M, class A>
+LZ4HIP_DEV void mail_writer2_t(W& w, const A& a, uint32_t* slots0, uint32_t* ctr0, uint32_t* slots1, uint32_t* ctr1) {
+  MailRingSide<W, M> r0, r1;
+  r0.slots = slots0; r0.ctr = ctr0;
+  r1.slots = slots1; r1.ctr = ctr1; r1.alive = slots1 != nullptr;
+  for (uint32_t spin = 1; r0.alive || r1.alive; spin++) {
+    const bool w0 = r0.waiting(spin), w1 = r1.waiting(spin);
+    if (w0) r0.serve(w, a);
+    if (w1) r1.serve(w, a);
+    if (!w0 && !w1) M::nap_writer();
+  }
+}
+
 }  // namespace lz4hip

@@ -290,4 +290,65 @@ int sim_mail_ring(const uint8_t* src, const uint64_t* src_off, const int32_t* sr
   return M::oob ? -1000 : 0;
 }
 
+// The ten-chain kernel's shape (compress_fast_v2wp_cu_kernel): `finders` finder threads, `writers` writer threads, writer j
+// serving the rings of finder j and finder j + writers (mail_writer2_t).  Blocks of 65547 bytes .. 4 MiB run with the packed table
+// entries that kernel uses, the others with the usual cores.  Results as sim_mail_ring.
+int sim_mail_ring_shared(const uint8_t* src, const uint64_t* src_off, const int32_t* src_len, uint8_t* dst, const uint64_t* dst_off,
+                         const int32_t* dst_cap, int32_t* out, uint32_t n, uint32_t finders, uint32_t writers, uint32_t dense64,
+                         uint32_t* routed, uint32_t* n_routed, uint64_t seed) {
+  using W = hostsim::WaveHost;
+  using M = hostsim::MailHost;
+  using Out = lz4hip::MailOutT<W, M>;
+  if (writers == 0 || finders < writers || finders > 2 * writers) return -1;
+  hostsim::SimBatch a{src, src_off, src_len, dst, dst_off, dst_cap, out, n};
+  std::atomic<uint32_t> q{0}, nr{0};
+  M::oob = 0;
+  std::vector<std::vector<uint32_t>> slots(finders, std::vector<uint32_t>(lz4hip::MAIL_RING * lz4hip::MAIL_SLOT_WORDS, 0xDEADBEEFu));
+  std::vector<std::vector<uint32_t>> ctr(finders, std::vector<uint32_t>(2, 0u));
+  std::vector<std::thread> th;
+  for (uint32_t j = 0; j < writers; j++)
+    th.emplace_back([&, j] {
+      M::rng = seed * 977u + j * 2u + 1u;
+      W w;
+      const uint32_t k = j + writers;
+      lz4hip::mail_writer2_t<W, M>(w, a, slots[j].data(), ctr[j].data(), k < finders ? slots[k].data() : nullptr, k < finders ? ctr[k].data() : nullptr);
+      if (w.oob) M::oob = 1;
+    });
+  for (uint32_t p = 0; p < finders; p++)
+    th.emplace_back([&, p] {
+      M::rng = seed * 977u + p * 2u + 2u;
+      W w;
+      w.rng = seed ? seed + p : w.rng;
+      uint32_t head = 0, tail_seen = 0;
+      for (;;) {
+        const uint32_t b = q.fetch_add(1);
+        Out o(w, slots[p].data(), ctr[p].data(), head);
+        o.tail_seen = tail_seen;
+        if (b >= a.n) { o.post(lz4hip::MAIL_EXIT, 0u, 0u); break; }
+        o.b = b;
+        const int32_t bn = a.src_len[b], cap = a.dst_cap[b];
+        if (bn >= 0 && (uint32_t)bn <= 0x7E000000u && cap >= 0) {
+          const uint8_t* s = a.src + a.src_off[b];
+          w.bounds(s, (size_t)bn, nullptr, 0);
+          o.dense64 = routed ? dense64 : 0u;
+          if (bn < 65547) { lz4hip::FastV2<W, Out> c(w, o, s, (uint32_t)bn); (void)c.run(); }
+          else if (bn <= (1 << 22)) { lz4hip::FastV2<W, Out, false, true> c(w, o, s, (uint32_t)bn); (void)c.run(); }
+          else { lz4hip::FastV2<W, Out, false> c(w, o, s, (uint32_t)bn); (void)c.run(); }
+          if (o.bail) {
+            o.post(lz4hip::MAIL_ABORT, 0u, 0u);
+            routed[nr.fetch_add(1)] = b;
+            a.out[b] = -2;
+          }
+        } else {
+          a.out[b] = 0;
+        }
+        head = o.head; tail_seen = o.tail_seen;
+      }
+      if (w.oob) M::oob = 1;
+    });
+  for (auto& t : th) t.join();
+  if (n_routed) *n_routed = nr.load();
+  return M::oob ? -1000 : 0;
+}
+
 }  // extern "C"

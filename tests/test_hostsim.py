@@ -472,7 +472,8 @@ def test_hc_core_optimal_parser(sim, ref, golden, corpus, O):
 
 
 
-def run_mail_ring(sim, blocks, caps, pairs, dense64, seed):
+def run_mail_ring(sim, blocks, caps, pairs, dense64, seed, writers=None):
+    """writers: None = a writer per finder (sim_mail_ring); k = `pairs` finders on k writers that serve two rings each (sim_mail_ring_shared)"""
     n = len(blocks)
     src = b"".join(blocks)
     so, do, p, q = [], [], 0, 0
@@ -482,8 +483,15 @@ def run_mail_ring(sim, blocks, caps, pairs, dense64, seed):
     out = (C.c_int32 * n)(*([-99] * n))
     routed = (C.c_uint32 * n)()
     nr = C.c_uint32(0)
-    rc = sim.sim_mail_ring(src, (C.c_uint64 * n)(*so), (C.c_int32 * n)(*[len(b) for b in blocks]), dst, (C.c_uint64 * n)(*do),
-                           (C.c_int32 * n)(*caps), out, n, pairs, dense64, routed if dense64 else None, C.byref(nr), seed)
+    if writers is None:
+        rc = sim.sim_mail_ring(src, (C.c_uint64 * n)(*so), (C.c_int32 * n)(*[len(b) for b in blocks]), dst, (C.c_uint64 * n)(*do),
+                               (C.c_int32 * n)(*caps), out, n, pairs, dense64, routed if dense64 else None, C.byref(nr), seed)
+    else:
+        sim.sim_mail_ring_shared.restype = C.c_int
+        sim.sim_mail_ring_shared.argtypes = [C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_int32), _u8p, C.POINTER(C.c_uint64), C.POINTER(C.c_int32),
+                                             C.POINTER(C.c_int32), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint64]
+        rc = sim.sim_mail_ring_shared(src, (C.c_uint64 * n)(*so), (C.c_int32 * n)(*[len(b) for b in blocks]), dst, (C.c_uint64 * n)(*do),
+                                      (C.c_int32 * n)(*caps), out, n, pairs, writers, dense64, routed if dense64 else None, C.byref(nr), seed)
     assert rc == 0, "a simulated wavefront touched memory outside its block / slot"
     res = [(out[i], bytes(dst[do[i]:do[i] + max(out[i], 0)])) for i in range(n)]
     return res, sorted(routed[:nr.value])
@@ -511,6 +519,34 @@ def test_mail_ring_two_threads(sim, ref, O, corpus):
         for v, cap, (r, c) in zip(blocks, caps, res):
             er, eb = ref.compress_fast_raw(v, cap)
             assert r == er and (er <= 0 or c == eb[:er]), (pairs, seed, len(v), cap, r, er)
+
+
+def test_mail_ring_writers_shared_by_two_finders(sim, ref, O, corpus):
+    """The ten-chain kernel of packed byU32 blocks has ten finders and six writers: a writer serves the rings of TWO finders
+    (csrc/mail_ring.h mail_writer2_t).  Host threads again -- 2 finders on 1 writer, 3 on 2, 5 on 3 -- over blocks of every size class
+    (those of 65547 bytes .. 4 MiB with the packed table entries), full and tight capacities, with and without the density probe."""
+    rng = random.Random(17)
+    book = corpus["book1[:200000]"]
+    blocks = [b"", b"c" * 13, O.gen_block(1000, 3), O.gen_block(70000, 4, win=4096), O.gen_block(65547, 5), O.gen_block(200000, 6),
+              book[:90000], O.gen_block(65536, 7), (rng.randbytes(300) + bytes(65300)) * 2, O.gen_block(120000, 8, litmax=4, win=64),
+              rng.randbytes(70000), O.gen_block(3000, 10, litmax=2, win=8), O.gen_block(300000, 11, win=65535)] * 2
+    rng.shuffle(blocks)
+    for finders, writers, seed in ((2, 1, 1), (3, 2, 2), (5, 3, 3), (2, 2, 4)):
+        caps = []
+        for v in blocks:
+            full = ref.compress_bound(len(v))
+            er, _ = ref.compress_fast_raw(v, full)
+            caps.append(rng.choice([full, full, max(0, er - 1), er, er + 3]))
+        res, routed = run_mail_ring(sim, blocks, caps, finders, 0, seed, writers=writers)
+        assert routed == []
+        for v, cap, (r, c) in zip(blocks, caps, res):
+            er, eb = ref.compress_fast_raw(v, cap)
+            assert r == er and (er <= 0 or c == eb[:er]), (finders, writers, seed, len(v), cap, r, er)
+    caps = [ref.compress_bound(len(v)) for v in blocks]
+    res, routed = run_mail_ring(sim, blocks, caps, 3, 64 * 20, 9, writers=2)
+    assert routed
+    for i, (v, (r, c)) in enumerate(zip(blocks, res)):
+        assert (r == -2) if i in routed else (c == ref.compress_fast(v)), (i, len(v))
 
 
 def test_mail_ring_abort_after_routed_block(sim, ref, O, corpus):
