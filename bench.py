@@ -419,9 +419,10 @@ def main():
         # default block size, LZ4FrameOutputStream.java:169-171); bit-exactness of these bytes: tests/test_gpu_scale.py
         wall3c, tk3c = timed(lambda: amd.DeviceBatch.compress_fast(s3, B3["so"], B3["sl"], c3, B3["co"], B3["cc"], B3["clen"]), 1, warm=0)
         cs3 = int(B3["clen"].sum().item())
+        # (blocks of 65547 bytes .. 4 MiB: the ten-chain kernel with packed table entries, kernels.hip compress_fast_v2wp_cu_kernel)
         extra["compress_4MiB"] = {"workload": "%d x 4 MiB blocks per GPU, App.F win 4096, LZ4_compress_default (byU32), ratio %.3f" % (n3, n3 * b3 / cs3),
                                   "value": round(world * float(n3) * b3 / wall3c / 1e9, 3), "unit": "GB/s", "verified": None,
-                                  "roofline": roof("compress_fast_v2w_cu_kernel", float(n3) * b3 + cs3, tk3c, None)}
+                                  "roofline": roof("compress_fast_v2wp_cu_kernel", float(n3) * b3 + cs3, tk3c, kernel_traffic(tr, world, "compress_fast_v2wp_cu_kernel"))}
         bk3 = torch.zeros(n3 * b3, dtype=u8, device=dev)
         wall, tk = timed(lambda: amd.DeviceBatch.decompress_safe(c3, B3["co"], B3["clen"], bk3, B3["so"], B3["sl"], B3["dlen"]), 2)
         ok3 = all_ok(bool(torch.equal(bk3, s3)))
