@@ -111,11 +111,30 @@ def spread(r, *keys):
     return {k: round(r[k] / r[k + "_median"], 3) for k in keys if r.get(k + "_median")}
 
 
+def cpu_quota():
+    """CPUs' worth of time the box's cgroup allows this process (cpu.max / cfs quota; None = unlimited or unknown): os.cpu_count()
+    counts the host's threads, and a box that is a slice of a node runs 256 baseline threads on whatever its quota is"""
+    try:
+        q, p_ = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else round(int(q) / int(p_), 2)
+    except Exception:
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else round(q / p_, 2)
+    except Exception:
+        return None
+
+
 def cpu_entry(fn):
     try:
-        return fn()
+        r = fn()
+        if isinstance(r, dict):
+            r.setdefault("cgroup_cpu_quota", cpu_quota())
+            r.setdefault("host_threads", os.cpu_count())
+        return r
     except Exception as e:  # a baseline is a reported extra, never a reason to lose the GPU line
-        return {"value": None, "unit": "GB/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
+        return {"value": None, "unit": "GB/s", "cores": len(os.sched_getaffinity(0)), "kind": "port", "sample": "failed: %r" % (e,)}
 
 
 def relaunch(n):
@@ -271,7 +290,12 @@ def main():
 
     extra = {}
     tr = measured_traffic(n, blk) or {}
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0)) or 1   # the CPUs this process may run on (a box can be a slice of its node: os.cpu_count() counts the node's)
+    except Exception:
+        cores = os.cpu_count() or 1
+    if cpu_quota():                                  # ... and the CPU time its cgroup grants: more threads than that only get throttled
+        cores = max(1, min(cores, int(cpu_quota() + 0.999)))
     want_cpu = world == 1 and rank == 0 and not args.no_cpu_baseline
     if not args.no_extra_configs:
         # ---- decompress_fast on the headline blocks (LZ4FastDecompressor: LZ4JNI.c:169) ----
