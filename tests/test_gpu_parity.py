@@ -443,11 +443,20 @@ def test_device_batch_and_generator(amd, O, ref):
 
 
 def test_large_blocks_byu32(amd, O, ref):
-    """blocks >= 65547 B use the 5-byte-hash / 4096 x u32 table; 4 MiB = LZ4Frame default"""
-    blocks = [O.gen_block(4 << 20, 0, win=4096), O.gen_block(1 << 20, 1, win=65535), O.gen_block(300000, 2, litmax=4, win=8)]
-    res = gpu_compress_many(amd, blocks, [ref.compress_bound(len(b)) for b in blocks])
-    for b, (r, c) in zip(blocks, res):
-        assert c == ref.compress_fast(b)
+    """blocks >= 65547 B use the 5-byte-hash / 4096-entry table; 4 MiB = LZ4Frame default.  One batch mixes the
+    three table kinds of the fast compressor -- byU16 blocks, byU32 blocks of at most 4 MiB (packed entries on the ten-chain kernel)
+    and bigger ones (64-bit entries) -- and runs with "compress_pack" 1 (default) and 0 (everything on the five-chain kernel)."""
+    blocks = [O.gen_block(4 << 20, 0, win=4096), O.gen_block(1 << 20, 1, win=65535), O.gen_block(300000, 2, litmax=4, win=8),
+              O.gen_block(65536, 3), O.gen_block((4 << 20) + 1, 4, win=4096), O.gen_block(65547, 5), O.gen_block(4000, 6), O.gen_block(5000000, 7, litmax=200)]
+    want = [ref.compress_fast(b) for b in blocks]
+    for pack in (0, 1):
+        amd.set_option("compress_pack", pack)
+        try:
+            res = gpu_compress_many(amd, blocks, [ref.compress_bound(len(b)) for b in blocks])
+        finally:
+            amd.set_option("compress_pack", 1)
+        for k, (b, (r, c)) in enumerate(zip(blocks, res)):
+            assert c == want[k], (pack, k, len(b))
     dec = gpu_decode_safe_many(amd, [c for _, c in res], [len(b) for b in blocks])
     for b, (r, d) in zip(blocks, dec):
         assert r == len(b) and d == b
