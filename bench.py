@@ -47,7 +47,7 @@ def kernel_source_hash():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "lz4-java_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith((".h", ".hip", ".cpp")):
+        if f.endswith((".h", ".hip", ".cpp", ".inc")):
             h.update(f.encode())
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]

@@ -46,7 +46,7 @@ def kernel_source_hash():   # same function as bench.py: marks which kernel sour
     h = hashlib.sha256()
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lz4-java_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith((".h", ".hip", ".cpp")):
+        if f.endswith((".h", ".hip", ".cpp", ".inc")):
             h.update(f.encode())
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
