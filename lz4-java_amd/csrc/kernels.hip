@@ -209,7 +209,7 @@ __global__ __launch_bounds__(64 * 2 * WAVES_PER_CU) void compress_fast_v2w_cu_ke
 constexpr uint32_t PK_FINDERS = LZ4HIP_PK_FINDERS, PK_WRITERS = LZ4HIP_PK_WRITERS;
 constexpr uint32_t PK_WGS_PER_CU = LZ4HIP_PK_WGS;
 static_assert(PK_WRITERS <= PK_FINDERS && PK_FINDERS <= 2 * PK_WRITERS && 64 * (PK_FINDERS + PK_WRITERS) <= 1024, "shape of the packed kernel");
-__global__ __launch_bounds__(64 * (PK_FINDERS + PK_WRITERS)) void compress_fast_v2wp_cu_kernel(BatchArgs a, uint32_t* ctl, uint32_t* q, uint32_t* routed, uint32_t dense64, uint32_t* mail_ctr, uint32_t* mail_slots) {
+__global__ __launch_bounds__(64 * (PK_FINDERS + PK_WRITERS)) void compress_fast_v2wp_cu_kernel(BatchArgs a, uint32_t* ctl, uint32_t* mail_ctr, uint32_t* mail_slots) {
   __shared__ __attribute__((aligned(16))) uint32_t tables[PK_FINDERS][4096];
   if (__builtin_amdgcn_readfirstlane(ctl[CTL_PK]) == 0u) return;   // (every wavefront: no such block in this batch)
   const uint32_t wv = threadIdx.x >> 6;
@@ -238,14 +238,13 @@ __global__ __launch_bounds__(64 * (PK_FINDERS + PK_WRITERS)) void compress_fast_
     out.b = b;
     const int32_t n = uniform_i32(a.src_len[b]);
     const uint8_t* s = uniform_ptr(a.src + a.src_off[b]);
-    out.dense64 = routed ? dense64 : 0u;
+    // No density probe here: with ten chains per CU this kernel beats the window-parallel core (five chains, 64-bit entries) on
+    // blocks of short sequences as well -- 2560 x 4 MiB of English text 57 against 32 GB/s, synthetic blocks of 2..8 literals per
+    // sequence 88-127 against 24-41 (profiles/r04_compress_study.txt) -- so these blocks are never routed.
+    out.dense64 = 0u;
     {
       FastV2<WaveDev, MailOut<WaveDev>, false, true> c(w, out, s, (uint32_t)n);
       (void)c.run();
-    }
-    if (out.bail) {
-      out.post(MAIL_ABORT, 0u, 0u);
-      if (__lane_id() == 0) routed[atomicAdd(q + 1, 1u)] = b;
     }
     head = out.head; tail_seen = out.tail_seen;
     WaveDev::sync();  // the table is reused
@@ -279,7 +278,7 @@ int launch_compress_fast_v2w(const BatchArgs& a, uint32_t* q, uint32_t* routed, 
     }
     hipLaunchKernelGGL(compress_classify_kernel, dim3((a.n + 255u) / 256u), dim3(256), 0, st, a.src_len, a.dst_cap, a.n, ctl);
     const uint32_t want = (a.n + PK_FINDERS - 1u) / PK_FINDERS, most = n_cus * PK_WGS_PER_CU;
-    hipLaunchKernelGGL(compress_fast_v2wp_cu_kernel, dim3(want < most ? want : most), dim3(64 * (PK_FINDERS + PK_WRITERS)), 0, st, a, ctl, q, routed, dense64, ctr, slots);
+    hipLaunchKernelGGL(compress_fast_v2wp_cu_kernel, dim3(want < most ? want : most), dim3(64 * (PK_FINDERS + PK_WRITERS)), 0, st, a, ctl, ctr, slots);
     e = hipMemsetAsync(ctr, 0, 2u * pairs_max * sizeof(uint32_t), st);   // the rings start empty again
     if (e != hipSuccess) return (int)e;
   }
