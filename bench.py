@@ -422,6 +422,36 @@ def main():
                             "unit": "GB/s", "cores": cores, "kind": r["_kind"],
                             "sample": "%d x 64 KiB slices of book1, %d threads, best (and median) of 3 repetitions of >= %d ms each" % (r["n_blocks"], cores, r.get("min_ms", 0))}
                 extra["real_book1"]["cpu_baseline"] = cpu_entry(fb)
+            # ---- the same text in 4 MiB blocks (the Frame format's largest block, the reference's default): every block is made of
+            # 70000-byte slices of book1 -- longer than the match window, and the same text comes back no closer than 130000 bytes,
+            # so a block is English text throughout.  Blocks of 65547 bytes .. 4 MiB run on the ten-chain kernel with packed table
+            # entries (no routing to the window-parallel core there: ten lean chains are the faster ones on text too). ----
+            bT, nT = 4 << 20, max(1, 2560 // world)
+            capT = amd.maxCompressedLength(bT)
+            sT = torch.empty(nT * bT, dtype=u8, device=dev)
+            slc = 70000
+            per = (bT + slc - 1) // slc
+            arT = torch.arange(slc, dtype=i64, device=dev)
+            for i in range(nT):
+                oT = (torch.arange(per, dtype=i64, device=dev) * 70000 + (i + rank * nT) * 7919) % (len(book) - slc)
+                sT[i * bT:(i + 1) * bT] = bdev[(oT[:, None] + arT[None, :]).reshape(-1)][:bT]
+            cT = torch.empty(nT * capT, dtype=u8, device=dev)
+            BT = batch(nT, bT, capT)
+            wT, tkT = timed(lambda: amd.DeviceBatch.compress_fast(sT, BT["so"], BT["sl"], cT, BT["co"], BT["cc"], BT["clen"]), 2)
+            csT = int(BT["clen"].sum().item())
+            okT = True
+            if O.ref_path():
+                clT = BT["clen"].cpu().tolist()
+                for i in sorted(set([0, nT // 2, nT - 1])):
+                    want = O.ref().compress_fast(sT[i * bT:(i + 1) * bT].cpu().numpy().tobytes())
+                    okT = okT and clT[i] == len(want) and cT[i * capT:i * capT + clT[i]].cpu().numpy().tobytes() == want
+            okT = all_ok(okT)
+            extra["real_book1_4MiB"] = {"workload": "%d x 4 MiB blocks of book1 text per GPU, fast compress (byU32, packed entries, ten chains per CU), ratio %.3f; "
+                                                    "compressed bytes of 3 blocks vs the reference library" % (nT, nT * bT / csT),
+                                        "value": round(world * float(nT) * bT / wT / 1e9, 3), "unit": "GB/s", "verified": okT,
+                                        "roofline": roof("compress_fast_v2wp_cu_kernel", float(nT) * bT + csT, tkT, None)}
+            ok = ok and okT
+            del sT, cT, BT, arT
             del bdev, offs
         del comp, back
         torch.cuda.empty_cache()
