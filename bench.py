@@ -432,9 +432,13 @@ def main():
             slc = 70000
             per = (bT + slc - 1) // slc
             arT = torch.arange(slc, dtype=i64, device=dev)
-            for i in range(nT):
-                oT = (torch.arange(per, dtype=i64, device=dev) * 70000 + (i + rank * nT) * 7919) % (len(book) - slc)
-                sT[i * bT:(i + 1) * bT] = bdev[(oT[:, None] + arT[None, :]).reshape(-1)][:bT]
+            blkT = (torch.arange(nT, dtype=i64, device=dev) + rank * nT) * 7919
+            sTv = sT.view(nT, bT)
+            for j in range(per):   # slice j of every block at once
+                wdt = min(slc, bT - j * slc)
+                oT = (blkT + j * 70000) % (len(book) - slc)
+                sTv[:, j * slc:j * slc + wdt] = bdev[oT[:, None] + arT[None, :wdt]]
+            del blkT, sTv
             cT = torch.empty(nT * capT, dtype=u8, device=dev)
             BT = batch(nT, bT, capT)
             wT, tkT = timed(lambda: amd.DeviceBatch.compress_fast(sT, BT["so"], BT["sl"], cT, BT["co"], BT["cc"], BT["clen"]), 2)
