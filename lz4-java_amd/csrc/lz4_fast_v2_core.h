@@ -381,6 +381,20 @@ struct FastV2 {
           if (ip > lim) break;
         }
       }
+#elif defined(LZ4HIP_HOST_ASM_EMU)
+      // CPU suite (tests/hostsim/hostsim_asm.cpp): the same calls, the loop's TEXT run by an interpreter of its instructions
+      // (tests/hostsim/asm_emu.h) -- the hand-scheduled loops had no check off the GPU before.
+      if constexpr (W::kAsmLean && OUT::kAsmPark) {
+        if (!st) {
+          if (ip - prev_hpos > (U16 ? 127u : 126u) && ip >= 2u && out.cnt < 63u) {
+            prev_hpos = ip - 2u;
+            prev_fa = w.ldu32(src, j4 + prev_hpos);
+          }
+          w.template lean_asm_emu<U16, PK>(ip, prev_hpos, pf_end, out.cnt, prev_fa, out.p_ms, out.p_ml, out.p_off, lim >= 192u ? lim - 192u : 0u, src, n);
+          if (out.cnt == 64u) { out.batch(); continue; }
+          if (ip > lim) break;
+        }
+      }
 #endif
       if (st) l_steps++;
       uint64_t tk = (st && LZ4HIP_V2_PROBE == 0) ? w.tick(ip) : tk_keep;

@@ -570,3 +570,84 @@ def test_mail_ring_abort_after_routed_block(sim, ref, O, corpus):
             else:
                 assert c == ref.compress_fast(v), (pairs, i, len(v))
         assert any(any(v is d for d in dense) for i, v in enumerate(blocks) if i in routed)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The hand-scheduled match-finder loops (csrc/lz4_fast_v2_asm.h, lz4_fast_v2_asm32.h, lz4_fast_v2_asm_body.inc) on the CPU:
+# their TEXT, extracted from the preprocessed device headers, is run by an interpreter of its instructions (tests/hostsim/asm_emu.h)
+# inside the lean core's lock-step simulation, wherever the GPU build runs the assembled loop.
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def asmsim():
+    d = os.path.join(ROOT, "tests", "hostsim")
+    inc, so = os.path.join(d, "lean_asm_text.inc"), os.path.join(d, "libhostsim_asm.so")
+    csrc = os.path.join(ROOT, "lz4-java_amd", "csrc")
+    srcs = [os.path.join(d, f) for f in ("hostsim_asm.cpp", "asm_emu.h", "wave_host.h", "gen_asm_text.py")] + \
+           [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".h", ".inc"))]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
+        rc = subprocess.call([os.sys.executable, os.path.join(d, "gen_asm_text.py"), inc])
+        if rc == 3:
+            pytest.skip("no hipcc here: the loops' text cannot be extracted")
+        assert rc == 0
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", so, os.path.join(d, "hostsim_asm.cpp")])
+    l = C.CDLL(so)
+    l.sim_asm_compress.restype = C.c_int
+    l.sim_asm_compress.argtypes = [C.c_char_p, C.c_int, _u8p, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.c_uint64]
+    return l
+
+
+def asm_compress(asmsim, v, cap, kind=0, seed=1):
+    out = (C.c_uint8 * max(cap, 1))()
+    st = (C.c_uint64 * 3)()
+    r = asmsim.sim_asm_compress(bytes(v), len(v), out, cap, kind, st, seed)
+    return r, bytes(out[:max(r, 0)]), list(st)
+
+
+def test_asm_loop_byu16_golden_and_fuzz(asmsim, ref, O, corpus):
+    """byU16 blocks through the lean core WITH the hand-scheduled loop (interpreted): golden corpus, the regression inputs that once
+    broke it on the GPU, 400 fuzz inputs x {full, tight, random} capacities, each run with its own order of the LDS atomics' lanes
+    and its own garbage in the registers the loop does not set: return values and bytes against the reference library"""
+    import glob
+    parked = hits = 0
+    for name, v in corpus.items():
+        if len(v) >= 65547:
+            continue
+        r, b, st = asm_compress(asmsim, v, ref.compress_bound(len(v)))
+        assert b == ref.compress_fast(v), name
+        parked += st[2]
+    for f in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "regress", "*.bin"))):
+        v = open(f, "rb").read()
+        r, b, st = asm_compress(asmsim, v, ref.compress_bound(len(v)), seed=5)
+        assert b == ref.compress_fast(v), f
+    rng = random.Random(71)
+    for v in rnd_inputs(O, corpus, 81, 400):
+        full = ref.compress_bound(len(v))
+        er, _ = ref.compress_fast_raw(v, full)
+        for cap in (full, max(0, er + rng.choice([-1, 0, 1, 2, -5, 5])), rng.randrange(0, full + 1)):
+            a = ref.compress_fast_raw(v, cap)
+            r, b, st = asm_compress(asmsim, v, cap, seed=rng.getrandbits(62) | 1)
+            assert r == a[0] and (r <= 0 or b == a[1]), (len(v), cap, r, a[0])
+            parked += st[2]
+    assert parked > 20000   # (the loop under test found the hits)
+
+
+def test_asm_loop_byu32_both_entry_kinds(asmsim, ref, O, corpus):
+    """blocks of 65547 bytes and more: the loop with packed 32-bit entries (blocks up to 4 MiB: kind 0) and with 64-bit entries
+    (kind 1) -- synthetic blocks of every literal / window mix, text, periodic and random data, copies at distances around 65535"""
+    rng = random.Random(72)
+    book = corpus["book1[:200000]"]
+    unit = rng.randbytes(700)
+    inputs = [O.gen_block(65547, 1), O.gen_block(200000, 2, win=4096), O.gen_block(150000, 3, litmax=4, win=64), book[:120000], O.gen_block(100000, 4, litmax=200, win=300),
+              (unit + rng.randbytes(65535 - 700)) * 2 + unit, (unit + rng.randbytes(65536 - 700)) * 2 + unit, bytes(rng.randrange(2) for _ in range(30000)) * 3,
+              rng.randbytes(70000), (rng.randbytes(41) * 2000)[:80000], O.gen_block(300000, 5, win=65535), corpus["pic[:65536]"] * 2]
+    parked = 0
+    for k, v in enumerate(inputs):
+        full = ref.compress_bound(len(v))
+        er, _ = ref.compress_fast_raw(v, full)
+        for kind in (0, 1):
+            for cap in (full, max(0, er + rng.choice([-1, 0, 1, -7]))):
+                a = ref.compress_fast_raw(v, cap)
+                r, b, st = asm_compress(asmsim, v, cap, kind=kind, seed=rng.getrandbits(62) | 1)
+                assert r == a[0] and (r <= 0 or b == a[1]), (k, len(v), kind, cap, r, a[0])
+                parked += st[2]
+    assert parked > 20000
