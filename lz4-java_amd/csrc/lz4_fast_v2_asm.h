@@ -46,6 +46,13 @@
 #ifndef LZ4HIP_V2_PF
 #define LZ4HIP_V2_PF 0   /* developer A/B: candidate lines of the next windows' tentative slots requested at the end of the shadow */
 #endif
+#ifndef LZ4HIP_FP_BITS
+#define LZ4HIP_FP_BITS 16   /* (lz4_fast_core.h: developer builds with narrower byU16 fingerprints) */
+#endif
+#ifndef LZ4HIP_V2_RETRY
+#define LZ4HIP_V2_RETRY 0   /* 1 (not the product yet: verified in the CPU suite's ISA interpreter only, tests/test_hostsim.py): a false hit -- fingerprints agree, bytes differ -- is
+                               handled inside the loop instead of leaving it; the lookups then start one position earlier (slot 0 = hit + 1) */
+#endif
 #ifndef LZ4HIP_V2_ASM_PROF
 #define LZ4HIP_V2_ASM_PROF 0   /* developer builds: shader-clock time per phase of the hand-scheduled step, summed into g_asm_prof */
 #endif
@@ -68,6 +75,21 @@ __device__ unsigned long long g_asm_prof[16];
 #define LZ4HIP_COUNT(acc) ""
 #endif
 
+#if LZ4HIP_V2_RETRY && LZ4HIP_V2_ASM_PROF
+#error "LZ4HIP_V2_RETRY and LZ4HIP_V2_ASM_PROF use the same scalar registers"
+#endif
+// where slot 0 of a lookup set lies behind the hit in flight, and from it the insert-only slot / the first probe slot of a match of length L
+#if LZ4HIP_V2_RETRY
+#define LZ4HIP_LEAN_S0 "1"
+#define LZ4HIP_LEAN_INS "-3"
+#define LZ4HIP_LEAN_PRB "-1"
+#define LZ4HIP_RETRY_CLOBBERS , "s92", "s93", "s96", "s97"
+#else
+#define LZ4HIP_LEAN_S0 "2"
+#define LZ4HIP_LEAN_INS "-4"
+#define LZ4HIP_LEAN_PRB "-2"
+#define LZ4HIP_RETRY_CLOBBERS
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define LZ4HIP_STR2(x) #x
 #define LZ4HIP_STR(x) LZ4HIP_STR2(x)
@@ -124,8 +146,8 @@ __device__ unsigned long long g_asm_prof[16];
       "  v_lshl_add_u32 v58, v58, 2, %[tbl]\n" \
       "  ds_read_b32 v55, v54\n" \
       "  ds_read_b32 v59, v58\n" \
-      "  v_bfe_u32 v76, v51, 3, 16\n" \
-      "  v_bfe_u32 v77, v53, 3, 16\n" \
+      "  v_bfe_u32 v76, v51, 3, " LZ4HIP_STR(LZ4HIP_FP_BITS) "\n" \
+      "  v_bfe_u32 v77, v53, 3, " LZ4HIP_STR(LZ4HIP_FP_BITS) "\n" \
       "  v_lshl_or_b32 v56, v78, 16, v76\n" \
       "  v_add_u32 v78, 64, v78\n" \
       "  v_lshl_or_b32 v60, v78, 16, v77\n" \
@@ -196,7 +218,7 @@ __device__ __forceinline__ uint32_t lean_asm_run(uint32_t& ip, uint32_t& php, ui
       : "memory", "vcc", "scc", "m0", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59",
         "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74",
         "v75", "v76", "v77", "v78", "v79", "v80", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82",
-        "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s94", "s95"
+        "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s94", "s95" LZ4HIP_RETRY_CLOBBERS
 #if LZ4HIP_V2_ASM_PROF
         , "s92", "s93", "s96", "s97", "s98"
 #endif

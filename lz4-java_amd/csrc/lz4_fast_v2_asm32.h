@@ -375,8 +375,11 @@ __device__ __forceinline__ uint32_t lean_asm_run32p(uint32_t& ip, uint32_t& php,
         [j4] "v"(j4), [j16] "v"(j16)
       : "memory", "vcc", "scc", "m0", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61",
         "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78",
+#if LZ4HIP_V2_RETRY
+        "v79", "v80",
+#endif
         "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87",
-        "s88", "s89", "s90", "s91", "s94", "s95");
+        "s88", "s89", "s90", "s91", "s94", "s95" LZ4HIP_RETRY_CLOBBERS);
   return code;
 }
 #endif

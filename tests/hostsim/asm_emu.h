@@ -291,6 +291,7 @@ struct AsmEmu {
       else if (op == "s_cmp_ge_u32") scc = (uint32_t)rd_s(o[0], false) >= (uint32_t)rd_s(o[1], false);
       else if (op == "s_cmp_lt_u32") scc = (uint32_t)rd_s(o[0], false) < (uint32_t)rd_s(o[1], false);
       else if (op == "s_cmp_eq_u32") scc = (uint32_t)rd_s(o[0], false) == (uint32_t)rd_s(o[1], false);
+      else if (op == "s_cmp_lg_u32") scc = (uint32_t)rd_s(o[0], false) != (uint32_t)rd_s(o[1], false);
       else if (op == "s_cmp_eq_u64") scc = rd_s(o[0], true) == rd_s(o[1], true);
       else if (op == "s_branch") next = in.target;
       else if (op == "s_cbranch_scc0") { if (!scc) next = in.target; }

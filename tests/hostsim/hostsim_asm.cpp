@@ -10,10 +10,15 @@
 #include <stdio.h>
 #include "wave_host.h"
 #include "asm_emu.h"
-#include "lean_asm_text.inc"
+#ifndef LZ4HIP_ASM_TEXT_INC
+#define LZ4HIP_ASM_TEXT_INC "lean_asm_text.inc"   /* (variant builds of the suite: the text generated with other -D flags) */
+#endif
+#include LZ4HIP_ASM_TEXT_INC
 #include "../../lz4-java_amd/csrc/lz4_fast_v2_core.h"
 
 namespace hostsim {
+
+namespace { thread_local AsmEmu* g_emu[3] = {nullptr, nullptr, nullptr}; }
 
 struct WaveHostAsm : WaveHost {
   static constexpr bool kAsmLean = true;
@@ -24,7 +29,9 @@ struct WaveHostAsm : WaveHost {
   template <bool U16, bool PK>
   void lean_asm_emu(uint32_t& ip, uint32_t& php, uint32_t& pfe, uint32_t& pc, VU& pfa, VU& pms, VU& pml, VU& pof, uint32_t lim,
                     const uint8_t* src, uint32_t n) {
-    static thread_local AsmEmu* emu = nullptr;
+    // (one interpreter per loop and per LIBRARY: a static inside this template would be one object for every variant of the
+    // simulator library loaded into the process -- such statics are unique symbols -- and a variant would run another one's text)
+    AsmEmu*& emu = g_emu[U16 ? 0 : (PK ? 2 : 1)];
     if (!emu) {
       emu = new AsmEmu();
       if (!emu->load(U16 ? kLeanAsmU16 : (PK ? kLeanAsmU32P : kLeanAsmU32))) { fprintf(stderr, "asm_emu: %s\n", emu->error.c_str()); asm_error = true; }
@@ -50,10 +57,16 @@ struct WaveHostAsm : WaveHost {
     e.g_lo = src; e.g_hi = src + n;
     const uint64_t before = e.executed;
     const uint32_t pc0 = pc;
+    const uint32_t ip0 = ip, php0 = php;
     if (!e.run()) { fprintf(stderr, "asm_emu: %s\n", e.error.c_str()); asm_error = true; oob = true; return; }
     asm_calls++; asm_insns += e.executed - before;
     ip = e.s[104]; php = e.s[105]; pfe = e.s[106]; pc = e.s[107];
     asm_parked += pc - pc0;
+    if (getenv("ASM_EMU_TRACE")) {
+      fprintf(stderr, "asm: ip %u php %d pc %u -> ip %u php %d pc %u code %u  parked:", ip0, (int)(ip0 - php0), pc0, ip, (int)(ip - php), pc, e.s[108]);
+      for (uint32_t k = pc0; k < pc && k < 64; k++) fprintf(stderr, " [%u +%u -%u]", e.v[201][k], e.v[202][k], e.v[203][k]);
+      fprintf(stderr, "\n");
+    }
     if (e.exec != ~0ull) { fprintf(stderr, "asm_emu: the loop left exec = %016llx\n", (unsigned long long)e.exec); asm_error = true; oob = true; }
     for (int l = 0; l < 64; l++) { pfa.v[l] = e.v[200][l]; pms.v[l] = e.v[201][l]; pml.v[l] = e.v[202][l]; pof.v[l] = e.v[203][l]; }
   }

@@ -577,23 +577,29 @@ def test_mail_ring_abort_after_routed_block(sim, ref, O, corpus):
 # their TEXT, extracted from the preprocessed device headers, is run by an interpreter of its instructions (tests/hostsim/asm_emu.h)
 # inside the lean core's lock-step simulation, wherever the GPU build runs the assembled loop.
 # ---------------------------------------------------------------------------------------------------------------------
-@pytest.fixture(scope="module")
-def asmsim():
+def build_asmsim(tag="", defs=()):
+    """the interpreter library; tag / defs: a variant -- the loops' text AND the C++ around it built with extra -D flags"""
     d = os.path.join(ROOT, "tests", "hostsim")
-    inc, so = os.path.join(d, "lean_asm_text.inc"), os.path.join(d, "libhostsim_asm.so")
+    inc, so = os.path.join(d, "lean_asm_text%s.inc" % tag), os.path.join(d, "libhostsim_asm%s.so" % tag)
     csrc = os.path.join(ROOT, "lz4-java_amd", "csrc")
     srcs = [os.path.join(d, f) for f in ("hostsim_asm.cpp", "asm_emu.h", "wave_host.h", "gen_asm_text.py")] + \
            [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".h", ".inc"))]
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
-        rc = subprocess.call([os.sys.executable, os.path.join(d, "gen_asm_text.py"), inc])
+        rc = subprocess.call([os.sys.executable, os.path.join(d, "gen_asm_text.py"), inc] + list(defs))
         if rc == 3:
             pytest.skip("no hipcc here: the loops' text cannot be extracted")
         assert rc == 0
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", so, os.path.join(d, "hostsim_asm.cpp")])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", '-DLZ4HIP_ASM_TEXT_INC="%s"' % os.path.basename(inc)] + list(defs) +
+                              ["-o", so, os.path.join(d, "hostsim_asm.cpp")])
     l = C.CDLL(so)
     l.sim_asm_compress.restype = C.c_int
     l.sim_asm_compress.argtypes = [C.c_char_p, C.c_int, _u8p, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.c_uint64]
     return l
+
+
+@pytest.fixture(scope="module")
+def asmsim():
+    return build_asmsim()
 
 
 def asm_compress(asmsim, v, cap, kind=0, seed=1):
@@ -651,3 +657,26 @@ def test_asm_loop_byu32_both_entry_kinds(asmsim, ref, O, corpus):
                 assert r == a[0] and (r <= 0 or b == a[1]), (k, len(v), kind, cap, r, a[0])
                 parked += st[2]
     assert parked > 20000
+
+
+def test_asm_loop_retry_path_with_narrow_fingerprints(ref, O, corpus):
+    """LZ4HIP_V2_RETRY = 1 (not the product's default yet: it has not been timed on the GPU): a FALSE hit -- fingerprints agree, the
+    candidate's bytes differ -- is handled inside the hand-scheduled loop (the probes behind it come out of the lookups already made,
+    which therefore start one position earlier; a retry commit has its own undo record) instead of leaving the loop.  Built with
+    6-bit byU16 fingerprints so that a fifth of the searches meet a false hit (the packed byU32 entries have ten bits anyway): the
+    loops' text in the interpreter against the reference library, fuzz inputs x {full, tight} capacities, both table kinds."""
+    sim = build_asmsim("_retry", ("-DLZ4HIP_V2_RETRY=1", "-DLZ4HIP_FP_BITS=6"))
+    rng = random.Random(73)
+    inputs = [O.gen_block(65536, 0), O.gen_block(65536, 1), corpus["geo[:65536]"], corpus["book1[:200000]"][:65536], corpus["pic[:65536]"],
+              O.gen_block(200000, 2, win=4096), O.gen_block(150000, 3, litmax=4, win=64), corpus["book1[:200000]"][:120000], O.gen_block(300000, 5, win=65535)]
+    inputs += rnd_inputs(O, corpus, 85, 300)
+    parked = calls = 0
+    for k, v in enumerate(inputs):
+        full = ref.compress_bound(len(v))
+        er, _ = ref.compress_fast_raw(v, full)
+        for cap in (full, max(0, er + rng.choice([-1, 0, 1, -6]))):
+            a = ref.compress_fast_raw(v, cap)
+            r, b, st = asm_compress(sim, v, cap, seed=rng.getrandbits(62) | 1)
+            assert r == a[0] and (r <= 0 or b == a[1]), (k, len(v), cap, r, a[0])
+            calls += st[0]; parked += st[2]
+    assert parked > 50000
