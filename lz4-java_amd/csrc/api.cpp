@@ -1057,12 +1057,13 @@ int lz4hip_set_option(const char* name, int value) {
     return LZ4HIP_OK;
   }
   if (name && strcmp(name, "decode_pipe") == 0) {
-    if (value < -1 || value > 3) return fail(LZ4HIP_E_ARG, "decode_pipe must be -1, 0, 1, 2 or 3");
+    if (value < -1 || value > 4) return fail(LZ4HIP_E_ARG, "decode_pipe must be -1, 0, 1, 2, 3 or 4");
     g_decode_pipe = value;
     return LZ4HIP_OK;
   }
   if (name && strcmp(name, "decode_ring") == 0) {
-    if (value != 0 && value != 256 && value != 512 && value != 1024 && value != 2048 && value != 4096) return fail(LZ4HIP_E_ARG, "decode_ring must be 0, 256, 512, 1024, 2048 or 4096");
+    if (value != 0 && value != 256 && value != 512 && value != 1024 && value != 2048 && value != 4096 && value != 8192 && value != 16384 && value != 32768 && value != 65536)
+      return fail(LZ4HIP_E_ARG, "decode_ring must be 0, 256 .. 4096 (ring loop) or 8192 .. 65536 (wave loop)");
     g_decode_ring = value;
     return LZ4HIP_OK;
   }

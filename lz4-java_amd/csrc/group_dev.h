@@ -413,4 +413,109 @@ struct GroupDev {
   }
 };
 
+
+// ---- backend of the wave loop (lz4_decode_wave.h): ONE WAVEFRONT PER BLOCK.  All 64 lanes move 4 bytes each (a step is 256 bytes, a
+// piece up to 252); the block's window of the compressed stream (KS bytes) and its recent output (KW bytes) live in LDS.
+// Layout of a wavefront's kWaveLds bytes: [stream ring KS | 16 tail][16 pad | output ring KW | 16 tail].
+//  * stream ring: indexed by stream position, refilled in 256-byte steps (a dword per lane), first 16 bytes mirrored behind the end so
+//    that the two aligned dwords around any index are contiguous;
+//  * output ring: index of output position p = (p + dbase) & (KW - 1), dbase = dst address & 255 -- 256-byte aligned steps of memory
+//    are aligned steps of the ring.  A dword written at ring index x is stored at t - 4 with t = (x + 4) & (KW - 1), and once more KW
+//    bytes further on when t < 8 (the mirror rule of the ring loop's backend above): reads never wrap.
+// A piece written at ring index w: lane 0 holds its bytes [0, 4) and stores them at w (the only unaligned lane), lane l >= 1 holds the
+// bytes [4 l - s, 4 l - s + 4), s = w & 3, and stores them at the aligned index (w & ~3) + 4 l.  The getters deliver a piece in that
+// shape for a given s: two aligned dwords around each lane's source index, funnelled (v_alignbyte).
+template <int KW, int KS>
+struct BlockWaveDev : GroupDev<64, 0> {
+  typedef GroupDev<64, 0> Base;
+  typedef typename Base::LChunk LChunk;   // one dword
+  static_assert(Base::LB == 4u, "a lane of the wave loop moves one dword");
+  static constexpr uint32_t kWaveLds = (uint32_t)KS + 16u + 16u + (uint32_t)KW + 16u;
+  uint8_t* wsb = nullptr;   // stream ring
+  uint8_t* wrb = nullptr;   // output ring, index 0
+  uint32_t wdb = 0;
+  uint32_t l4;              // 4 * lane
+  __device__ __forceinline__ BlockWaveDev() : Base(), l4((threadIdx.x & 63u) * 4u) {}
+  __device__ __forceinline__ void wv_begin(uint8_t* lds, const uint8_t* dst) { wsb = lds; wrb = lds + KS + 32; wdb = (uint32_t)(uintptr_t)dst & 255u; }
+  __device__ __forceinline__ static constexpr uint32_t wv_ring() { return (uint32_t)KW; }
+  __device__ __forceinline__ static constexpr uint32_t wv_stream() { return (uint32_t)KS; }
+  __device__ __forceinline__ uint32_t wv_dbase() const { return wdb; }
+  __device__ __forceinline__ static uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+  // a piece on its way to ring index w: this lane's dword and its byte offset inside the piece (lane 0: 0; lane l: 4 l - (w & 3))
+  struct WPiece { uint32_t v, dl; };
+  // (4 l - s saturated at zero is lane 0's 0: ONE instruction, v_sub_u32 with the clamp bit)
+  __device__ __forceinline__ uint32_t delta(uint32_t w) const { return __builtin_elementwise_sub_sat(l4, w & 3u); }
+  // stream side (shadow the ring loop's: this ring has KS bytes)
+  __device__ __forceinline__ LChunk rs_fetch(const uint8_t* src, uint32_t pos) const {   // pos: multiple of 256; [pos, pos + 256) is readable
+    LChunk r;
+    __builtin_memcpy(&r, src + pos + l4, 4);
+    return r;
+  }
+  __device__ __forceinline__ void rs_put(uint32_t pos, const LChunk& r) {
+    const uint32_t q = (pos & ((uint32_t)KS - 1u)) + l4;
+    *Base::dwp(wsb + q) = r.w[0];
+    if (q < 16u) *Base::dwp(wsb + KS + q) = r.w[0];
+  }
+  __device__ __forceinline__ uint64_t rs_ld64(uint32_t p) const {   // the 8 stream bytes at p (every lane the same)
+    const uint32_t* q = Base::dwp(wsb + (p & ((uint32_t)KS - 1u) & ~3u));
+    const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], s = p & 3u;
+    return (uint64_t)__builtin_amdgcn_alignbyte(d1, d0, s) | ((uint64_t)__builtin_amdgcn_alignbyte(d2, d1, s) << 32);
+  }
+  // getters: the piece that starts at source index sp, shaped for ring index w
+  __device__ __forceinline__ WPiece wv_get_stream(uint32_t sp, uint32_t w) const {
+    WPiece r;
+    r.dl = delta(w);
+    const uint32_t a = sp + r.dl;
+    const uint32_t* q = Base::dwp(wsb + (a & ((uint32_t)KS - 1u) & ~3u));
+    r.v = __builtin_amdgcn_alignbyte(q[1], q[0], a & 3u);
+    return r;
+  }
+  __device__ __forceinline__ WPiece wv_get_ring(uint32_t sw, uint32_t w) const {   // sw: ring coordinates of the source
+    WPiece r;
+    r.dl = delta(w);
+    const uint32_t a = sw + r.dl;
+    const uint32_t* q = Base::dwp(wrb + (a & ((uint32_t)KW - 1u) & ~3u));
+    r.v = __builtin_amdgcn_alignbyte(q[1], q[0], a & 3u);
+    return r;
+  }
+  __device__ __forceinline__ WPiece wv_get_mem(const uint8_t* m, uint32_t w) const {   // [m, m + 256) is readable
+    WPiece r;
+    r.dl = delta(w);
+    const typename Base::vecLB t = LZ4HIP_MATCH_LOAD((const typename Base::vecLB*)(m + r.dl));
+    __builtin_memcpy(&r.v, &t, 4);
+    return r;
+  }
+  // (lane 0's ring index is w, lane l's (w & ~3) + 4 l: both are w + dl.  One store instruction serves the aligned lanes and the one
+  // that is not -- the compiler emits ds_write_b32 for either)
+  __device__ __forceinline__ void wv_put(uint32_t w, const WPiece& c) {
+    const uint32_t t = (w + 4u + c.dl) & ((uint32_t)KW - 1u);
+    uint8_t* a = (wrb - 4) + t;
+    __builtin_memcpy(a, &c.v, 4);
+    const uint32_t u = (w + 4u) & ((uint32_t)KW - 1u);               // wave-uniform: does any lane of this piece lie at the ring's ends?
+    if (__builtin_expect((u < 8u) | (u > (uint32_t)KW - 264u), 0)) {
+      asm volatile("; a piece at the ring's ends" ::: "memory");       // (keeps this a scalar branch: flattened into a predicate it cost five instructions per piece)
+      if (t < 8u) __builtin_memcpy(a + KW, &c.v, 4);
+    }
+  }
+  __device__ __forceinline__ LChunk wv_read_al(uint32_t fw) const {   // fw: a multiple of 256 in ring coordinates
+    LChunk v;
+    v.w[0] = *Base::dwp(wrb + ((fw + l4) & ((uint32_t)KW - 1u)));
+    return v;
+  }
+  // the step at ring coordinates fw (a multiple of 256) to memory: its bytes inside [lo, hi) (ring coordinates), nothing else
+  __device__ __forceinline__ void wv_store(uint8_t* dst, uint32_t fw, const LChunk& c, uint32_t lo, uint32_t hi) const {
+    uint8_t* p = dst + (intptr_t)(int32_t)(fw + l4 - wdb);
+    if (__builtin_expect((fw >= lo) & (fw + 256u <= hi), 1)) {
+      *(uint32_t*)__builtin_assume_aligned(p, 4) = c.w[0];
+    } else {
+      const uint32_t a = fw + l4;
+      if ((a >= lo) & (a + 4u <= hi)) *(uint32_t*)__builtin_assume_aligned(p, 4) = c.w[0];
+      else {
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; k++) if ((a + k >= lo) & (a + k < hi)) p[k] = (uint8_t)(c.w[0] >> (8u * k));
+      }
+    }
+  }
+};
+
 }  // namespace lz4hip

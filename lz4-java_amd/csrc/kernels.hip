@@ -19,6 +19,7 @@
 //   gen_blocks_kernel    : SURVEY.md App. F workload generator (setup only, never timed).
 // No MFMA anywhere: this is byte shuffling, not a contraction.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <stdint.h>
@@ -865,6 +866,60 @@ static int launch_decode_ring(const BatchArgs& a, bool safe, hipStream_t st, con
   else hipLaunchKernelGGL((decode_ring_kernel<GL, KW, false>), dim3(grid), dim3(64), 0, st, a, route, want);
   return (int)hipGetLastError();
 }
+// the wave loop's kernel (lz4_decode_wave.h): ONE WAVEFRONT PER BLOCK, W wavefronts per workgroup, one workgroup per CU (it declares
+// the LDS of its W wavefronts: a stream ring of KS bytes and an output ring of KW bytes each; workgroups that SHARE a CU get 128 KB of
+// its LDS between them, a single one all 160 KB -- DESIGN.md 2.1).  No barrier: the wavefronts are independent, each takes the blocks
+// blockIdx.x * W + wave, + gridDim.x * W, ...  The launch picks W so that the blocks of the batch spread over all CUs with the largest
+// ring that fits: up to one block per CU a 64 KB ring (a 64 KiB block never leaves the chip), ... sixteen per CU an 8 KB ring.
+template <int W, int KW, int KS, bool SAFE>
+__global__ __launch_bounds__(64 * W) void decode_wave_kernel(BatchArgs a, const uint32_t* route, uint32_t want) {
+  if (route && *route != want) return;   // (the launch was routed to another decoder: launch_decompress)
+  typedef BlockWaveDev<KW, KS> G;
+  __shared__ __attribute__((aligned(16))) uint8_t wave_mem[W * G::kWaveLds];
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  uint8_t* lds = wave_mem + wave * G::kWaveLds;
+  for (uint32_t b = blockIdx.x * W + wave; b < a.n; b += gridDim.x * W) {
+    G g;
+    const int r = decode_block<G, SAFE, 4, false>(g, a.src + a.src_off[b], a.src_len[b], a.dst + a.dst_off[b], a.dst_cap[b], lds);
+    if (g.l == 0) a.out[b] = r;
+  }
+}
+static uint32_t device_cus() {   // compute units of the current device (cached per device)
+  static std::atomic<uint32_t> cus[64];
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) d = 0;
+  uint32_t c = cus[d].load(std::memory_order_relaxed);
+  if (c == 0) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || v <= 0) v = 256;
+    c = (uint32_t)v;
+    cus[d].store(c, std::memory_order_relaxed);
+  }
+  return c;
+}
+template <int W, int KW, int KS>
+static int launch_decode_wave_w(const BatchArgs& a, bool safe, hipStream_t st, const uint32_t* route, uint32_t want) {
+  const uint32_t wgs = (a.n + W - 1u) / W, cus = device_cus();
+  const uint32_t grid = wgs < cus ? wgs : cus;
+  if (safe) hipLaunchKernelGGL((decode_wave_kernel<W, KW, KS, true>), dim3(grid), dim3(64 * W), 0, st, a, route, want);
+  else hipLaunchKernelGGL((decode_wave_kernel<W, KW, KS, false>), dim3(grid), dim3(64 * W), 0, st, a, route, want);
+  return (int)hipGetLastError();
+}
+// ring: bytes of the output ring (8192 / 16384 / 32768 / 65536; 0 = the largest that lets the batch spread over all CUs)
+static int launch_decode_wave(const BatchArgs& a, bool safe, int ring, hipStream_t st, const uint32_t* route = nullptr, uint32_t want = 0) {
+  if (ring == 0) {
+    const uint32_t cus = device_cus();
+    ring = a.n <= 2u * cus ? 65536 : a.n <= 4u * cus ? 32768 : a.n <= 8u * cus ? 16384 : 8192;
+  }
+  switch (ring) {
+    case 65536: return a.n <= device_cus() ? launch_decode_wave_w<1, 65536, 2048>(a, safe, st, route, want) : launch_decode_wave_w<2, 65536, 2048>(a, safe, st, route, want);
+    case 32768: return launch_decode_wave_w<4, 32768, 2048>(a, safe, st, route, want);
+    case 16384: return launch_decode_wave_w<8, 16384, 2048>(a, safe, st, route, want);
+    case 8192: return launch_decode_wave_w<16, 8192, 1024>(a, safe, st, route, want);
+    default: return (int)hipErrorInvalidValue;
+  }
+}
+
 // Which decoder a mid-sized batch gets is decided ON THE DEVICE from the blocks' compressed sizes (the launch is asynchronous and
 // its arguments live in device memory): *route = 1 when a sample of the blocks averages at least `big` compressed bytes -- big
 // blocks with (typically) a short match window, where the ring loop with a 2 KiB output ring wins (BASELINE configs[2]: 847 vs 808-835
@@ -910,6 +965,7 @@ int ring_stats_fetch(unsigned long long* out8) {   // developer build: reads and
 int launch_decompress(const BatchArgs& a, bool safe, int lanes_per_block, int pipe, int stage, int ring, void* stream, uint32_t* route_word) {
   if (a.n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
+  if (pipe == 4) return launch_decode_wave(a, safe, ring, st);   // the wave loop: a wavefront per block (lanes_per_block is 64 by construction)
   if (pipe == 3) {   // the ring loop: lanes 4 / 8 / 16, output ring 512 .. 4096 bytes (0 = 512 with 4 lanes, 4096 otherwise)
     const int gl = lanes_per_block == 0 ? 4 : lanes_per_block;
     const int kw = ring ? ring : (gl == 1 ? 256 : gl == 4 ? 512 : 4096);

@@ -38,6 +38,7 @@
 #endif
 #include "lz4_decode_deep.h"
 #include "lz4_decode_ring.h"
+#include "lz4_decode_wave.h"
 namespace lz4hip {
 
 // SAFE: LZ4_decompress_safe(src, dst, src_size, out_size) -> decoded size or negative.
@@ -50,6 +51,8 @@ namespace lz4hip {
 //       are left to loop 1.
 //       3 = the ring loop of lz4_decode_ring.h (stream AND recent output in LDS rings at `stage`, Grp::kRingLds bytes; near matches
 //       never leave the chip, far ones are pipelined through slots, output leaves as whole aligned 64-byte steps).
+//       4 = the wave loop of lz4_decode_wave.h (ONE WAVEFRONT PER BLOCK, Grp = BlockWaveDev: stream ring and an output ring of 8 .. 64 KB
+//       in LDS at `stage`, wave-uniform parse, one LDS round trip per sequence): launches of few blocks.
 // STAGE: the interior loop writes through an LDS staging buffer (`stage`, Grp::kStage bytes for this block) and output leaves
 //        it as whole 128-byte lines (group_dev.h st_*).
 template <class Grp, bool SAFE, int PIPE = 0, bool STAGE = false>
@@ -120,7 +123,10 @@ LZ4HIP_DEV int decode_block(Grp& g, const uint8_t* src, int src_size, uint8_t* d
       if (op >= 64 && ip + 320 <= iend && ip <= iend - 306 && op <= oend - 606)
         if (decode_ring_loop(g, src, iend, dst, oend, ip, op, stage)) goto interior;
     }
-    if ((PIPE == 1 || (PIPE == 2 && ip + 2048 > iend) || (PIPE == 3 && ip + 320 > iend)) && ip <= iend - 306 && op <= oend - 606) {   // (2, 3: only the tail of the stream)
+    if constexpr (PIPE == 4) {   // the wave loop (lz4_decode_wave.h); what it leaves at ip is done by the exact code below, which comes back
+      if (ip + 1024 <= iend && ip <= iend - 306 && op <= oend - 606) decode_wave_loop(g, src, iend, dst, oend, ip, op, stage);
+    }
+    if ((PIPE == 1 || (PIPE == 2 && ip + 2048 > iend) || (PIPE == 3 && ip + 320 > iend) || (PIPE == 4 && ip + 1024 > iend)) && ip <= iend - 306 && op <= oend - 606) {   // (2, 3, 4: only the tail of the stream)
       // ---- the same loop, software-pipelined.  A wavefront's memory operations retire in order, so a wait for a load also
       // waits for every OLDER store.  Here (a) the next sequence's offset word is requested as soon as this sequence's header
       // is parsed, (b) a "simple" sequence (literals and match take one step each, match source entirely before the

@@ -6,6 +6,7 @@
 #pragma once
 #include <stdint.h>
 #include <string.h>
+#include <vector>
 
 namespace hostsim {
 
@@ -208,7 +209,10 @@ struct GroupHost {
   uint32_t ring_dbase() const { return dbase; }
   uint32_t rs_tail() const { return lb() < 16u ? 16u : lb(); }
   uint32_t ring_lds() const { return kRs + rs_tail() + kRing + 3u * lb() + (GL == 1 ? 32u : 0u); }
-  bool rl_ok(const uint8_t* p, uint32_t k) { if (p < ring_mem || p + k > ring_mem + ring_lds()) { oob = true; return false; } return true; }
+  bool rl_ok(const uint8_t* p, uint32_t k) {
+    if (wave_mode) { if (p < wv_mem.data() || p + k > wv_mem.data() + wv_mem.size()) { oob = true; return false; } return true; }
+    if (p < ring_mem || p + k > ring_mem + ring_lds()) { oob = true; return false; } return true;
+  }
   void ring_begin(uint8_t*, const uint8_t* dst) {
     ring_entries++;
     memset(ring_mem, 0xEE, sizeof ring_mem);
@@ -272,6 +276,76 @@ struct GroupHost {
   static bool any(bool x) { return x; }   // (the simulated "wavefront" is this one group)
   static void settle(uint32_t&) {}
   static LChunk pick(bool first, const LChunk& a, const LChunk& b) { return first ? a : b; }
+
+  // ---- backend of the wave loop (lz4_decode_wave.h; group_dev.h BlockWaveDev): one wavefront (GL == 64) per block, a dword per lane; the
+  // stream ring (kWs bytes + 16 tail) and the output ring (16 pad | kWv bytes | 16 tail) in "LDS" with the device backend's layout,
+  // mirror rule and per-lane index arithmetic; every call is one instruction (all lanes' loads, then all lanes' stores); an index
+  // outside the wavefront's LDS bytes counts as oob.  rs_fetch / rs_put / rs_ld64 above serve this ring too (rsb = wsb, kRs = kWs).
+  bool wave_mode = false;
+  uint32_t kWv = 8192u, kWs = 2048u;
+  std::vector<uint8_t> wv_mem;
+  uint8_t* wsb = nullptr; uint8_t* wrb = nullptr;
+  uint32_t wdb = 0;
+  static inline uint64_t wave_trips = 0, wave_entries = 0, wave_far = 0, wave_mirror = 0;
+  uint32_t wv_ring() const { return kWv; }
+  uint32_t wv_stream() const { return kWs; }
+  uint32_t wv_dbase() const { return wdb; }
+  static uint32_t uni(uint32_t x) { return x; }
+  void wv_begin(uint8_t*, const uint8_t* dst) {
+    wave_entries++;
+    wave_mode = true;
+    wv_mem.assign(kWs + 32u + kWv + 16u, 0xEE);
+    wsb = wv_mem.data(); wrb = wsb + kWs + 32u; wdb = (uint32_t)(uintptr_t)dst & 255u;
+    rsb = wsb; kRs = kWs;
+  }
+  struct WPiece { uint8_t b[64][4]; uint32_t dl[64]; };
+  uint32_t wv_delta(int l, uint32_t w) const { return l == 0 ? 0u : 4u * (uint32_t)l - (w & 3u); }
+  WPiece wv_get(uint8_t* base, uint32_t mask, uint32_t sp, uint32_t w) {
+    WPiece v; memset(&v, 0, sizeof v);
+    for (int l = 0; l < GL; l++) {
+      v.dl[l] = wv_delta(l, w);
+      const uint32_t a = sp + v.dl[l], idx = a & mask;
+      if (rl_ok(base + (idx & ~3u), 8)) memcpy(v.b[l], base + idx, 4);   // (the device reads the two aligned dwords around the index)
+    }
+    return v;
+  }
+  WPiece wv_get_stream(uint32_t sp, uint32_t w) { wave_trips++; return wv_get(wsb, kWs - 1u, sp, w); }
+  WPiece wv_get_ring(uint32_t sw, uint32_t w) { return wv_get(wrb, kWv - 1u, sw, w); }
+  WPiece wv_get_mem(const uint8_t* m, uint32_t w) {
+    wave_far++;
+    WPiece v; memset(&v, 0, sizeof v);
+    for (int l = 0; l < GL; l++) { v.dl[l] = wv_delta(l, w); if (rd_ok(m + v.dl[l], 4)) memcpy(v.b[l], m + v.dl[l], 4); }
+    return v;
+  }
+  void wv_put(uint32_t w, const WPiece& c) {
+    const uint32_t u = (w + 4u) & (kWv - 1u);
+    const bool ends = (u < 8u) | (u > kWv - 264u);     // the device's wave-uniform test in front of the mirror stores
+    for (int l = 0; l < GL; l++) {
+      if (c.dl[l] != wv_delta(l, w)) oob = true;       // the piece was shaped for another ring index
+      const uint32_t t = (w + 4u + c.dl[l]) & (kWv - 1u);
+      uint8_t* a = (wrb - 4) + t;
+      if (l != 0 && ((uintptr_t)(a - wrb) & 3u)) oob = true;   // lanes 1.. store aligned dwords
+      if (rl_ok(a, 4)) memcpy(a, c.b[l], 4);
+      if (t < 8u) {
+        wave_mirror++;
+        if (!ends) oob = true;                        // a mirror store the device would have skipped
+        if (rl_ok(a + kWv, 4)) memcpy(a + kWv, c.b[l], 4);
+      }
+    }
+  }
+  LChunk wv_read_al(uint32_t fw) {
+    if (fw & 255u) oob = true;
+    LChunk v; memset(&v, 0, sizeof v);
+    for (int l = 0; l < GL; l++) { const uint8_t* q = wrb + ((fw + 4u * (uint32_t)l) & (kWv - 1u)); if (rl_ok(q, 4)) memcpy(v.b[l], q, 4); }
+    return v;
+  }
+  void wv_store(uint8_t* dst, uint32_t fw, const LChunk& c, uint32_t lo, uint32_t hi) {
+    for (int l = 0; l < GL; l++)
+      for (uint32_t k = 0; k < 4u; k++) {
+        const uint32_t a = fw + 4u * (uint32_t)l + k;
+        if (a >= lo && a < hi) { uint8_t* p = dst + (intptr_t)(int32_t)(a - wdb); if (wr_ok(p, 1)) *p = c.b[l][k]; }
+      }
+  }
 
   void copy_match(uint8_t* dst, uint32_t op, uint32_t offset, uint32_t len, bool wild) {
     uint8_t* d = dst + op;

@@ -28,8 +28,11 @@ def test_gpu_fuzz_slice(seed):
     assert "core 3: 2500 inputs bit-exact" in out and "decode safe/fast" in out
 
 
-def test_gpu_fuzz_deep_slice():
-    out = run("gpu_fuzz_deep.py", 400, 2026)
+@pytest.mark.parametrize("pipe,ring", [(2, 0), (3, 2048), (4, 0), (4, 8192)])
+def test_gpu_fuzz_deep_slice(pipe, ring):
+    """long streams, valid and damaged, through the deep loop, the ring loop with the 2 KiB ring the routed default uses, and the wave
+    loop (its default ring for the batch and the smallest one)"""
+    out = run("gpu_fuzz_deep.py", 400, 2026 + pipe, env={"FUZZ_PIPE": str(pipe), "FUZZ_RING": str(ring)})
     assert "deep fuzz ok" in out
 
 

@@ -91,17 +91,74 @@ def test_cfg3_reference_compressed_4MiB_blocks_every_decoder_variant(amd, ref, O
     cl = torch.tensor([len(s) for s in streams], dtype=torch.int32, device=dev)
     back = torch.empty(n * blk, dtype=torch.uint8, device=dev)
     try:
-        for lanes, pipe, stage in ((0, -1, -1), (4, 0, 0), (4, 1, 0), (8, 1, 0), (16, 0, 0), (16, 1, 0), (32, 1, 0), (64, 0, 0), (64, 1, 0), (4, 0, 1), (8, 0, 1), (16, 0, 1), (64, 0, 1),
-                                   (4, 2, 0), (8, 2, 0), (16, 2, 0)):
-            amd.set_option("decode_lanes", lanes); amd.set_option("decode_pipe", pipe); amd.set_option("decode_stage", stage)
+        for lanes, pipe, stage, ring in ((0, -1, -1, 0), (4, 0, 0, 0), (4, 1, 0, 0), (8, 1, 0, 0), (16, 0, 0, 0), (16, 1, 0, 0), (32, 1, 0, 0), (64, 0, 0, 0), (64, 1, 0, 0), (4, 0, 1, 0), (8, 0, 1, 0), (16, 0, 1, 0), (64, 0, 1, 0),
+                                         (4, 2, 0, 0), (8, 2, 0, 0), (16, 2, 0, 0),
+                                         (4, 3, 0, 2048), (8, 3, 0, 2048), (8, 3, 0, 4096), (16, 3, 0, 4096),          # the ring loop; (4, 3, 2048) is what a routed batch of 12288..40959 such blocks gets
+                                         (64, 4, 0, 0), (64, 4, 0, 8192), (64, 4, 0, 16384), (64, 4, 0, 32768)):     # the wave loop: a wavefront per block
+            amd.set_option("decode_lanes", lanes); amd.set_option("decode_pipe", pipe); amd.set_option("decode_stage", stage); amd.set_option("decode_ring", ring)
             back.zero_()
             amd.DeviceBatch.decompress_safe(dcomp, co, cl, back, B["so"], B["sl"], B["dlen"])
-            assert torch.equal(back, dsrc) and torch.equal(B["dlen"], B["sl"]), (lanes, pipe, stage)
+            assert torch.equal(back, dsrc) and torch.equal(B["dlen"], B["sl"]), (lanes, pipe, stage, ring)
             back.zero_()
             amd.DeviceBatch.decompress_fast(dcomp, co, cl + 3, back, B["so"], B["sl"], B["dlen"])
-            assert torch.equal(back, dsrc) and torch.equal(B["dlen"], cl), (lanes, pipe, stage)
+            assert torch.equal(back, dsrc) and torch.equal(B["dlen"], cl), (lanes, pipe, stage, ring)
     finally:
-        amd.set_option("decode_lanes", 0); amd.set_option("decode_pipe", -1); amd.set_option("decode_stage", -1)
+        amd.set_option("decode_lanes", 0); amd.set_option("decode_pipe", -1); amd.set_option("decode_stage", -1); amd.set_option("decode_ring", 0)
+
+
+def test_routed_batch_of_big_blocks_vs_reference(amd, ref):
+    """Every decode knob at its default and a batch of 12288..40959 blocks whose compressed size averages >= 512 KiB: the launch is
+    routed ON THE DEVICE (decode_route_kernel) to the ring loop with 4 lanes and a 2 KiB ring -- the instantiation behind the
+    configs[2] number of the bench line.  12288 blocks of 1.25 MiB; a sample of the streams is the reference library's own bytes
+    (asserted), a second sample is damaged (flipped bytes, truncated, capacity too small): sizes, bytes and error codes against
+    LZ4_decompress_safe (LZ4JNI.c:216), and the untouched blocks against their source."""
+    import numpy as np
+    import torch
+    dev = torch.device("cuda:0")
+    n, blk = 12288, 1310720
+    cap = amd.maxCompressedLength(blk)
+    src = torch.empty(n * blk, dtype=torch.uint8, device=dev)
+    amd.DeviceBatch.gen_blocks(src, blk, blk, n, first_idx=5 << 24, win=4096)
+    comp = torch.empty(n * cap, dtype=torch.uint8, device=dev)
+    B = _batch(torch, dev, n, blk, cap)
+    amd.DeviceBatch.compress_fast(src, B["so"], B["sl"], comp, B["co"], B["cc"], B["clen"])
+    torch.cuda.synchronize()
+    clen = B["clen"].cpu().numpy().copy()
+    assert clen.min() > 0 and clen.mean() >= (512 << 10), clen.mean()      # (the route's threshold)
+    rng = random.Random(12288)
+    sample = rng.sample(range(n), 40)
+    good, bad = sample[:20], sample[20:]
+    hsrc = {i: src[i * blk:(i + 1) * blk].cpu().numpy().tobytes() for i in sample}
+    streams = {i: comp[i * cap:i * cap + int(clen[i])].cpu().numpy().tobytes() for i in sample}
+    for i in good:
+        assert streams[i] == ref.compress_fast(hsrc[i]), i                 # these streams ARE the reference library's bytes
+    caps = np.full(n, blk, dtype=np.int32)
+    for k, i in enumerate(bad):
+        c = bytearray(streams[i])
+        if k % 3 == 0:
+            for _ in range(rng.randrange(1, 4)):
+                c[rng.randrange(len(c))] = rng.randrange(256)
+            comp[i * cap:i * cap + len(c)] = torch.from_numpy(np.frombuffer(bytes(c), dtype=np.uint8).copy()).to(dev)
+        elif k % 3 == 1:
+            clen[i] = rng.randrange(len(c) // 3, len(c)); c = c[:clen[i]]
+        else:
+            caps[i] = blk - rng.randrange(1, 5000)
+        streams[i] = bytes(c)
+    cl = torch.from_numpy(clen).to(dev)
+    dc = torch.from_numpy(caps).to(dev)
+    back = torch.zeros(n * blk, dtype=torch.uint8, device=dev)
+    amd.DeviceBatch.decompress_safe(comp, B["co"], cl, back, B["so"], dc, B["dlen"])
+    torch.cuda.synchronize()
+    dlen = B["dlen"].cpu().numpy()
+    for i in bad:
+        er, ed = ref.decompress_safe_raw(streams[i], int(caps[i]))
+        assert int(dlen[i]) == er, (i, int(dlen[i]), er)
+        if er >= 0:
+            assert back[i * blk:i * blk + er].cpu().numpy().tobytes() == ed[:er], i
+    ok = np.ones(n, dtype=bool); ok[bad] = False
+    assert (dlen[ok] == blk).all()
+    okt = torch.from_numpy(ok).to(dev)
+    assert torch.equal(back.view(n, blk)[okt], src.view(n, blk)[okt])
 
 
 def test_cfg4_256_blocks_hc9_every_block_vs_reference(amd, ref):

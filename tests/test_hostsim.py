@@ -18,7 +18,7 @@ def load_sim():
     d = os.path.join(ROOT, "tests", "hostsim")
     so = os.path.join(d, "libhostsim.so")
     srcs = [os.path.join(d, f) for f in ("hostsim.cpp", "wave_host.h", "group_host.h")] + \
-           [os.path.join(ROOT, "lz4-java_amd", "csrc", f) for f in ("lz4_fast_core.h", "lz4_fast_ms_core.h", "lz4_fast_v2_core.h", "lz4_decode_core.h", "lz4_decode_deep.h", "lz4_hc_core.h")]
+           [os.path.join(ROOT, "lz4-java_amd", "csrc", f) for f in ("lz4_fast_core.h", "lz4_fast_ms_core.h", "lz4_fast_v2_core.h", "lz4_decode_core.h", "lz4_decode_deep.h", "lz4_decode_ring.h", "lz4_decode_wave.h", "lz4_hc_core.h")]
     srcs.append(os.path.join(ROOT, "lz4-java_amd", "csrc", "mail_ring.h"))
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", so, os.path.join(d, "hostsim.cpp")])
@@ -392,6 +392,79 @@ def test_ring_decoder_loop(sim, ref, O, corpus):
             r4, d4 = sim_decode(sim, c + bytes(scap - len(c)), cap, 0, flag, src_size=scap, shift=shift)
             assert r3 == r4 and (r3 < 0 or d3[:cap] == d4[:cap]), ("fast", k, gl, rl, len(c), cap, scap, r3, r4)
     assert sim.sim_ring_trips() - trips0 > 500000   # (the loop under test did the work)
+
+
+def wave_flag(log, ks1k=False):
+    """sim_decompress flag of the wave loop: 64 lanes, bit 16, bits 17..21 = log2 of the output ring, bit 22 = 1 KB stream ring"""
+    return 64 | 0x10000 | (log << 17) | (0x400000 if ks1k else 0)
+
+
+def test_wave_decoder_loop(sim, ref, O, corpus):
+    """The wave loop (csrc/lz4_decode_wave.h: one wavefront per block, stream ring + an output ring of 4 .. 64 KB in LDS, wave-uniform
+    parse, pieces of up to 252 bytes stored as aligned dwords, far sources from flushed memory, byte-exact entry / exit flushes) in
+    the lock-step simulator: the long-stream cases of the deep and ring loops' tests (real and synthetic blocks, hand-assembled
+    mixes of every kind of sequence -- literal runs over 252 bytes, matches that overlap their own output, long matches, offsets
+    beyond every ring size --, the same streams corrupted / truncated / with wrong capacities) plus text-like and run-heavy data,
+    at every kind of address alignment of the destination slot: return codes and bytes against the reference library (safe) and
+    the C restatement's bounded fast decoder.  Every access outside the block's slots or the wavefront's LDS bytes, every
+    unaligned store by lanes 1.., every mirror store the device's wave-uniform pre-test would have skipped counts as a failure."""
+    rng = random.Random(20250924)
+    from conftest import deep_decoder_cases
+    valid, cases = deep_decoder_cases(ref, O, corpus, rng, _lz4_seq)
+    extra = [corpus["book1[:200000]"][1000:40000], O.gen_block(50000, 7, litmax=3, win=40), O.gen_block(50000, 8, litmax=20, win=500),
+             O.gen_block(150000, 9, win=4096), O.gen_block(65536, 10), O.gen_block(200000, 11, litmax=300, win=65535),
+             bytes(rng.randrange(4) for _ in range(30000)), (rng.randbytes(37) * 3000)[:70000],
+             (rng.randbytes(255) * 400)[:90000], (rng.randbytes(3) * 40000)[:100000]]
+    for v in extra:
+        c = ref.compress_fast(v)
+        valid.append((c, len(v))); cases.insert(len(valid) - 1, (c, len(v)))
+    st = (C.c_ulonglong * 4)()
+    sim.sim_wave_stats(st)
+    trips0, far0, mir0 = st[0], st[2], st[3]
+    for k, (c, cap) in enumerate(cases):
+        want_r, want = ref.decompress_safe_raw(c, cap)
+        full = k < len(valid)
+        for log, ks1k in (((12, False), (13, True), (14, False), (16, False)) if full else ((rng.choice([12, 13, 14, 15, 16]), rng.random() < 0.3),)):
+            flag = wave_flag(log, ks1k)
+            shift = rng.choice([0, 0, 1, 2, 3, 7, 16, 33, 63, 64, 100, 255, 256, 257])
+            r, d = sim_decode(sim, c, cap, 1, flag, shift=shift)
+            assert r == want_r and (want_r < 0 or d[:want_r] == want[:want_r]), ("safe", k, log, ks1k, shift, len(c), cap, r, want_r)
+            scap = len(c) + rng.choice([0, 0, 5, 64])
+            r3, d3 = O.decompress_fast_bounded(c, scap, cap)
+            r4, d4 = sim_decode(sim, c + bytes(scap - len(c)), cap, 0, flag, src_size=scap, shift=shift)
+            assert r3 == r4 and (r3 < 0 or d3[:cap] == d4[:cap]), ("fast", k, log, ks1k, len(c), cap, scap, r3, r4)
+    sim.sim_wave_stats(st)
+    assert st[0] - trips0 > 500000 and st[2] - far0 > 1000 and st[3] - mir0 > 1000   # the loop did the work: pieces, far sources, ring wraps
+
+
+def test_wave_decoder_small_and_fuzz(sim, ref, O, corpus):
+    """the wave loop's instantiation of decode_block on everything the other decoders' fuzz test sees (short, empty, damaged and
+    random streams: mostly the exact tiers with 64 lanes, the wave loop where a stream is long enough)"""
+    rng = random.Random(99)
+    for v in rnd_inputs(O, corpus, 57, 1200, max_n=40000):
+        c = bytearray(ref.compress_fast(v))
+        mode, cap = rng.randrange(6), len(v)
+        if mode == 1:
+            cap = max(0, len(v) + rng.choice([-1, 1, -5, 5, -12, 12, -33, 33, 64, 100]))
+        elif mode == 2 and c:
+            for _ in range(rng.randrange(1, 4)):
+                c[rng.randrange(len(c))] = rng.randrange(256)
+        elif mode == 3 and len(c) > 1:
+            c = c[:rng.randrange(1, len(c))]
+        elif mode == 4:
+            c = c + rng.randbytes(rng.randrange(1, 20))
+        elif mode == 5:
+            c, cap = bytearray(rng.randbytes(rng.randrange(1, 40))), rng.randrange(0, 200)
+        c = bytes(c)
+        flag = wave_flag(rng.choice([12, 13, 16]), rng.random() < 0.5)
+        shift = rng.choice([0, 1, 5, 64, 131])
+        r2, d2 = ref.decompress_safe_raw(c, cap)
+        r1, d1 = sim_decode(sim, c, cap, 1, flag, shift=shift)
+        assert r1 == r2 and (r2 < 0 or d1[:r2] == d2[:r2]), ("safe", mode, len(v), cap, r1, r2)
+        scap = max(len(c) + rng.choice([0, 0, 0, 3, 16, -1]), 0)
+        r3, d3 = O.decompress_fast_bounded(c, scap, cap)
+        r4, d4 = sim_decode(sim, c + bytes(max(0, scap - len(c))), cap, 0, flag, src_size=scap, shift=shift)
+        assert r3 == r4 and (r3 < 0 or d3[:cap] == d4[:cap]), ("fast", mode, len(v), cap, scap, r3, r4)
 
 
 def test_decode_core_malformed_vectors(sim, golden):
