@@ -416,12 +416,12 @@ struct GroupDev {
 
 // ---- backend of the wave loop (lz4_decode_wave.h): ONE WAVEFRONT PER BLOCK.  All 64 lanes move 4 bytes each (a step is 256 bytes, a
 // piece up to 252); the block's window of the compressed stream (KS bytes) and its recent output (KW bytes) live in LDS.
-// Layout of a wavefront's kWaveLds bytes: [stream ring KS | 16 tail][16 pad | output ring KW | 16 tail].
+// Layout of a wavefront's kWaveLds bytes: [stream ring KS | 16 tail][16 pad | output ring KW | 32 tail].
 //  * stream ring: indexed by stream position, refilled in 256-byte steps (a dword per lane), first 16 bytes mirrored behind the end so
 //    that the two aligned dwords around any index are contiguous;
 //  * output ring: index of output position p = (p + dbase) & (KW - 1), dbase = dst address & 255 -- 256-byte aligned steps of memory
 //    are aligned steps of the ring.  A dword written at ring index x is stored at t - 4 with t = (x + 4) & (KW - 1), and once more KW
-//    bytes further on when t < 8 (the mirror rule of the ring loop's backend above): reads never wrap.
+//    bytes further on when t < 20 (the mirror rule of the ring loop's backend above, for the ring's first 16 bytes): reads of up to 16 bytes never wrap.
 // A piece written at ring index w: lane 0 holds its bytes [0, 4) and stores them at w (the only unaligned lane), lane l >= 1 holds the
 // bytes [4 l - s, 4 l - s + 4), s = w & 3, and stores them at the aligned index (w & ~3) + 4 l.  The getters deliver a piece in that
 // shape for a given s: two aligned dwords around each lane's source index, funnelled (v_alignbyte).
@@ -430,7 +430,7 @@ struct BlockWaveDev : GroupDev<64, 0> {
   typedef GroupDev<64, 0> Base;
   typedef typename Base::LChunk LChunk;   // one dword
   static_assert(Base::LB == 4u, "a lane of the wave loop moves one dword");
-  static constexpr uint32_t kWaveLds = (uint32_t)KS + 16u + 16u + (uint32_t)KW + 16u;
+  static constexpr uint32_t kWaveLds = (uint32_t)KS + 16u + 16u + (uint32_t)KW + 32u;   // (32 tail: the first 16 ring bytes mirrored, plus a dword's reach)
   uint8_t* wsb = nullptr;   // stream ring
   uint8_t* wrb = nullptr;   // output ring, index 0
   uint32_t wdb = 0;
@@ -486,21 +486,162 @@ struct BlockWaveDev : GroupDev<64, 0> {
     return r;
   }
   // (lane 0's ring index is w, lane l's (w & ~3) + 4 l: both are w + dl.  One store instruction serves the aligned lanes and the one
-  // that is not -- the compiler emits ds_write_b32 for either)
+  // that is not -- the compiler emits ds_write_b32 for either.  Measured, gpurun_out/r05b: lane 0 in a store instruction of its own
+  // -- the ring loop's rule for its 4..16 group leaders -- is 14 % SLOWER here (2048 x 4 MiB 52.4 -> 61.6 ms): one misaligned lane
+  // costs the LDS a cycle, the exec juggling around a second store costs the wavefront a dozen instructions)
   __device__ __forceinline__ void wv_put(uint32_t w, const WPiece& c) {
     const uint32_t t = (w + 4u + c.dl) & ((uint32_t)KW - 1u);
     uint8_t* a = (wrb - 4) + t;
     __builtin_memcpy(a, &c.v, 4);
     const uint32_t u = (w + 4u) & ((uint32_t)KW - 1u);               // wave-uniform: does any lane of this piece lie at the ring's ends?
-    if (__builtin_expect((u < 8u) | (u > (uint32_t)KW - 264u), 0)) {
+    if (__builtin_expect((u < 20u) | (u > (uint32_t)KW - 264u), 0)) {
       asm volatile("; a piece at the ring's ends" ::: "memory");       // (keeps this a scalar branch: flattened into a predicate it cost five instructions per piece)
-      if (t < 8u) __builtin_memcpy(a + KW, &c.v, 4);
+      if (t < 20u) __builtin_memcpy(a + KW, &c.v, 4);                  // (the ring's first 16 bytes are kept behind its end as well: the parallel trips read 16 bytes at any index)
     }
   }
   __device__ __forceinline__ LChunk wv_read_al(uint32_t fw) const {   // fw: a multiple of 256 in ring coordinates
     LChunk v;
     v.w[0] = *Base::dwp(wrb + ((fw + l4) & ((uint32_t)KW - 1u)));
     return v;
+  }
+  // ---- lane-parallel side (the parallel trips of lz4_decode_wave.h): per-lane values are plain scalars (SIMT) ----
+  typedef uint32_t VU;
+  typedef bool VB;
+  __device__ __forceinline__ VU vlane() const { return this->l; }
+  __device__ __forceinline__ static VU vsel(bool c, VU a, VU b) { return c ? a : b; }
+  __device__ __forceinline__ static uint64_t vballot(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+  __device__ __forceinline__ static uint32_t vreadlane(VU v, uint32_t i) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)i); }
+  __device__ __forceinline__ static VU vwritelane(VU v, uint32_t s, uint32_t i) {
+    asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(s), "s"(i) : "m0");
+    return v;
+  }
+  __device__ __forceinline__ static VU vshfl(VU v, VU srcl) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(srcl << 2), (int)v); }
+  __device__ __forceinline__ static VU vexcl_scan(VU a) {   // exclusive prefix sum across the wavefront: row_shr DPP adds + row_bcast15/31
+    int x = (int)a;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+    return (uint32_t)x - a;
+  }
+  __device__ __forceinline__ static VU vmin(VU a, VU b) { return a < b ? a : b; }
+  // the trip's window: stream bytes [ip + 4 l, ip + 4 l + 8) of lane l, from three ALIGNED dwords (ip is wave-uniform)
+  __device__ __forceinline__ void vs_win(uint32_t ip, VU& lo, VU& hi) const {
+    const uint32_t* q = Base::dwp(wsb + (((ip & ~3u) + l4) & ((uint32_t)KS - 1u)));
+    const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], s = ip & 3u;
+    lo = __builtin_amdgcn_alignbyte(d1, d0, s);
+    hi = __builtin_amdgcn_alignbyte(d2, d1, s);
+  }
+  // the 4 stream bytes at a per-lane position: the two aligned dwords around it, funnelled
+  __device__ __forceinline__ VU vs_ld32(VU p) const {
+    const uint32_t* q = Base::dwp(wsb + (p & ((uint32_t)KS - 1u) & ~3u));
+    return __builtin_amdgcn_alignbyte(q[1], q[0], p & 3u);
+  }
+  // n bytes (1 .. 16) to ring coordinates w: where they belong, and once more KW bytes on when they touch the ring's first 16 bytes
+  // or reach past its end (stored at t - 16, t = (index + 16) & (KW - 1): a store that straddles the end lands in the pad + the
+  // ring's first bytes AND in its last bytes + the tail).  T: an unaligned 16 / 8 / 4 / 2 / 1-byte type
+  typedef uint32_t u4a __attribute__((ext_vector_type(4), aligned(1)));
+  typedef uint32_t u2a __attribute__((ext_vector_type(2), aligned(1)));
+  typedef uint32_t u1a __attribute__((aligned(1)));
+  typedef uint16_t h1a __attribute__((aligned(1)));
+  template <class T> __device__ __forceinline__ void vput(VU w, const T& v, bool m) {
+    const uint32_t t = (w + 16u) & ((uint32_t)KW - 1u);
+    uint8_t* a = (wrb - 16) + t;
+    if (m) *(T*)a = v;
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(m & (t < 32u)) != 0ull, 0)) {
+      if (m & (t < 32u)) *(T*)(a + KW) = v;
+    }
+  }
+  // EXACT lane-per-sequence copy of len bytes (lanes with go) from the stream ring (FROM_STREAM) or the output ring (source in ring
+  // coordinates) to ring coordinates dw: 16 bytes at a time while 16 are left, then 8 / 4 / 2 / 1.  Nothing outside [dw, dw + len)
+  // is written; sources and destinations of different lanes do not overlap (the caller's dependency rule)
+  template <class T> __device__ __forceinline__ void vstep(const uint8_t* sb, uint32_t sm, VU dw, VU sp, VU c, bool m) {
+    T v = T();
+    if (m) v = *(const T*)(sb + ((sp + c) & sm));
+    vput<T>(dw + c, v, m);
+  }
+  // SRC 0: the stream ring, 1: the output ring (sp in ring coordinates), 2: memory (sb + sp is the source; [sb + sp, + len) is readable)
+  template <int SRC> __device__ __forceinline__ void vcopy(VU dw, const uint8_t* sb0, VU sp, VU len, bool go) {
+    const uint8_t* sb = SRC == 0 ? wsb : SRC == 1 ? wrb : sb0;
+    const uint32_t sm = SRC == 0 ? (uint32_t)KS - 1u : SRC == 1 ? (uint32_t)KW - 1u : 0xFFFFFFFFu;
+    for (uint32_t c = 0u;; c += 16u) {
+      const bool m = go && (c + 16u <= len);
+      if (__builtin_amdgcn_ballot_w64(m) == 0ull) break;
+      vstep<u4a>(sb, sm, dw, sp, c, m);
+    }
+    uint32_t c = len & ~15u;
+    bool m = go && ((len & 8u) != 0u);
+    vstep<u2a>(sb, sm, dw, sp, c, m);
+    c += m ? 8u : 0u;
+    m = go && ((len & 4u) != 0u);
+    vstep<u1a>(sb, sm, dw, sp, c, m);
+    c += m ? 4u : 0u;
+    m = go && ((len & 2u) != 0u);
+    vstep<h1a>(sb, sm, dw, sp, c, m);
+    c += m ? 2u : 0u;
+    m = go && ((len & 1u) != 0u);
+    vstep<uint8_t>(sb, sm, dw, sp, c, m);
+  }
+  // Both copies of a trip: literals (stream position sp, lenl bytes) to ring coordinates dw, the match (source sw, lenm bytes) behind
+  // them.  The usual trip -- every active length <= 64, no destination at the ring's ends -- issues ALL its reads (4 x 16 bytes and
+  // an 8 / 4 / 2 / 1 cascade per copy, only the active lanes: an unaligned LDS access costs a cycle per lane) in front of ONE wait
+  // and then the predicated stores; the step-by-step form above waited for the LDS once per step (14 round trips per trip, 43 % of
+  // the wavefront's cycles: profiles/r05_wave_notes.txt)
+  struct Run16 { u4a a0, a1, a2, a3; u2a b; uint32_t c; uint32_t d; uint32_t e; };
+  __device__ __forceinline__ static Run16 vrun_load(const uint8_t* sb, uint32_t sm, VU sp, VU len) {
+    Run16 r;
+    r.a0 = *(const u4a*)(sb + (sp & sm));
+    r.a1 = *(const u4a*)(sb + ((sp + 16u) & sm));
+    r.a2 = *(const u4a*)(sb + ((sp + 32u) & sm));
+    r.a3 = *(const u4a*)(sb + ((sp + 48u) & sm));
+    uint32_t c = len & ~15u;
+    r.b = *(const u2a*)(sb + ((sp + c) & sm));
+    c += len & 8u;
+    r.c = *(const u1a*)(sb + ((sp + c) & sm));
+    c += len & 4u;
+    r.d = *(const h1a*)(sb + ((sp + c) & sm));
+    c += len & 2u;
+    r.e = *(sb + ((sp + c) & sm));
+    return r;
+  }
+  __device__ __forceinline__ void vrun_store(VU dw, VU len, const Run16& r) {   // (no destination at the ring's ends: no mirror stores)
+    uint8_t* a = wrb + (dw & ((uint32_t)KW - 1u));   // (contiguous: the caller checked that [dw, dw + len) does not reach the end)
+    if (len >= 16u) *(u4a*)a = r.a0;
+    if (len >= 32u) *(u4a*)(a + 16) = r.a1;
+    if (len >= 48u) *(u4a*)(a + 32) = r.a2;
+    if (len >= 64u) *(u4a*)(a + 48) = r.a3;
+    uint32_t c = len & ~15u;
+    if (len & 8u) *(u2a*)(a + c) = r.b;
+    c += len & 8u;
+    if (len & 4u) *(u1a*)(a + c) = r.c;
+    c += len & 4u;
+    if (len & 2u) *(h1a*)(a + c) = (uint16_t)r.d;
+    c += len & 2u;
+    if (len & 1u) a[c] = (uint8_t)r.e;
+  }
+  // far: the match source of this lane is not in the ring: it is mem[mpos, mpos + lenm) (the block's flushed output; 80 bytes from
+  // mpos on are readable).  The far lanes of a trip have their loads in flight together, behind the ring reads of the others
+  __device__ __forceinline__ void vcopy_seq(VU dw, VU sp, VU lenl, VU sw, VU lenm, bool go, const uint8_t* mem, VU mpos, bool far) {
+    const uint32_t x = dw & ((uint32_t)KW - 1u);
+    const bool odd = go && ((lenl > 64u) || (lenm > 64u) || (x < 16u) || (x + lenl + lenm + 16u > (uint32_t)KW));
+    const bool gf = go && far;
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(odd) == 0ull, 1)) {
+      if (go) {
+        const Run16 rl = vrun_load(wsb, (uint32_t)KS - 1u, sp, lenl);
+        Run16 rm = vrun_load(wrb, (uint32_t)KW - 1u, sw, lenm);
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(gf) != 0ull, 0)) {
+          if (gf) rm = vrun_load(mem, 0xFFFFFFFFu, mpos, lenm);
+        }
+        vrun_store(dw, lenl, rl);
+        vrun_store(dw + lenl, lenm, rm);
+      }
+    } else {
+      vcopy<0>(dw, nullptr, sp, lenl, go);
+      vcopy<1>(dw + lenl, nullptr, sw, lenm, go && !far);
+      if (__builtin_amdgcn_ballot_w64(gf) != 0ull) vcopy<2>(dw + lenl, mem, mpos, lenm, gf);
+    }
   }
   // the step at ring coordinates fw (a multiple of 256) to memory: its bytes inside [lo, hi) (ring coordinates), nothing else
   __device__ __forceinline__ void wv_store(uint8_t* dst, uint32_t fw, const LChunk& c, uint32_t lo, uint32_t hi) const {

@@ -803,7 +803,7 @@ int launch_container_read(int kind, int block_checksum, const uint8_t* body, uin
   int e;
   if (kind == 0 && block_checksum && (e = launch_xxh32(body, c.pay_off, c.pay_len, 0u, c.hashes, n_max, stream)) != 0) return e;
   BatchArgs a{body, c.src_off, c.src_len, dst, c.dst_off, c.dst_cap, c.out, n_max};
-  if ((e = launch_decompress(a, kind == 0, 0, -1, -1, 0, stream, nullptr)) != 0) return e;
+  if ((e = launch_decompress(a, kind == 0, 0, -1, -1, 0, stream, c.walk + 8)) != 0) return e;   // (c.walk + 8: a scratch word for the device-side route, so that a frame of 12288+ big blocks gets the ring loop like a plain batch)
   hipLaunchKernelGGL(container_raw_kernel, dim3(n_max), dim3(256), 0, st, kind, body, dst, c, hash_len);
   if (kind == 1 && (e = launch_xxh32(dst, c.dst_off, hash_len, 0x9747b28cu, c.hashes, n_max, stream)) != 0) return e;
   hipLaunchKernelGGL(container_verdict_kernel, dim3(1), dim3(1024), 0, st, kind, block_checksum, c, sizes, info);
@@ -871,7 +871,7 @@ static int launch_decode_ring(const BatchArgs& a, bool safe, hipStream_t st, con
 // its LDS between them, a single one all 160 KB -- DESIGN.md 2.1).  No barrier: the wavefronts are independent, each takes the blocks
 // blockIdx.x * W + wave, + gridDim.x * W, ...  The launch picks W so that the blocks of the batch spread over all CUs with the largest
 // ring that fits: up to one block per CU a 64 KB ring (a 64 KiB block never leaves the chip), ... sixteen per CU an 8 KB ring.
-template <int W, int KW, int KS, bool SAFE>
+template <int W, int KW, int KS, bool SAFE, int PIPE>
 __global__ __launch_bounds__(64 * W) void decode_wave_kernel(BatchArgs a, const uint32_t* route, uint32_t want) {
   if (route && *route != want) return;   // (the launch was routed to another decoder: launch_decompress)
   typedef BlockWaveDev<KW, KS> G;
@@ -880,7 +880,7 @@ __global__ __launch_bounds__(64 * W) void decode_wave_kernel(BatchArgs a, const 
   uint8_t* lds = wave_mem + wave * G::kWaveLds;
   for (uint32_t b = blockIdx.x * W + wave; b < a.n; b += gridDim.x * W) {
     G g;
-    const int r = decode_block<G, SAFE, 4, false>(g, a.src + a.src_off[b], a.src_len[b], a.dst + a.dst_off[b], a.dst_cap[b], lds);
+    const int r = decode_block<G, SAFE, PIPE, false>(g, a.src + a.src_off[b], a.src_len[b], a.dst + a.dst_off[b], a.dst_cap[b], lds);
     if (g.l == 0) a.out[b] = r;
   }
 }
@@ -898,24 +898,29 @@ static uint32_t device_cus() {   // compute units of the current device (cached 
   return c;
 }
 template <int W, int KW, int KS>
-static int launch_decode_wave_w(const BatchArgs& a, bool safe, hipStream_t st, const uint32_t* route, uint32_t want) {
+static int launch_decode_wave_w(const BatchArgs& a, bool safe, bool par, hipStream_t st, const uint32_t* route, uint32_t want) {
   const uint32_t wgs = (a.n + W - 1u) / W, cus = device_cus();
   const uint32_t grid = wgs < cus ? wgs : cus;
-  if (safe) hipLaunchKernelGGL((decode_wave_kernel<W, KW, KS, true>), dim3(grid), dim3(64 * W), 0, st, a, route, want);
-  else hipLaunchKernelGGL((decode_wave_kernel<W, KW, KS, false>), dim3(grid), dim3(64 * W), 0, st, a, route, want);
+  if (par) {   // (PIPE 5: several sequences of the block per trip)
+    if (safe) hipLaunchKernelGGL((decode_wave_kernel<W, KW, KS, true, 5>), dim3(grid), dim3(64 * W), 0, st, a, route, want);
+    else hipLaunchKernelGGL((decode_wave_kernel<W, KW, KS, false, 5>), dim3(grid), dim3(64 * W), 0, st, a, route, want);
+  } else {
+    if (safe) hipLaunchKernelGGL((decode_wave_kernel<W, KW, KS, true, 4>), dim3(grid), dim3(64 * W), 0, st, a, route, want);
+    else hipLaunchKernelGGL((decode_wave_kernel<W, KW, KS, false, 4>), dim3(grid), dim3(64 * W), 0, st, a, route, want);
+  }
   return (int)hipGetLastError();
 }
 // ring: bytes of the output ring (8192 / 16384 / 32768 / 65536; 0 = the largest that lets the batch spread over all CUs)
-static int launch_decode_wave(const BatchArgs& a, bool safe, int ring, hipStream_t st, const uint32_t* route = nullptr, uint32_t want = 0) {
+static int launch_decode_wave(const BatchArgs& a, bool safe, bool par, int ring, hipStream_t st, const uint32_t* route = nullptr, uint32_t want = 0) {
   if (ring == 0) {
     const uint32_t cus = device_cus();
     ring = a.n <= 2u * cus ? 65536 : a.n <= 4u * cus ? 32768 : a.n <= 8u * cus ? 16384 : 8192;
   }
   switch (ring) {
-    case 65536: return a.n <= device_cus() ? launch_decode_wave_w<1, 65536, 2048>(a, safe, st, route, want) : launch_decode_wave_w<2, 65536, 2048>(a, safe, st, route, want);
-    case 32768: return launch_decode_wave_w<4, 32768, 2048>(a, safe, st, route, want);
-    case 16384: return launch_decode_wave_w<8, 16384, 2048>(a, safe, st, route, want);
-    case 8192: return launch_decode_wave_w<16, 8192, 1024>(a, safe, st, route, want);
+    case 65536: return a.n <= device_cus() ? launch_decode_wave_w<1, 65536, 2048>(a, safe, par, st, route, want) : launch_decode_wave_w<2, 65536, 2048>(a, safe, par, st, route, want);
+    case 32768: return launch_decode_wave_w<4, 32768, 2048>(a, safe, par, st, route, want);
+    case 16384: return launch_decode_wave_w<8, 16384, 2048>(a, safe, par, st, route, want);
+    case 8192: return launch_decode_wave_w<16, 8192, 1024>(a, safe, par, st, route, want);
     default: return (int)hipErrorInvalidValue;
   }
 }
@@ -965,7 +970,7 @@ int ring_stats_fetch(unsigned long long* out8) {   // developer build: reads and
 int launch_decompress(const BatchArgs& a, bool safe, int lanes_per_block, int pipe, int stage, int ring, void* stream, uint32_t* route_word) {
   if (a.n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  if (pipe == 4) return launch_decode_wave(a, safe, ring, st);   // the wave loop: a wavefront per block (lanes_per_block is 64 by construction)
+  if (pipe == 4 || pipe == 5) return launch_decode_wave(a, safe, pipe == 5, ring, st);   // the wave loops: a wavefront per block (lanes_per_block is 64 by construction); 5: several sequences per trip
   if (pipe == 3) {   // the ring loop: lanes 4 / 8 / 16, output ring 512 .. 4096 bytes (0 = 512 with 4 lanes, 4096 otherwise)
     const int gl = lanes_per_block == 0 ? 4 : lanes_per_block;
     const int kw = ring ? ring : (gl == 1 ? 256 : gl == 4 ? 512 : 4096);
@@ -993,6 +998,12 @@ int launch_decompress(const BatchArgs& a, bool safe, int lanes_per_block, int pi
   //                    616; text 2048: 17 -> 34, 8192: 65 -> 125, 16384: 105 -> 153, 32768: 127 -> 133.  (16 lanes, the old choice
   //                    below 8192 blocks, are slower than 8 with this loop: 4096 blocks 182 vs 215.)
   const bool auto_lanes = lanes_per_block == 0;
+  // Round 5: launches that cannot fill the GPU with blocks -- up to 16 per CU: the 8-GPU shard of BASELINE configs[2] (2048 x 4 MiB per
+  // GPU), the readers' batches, the Java single-call path -- give every block a WAVEFRONT and decode several sequences of it per
+  // trip (lz4_decode_wave.h, decode_pipe 5).  Against the lane-group loops below (GB/s of output, gpurun_out/r05j): 4 MiB blocks 256:
+  // 17 -> 45, 2048: 135 -> 285, 4096: 272 -> 403 (8192: 519 -> 404, so not beyond 16 per CU); 64 KiB App. F 512: 31 -> 50, 2048: 120 -> 146,
+  // 4096: 213 -> 232; 64 KiB text 512: 4.2 -> 16.1, 2048: 16.4 -> 49.6, 4096: 30.7 -> 66.4; one 64 KiB block 0.71 -> 0.43 ms.
+  if (auto_lanes && pipe < 0 && stage < 0 && a.n <= 16u * device_cus()) return launch_decode_wave(a, safe, true, 0, st);
   if (auto_lanes) lanes_per_block = a.n >= 40960u ? 4 : 8;
   const int p = pipe < 0 ? ((a.n < 40960u && lanes_per_block >= 8) ? (lanes_per_block <= 16 ? 2 : 1) : 0) : pipe;
   // staging (whole-line output through LDS) pays where the batch is bandwidth-bound: App. F 65536 blocks 487 -> 680 GB/s

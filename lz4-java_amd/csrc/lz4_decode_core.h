@@ -53,6 +53,7 @@ namespace lz4hip {
 //       never leave the chip, far ones are pipelined through slots, output leaves as whole aligned 64-byte steps).
 //       4 = the wave loop of lz4_decode_wave.h (ONE WAVEFRONT PER BLOCK, Grp = BlockWaveDev: stream ring and an output ring of 8 .. 64 KB
 //       in LDS at `stage`, wave-uniform parse, one LDS round trip per sequence): launches of few blocks.
+//       5 = the parallel wave loop (same file, same rings): every sequence that starts in a 256-byte window of the stream per trip.
 // STAGE: the interior loop writes through an LDS staging buffer (`stage`, Grp::kStage bytes for this block) and output leaves
 //        it as whole 128-byte lines (group_dev.h st_*).
 template <class Grp, bool SAFE, int PIPE = 0, bool STAGE = false>
@@ -126,7 +127,10 @@ LZ4HIP_DEV int decode_block(Grp& g, const uint8_t* src, int src_size, uint8_t* d
     if constexpr (PIPE == 4) {   // the wave loop (lz4_decode_wave.h); what it leaves at ip is done by the exact code below, which comes back
       if (ip + 1024 <= iend && ip <= iend - 306 && op <= oend - 606) decode_wave_loop(g, src, iend, dst, oend, ip, op, stage);
     }
-    if ((PIPE == 1 || (PIPE == 2 && ip + 2048 > iend) || (PIPE == 3 && ip + 320 > iend) || (PIPE == 4 && ip + 1024 > iend)) && ip <= iend - 306 && op <= oend - 606) {   // (2, 3, 4: only the tail of the stream)
+    if constexpr (PIPE == 5) {   // the parallel wave loop: several sequences of the block per trip
+      if (ip + 1536 <= iend && ip <= iend - 306 && op <= oend - 606) decode_wave_par_loop(g, src, iend, dst, oend, ip, op, stage);
+    }
+    if ((PIPE == 1 || (PIPE == 2 && ip + 2048 > iend) || (PIPE == 3 && ip + 320 > iend) || (PIPE == 4 && ip + 1024 > iend) || (PIPE == 5 && ip + 1536 > iend)) && ip <= iend - 306 && op <= oend - 606) {   // (2 .. 5: only the tail of the stream)
       // ---- the same loop, software-pipelined.  A wavefront's memory operations retire in order, so a wait for a load also
       // waits for every OLDER store.  Here (a) the next sequence's offset word is requested as soon as this sequence's header
       // is parsed, (b) a "simple" sequence (literals and match take one step each, match source entirely before the

@@ -167,4 +167,208 @@ LZ4HIP_DEV void decode_wave_loop(Grp& g, const uint8_t* src, const int iend, uin
   ip_io = (int)ip; op_io = (int)op;
 }
 
+
+// ================================================================================================================================
+// The PARALLEL wave loop (decode_block PIPE == 5): SEVERAL SEQUENCES OF THE BLOCK PER TRIP.
+//
+// Measured on the loop above (gpurun_out/r05a-c; PMC: profiles/r05_wave_notes.txt): a wavefront issues one instruction per 4 cycles
+// whatever its kind, a trip of the one-sequence loop is ~198 instructions (131 of them scalar), i.e. ~1100 cycles per sequence and
+// ~38 ms per 4 MiB block when a wavefront has a SIMD to itself -- 1.7x the lane-group loops on a nearly empty GPU and no more: with
+// one sequence per trip the trip IS the floor.  Here a trip decodes every sequence that starts in a 256-byte window of the stream:
+//  1. DISCOVERY, lane-parallel and speculative: lane l assumes a token at each of the window's bytes 4 l .. 4 l + 3 and decodes it
+//     (token, literal-length byte, the offset word and match-length byte behind the literals: aligned dword reads, funnelled)
+//     into a record {offset, literal length, match length} and the window position of the NEXT token (255: none / not simple);
+//  2. WALK: the four next-positions of a lane are one dword, so the chain 0 -> next(0) -> ... is a scalar walk of v_readlane's
+//     (~7 instructions per sequence, no memory); the k-th start goes to lane k (v_writelane);
+//  3. RECORDS: lane k fetches the record of its start from the lane that decoded it (ds_bpermute), an exclusive prefix sum (DPP)
+//     of literal + match lengths gives every sequence its output position, and one ballot finds the first sequence that is not for
+//     this trip: invalid offset, not simple, or -- the dependency rule -- a match source that reaches into THIS TRIP'S OWN OUTPUT
+//     (a source the ring no longer holds is read from the block's flushed output in memory, all such lanes of a trip together).  The trip ends in front of it; as the first sequence of the next trip its source lies
+//     below that trip's output (or it is handed to the one-sequence step below);
+//  4. COPIES, a lane per sequence, exact: literals stream ring -> output ring, matches output ring -> output ring, 16 bytes at a
+//     time and an 8 / 4 / 2 / 1 cascade for the rest -- no byte outside a sequence's own output is written, so the lanes need no
+//     order between them.
+// What a trip cannot take as its FIRST sequence (a match that overlaps its own output or reaches into its own literals, a far
+// source, literal runs over 255 / matches over 259 bytes) is decoded by `wave_single_step` -- the one-sequence trip above without
+// its pipelining; what that cannot take either leaves the loop for the exact code of decode_block.
+// ================================================================================================================================
+
+// one sequence at ip through the rings, wave-wide pieces (the body of decode_wave_loop, not pipelined).  false: not for this loop.
+template <class Grp>
+LZ4HIP_DEV bool wave_single_step(Grp& g, const uint8_t* dst, uint32_t& ip, uint32_t& op, const uint32_t op0, const uint32_t fl, const uint32_t db,
+                                 const uint32_t ilim, const uint32_t olim) {
+  constexpr uint32_t STEP = 256u, PIECE = 252u;
+  const uint32_t KW = g.wv_ring();
+  const uint64_t t8 = g.rs_ld64(ip);
+  const uint32_t t4 = g.uni((uint32_t)t8);
+  const uint32_t tl = (t4 >> 4) & 15u, e1 = (t4 >> 8) & 255u;
+  const bool l15 = tl == 15u;
+  const uint32_t lit = tl + (l15 ? e1 : 0u), hdr = l15 ? 2u : 1u;
+  const uint64_t h8 = g.rs_ld64(ip + hdr + lit);
+  const uint64_t o8 = (uint64_t)g.uni((uint32_t)h8) | ((uint64_t)g.uni((uint32_t)(h8 >> 32)) << 32);
+  const uint32_t off = (uint32_t)o8 & 0xFFFFu, tm = t4 & 15u, e2 = (uint32_t)(o8 >> 16) & 255u;
+  const bool m15 = tm == 15u;
+  const uint32_t ml = tm + 4u + (m15 ? e2 : 0u);
+  const uint32_t mpos = op + lit - off, send = mpos + ml, op2 = op + lit + ml;
+  const uint32_t farw = (mpos - op0) | (mpos + KW - (op2 + STEP));
+  const uint32_t oddw = (269u - tl - e1) | (ilim - ip) | (olim - op) | (off - 1u) | mpos | (269u - tm - e2);
+  if ((int32_t)oddw < 0) return false;
+  if ((int32_t)farw < 0) { if ((int32_t)((fl - (send + db)) & (op0 - send)) < 0) return false; }
+  g.wv_put(op + db, g.wv_get_stream(ip + hdr, op + db));
+  if (lit > PIECE) g.wv_put(op + db + PIECE, g.wv_get_stream(ip + hdr + PIECE, op + db + PIECE));
+  const uint32_t pos = op + lit + db;
+  if ((int32_t)farw >= 0) {
+    g.wv_put(pos, g.wv_get_ring(pos - off, pos));
+    if ((int32_t)((off - ml) | (PIECE - ml)) < 0) {
+      uint32_t o = off, n = o < PIECE ? o : PIECE, p = pos, rem = ml;
+      do {
+        rem -= n; p += n;
+        o = n == o ? 2u * o : o;
+        n = rem < o ? rem : o;
+        n = n < PIECE ? n : PIECE;
+        g.wv_put(p, g.wv_get_ring(p - o, p));
+      } while (rem > n);
+    }
+  } else {
+    g.wv_put(pos, g.wv_get_mem(dst + mpos, pos));
+    if (ml > PIECE) g.wv_put(pos + PIECE, g.wv_get_mem(dst + mpos + PIECE, pos + PIECE));
+  }
+  ip += hdr + lit + (m15 ? 3u : 2u);
+  op = op2;
+  return true;
+}
+
+// entry: ip + 1536 <= iend, ip <= iend - 306, op <= oend - 606.  Leaves with ip / op at the first sequence it did not decode;
+// everything below op is in memory then.
+template <class Grp>
+LZ4HIP_DEV void decode_wave_par_loop(Grp& g, const uint8_t* src, const int iend, uint8_t* dst, const int oend, int& ip_io, int& op_io, uint8_t* lds) {
+  typedef typename Grp::LChunk LChunk;
+  typedef typename Grp::VU VU;
+  typedef typename Grp::VB VB;
+  constexpr uint32_t STEP = 256u, WIN = 256u, TRIPMAX = 2048u;   // a trip's window of the stream; the most output a trip produces
+  constexpr uint32_t AHEAD = WIN + 256u;   // stream bytes a trip may read from ip on: a sequence that starts at window position <= 250 has its offset word at <= 250 + 2 + 255 and reads 4 bytes there; the copies' 80-byte reads start at <= 252
+                                           // (512: what a 1 KB stream ring always holds in front of ip with one refill step on its way)
+  const uint32_t KW = g.wv_ring(), KS = g.wv_stream();
+  uint32_t ip = (uint32_t)ip_io, op = (uint32_t)op_io;
+  const uint32_t ilim = (uint32_t)iend - 306u, olim = (uint32_t)oend - 606u;
+  g.wv_begin(lds, dst);
+  const uint32_t db = g.wv_dbase();
+  const uint32_t op0 = op;
+  uint32_t avail = ip & ~(STEP - 1u);
+  {
+    const LChunk a0 = g.rs_fetch(src, avail), a1 = g.rs_fetch(src, avail + STEP), a2 = g.rs_fetch(src, avail + 2u * STEP), a3 = g.rs_fetch(src, avail + 3u * STEP);
+    g.rs_put(avail, a0); g.rs_put(avail + STEP, a1); g.rs_put(avail + 2u * STEP, a2); g.rs_put(avail + 3u * STEP, a3);
+    avail += 4u * STEP;
+  }
+  uint32_t fetched = avail;
+  LChunk rf = LChunk();
+  uint32_t fl = (op + db) & ~(STEP - 1u);
+  const VU lane = g.vlane();
+  const VU p0 = lane * 4u;
+
+  for (;;) {
+    if (!((ip <= ilim) & (op <= olim))) break;
+    // ---- the stream ring holds what this trip may read ----
+    if (LZ4HIP_UNLIKELY(ip + AHEAD > avail)) {
+      if (fetched != avail) { g.rs_put(fetched - STEP, rf); avail = fetched; }
+      while ((ip + AHEAD > avail) & (fetched + STEP <= (uint32_t)iend) & (fetched + STEP <= (ip & ~(STEP - 1u)) + KS)) {
+        g.rs_put(fetched, g.rs_fetch(src, fetched));
+        fetched += STEP; avail = fetched;
+      }
+      if (ip + AHEAD > avail) break;            // (the end of the stream is near: the loops behind this one do the rest)
+    }
+    // ---- 1. discovery: every byte of the window as if a token started there ----
+    // (all reads are ALIGNED dwords funnelled in registers: five unaligned reads by 64 lanes kept the CU's LDS busy for ~400 cycles
+    // per trip -- SQ_LDS_UNALIGNED_STALL was 80 % of SQ_LDS_IDX_ACTIVE and at 16 wavefronts per CU the LDS, not the wavefronts, set
+    // the pace: 4096 x 4 MiB 110 ms, gpurun_out/r05g)
+    VU blo, bhi;
+    g.vs_win(ip, blo, bhi);                     // stream bytes [ip + 4 l, ip + 4 l + 8)
+    VU rec[4];
+    VU nxpack = VU(0u);
+#pragma unroll
+    for (uint32_t j = 0; j < 4u; j++) {
+      const VU w = j == 0u ? blo : ((blo >> (8 * (int)j)) | (bhi << (32 - 8 * (int)j)));   // bytes j, j + 1, ..
+      const VU tl = (w >> 4) & 15u, tm = w & 15u, e1 = (w >> 8) & 255u;
+      const VB l15 = tl == 15u;
+      const VU lit = tl + Grp::vsel(l15, e1, VU(0u));
+      const VU q = p0 + (j + 1u) + Grp::vsel(l15, VU(1u), VU(0u)) + lit;                     // window position of the offset word
+      const VU ow = g.vs_ld32(ip + q);
+      const VU e2 = (ow >> 16) & 255u;
+      const VB m15 = tm == 15u;
+      const VU mlx = tm + Grp::vsel(m15, e2, VU(0u));                                       // match length - 4
+      const VU nxt = q + 2u + Grp::vsel(m15, VU(1u), VU(0u));
+      // lengths of 255 and more are marked 255: "not for a trip" (that includes every run of two or more length bytes)
+      rec[j] = (ow & 0xFFFFu) | (Grp::vmin(lit, VU(255u)) << 16) | (Grp::vmin(mlx, VU(255u)) << 24);
+      nxpack = nxpack | (Grp::vsel(nxt <= 250u, nxt, VU(255u)) << (8 * (int)j));
+    }
+    // ---- 2. walk: the starts of the sequences in the window, the k-th to lane k ----
+    VU posv = VU(0u);
+    uint32_t T = 0u, s = 0u;
+    do {
+      posv = Grp::vwritelane(posv, s, T);
+      T++;
+      const uint32_t d = Grp::vreadlane(nxpack, s >> 2);
+      s = (d >> ((s & 3u) * 8u)) & 255u;
+    } while ((s != 255u) & (T < 64u));
+    // ---- 3. records, output positions, the first sequence that is not for this trip ----
+    const VB act = lane < T;
+    const VU sl = posv >> 2, slot = posv & 3u;
+    const VU r = Grp::vsel(slot == 0u, Grp::vshfl(rec[0], sl), Grp::vsel(slot == 1u, Grp::vshfl(rec[1], sl), Grp::vsel(slot == 2u, Grp::vshfl(rec[2], sl), Grp::vshfl(rec[3], sl))));
+    const VU off = r & 0xFFFFu, lit = (r >> 16) & 255u, ml = (r >> 24) + 4u;
+    const VB simple = (off != 0u) & (lit != 255u) & (ml != 259u);   // (tested here, once per real start, not at every speculative position)
+    const VU tot = Grp::vsel(act, lit + ml, VU(0u));
+    const VU ex = Grp::vexcl_scan(tot);
+    const VU o = ex + op;                       // where the sequence's output starts
+    const VU mp = o + lit - off;                // where its match copies from (negative: invalid offset)
+    const VU oe = o + tot;
+    // independent: the whole source lies below this trip's output.  held: the ring has the source and keeps it while the trip is
+    // written (the trip touches at most [op, bound): the ring loses what lies below bound - KW); a source the ring does not hold is
+    // FAR and comes from the block's flushed output in memory -- which has everything below the flusher's position (and below the
+    // loop's entry position)
+    const uint32_t oe_all = Grp::vreadlane(oe, T - 1u);
+    const uint32_t bound = (oe_all - op < TRIPMAX ? oe_all : op + TRIPMAX) + 16u;
+    const uint32_t memlim = fl > op0 + db ? fl - db : op0;
+    const VB held = (mp >= VU(op0)) & ((mp + KW) >= VU(bound));
+    const VB ok = act & simple & (mp < VU(0x80000000u)) & ((mp + ml) <= VU(op)) & (held | ((mp + ml) <= VU(memlim))) &
+                  ((posv + ip) <= VU(ilim)) & (o <= VU(olim)) & ((oe - op) <= VU(TRIPMAX));
+    // (mp "negative" -- an offset that reaches in front of the block -- is a huge unsigned number: tested by itself, the sums may wrap)
+#ifdef LZ4HIP_WAVE_DBG   /* developer build of the simulator: why trips end (tests/hostsim) */
+    g.vnote(act, simple, mp < VU(0x80000000u), (mp + ml) <= VU(op), held | ((mp + ml) <= VU(memlim)), held, (oe - op) <= VU(TRIPMAX), ok);
+#endif
+    // ---- stream refill, HERE: the step requested a trip ago goes into the ring and the next one is requested.  Stores count in
+    // vmcnt on this part, so the wait for the requested step is a wait for the flusher's stores too: at the end of the trip (right
+    // behind them, or right in front of them) it cost 2048 x 4 MiB 32.0 ms against 30.1 ms here, where they are half a trip old
+    // (gpurun_out/r05i-k).  The ring keeps everything from ip & ~255 on: this trip's reads ----
+    if ((fetched + STEP <= (uint32_t)iend) & (fetched + STEP <= (ip & ~(STEP - 1u)) + KS)) {
+      if (fetched != avail) { g.rs_put(fetched - STEP, rf); avail = fetched; }
+      rf = g.rs_fetch(src, fetched);
+      fetched += STEP;
+    }
+    const uint64_t okm = Grp::vballot(ok);
+    const uint32_t Te = (uint32_t)__builtin_ctzll(~okm | (1ull << 63));   // leading sequences that are fine (< 64: lane 63 is never needed)
+    if (LZ4HIP_UNLIKELY(Te == 0u)) {
+      if (!wave_single_step(g, dst, ip, op, op0, fl, db, ilim, olim)) break;
+    } else {
+      // ---- 4. copies: a lane per sequence, exact ----
+      const VB go = lane < Te;
+      const VU lp = posv + ip + Grp::vsel(lit >= 15u, VU(2u), VU(1u));
+      g.vcopy_seq(o + db, lp, lit, mp + db, ml, go, dst, mp, !held);
+      const uint32_t outb = Grp::vreadlane(oe, Te - 1u) - op;
+      uint32_t used;
+      if (Te < T) used = Grp::vreadlane(posv, Te);
+      else {                                    // every start of the window was taken: the next token lies behind the last sequence
+        const uint32_t lr = Grp::vreadlane(r, Te - 1u), lpv = Grp::vreadlane(posv, Te - 1u);
+        const uint32_t llit = (lr >> 16) & 255u, lmx = lr >> 24;
+        used = lpv + 1u + (llit >= 15u ? 1u : 0u) + llit + 2u + (lmx >= 15u ? 1u : 0u);
+      }
+      ip += used; op += outb;
+    }
+    // ---- flusher: whole aligned steps below op ----
+    while (op + db - fl >= STEP) { g.wv_store(dst, fl, g.wv_read_al(fl), op0 + db, 0xFFFFFFFFu); fl += STEP; }
+  }
+  while (op + db - fl >= STEP) { g.wv_store(dst, fl, g.wv_read_al(fl), op0 + db, 0xFFFFFFFFu); fl += STEP; }
+  if (op + db != fl) g.wv_store(dst, fl, g.wv_read_al(fl), op0 + db, op + db);
+  ip_io = (int)ip; op_io = (int)op;
+}
+
 }  // namespace lz4hip

@@ -7,6 +7,7 @@
 #include <stdint.h>
 #include <string.h>
 #include <vector>
+#include "wave_host.h"
 
 namespace hostsim {
 
@@ -294,7 +295,7 @@ struct GroupHost {
   void wv_begin(uint8_t*, const uint8_t* dst) {
     wave_entries++;
     wave_mode = true;
-    wv_mem.assign(kWs + 32u + kWv + 16u, 0xEE);
+    wv_mem.assign(kWs + 32u + kWv + 32u, 0xEE);
     wsb = wv_mem.data(); wrb = wsb + kWs + 32u; wdb = (uint32_t)(uintptr_t)dst & 255u;
     rsb = wsb; kRs = kWs;
   }
@@ -319,18 +320,120 @@ struct GroupHost {
   }
   void wv_put(uint32_t w, const WPiece& c) {
     const uint32_t u = (w + 4u) & (kWv - 1u);
-    const bool ends = (u < 8u) | (u > kWv - 264u);     // the device's wave-uniform test in front of the mirror stores
+    const bool ends = (u < 20u) | (u > kWv - 264u);    // the device's wave-uniform test in front of the mirror stores
     for (int l = 0; l < GL; l++) {
       if (c.dl[l] != wv_delta(l, w)) oob = true;       // the piece was shaped for another ring index
       const uint32_t t = (w + 4u + c.dl[l]) & (kWv - 1u);
       uint8_t* a = (wrb - 4) + t;
       if (l != 0 && ((uintptr_t)(a - wrb) & 3u)) oob = true;   // lanes 1.. store aligned dwords
       if (rl_ok(a, 4)) memcpy(a, c.b[l], 4);
-      if (t < 8u) {
+      if (t < 20u) {
         wave_mirror++;
         if (!ends) oob = true;                        // a mirror store the device would have skipped
         if (rl_ok(a + kWv, 4)) memcpy(a + kWv, c.b[l], 4);
       }
+    }
+  }
+  // ---- lane-parallel side (the parallel trips): per-lane values are 64-element vectors, every call is one instruction ----
+  typedef V<uint32_t> VU;
+  typedef V<bool> VB;
+  static inline uint64_t par_trips = 0, par_seqs = 0, par_single = 0, par_far = 0;
+  static VU vlane() { VU r; for (int i = 0; i < 64; i++) r.v[i] = (uint32_t)i; return r; }
+  static VU vsel(const VB& c, const VU& a, const VU& b) { VU r; for (int i = 0; i < 64; i++) r.v[i] = c.v[i] ? a.v[i] : b.v[i]; return r; }
+  static uint64_t vballot(const VB& b) { uint64_t m = 0; for (int i = 0; i < 64; i++) if (b.v[i]) m |= 1ull << i; return m; }
+  static uint32_t vreadlane(const VU& v, uint32_t i) { return v.v[i & 63u]; }
+  static VU vwritelane(const VU& v, uint32_t s, uint32_t i) { VU r = v; r.v[i & 63u] = s; return r; }
+  static VU vshfl(const VU& v, const VU& srcl) { VU r; for (int i = 0; i < 64; i++) r.v[i] = v.v[srcl.v[i] & 63u]; return r; }
+  static VU vexcl_scan(const VU& a) { par_trips++; VU r; uint32_t acc = 0; for (int l = 0; l < 64; l++) { r.v[l] = acc; acc += a.v[l]; } return r; }
+  static inline uint64_t why[8] = {0};
+  void vnote(const VB& act, const VB& a, const VB& b, const VB& c, const VB& d, const VB& e, const VB& f, const VB& ok) {
+    int k = 0; while (k < 64 && ok.v[k]) k++;
+    if (k == 64) return;
+    if (!act.v[k]) why[0]++; else if (!a.v[k]) why[1]++; else if (!b.v[k]) why[2]++; else if (!c.v[k]) why[3]++; else if (!d.v[k]) why[4]++; else if (!e.v[k]) why[5]++; else if (!f.v[k]) why[6]++; else why[7]++;
+  }
+  static VU vmin(const VU& a, const VU& b) { VU r; for (int l = 0; l < 64; l++) r.v[l] = a.v[l] < b.v[l] ? a.v[l] : b.v[l]; return r; }
+  void vs_win(uint32_t ip, VU& lo, VU& hi) {   // (the device reads the three aligned dwords at ((ip & ~3) + 4 l) & mask)
+    for (int l = 0; l < 64; l++) {
+      const uint32_t a = ((ip & ~3u) + 4u * (uint32_t)l) & (kWs - 1u);
+      uint8_t b[12] = {0};
+      if (rl_ok(wsb + a, 12)) memcpy(b, wsb + a, 12);
+      memcpy(&lo.v[l], b + (ip & 3u), 4); memcpy(&hi.v[l], b + (ip & 3u) + 4, 4);
+    }
+  }
+  VU vs_ld32(const VU& p) {
+    VU r;
+    for (int l = 0; l < 64; l++) { const uint32_t idx = p.v[l] & (kWs - 1u); if (rl_ok(wsb + (idx & ~3u), 8)) memcpy(&r.v[l], wsb + idx, 4); }
+    return r;
+  }
+  // one store instruction of n bytes per active lane, with the device backend's mirror rule; all lanes' data were read before
+  void vput(uint32_t n, const VU& w, const uint8_t (*v)[16], const VB& m) {
+    for (int l = 0; l < 64; l++) {
+      if (!m.v[l]) continue;
+      const uint32_t t = (w.v[l] + 16u) & (kWv - 1u);
+      uint8_t* a = (wrb - 16) + t;
+      if (rl_ok(a, n)) memcpy(a, v[l], n);
+      if (t < 32u && rl_ok(a + kWv, n)) memcpy(a + kWv, v[l], n);
+    }
+  }
+  // src 0: stream ring, 1: output ring, 2: memory (mem + sp)
+  void vcopy(int src, const VU& dw, const VU& sp, const VU& len, const VB& go, const uint8_t* mem = nullptr) {
+    const uint8_t* sb = src == 0 ? wsb : src == 1 ? wrb : mem;
+    const uint32_t sm = src == 0 ? kWs - 1u : src == 1 ? kWv - 1u : 0xFFFFFFFFu;
+    uint8_t v[64][16];
+    auto step = [&](uint32_t n, const VU& c, const VB& m) {
+      memset(v, 0, sizeof v);
+      for (int l = 0; l < 64; l++) if (m.v[l]) { const uint8_t* q = sb + ((sp.v[l] + c.v[l]) & sm); if (src == 2 ? rd_ok(q, n) : rl_ok(q, n)) memcpy(v[l], q, n); }
+      vput(n, dw + c, v, m);
+    };
+    for (uint32_t c = 0;; c += 16u) {
+      VB m; bool any = false;
+      for (int l = 0; l < 64; l++) { m.v[l] = go.v[l] && c + 16u <= len.v[l]; any |= m.v[l]; }
+      if (!any) break;
+      step(16u, VU(c), m);
+    }
+    VU c;
+    for (int l = 0; l < 64; l++) c.v[l] = len.v[l] & ~15u;
+    for (uint32_t n = 8u; n >= 1u; n >>= 1) {
+      VB m;
+      for (int l = 0; l < 64; l++) m.v[l] = go.v[l] && (len.v[l] & n) != 0u;
+      step(n, c, m);
+      for (int l = 0; l < 64; l++) if (m.v[l]) c.v[l] += n;
+    }
+  }
+  // both copies of a trip (group_dev.h vcopy_seq): the usual trip reads EVERYTHING (literals and match sources of all lanes) before
+  // it stores anything, and stores no mirror copies -- the rule that decides it is the device's
+  void vcopy_seq(const VU& dw, const VU& sp, const VU& lenl, const VU& sw, const VU& lenm, const VB& go, const uint8_t* mem, const VU& mpos, const VB& far) {
+    for (int l = 0; l < 64; l++) { par_seqs += go.v[l] ? 1u : 0u; par_far += (go.v[l] && far.v[l]) ? 1u : 0u; }
+    bool odd = false;
+    for (int l = 0; l < 64; l++) {
+      const uint32_t x = dw.v[l] & (kWv - 1u);
+      odd |= go.v[l] && (lenl.v[l] > 64u || lenm.v[l] > 64u || x < 16u || x + lenl.v[l] + lenm.v[l] + 16u > kWv);
+    }
+    VB gr, gf;
+    for (int l = 0; l < 64; l++) { gr.v[l] = go.v[l] && !far.v[l]; gf.v[l] = go.v[l] && far.v[l]; }
+    if (odd) { vcopy(0, dw, sp, lenl, go); vcopy(1, dw + lenl, sw, lenm, gr); vcopy(2, dw + lenl, mpos, lenm, gf, mem); return; }
+    static uint8_t bl[64][80], bm[64][80];
+    for (int l = 0; l < 64; l++) {
+      if (!go.v[l]) continue;
+      // (the device reads 64 + 15 bytes from each source whatever the lengths: every index it forms must lie in the LDS bytes /
+      // the block's slot)
+      for (uint32_t c = 0; c < 64u; c += 16u) { const uint8_t* q = wsb + ((sp.v[l] + c) & (kWs - 1u)); if (rl_ok(q, 16)) memcpy(bl[l] + c, q, 16); }
+      for (uint32_t c = 0; c < 64u; c += 16u) { const uint8_t* q = wrb + ((sw.v[l] + c) & (kWv - 1u)); if (rl_ok(q, 16)) memcpy(bm[l] + c, q, 16); }
+      auto tail = [&](const uint8_t* base, uint32_t mask, uint32_t s0, uint32_t len, uint8_t* out, bool is_mem) {
+        uint32_t c = len & ~15u;
+        for (uint32_t n = 8u; n >= 1u; n >>= 1) { const uint8_t* q = base + ((s0 + c) & mask); if ((is_mem ? rd_ok(q, n) : rl_ok(q, n)) && (len & n)) memcpy(out + c, q, n); c += len & n; }
+      };
+      tail(wsb, kWs - 1u, sp.v[l], lenl.v[l], bl[l], false);
+      tail(wrb, kWv - 1u, sw.v[l], lenm.v[l], bm[l], false);
+      if (far.v[l]) {
+        for (uint32_t c = 0; c < 64u; c += 16u) { const uint8_t* q = mem + mpos.v[l] + c; if (rd_ok(q, 16)) memcpy(bm[l] + c, q, 16); }
+        tail(mem, 0xFFFFFFFFu, mpos.v[l], lenm.v[l], bm[l], true);
+      }
+    }
+    for (int l = 0; l < 64; l++) {
+      if (!go.v[l]) continue;
+      uint8_t* a = wrb + (dw.v[l] & (kWv - 1u));
+      if (rl_ok(a, lenl.v[l] + lenm.v[l])) { memcpy(a, bl[l], lenl.v[l]); memcpy(a + lenl.v[l], bm[l], lenm.v[l]); }
     }
   }
   LChunk wv_read_al(uint32_t fw) {

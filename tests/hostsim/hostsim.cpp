@@ -184,6 +184,8 @@ int sim_compress_fast_ms(const uint8_t* src, int n, uint8_t* dst, int cap, uint6
 
 void sim_ring_stats(unsigned long long* out3) { out3[0] = hostsim::GroupHost::ring_trips; out3[1] = hostsim::GroupHost::ring_entries; out3[2] = hostsim::GroupHost::ring_repl; }
 unsigned long long sim_ring_trips() { return hostsim::GroupHost::ring_trips; }   // offset words the ring loop has parsed so far
+void sim_wave_why(unsigned long long* out8) { for (int i = 0; i < 8; i++) out8[i] = hostsim::GroupHost::why[i]; }
+void sim_wave_par_stats(unsigned long long* out3) { out3[0] = hostsim::GroupHost::par_trips; out3[1] = hostsim::GroupHost::par_seqs; out3[2] = hostsim::GroupHost::par_far; }
 void sim_wave_stats(unsigned long long* out4) { out4[0] = hostsim::GroupHost::wave_trips; out4[1] = hostsim::GroupHost::wave_entries; out4[2] = hostsim::GroupHost::wave_far; out4[3] = hostsim::GroupHost::wave_mirror; }
 unsigned long long sim_deep_trips() { return hostsim::GroupHost::deep_trips; }   // offset words the deep decoder loop has parsed so far
 
@@ -198,13 +200,17 @@ int sim_decompress(const uint8_t* src, int src_size, uint8_t* dst, int out_size,
   const bool wave = (gl & 0x10000) != 0; // bit 16: the wave loop (lz4_decode_wave.h; 64 lanes); bits 17..21: log2 of its output ring's bytes (default 8 KB), bit 22: a 1 KB stream ring
   const int wave_log = (gl >> 17) & 31;
   const bool wave_ks1k = (gl & 0x400000) != 0;
+  const int gl0 = gl;
   gl &= 0xFF;
   hostsim::GroupHost g(gl, src, src_size, dst, out_size);
   if (ring_log) g.kRing = 1u << ring_log;
   if (wave_log) g.kWv = 1u << wave_log;
   if (wave_ks1k) g.kWs = 1024u;
   int r;
-  if (wave) r = safe ? lz4hip::decode_block<hostsim::GroupHost, true, 4>(g, src, src_size, dst, out_size, g.stg_buf)
+  const bool wave_par = (gl0 & 0x800000) != 0;   // bit 23: the parallel wave loop (several sequences of the block per trip)
+  if (wave && wave_par) r = safe ? lz4hip::decode_block<hostsim::GroupHost, true, 5>(g, src, src_size, dst, out_size, g.stg_buf)
+                                 : lz4hip::decode_block<hostsim::GroupHost, false, 5>(g, src, src_size, dst, out_size, g.stg_buf);
+  else if (wave) r = safe ? lz4hip::decode_block<hostsim::GroupHost, true, 4>(g, src, src_size, dst, out_size, g.stg_buf)
                      : lz4hip::decode_block<hostsim::GroupHost, false, 4>(g, src, src_size, dst, out_size, g.stg_buf);
   else if (ring) r = safe ? lz4hip::decode_block<hostsim::GroupHost, true, 3>(g, src, src_size, dst, out_size, g.stg_buf)
                      : lz4hip::decode_block<hostsim::GroupHost, false, 3>(g, src, src_size, dst, out_size, g.stg_buf);

@@ -143,7 +143,8 @@ def test_decode_fuzz_bit_exact(amd, ref, O, corpus):
                                      (32, 0, 1, 0), (64, 0, 1, 0),
                                      (4, 2, 0, 0), (8, 2, 0, 0), (16, 2, 0, 0),     # pipe 2: the deep interior loop (lz4_decode_deep.h)
                                      (1, 3, 0, 256), (1, 3, 0, 512), (4, 3, 0, 512), (4, 3, 0, 1024), (4, 3, 0, 2048), (8, 3, 0, 512), (8, 3, 0, 4096), (16, 3, 0, 4096),   # pipe 3: the ring loop (lz4_decode_ring.h); (4, 3, 2048) is the routed default of 12288..40959 big blocks
-                                     (64, 4, 0, 0), (64, 4, 0, 8192), (64, 4, 0, 16384), (64, 4, 0, 32768), (64, 4, 0, 65536)):   # pipe 4: the wave loop (lz4_decode_wave.h), a wavefront per block
+                                     (64, 4, 0, 0), (64, 4, 0, 8192), (64, 4, 0, 16384), (64, 4, 0, 32768), (64, 4, 0, 65536),   # pipe 4: the wave loop (lz4_decode_wave.h), a wavefront per block
+                                     (64, 5, 0, 0), (64, 5, 0, 8192), (64, 5, 0, 16384), (64, 5, 0, 32768), (64, 5, 0, 65536)):   # pipe 5: its parallel form, several sequences of the block per trip
         amd.set_option("decode_lanes", lanes)
         amd.set_option("decode_pipe", pipe)
         amd.set_option("decode_stage", stage)
@@ -296,7 +297,8 @@ def test_decode_variants_at_odd_offsets(amd, ref, corpus):
     total = pos + 77
     for lanes, pipe, stage, ring in ((4, 0, 1, 0), (8, 0, 1, 0), (16, 0, 1, 0), (64, 0, 1, 0), (4, 0, 0, 0), (8, 1, 0, 0), (16, 1, 0, 0), (4, 2, 0, 0), (8, 2, 0, 0), (16, 2, 0, 0),
                                      (1, 3, 0, 0), (4, 3, 0, 0), (4, 3, 0, 2048), (8, 3, 0, 0), (16, 3, 0, 0),   # (3: the ring loop flushes address-aligned steps)
-                                     (64, 4, 0, 0), (64, 4, 0, 8192), (64, 4, 0, 16384), (64, 4, 0, 65536)):   # (4: the wave loop flushes 256-byte steps, its first and last byte-exactly)
+                                     (64, 4, 0, 0), (64, 4, 0, 8192), (64, 4, 0, 16384), (64, 4, 0, 65536),   # (4: the wave loop flushes 256-byte steps, its first and last byte-exactly)
+                                     (64, 5, 0, 0), (64, 5, 0, 8192), (64, 5, 0, 16384), (64, 5, 0, 65536)):
         amd.set_option("decode_lanes", lanes); amd.set_option("decode_pipe", pipe); amd.set_option("decode_stage", stage); amd.set_option("decode_ring", ring)
         dst = bytearray(b"\xC3" * total)
         out = amd.LZ4HIPBatch.decompressSafe(bytes(src), so, [len(c) for c in comp], dst, dst_off, [len(b) for b in blocks])
@@ -321,7 +323,8 @@ def test_deep_decoder_loop_long_streams(amd, ref, O, corpus):
     want = [ref.decompress_safe_raw(c, cap) for c, cap in cases]
     try:
         for lanes, pipe, ring in ((4, 2, 0), (8, 2, 0), (16, 2, 0), (1, 3, 256), (1, 3, 512), (4, 3, 512), (4, 3, 1024), (4, 3, 2048), (8, 3, 512), (8, 3, 2048), (8, 3, 4096), (16, 3, 2048), (16, 3, 4096),
-                                  (64, 4, 0), (64, 4, 8192), (64, 4, 16384), (64, 4, 32768), (64, 4, 65536)):
+                                  (64, 4, 0), (64, 4, 8192), (64, 4, 16384), (64, 4, 32768), (64, 4, 65536),
+                                  (64, 5, 0), (64, 5, 8192), (64, 5, 16384), (64, 5, 32768), (64, 5, 65536)):
             amd.set_option("decode_lanes", lanes); amd.set_option("decode_pipe", pipe); amd.set_option("decode_stage", 0); amd.set_option("decode_ring", ring)
             res = gpu_decode_safe_many(amd, streams, caps)
             for k, ((r, d), (er, ed)) in enumerate(zip(res, want)):

@@ -394,12 +394,14 @@ def test_ring_decoder_loop(sim, ref, O, corpus):
     assert sim.sim_ring_trips() - trips0 > 500000   # (the loop under test did the work)
 
 
-def wave_flag(log, ks1k=False):
-    """sim_decompress flag of the wave loop: 64 lanes, bit 16, bits 17..21 = log2 of the output ring, bit 22 = 1 KB stream ring"""
-    return 64 | 0x10000 | (log << 17) | (0x400000 if ks1k else 0)
+def wave_flag(log, ks1k=False, par=False):
+    """sim_decompress flag of the wave loop: 64 lanes, bit 16, bits 17..21 = log2 of the output ring, bit 22 = 1 KB stream ring,
+    bit 23 = the parallel loop (several sequences of the block per trip)"""
+    return 64 | 0x10000 | (log << 17) | (0x400000 if ks1k else 0) | (0x800000 if par else 0)
 
 
-def test_wave_decoder_loop(sim, ref, O, corpus):
+@pytest.mark.parametrize("par", [False, True])
+def test_wave_decoder_loop(sim, ref, O, corpus, par):
     """The wave loop (csrc/lz4_decode_wave.h: one wavefront per block, stream ring + an output ring of 4 .. 64 KB in LDS, wave-uniform
     parse, pieces of up to 252 bytes stored as aligned dwords, far sources from flushed memory, byte-exact entry / exit flushes) in
     the lock-step simulator: the long-stream cases of the deep and ring loops' tests (real and synthetic blocks, hand-assembled
@@ -407,7 +409,10 @@ def test_wave_decoder_loop(sim, ref, O, corpus):
     beyond every ring size --, the same streams corrupted / truncated / with wrong capacities) plus text-like and run-heavy data,
     at every kind of address alignment of the destination slot: return codes and bytes against the reference library (safe) and
     the C restatement's bounded fast decoder.  Every access outside the block's slots or the wavefront's LDS bytes, every
-    unaligned store by lanes 1.., every mirror store the device's wave-uniform pre-test would have skipped counts as a failure."""
+    unaligned store by lanes 1.., every mirror store the device's wave-uniform pre-test would have skipped counts as a failure.
+    par: the PARALLEL loop -- every sequence that starts in a 256-byte window of the stream per trip (speculative lane-parallel
+    discovery, scalar walk, records by lane shuffle, prefix-summed output positions, the dependency rule, exact lane-per-sequence
+    copies), with the one-sequence step for what a trip cannot start with."""
     rng = random.Random(20250924)
     from conftest import deep_decoder_cases
     valid, cases = deep_decoder_cases(ref, O, corpus, rng, _lz4_seq)
@@ -425,7 +430,7 @@ def test_wave_decoder_loop(sim, ref, O, corpus):
         want_r, want = ref.decompress_safe_raw(c, cap)
         full = k < len(valid)
         for log, ks1k in (((12, False), (13, True), (14, False), (16, False)) if full else ((rng.choice([12, 13, 14, 15, 16]), rng.random() < 0.3),)):
-            flag = wave_flag(log, ks1k)
+            flag = wave_flag(log, ks1k, par)
             shift = rng.choice([0, 0, 1, 2, 3, 7, 16, 33, 63, 64, 100, 255, 256, 257])
             r, d = sim_decode(sim, c, cap, 1, flag, shift=shift)
             assert r == want_r and (want_r < 0 or d[:want_r] == want[:want_r]), ("safe", k, log, ks1k, shift, len(c), cap, r, want_r)
@@ -434,10 +439,16 @@ def test_wave_decoder_loop(sim, ref, O, corpus):
             r4, d4 = sim_decode(sim, c + bytes(scap - len(c)), cap, 0, flag, src_size=scap, shift=shift)
             assert r3 == r4 and (r3 < 0 or d3[:cap] == d4[:cap]), ("fast", k, log, ks1k, len(c), cap, scap, r3, r4)
     sim.sim_wave_stats(st)
-    assert st[0] - trips0 > 500000 and st[2] - far0 > 1000 and st[3] - mir0 > 1000   # the loop did the work: pieces, far sources, ring wraps
+    if not par:
+        assert st[0] - trips0 > 500000 and st[2] - far0 > 1000 and st[3] - mir0 > 1000   # the loop did the work: pieces, far sources, ring wraps
+    else:
+        ps = (C.c_ulonglong * 3)()
+        sim.sim_wave_par_stats(ps)
+        assert ps[0] > 100000 and ps[1] > 1.2 * ps[0], list(ps)   # trips did the work (this corpus is mostly irregular streams: App. F data runs 9-12 sequences per trip, text 18)
 
 
-def test_wave_decoder_small_and_fuzz(sim, ref, O, corpus):
+@pytest.mark.parametrize("par", [False, True])
+def test_wave_decoder_small_and_fuzz(sim, ref, O, corpus, par):
     """the wave loop's instantiation of decode_block on everything the other decoders' fuzz test sees (short, empty, damaged and
     random streams: mostly the exact tiers with 64 lanes, the wave loop where a stream is long enough)"""
     rng = random.Random(99)
@@ -456,7 +467,7 @@ def test_wave_decoder_small_and_fuzz(sim, ref, O, corpus):
         elif mode == 5:
             c, cap = bytearray(rng.randbytes(rng.randrange(1, 40))), rng.randrange(0, 200)
         c = bytes(c)
-        flag = wave_flag(rng.choice([12, 13, 16]), rng.random() < 0.5)
+        flag = wave_flag(rng.choice([12, 13, 16]), rng.random() < 0.5, par)
         shift = rng.choice([0, 1, 5, 64, 131])
         r2, d2 = ref.decompress_safe_raw(c, cap)
         r1, d1 = sim_decode(sim, c, cap, 1, flag, shift=shift)
