@@ -224,6 +224,13 @@ int lz4hip_container_decode_dev(int kind, int flags, const uint8_t* body, uint64
  * info[5] as above */
 int lz4hip_container_decode(int kind, int flags, const uint8_t* body, uint64_t body_bytes, uint32_t max_block, uint32_t n_max,
                             uint8_t* dst, uint64_t dst_cap, int32_t* sizes, uint64_t* info);
+/* what a caller of lz4hip_container_decode must provide: a host-side walk of the size words / headers (no device work): *n_blocks =
+ * whole blocks of the first n_max that body holds, *dst_bytes = the most their decoded forms can need (frame: max_block per
+ * compressed block, the stored size of a raw one; LZ4Block: the headers' original lengths) -- so that a 100-byte frame asks for one
+ * block's worth of destination, not n_max x max_block (the readers of LZ4FrameInputStream.java:258-322 / LZ4BlockInputStream.java:
+ * 191-264 allocate one block at a time).  lz4hip_container_decode sizes its own device slots the same way.                      */
+int lz4hip_container_decode_bound(int kind, int flags, const uint8_t* body, uint64_t body_bytes, uint32_t max_block, uint32_t n_max,
+                                  uint32_t* n_blocks, uint64_t* dst_bytes);
 
 /* ---- workload helper (not part of the reference API) ------------------------------------------
  * Fills n_blocks slots of `block_len` bytes at dst + i*stride with the SURVEY.md App. F synthetic

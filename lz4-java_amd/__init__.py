@@ -80,6 +80,7 @@ C_ABI = {
     "lz4hip_container_decode_dev": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p,
                                               C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "lz4hip_container_decode": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "lz4hip_container_decode_bound": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
     "lz4hip_gen_blocks_dev": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
                                         C.c_uint32, C.c_int, C.c_void_p]),
 }
@@ -590,10 +591,12 @@ class LZ4HIPBatch:
         """the READ path of the container formats on the device: the data blocks of an LZ4 Frame body / of an LZ4Block stream in `body`
         are walked, verified and decoded there (LZ4FrameInputStream.readBlock / LZ4BlockInputStream.refill for a run of blocks)
         -> (decoded bytes of the delivered blocks, [their sizes], bytes of body consumed, stop reason, liblz4 code of a failed decode)"""
-        dst = bytearray(max(maxBlock * nMax, 1))
+        sp, sk = _ro_ptr(body)
+        nb, need = C.c_uint32(0), C.c_uint64(0)   # the destination by what the body holds, not by nMax x maxBlock (round-4 advisor)
+        _chk(lib().lz4hip_container_decode_bound(kind, 1 if blockChecksum else 0, sp, len(body), maxBlock, nMax, C.byref(nb), C.byref(need)))
+        dst = bytearray(max(need.value, 1))
         sizes = (C.c_int32 * nMax)()
         info = (C.c_uint64 * 5)()
-        sp, sk = _ro_ptr(body)
         dp, dk = _rw_ptr(dst)
         _chk(lib().lz4hip_container_decode(kind, 1 if blockChecksum else 0, sp, len(body), maxBlock, nMax, dp, len(dst), sizes, info))
         n_ok, consumed, why, total, code = (int(info[i]) for i in range(5))

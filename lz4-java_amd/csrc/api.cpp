@@ -866,19 +866,74 @@ int lz4hip_container_decode_dev(int kind, int flags, const uint8_t* body, uint64
   if (e) return fail(LZ4HIP_E_HIP, "kernel launch", (hipError_t)e);
   return LZ4HIP_OK;
 }
+// Host-side walk of the size words / headers of a container body IN HOST MEMORY (no device work, no decoding): how many whole blocks
+// of the first n_max the body holds, how many bytes their decoded forms can need at most (frame: max_block per compressed block, the
+// stored size of a raw one; LZ4Block: the header's original length) and
+// the largest of those bounds (incl. the block the walk stopped at, when its header is readable).  It follows the device walk's
+// positions (container_walk_kernel) and stops where that stops.  What it is for (round-4 advisor): lz4hip_container_decode sized its
+// device slots -- and its callers their destination -- by max_block x n_max whatever the body held: 256 MiB for a 100-byte frame,
+// gigabytes for a 21-byte LZ4Block header with level nibble 15.
+static void container_prewalk(int kind, int flags, const uint8_t* body, uint64_t body_bytes, uint32_t max_block, uint32_t n_max,
+                              uint32_t* n_blocks, uint64_t* dst_bytes, uint64_t* slot_max) {
+  auto rd32 = [](const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); };
+  uint64_t p = 0, total = 0, smax = 0;
+  uint32_t k = 0;
+  while (k < n_max && p < body_bytes) {
+    uint64_t need, bound;
+    if (kind == 0) {
+      if (p + 4u > body_bytes) break;
+      const uint32_t word = rd32(body + p), size = word & 0x7FFFFFFFu;
+      if (size == 0u || size > max_block) break;
+      bound = (word & 0x80000000u) ? size : max_block;   // (a compressed block decodes into max_block bytes of capacity, as in the reference: a smaller one could change which check a damaged stream fails first)
+      need = 4ull + size + ((flags & 1) ? 4u : 0u);
+    } else {
+      if (p + 21u > body_bytes) break;
+      const uint8_t* h = body + p;
+      if (memcmp(h, "LZ4Block", 8) != 0) break;
+      const uint32_t method = h[8] & 0xF0u, level = 10u + (h[8] & 0x0Fu);
+      const int32_t clen = (int32_t)rd32(h + 9), olen = (int32_t)rd32(h + 13);
+      if ((method != 0x10u && method != 0x20u) || olen > (int32_t)(1u << level) || olen <= 0 || clen <= 0 || (method == 0x10u && olen != clen)) break;
+      bound = (uint64_t)olen;
+      need = 21ull + (uint64_t)clen;
+    }
+    if (bound > smax) smax = bound;             // (also for a block whose payload is cut short: the device walk looks at it)
+    if (p + need > body_bytes) break;
+    total += bound; p += need; k++;
+  }
+  *n_blocks = k; *dst_bytes = total; *slot_max = smax;
+}
+int lz4hip_container_decode_bound(int kind, int flags, const uint8_t* body, uint64_t body_bytes, uint32_t max_block, uint32_t n_max,
+                                  uint32_t* n_blocks, uint64_t* dst_bytes) {
+  if (kind != 0 && kind != 1) return fail(LZ4HIP_E_ARG, "container kind must be 0 (LZ4 Frame blocks) or 1 (LZ4Block blocks)");
+  if ((body_bytes && !body) || !n_blocks || !dst_bytes) return fail(LZ4HIP_E_ARG, "null pointer argument");
+  if (n_max == 0 || n_max > 0x7FFFFFFFu || max_block == 0 || max_block > 0x7FFFFFFFu) return fail(LZ4HIP_E_ARG, "n_max and max_block must be 1 .. 2^31 - 1");
+  uint64_t smax = 0;
+  container_prewalk(kind, flags, body, body_bytes, max_block, n_max, n_blocks, dst_bytes, &smax);
+  return LZ4HIP_OK;
+}
 // host pointers: H2D of the container bytes, the device path above, D2H of the delivered blocks back to back into dst
 int lz4hip_container_decode(int kind, int flags, const uint8_t* body, uint64_t body_bytes, uint32_t max_block, uint32_t n_max, uint8_t* dst,
                             uint64_t dst_cap, int32_t* sizes, uint64_t* info) {
   int rc = ensure_init();
   if (rc) return fail(rc, "no HIP device: liblz4hip has no CPU fallback");
+  if (kind != 0 && kind != 1) return fail(LZ4HIP_E_ARG, "container kind must be 0 (LZ4 Frame blocks) or 1 (LZ4Block blocks)");
   if ((body_bytes && !body) || !sizes || !info || (dst_cap && !dst)) return fail(LZ4HIP_E_ARG, "null pointer argument");
-  if (n_max == 0 || max_block == 0 || max_block > 0x7FFFFFFFu) return fail(LZ4HIP_E_ARG, "n_max and max_block must be positive");
+  if (n_max == 0 || n_max > 0x7FFFFFFFu || max_block == 0 || max_block > 0x7FFFFFFFu) return fail(LZ4HIP_E_ARG, "n_max and max_block must be 1 .. 2^31 - 1");
   for (int i = 0; i < 5; i++) info[i] = 0;
   int ord;
   if (ordinal(0, &ord)) return fail(LZ4HIP_E_NO_DEVICE, "no device");
   DeviceGuard g(ord);
+  // slots and their number by what the body holds, not by what the caller allows: one slot more than the whole blocks present (the
+  // device walk finds out why the run ends there), each as big as the largest decoded block can be
+  uint64_t slot_need;
+  {
+    uint32_t nb = 0; uint64_t db = 0, smax = 0;
+    container_prewalk(kind, flags, body, body_bytes, max_block, n_max, &nb, &db, &smax);
+    if (nb + 1u < n_max) n_max = nb + 1u;
+    slot_need = smax ? smax : 1u;
+  }
   const size_t wsb = lz4hip_container_decode_workspace_bytes(n_max);
-  const uint64_t slot = ((uint64_t)max_block + 63u) & ~63ull;
+  const uint64_t slot = (slot_need + 63u) & ~63ull;
   hipStream_t st = nullptr;
   uint8_t *d_body = nullptr, *d_dst = nullptr, *d_ws = nullptr;
   int32_t* d_sizes = nullptr;

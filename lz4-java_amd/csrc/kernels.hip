@@ -253,8 +253,8 @@ __global__ __launch_bounds__(64 * (PK_FINDERS + PK_WRITERS)) void compress_fast_
 }
 // scratch words the two-wave kernels need after the three queue words: the control words, the counters of every pair (ten per CU
 // at most), then (1024-byte aligned) the rings
-static int g_compress_pack = 1;   // "compress_pack": 0 = every block on the five-pair kernel (developer A/B)
-void set_compress_pack(int v) { g_compress_pack = v; }
+static std::atomic<int> g_compress_pack{1};   // "compress_pack": 0 = every block on the five-pair kernel (developer A/B); an atomic like the other knobs (round-4 advisor: a plain int read by concurrent launches was a data race)
+void set_compress_pack(int v) { g_compress_pack.store(v, std::memory_order_relaxed); }
 size_t compress_fast_v2w_scratch_words(uint32_t n_cus) {
   const size_t pairs = (size_t)n_cus * (PK_FINDERS * PK_WGS_PER_CU > WAVES_PER_CU ? PK_FINDERS * PK_WGS_PER_CU : WAVES_PER_CU);
   return CTL_WORDS + 2u * pairs + 256u + pairs * (MAIL_RING * MAIL_SLOT_WORDS);
@@ -262,7 +262,19 @@ size_t compress_fast_v2w_scratch_words(uint32_t n_cus) {
 int launch_compress_fast_v2w(const BatchArgs& a, uint32_t* q, uint32_t* routed, uint32_t dense64, uint32_t n_cus, uint32_t* mail, void* stream) {
   if (a.n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  const bool pack = g_compress_pack != 0;
+  bool pack = g_compress_pack.load(std::memory_order_relaxed) != 0;
+  if (pack) {   // the packed kernel is ONE workgroup of 1024 threads with 160 KB of static LDS: a device that cannot run it gets the five-pair kernel for every block
+    static std::atomic<int> fits[64];   // per device: 0 = not asked yet, 1 = fits, 2 = does not
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) d = 0;
+    int f = fits[d].load(std::memory_order_relaxed);
+    if (f == 0) {
+      int lds = 0;
+      f = (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, d) == hipSuccess && lds >= 160 * 1024) ? 1 : 2;
+      fits[d].store(f, std::memory_order_relaxed);
+    }
+    if (f != 1) pack = false;
+  }
   const size_t pairs_max = (size_t)n_cus * (PK_FINDERS * PK_WGS_PER_CU > WAVES_PER_CU ? PK_FINDERS * PK_WGS_PER_CU : WAVES_PER_CU);
   uint32_t* ctl = mail;
   uint32_t* ctr = mail + CTL_WORDS;
@@ -278,8 +290,10 @@ int launch_compress_fast_v2w(const BatchArgs& a, uint32_t* q, uint32_t* routed, 
       fprintf(stderr, "[lz4hip] compress_fast_v2wp_cu_kernel: %d workgroups per CU (%s)\n", nb, hipGetErrorString(oe));
     }
     hipLaunchKernelGGL(compress_classify_kernel, dim3((a.n + 255u) / 256u), dim3(256), 0, st, a.src_len, a.dst_cap, a.n, ctl);
+    if ((e = hipGetLastError()) != hipSuccess) return (int)e;   // (each launch checked by itself: the five-pair kernel SKIPS the blocks ctl gives to the packed one)
     const uint32_t want = (a.n + PK_FINDERS - 1u) / PK_FINDERS, most = n_cus * PK_WGS_PER_CU;
     hipLaunchKernelGGL(compress_fast_v2wp_cu_kernel, dim3(want < most ? want : most), dim3(64 * (PK_FINDERS + PK_WRITERS)), 0, st, a, ctl, ctr, slots);
+    if ((e = hipGetLastError()) != hipSuccess) return (int)e;
     e = hipMemsetAsync(ctr, 0, 2u * pairs_max * sizeof(uint32_t), st);   // the rings start empty again
     if (e != hipSuccess) return (int)e;
   }

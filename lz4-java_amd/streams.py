@@ -298,6 +298,20 @@ class _Reader:
     def unread(self, b):
         self.back = bytes(b) + self.back
 
+    def seekable(self):
+        try:
+            return bool(self.inp.seekable())
+        except Exception:
+            return False
+
+    def give_back(self):
+        """the container ended and the caller goes on reading `inp` itself (readSingleFrame / stopOnEmptyBlock): the bytes the device
+        read path took beyond the container's end go back to `inp` -- the reference's readers consume exactly the container
+        (LZ4FrameInputStream.java:258-322, LZ4BlockInputStream.java:191-264).  Only seekable inputs get the device path in those modes."""
+        if self.back:
+            self.inp.seek(-len(self.back), 1)
+            self.back = b""
+
     def read_upto(self, n):
         parts, got = [], 0
         if self.back:
@@ -432,8 +446,14 @@ class LZ4FrameInputStream(io.RawIOBase):
 
     def _readBlocks(self):
         """LZ4FrameInputStream.readBlock (:258-322) for up to batchBlocks blocks"""
-        if not self.hostWalk and hasattr(self.engine, "containerDecode"):
-            return self._readBlocksDevice()
+        # (the device path takes a whole chunk of container bytes from `inp`: with readSingleFrame the caller reads on behind the
+        # frame, so it needs an input it can hand the surplus back to -- round-4 advisor; a pipe or socket gets the host walk, which
+        # consumes exactly the frame and never waits for bytes beyond it)
+        if not self.hostWalk and hasattr(self.engine, "containerDecode") and (not self.readSingleFrame or self.r.seekable()):
+            self._readBlocksDevice()
+            if self.readSingleFrame and self.frame_finished:
+                self.r.give_back()
+            return
         blocks = []  # (compressed?, payload, stored checksum | None)
         end_mark = False
         exc = None
@@ -728,6 +748,13 @@ class LZ4BlockInputStream(io.RawIOBase):
         if why == B.CR_BLOCK_TOO_BIG:
             self.r.unread(chunk)
             return False
+        if consumed == 0 and not decoded and why in (B.CR_TRUNCATED, B.CR_MORE) and not at_eof:
+            # no progress and more input to come: the first header announces a payload longer than this chunk (compressedLen is not
+            # bounded by the block size: one flipped bit is enough).  The host path reads exactly what the header says and raises
+            # the reference's exception (LZ4BlockInputStream.java:236-253); asking the device again with the same bytes would
+            # never end (round-4 advisor, high)
+            self.r.unread(chunk)
+            return False
         rest = chunk[consumed:]
         self.ready += decoded
         self.r.unread(rest)
@@ -745,7 +772,12 @@ class LZ4BlockInputStream(io.RawIOBase):
         return True
 
     def _refill(self):  # LZ4BlockInputStream.java:191-264, for up to batchBlocks blocks
-        if self.checksum is None and not self.hostWalk and hasattr(self.engine, "containerDecode") and self._refillDevice():
+        # (stopOnEmptyBlock: the caller reads on behind the empty block, so the device path -- which takes whole chunks from `inp` --
+        # needs an input it can hand the surplus back to; see LZ4FrameInputStream._readBlocks)
+        if (self.checksum is None and not self.hostWalk and hasattr(self.engine, "containerDecode")
+                and (not self.stopOnEmptyBlock or self.r.seekable()) and self._refillDevice()):
+            if self.stopOnEmptyBlock and self.finished:
+                self.r.give_back()
             return
         blocks = []  # (method, payload, originalLen, check)
         exc = None

@@ -6,6 +6,8 @@ import io
 import os
 import shutil
 import struct
+
+import pytest
 import subprocess
 import tempfile
 
@@ -69,6 +71,153 @@ class OracleEngine:
             def close(self):
                 pass
         return H()
+
+
+class OracleDeviceEngine(OracleEngine):
+    """OracleEngine + `containerDecode`: a host restatement of the device read path (kernels.hip container_walk_kernel / _raw_kernel /
+    _verdict_kernel: the walk's rules in their order, the first failing block in the readers' order of checks), so that the CPU suite
+    runs the readers' DEVICE-PATH logic (chunking, hand-back of unconsumed bytes, stop reasons -> exceptions) that
+    tests/test_gpu_streams.py runs on the GPU.  Test infrastructure only."""
+    CR_END, CR_MORE, CR_TRUNCATED, CR_BLOCK_TOO_BIG, CR_BLOCK_CHECKSUM, CR_DECODE, CR_CORRUPT, CR_SLOTS = range(8)
+
+    def __init__(self, port, O, hcLevel=None):
+        super().__init__(port, O, hcLevel)
+        self.calls = 0
+
+    def containerDecode(self, kind, body, maxBlock, nMax, blockChecksum=False):
+        self.calls += 1
+        body = bytes(body)
+        n, p, why, blocks = len(body), 0, self.CR_SLOTS, []
+        u32 = lambda o: struct.unpack_from("<I", body, o)[0]
+        i32 = lambda o: struct.unpack_from("<i", body, o)[0]
+        while len(blocks) < nMax:
+            if p == n:
+                why = self.CR_MORE; break
+            if kind == 0:
+                if p + 4 > n:
+                    why = self.CR_TRUNCATED; break
+                word = u32(p); size = word & 0x7FFFFFFF
+                if size == 0:
+                    p += 4; why = self.CR_END; break
+                if size > maxBlock:
+                    why = self.CR_BLOCK_TOO_BIG; break
+                need = 4 + size + (4 if blockChecksum else 0)
+                if p + need > n:
+                    why = self.CR_TRUNCATED; break
+                blocks.append(dict(raw=bool(word & 0x80000000), pay=body[p + 4:p + 4 + size], cap=maxBlock,
+                                   stored=u32(p + 4 + size) if blockChecksum else 0, end=p + need))
+                p += need
+            else:
+                if p + 21 > n:
+                    why = self.CR_TRUNCATED; break
+                token = body[p + 8]; method = token & 0xF0; level = 10 + (token & 0x0F)
+                clen, olen, check = i32(p + 9), i32(p + 13), u32(p + 17)
+                bad = body[p:p + 8] != b"LZ4Block" or method not in (0x10, 0x20) or olen > (1 << level) or olen < 0 or clen < 0 or \
+                    (olen == 0 and clen != 0) or (olen != 0 and clen == 0) or (method == 0x10 and olen != clen)
+                if bad:
+                    why = self.CR_CORRUPT; break
+                if olen == 0:
+                    if check != 0:
+                        why = self.CR_CORRUPT; break
+                    p += 21; why = self.CR_END; break
+                if olen > maxBlock:
+                    why = self.CR_BLOCK_TOO_BIG; break
+                if p + 21 + clen > n:
+                    why = self.CR_TRUNCATED; break
+                blocks.append(dict(raw=method == 0x10, pay=body[p + 21:p + 21 + clen], cap=olen, stored=check, end=p + 21 + clen))
+                p += 21 + clen
+        if len(blocks) == nMax and p == n:
+            why = self.CR_MORE
+        out, sizes, code = bytearray(), [], 0
+        for k, b in enumerate(blocks):
+            if kind == 0:
+                if blockChecksum and self.port.xxh32(b["pay"], 0) != b["stored"]:
+                    return bytes(out), sizes, (blocks[k - 1]["end"] if k else 0), self.CR_BLOCK_CHECKSUM, 0
+                if b["raw"]:
+                    dec = b["pay"]
+                else:
+                    r, d = self.port.decompress_safe_raw(b["pay"], b["cap"])
+                    if r < 0:
+                        return bytes(out), sizes, (blocks[k - 1]["end"] if k else 0), self.CR_DECODE, r
+                    dec = d[:r]
+            else:
+                if b["raw"]:
+                    dec = b["pay"]
+                else:
+                    r, d = self.O.decompress_fast_bounded(b["pay"], len(b["pay"]), b["cap"])
+                    if r != len(b["pay"]):
+                        return bytes(out), sizes, (blocks[k - 1]["end"] if k else 0), self.CR_CORRUPT, 0
+                    dec = d[:b["cap"]]
+                if (self.port.xxh32(dec, 0x9747b28c) & 0x0FFFFFFF) != b["stored"]:
+                    return bytes(out), sizes, (blocks[k - 1]["end"] if k else 0), self.CR_CORRUPT, 0
+            out += dec; sizes.append(len(dec))
+        return bytes(out), sizes, p, why, code
+
+
+class _NoSeek:
+    """a pipe-like input: read() only, and it remembers how much was taken"""
+
+    def __init__(self, b):
+        self.b, self.pos = bytes(b), 0
+
+    def read(self, n=-1):
+        n = len(self.b) - self.pos if n is None or n < 0 else n
+        c = self.b[self.pos:self.pos + n]
+        self.pos += len(c)
+        return c
+
+    def seekable(self):
+        return False
+
+
+def case_device_read_path_advisor_findings(S, engine, data):
+    """round-4 advisor: (1) an LZ4Block header in the middle of a long stream whose compressedLen exceeds the reader's chunk made the
+    device read path spin (no progress, no exception); (2) with readSingleFrame / stopOnEmptyBlock the device path left `inp` far
+    behind the container's end.  `engine` has containerDecode (the GPU engine, or OracleDeviceEngine on the CPU suite)."""
+    B = S.FLG.Bits
+    # (1) LZ4Block: blocks of 1 KiB, tiny batches, a compressedLen of 0x7FFFFFF0 / one flipped top bit in block 5's header
+    d = data[:40000]
+    bs = block_stream_bytes(S, d, engine, 1024, chunk=7000, batchBlocks=4)
+    heads = [i for i in range(len(bs) - 8) if bs[i:i + 8] == b"LZ4Block"]
+    for newlen in (0x7FFFFFF0, None):
+        bad = bytearray(bs)
+        h = heads[5]
+        if newlen is None:
+            bad[h + 12] ^= 0x40          # top byte of compressedLen: + 1 GiB
+        else:
+            bad[h + 9:h + 13] = struct.pack("<i", newlen)
+        rd = S.LZ4BlockInputStream(io.BytesIO(bytes(bad) + bytes(300000)), engine=engine, batchBlocks=4)
+        got = bytearray()
+        with pytest.raises((S.IOException, EOFError)):
+            for _ in range(10000):        # (bounded: the defect was an endless loop)
+                c = rd.read(1 << 16)
+                if not c:
+                    break
+                got += c
+            else:
+                raise AssertionError("the reader makes no progress")
+        assert bytes(got) == d[:len(got)] and len(got) >= 4 * 1024
+    # (2a) a single frame followed by other bytes: the input is left right behind the frame
+    fr = frame_bytes(S, data[:150000], engine, S.BLOCKSIZE.SIZE_64KB, (B.BLOCK_INDEPENDENCE, B.CONTENT_CHECKSUM))
+    tail = b"TRAILER-" * 5000
+    inp = io.BytesIO(fr + tail)
+    one = S.LZ4FrameInputStream(inp, readSingleFrame=True, engine=engine, batchBlocks=8)
+    assert one.read() == data[:150000]
+    assert inp.read() == tail
+    pipe = _NoSeek(fr + tail)             # not seekable: the host walk, which takes exactly the frame
+    one = S.LZ4FrameInputStream(pipe, readSingleFrame=True, engine=engine, batchBlocks=8)
+    assert one.read() == data[:150000]
+    assert pipe.read() == tail
+    # (2b) an LZ4Block stream that stops at its empty block (the default), embedded in another protocol
+    bs2 = block_stream_bytes(S, data[:90000], engine, 1 << 16)
+    inp = io.BytesIO(bs2 + tail)
+    rd = S.LZ4BlockInputStream(inp, engine=engine)
+    assert rd.read() == data[:90000]
+    assert inp.read() == tail
+    pipe = _NoSeek(bs2 + tail)
+    rd = S.LZ4BlockInputStream(pipe, engine=engine)
+    assert rd.read() == data[:90000]
+    assert pipe.read() == tail
 
 
 def payload(corpus, O):

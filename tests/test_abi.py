@@ -54,6 +54,38 @@ def test_compress_bound(amd, golden):
         amd.maxCompressedLength(0x7E000000)                    # LZ4Utils.java:37-39
 
 
+def test_container_decode_bound_is_a_host_walk(amd):
+    """lz4hip_container_decode_bound (no device work: runs without a GPU) sizes the destination of lz4hip_container_decode by what
+    the body holds -- round-4 advisor: the readers allocated nMax x maxBlock (256 MiB for a 100-byte frame; gigabytes for one LZ4Block
+    header with level nibble 15).  Frame bodies: max_block per compressed block, the stored size of a raw one; LZ4Block: the headers'
+    original lengths; the walk stops where the device walk stops (end mark, a block cut short, a damaged header, n_max)."""
+    import ctypes as C
+    import struct
+    l = amd.lib()
+
+    def bound(kind, flags, body, max_block, n_max):
+        nb, need = C.c_uint32(0), C.c_uint64(0)
+        buf = (C.c_uint8 * max(len(body), 1)).from_buffer_copy(body + b"\0" * (0 if body else 1))
+        assert l.lz4hip_container_decode_bound(kind, flags, buf, len(body), max_block, n_max, C.byref(nb), C.byref(need)) == 0
+        return nb.value, need.value
+    blk = lambda size, raw=False: struct.pack("<I", size | (0x80000000 if raw else 0)) + bytes(size)
+    body = blk(100) + blk(70, raw=True) + blk(5) + struct.pack("<I", 0) + b"trailing"
+    assert bound(0, 0, body, 4 << 20, 64) == (3, 2 * (4 << 20) + 70)
+    assert bound(0, 0, body, 4 << 20, 2) == (2, (4 << 20) + 70)            # n_max
+    assert bound(0, 0, body[:150], 4 << 20, 64) == (1, 4 << 20)            # the second block is cut short
+    assert bound(0, 1, blk(10) + b"CKSM" + blk(10)[:8], 65536, 64) == (1, 65536)   # block checksums: 4 more bytes per block
+    assert bound(0, 0, blk(70000), 65536, 64) == (0, 0)                    # size > max_block: the walk stops (the device says why)
+    assert bound(0, 0, b"", 65536, 64) == (0, 0)
+    hdr = lambda method, level, clen, olen: b"LZ4Block" + bytes([method | level]) + struct.pack("<iiI", clen, olen, 0)
+    bs = hdr(0x20, 6, 50, 1000) + bytes(50) + hdr(0x10, 6, 30, 30) + bytes(30) + hdr(0x10, 6, 0, 0)
+    assert bound(1, 0, bs, 1 << 16, 256) == (2, 1030)                      # stops at the empty block
+    assert bound(1, 0, hdr(0x20, 15, 0x7FFFFFF0, 1 << 25), 1 << 25, 256) == (0, 0)   # one header, a huge compressedLen: nothing to allocate
+    assert bound(1, 0, b"LZ4Blocc" + bs[8:], 1 << 16, 256) == (0, 0)       # damaged magic
+    nb, need = C.c_uint32(0), C.c_uint64(0)
+    assert l.lz4hip_container_decode_bound(2, 0, None, 0, 65536, 1, C.byref(nb), C.byref(need)) != 0      # kind
+    assert l.lz4hip_container_decode_bound(0, 0, None, 0, 65536, 0, C.byref(nb), C.byref(need)) != 0      # n_max
+
+
 def test_range_checks_before_native(amd):
     """argument checking order of LZ4JNICompressor.java:47-49 / SafeUtils.java:24-42 (no GPU needed:
     the checks fire before the native call)"""

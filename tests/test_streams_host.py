@@ -61,6 +61,27 @@ def test_with_length(S, engine, port, O, data):
     sc.case_with_length(S, engine, port, data, hc_engine=sc.OracleEngine(port, O, hcLevel=9))
 
 
+@pytest.fixture(scope="module")
+def dev_engine(port, O):
+    return sc.OracleDeviceEngine(port, O)
+
+
+def test_device_read_path_logic_on_the_cpu(S, dev_engine, port, data):
+    """the readers' DEVICE-PATH logic (a chunk of container bytes to engine.containerDecode, stop reasons -> the reference's
+    exceptions, unconsumed bytes handed back) with a host restatement of the device walk standing in for the GPU: the frame and
+    LZ4Block cases of this file once more, through that path"""
+    c0 = dev_engine.calls
+    sc.case_frame_layout_and_roundtrip(S, dev_engine, port, data)
+    sc.case_frame_concat_skippable_single(S, dev_engine, data)
+    sc.case_frame_errors(S, dev_engine, data)
+    sc.case_block_stream(S, dev_engine, port, data)
+    assert dev_engine.calls - c0 > 50          # (the device path did the reading)
+
+
+def test_device_read_path_advisor_findings(S, dev_engine, data):
+    sc.case_device_read_path_advisor_findings(S, dev_engine, data)
+
+
 def test_default_engine_is_the_gpu_batch_engine_and_fails_loudly_without_a_gpu(S, amd):
     import io
     import torch
