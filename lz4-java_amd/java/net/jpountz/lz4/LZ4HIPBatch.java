@@ -103,4 +103,57 @@ public final class LZ4HIPBatch {
     }
     return r;
   }
+
+  /** Stop reasons of {@link #containerDecode} ({@code info[2]}; include/lz4hip.h). */
+  public static final int CR_END = 0, CR_MORE = 1, CR_TRUNCATED = 2, CR_BLOCK_TOO_BIG = 3, CR_BLOCK_CHECKSUM = 4, CR_DECODE = 5,
+      CR_CORRUPT = 6, CR_SLOTS = 7;
+
+  /**
+   * Destination bytes a {@link #containerDecode} call over {@code src[srcOff, srcOff+len)} can need: a host-side walk of the size
+   * words / headers (frame: {@code maxBlock} per compressed block, the stored size of a raw one; LZ4Block: the headers' original
+   * lengths).  {@code blocks[0]} receives the number of whole blocks present (at most {@code nMax}).
+   */
+  public static long containerDecodeBound(int kind, boolean blockChecksum, ByteBuffer src, long srcOff, long len, int maxBlock, int nMax,
+                                          int[] blocks) {
+    if (!src.isDirect()) {
+      throw new IllegalArgumentException("LZ4HIPBatch needs direct ByteBuffers");
+    }
+    if (srcOff < 0 || len < 0 || srcOff + len > src.capacity()) {
+      throw new ArrayIndexOutOfBoundsException();
+    }
+    final long r = LZ4HIPJNI.LZ4HIP_containerDecodeBound(kind, blockChecksum ? 1 : 0, src, srcOff, len, maxBlock, nMax, blocks);
+    if (r < 0) {
+      throw new LZ4Exception("liblz4hip status " + r + ": " + LZ4HIPJNI.lastError());
+    }
+    return r;
+  }
+
+  /**
+   * The READ side of the container formats on the device: the data blocks of an LZ4 Frame body ({@link #FRAME_BLOCKS}: {@code src}
+   * from the first block's size word on; {@code maxBlock} = the frame's block maximum size) or of an LZ4Block stream
+   * ({@link #LZ4BLOCK_BLOCKS}; {@code maxBlock} = an upper bound of the original lengths, {@code 1 << (10 + level nibble)}) are
+   * walked, verified and decoded there -- what {@code LZ4FrameInputStream.readBlock} / {@code LZ4BlockInputStream.refill} do block
+   * by block, for up to {@code nMax} blocks in one call.  The decoded blocks land back to back at {@code dest[destOff..)},
+   * {@code sizes[k]} = decoded size of block k, {@code info} = {blocks delivered, bytes of src consumed, stop reason (CR_*), decoded
+   * bytes, liblz4's code of a failed decode}.  The reader maps the stop reason to the reference's exception and goes on from
+   * {@code srcOff + info[1]}.
+   */
+  public static void containerDecode(int kind, boolean blockChecksum, ByteBuffer src, long srcOff, long len, int maxBlock, int nMax,
+                                     ByteBuffer dest, long destOff, int[] sizes, long[] info) {
+    if (!src.isDirect() || !dest.isDirect()) {
+      throw new IllegalArgumentException("LZ4HIPBatch needs direct ByteBuffers");
+    }
+    if (dest.isReadOnly()) {
+      throw new java.nio.ReadOnlyBufferException();
+    }
+    if (srcOff < 0 || len < 0 || destOff < 0 || srcOff + len > src.capacity() || destOff > dest.capacity() || sizes.length < nMax
+        || info.length < 5) {
+      throw new ArrayIndexOutOfBoundsException();
+    }
+    final int r = LZ4HIPJNI.LZ4HIP_containerDecode(kind, blockChecksum ? 1 : 0, src, srcOff, len, maxBlock, nMax, dest, destOff,
+        dest.capacity() - destOff, sizes, info);
+    if (r != 0) {
+      throw new LZ4Exception("liblz4hip status " + r + ": " + LZ4HIPJNI.lastError());
+    }
+  }
 }

@@ -66,5 +66,13 @@ enum LZ4HIPJNI {
   static native long LZ4HIP_containerBlocks(int kind, int flags, int level, ByteBuffer src, long srcOff, long len, int blockSize,
       ByteBuffer dest, long destOff, long destCap);
 
+  /** The read side on the device (LZ4HIPBatch.containerDecode); returns 0 or the negative lz4hip_status. */
+  static native int LZ4HIP_containerDecode(int kind, int flags, ByteBuffer src, long srcOff, long len, int maxBlock, int nMax,
+      ByteBuffer dest, long destOff, long destCap, int[] sizes, long[] info);
+
+  /** Destination bytes a containerDecode call can need (host-side walk of the headers); blocks[0] = whole blocks present. */
+  static native long LZ4HIP_containerDecodeBound(int kind, int flags, ByteBuffer src, long srcOff, long len, int maxBlock, int nMax,
+      int[] blocks);
+
   static native String lastError();
 }

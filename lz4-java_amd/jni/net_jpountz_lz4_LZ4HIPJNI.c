@@ -181,6 +181,47 @@ JNIEXPORT jlong JNICALL Java_net_jpountz_lz4_LZ4HIPJNI_LZ4HIP_1containerBlocks(J
   return rc == 0 ? (jlong)out : (jlong)rc;   /* (status codes are negative) */
 }
 
+/* the READ side (include/lz4hip.h lz4hip_container_decode): the data blocks of an LZ4 Frame body (kind 0: from the first block's size
+ * word on; flags & 1 = block checksums; maxBlock = the frame's block maximum) / of an LZ4Block stream (kind 1) in
+ * src[srcOff, srcOff + len) are walked, verified and decoded on the device -- LZ4FrameInputStream.readBlock (LZ4FrameInputStream.java:
+ * 258-322) / LZ4BlockInputStream.refill (LZ4BlockInputStream.java:191-264) for a run of up to nMax blocks in one call.  The decoded
+ * blocks land back to back at dest[destOff ..); sizes[k] = decoded size of block k; info[0..4] = { blocks delivered, bytes of src
+ * consumed, stop reason, decoded bytes, liblz4's code of a failed decode }.  Direct buffers; returns 0 or the (negative)
+ * lz4hip_status.  LZ4HIPBatch.containerDecodeBound tells how much of dest a call can need. */
+JNIEXPORT jint JNICALL Java_net_jpountz_lz4_LZ4HIPJNI_LZ4HIP_1containerDecode(JNIEnv* env, jclass cls, jint kind, jint flags, jobject src, jlong srcOff,
+    jlong len, jint maxBlock, jint nMax, jobject dest, jlong destOff, jlong destCap, jintArray sizes, jlongArray info) {
+  (void)cls;
+  const uint8_t* s = (const uint8_t*)(*env)->GetDirectBufferAddress(env, src);
+  uint8_t* d = (uint8_t*)(*env)->GetDirectBufferAddress(env, dest);
+  if (s == NULL || d == NULL || srcOff < 0 || len < 0 || destOff < 0 || destCap < 0 || maxBlock <= 0 || nMax <= 0) return LZ4HIP_E_ARG;
+  if ((*env)->GetArrayLength(env, sizes) < nMax || (*env)->GetArrayLength(env, info) < 5) return LZ4HIP_E_ARG;
+  jint* sz = (*env)->GetIntArrayElements(env, sizes, NULL);
+  jlong* inf = (*env)->GetLongArrayElements(env, info, NULL);
+  jint rc = LZ4HIP_E_NOMEM;
+  if (sz && inf) rc = lz4hip_container_decode(kind, flags, s + srcOff, (uint64_t)len, (uint32_t)maxBlock, (uint32_t)nMax, d + destOff, (uint64_t)destCap,
+                                              (int32_t*)sz, (uint64_t*)inf);
+  if (sz) (*env)->ReleaseIntArrayElements(env, sizes, sz, 0);
+  if (inf) (*env)->ReleaseLongArrayElements(env, info, inf, 0);
+  return rc;
+}
+/* what a containerDecode call can need of dest (a host-side walk of the headers, no device work): returns the bytes, or the (negative)
+ * lz4hip_status; blocks[0] = whole blocks of the first nMax that src holds */
+JNIEXPORT jlong JNICALL Java_net_jpountz_lz4_LZ4HIPJNI_LZ4HIP_1containerDecodeBound(JNIEnv* env, jclass cls, jint kind, jint flags, jobject src, jlong srcOff,
+    jlong len, jint maxBlock, jint nMax, jintArray blocks) {
+  (void)cls;
+  const uint8_t* s = (const uint8_t*)(*env)->GetDirectBufferAddress(env, src);
+  if (s == NULL || srcOff < 0 || len < 0 || (*env)->GetArrayLength(env, blocks) < 1) return (jlong)LZ4HIP_E_ARG;
+  uint32_t nb = 0;
+  uint64_t need = 0;
+  const int rc = lz4hip_container_decode_bound(kind, flags, s + srcOff, (uint64_t)len, (uint32_t)maxBlock, (uint32_t)nMax, &nb, &need);
+  if (rc != 0) return (jlong)rc;
+  jint* b = (*env)->GetIntArrayElements(env, blocks, NULL);
+  if (b == NULL) return (jlong)LZ4HIP_E_NOMEM;
+  b[0] = (jint)nb;
+  (*env)->ReleaseIntArrayElements(env, blocks, b, 0);
+  return (jlong)need;
+}
+
 /* ---- xxhash (XXHashJNI.c:42-82, :152-192 counterparts) ---- */
 static int hash_region(JNIEnv* env, jbyteArray arr, jobject buf, jint off, jint len, int is64, uint64_t seed, uint64_t* out) {
   region_t in;

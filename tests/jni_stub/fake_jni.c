@@ -55,8 +55,10 @@ static jint* f_GetInts(JNIEnv* e, jintArray a, jboolean* c) { (void)e; if (c) *c
 static void f_RelLongs(JNIEnv* e, jlongArray a, jlong* p, jint m) { (void)e; (void)p; (void)m; ((fobj*)a)->pins--; }
 static void f_RelInts(JNIEnv* e, jintArray a, jint* p, jint m) { (void)e; (void)p; (void)m; ((fobj*)a)->pins--; }
 
+static jint f_ArrayLength(JNIEnv* e, jarray a) { (void)e; const fobj* o = (const fobj*)a; return (jint)(o->bytes / (o->kind == 3 ? 8u : o->kind == 2 ? 4u : 1u)); }
+
 static const struct JNINativeInterface_ g_table = {f_FindClass, f_ThrowNew, f_NewGlobalRef, f_GetCritical, f_ReleaseCritical, f_GetDirect,
-                                                   f_NewStringUTF, f_GetLongs, f_GetInts, f_RelLongs, f_RelInts};
+                                                   f_NewStringUTF, f_GetLongs, f_GetInts, f_RelLongs, f_RelInts, f_ArrayLength};
 static JNIEnv g_env = &g_table;
 
 static fobj* mk(int kind, size_t bytes) { fobj* o = calloc(1, sizeof *o); o->kind = kind; o->bytes = bytes; o->data = calloc(bytes ? bytes : 1, 1); return o; }
@@ -73,6 +75,8 @@ JNIEXPORT jint JNICALL Java_net_jpountz_lz4_LZ4HIPJNI_LZ4HIP_1compressBound(JNIE
 JNIEXPORT jstring JNICALL Java_net_jpountz_lz4_LZ4HIPJNI_lastError(JNIEnv*, jclass);
 JNIEXPORT jint JNICALL Java_net_jpountz_lz4_LZ4HIPJNI_LZ4HIP_1batch(JNIEnv*, jclass, jint, jint, jobject, jlongArray, jintArray, jobject, jlongArray, jintArray, jintArray, jint);
 JNIEXPORT jlong JNICALL Java_net_jpountz_lz4_LZ4HIPJNI_LZ4HIP_1containerBlocks(JNIEnv*, jclass, jint, jint, jint, jobject, jlong, jlong, jint, jobject, jlong, jlong);
+JNIEXPORT jint JNICALL Java_net_jpountz_lz4_LZ4HIPJNI_LZ4HIP_1containerDecode(JNIEnv*, jclass, jint, jint, jobject, jlong, jlong, jint, jint, jobject, jlong, jlong, jintArray, jlongArray);
+JNIEXPORT jlong JNICALL Java_net_jpountz_lz4_LZ4HIPJNI_LZ4HIP_1containerDecodeBound(JNIEnv*, jclass, jint, jint, jobject, jlong, jlong, jint, jint, jintArray);
 JNIEXPORT jint JNICALL Java_net_jpountz_xxhash_XXHashHIPJNI_XXH32(JNIEnv*, jclass, jbyteArray, jint, jint, jint);
 JNIEXPORT jint JNICALL Java_net_jpountz_xxhash_XXHashHIPJNI_XXH32BB(JNIEnv*, jclass, jobject, jint, jint, jint);
 JNIEXPORT jlong JNICALL Java_net_jpountz_xxhash_XXHashHIPJNI_XXH64(JNIEnv*, jclass, jbyteArray, jint, jint, jlong);
@@ -208,7 +212,34 @@ int main(int argc, char** argv) {
         p += 4 + (size_t)c;
       }
       CHECK((jlong)p == got);
-      CHECK(Java_net_jpountz_lz4_LZ4HIPJNI_LZ4HIP_1containerBlocks(env, NULL, 0, 0, 0, (jobject)dsrc, 100, (jlong)n * blk, blk, (jobject)dback, 0, 10) < 0); } }
+      CHECK(Java_net_jpountz_lz4_LZ4HIPJNI_LZ4HIP_1containerBlocks(env, NULL, 0, 0, 0, (jobject)dsrc, 100, (jlong)n * blk, blk, (jobject)dback, 0, 10) < 0);
+      /* ... and the READ side (LZ4HIPBatch.containerDecode): the frame body just assembled, walked and decoded on the device: every
+         block back, the whole body consumed, stop reason 1 (the body ended at a block boundary); then the same body with an end mark
+         behind it (reason 0), cut short inside the last block (reason 2, n - 1 blocks), and with a damaged payload (reason 5) */
+      fobj* body = mk(4, (size_t)got + 16);
+      memcpy(body->data, dback->data, (size_t)got);
+      fobj* szs = mk(2, sizeof(jint) * 64); fobj* inf = mk(3, sizeof(jlong) * 5); fobj* nbk = mk(2, sizeof(jint));
+      const jlong need = Java_net_jpountz_lz4_LZ4HIPJNI_LZ4HIP_1containerDecodeBound(env, NULL, 0, 0, (jobject)body, 0, got, blk, 64, (jintArray)nbk);
+      CHECK(no_exc() && need == (jlong)n * blk && ((jint*)nbk->data)[0] == n);
+      fobj* dec = mk(4, (size_t)need + 64);
+      jint rc2 = Java_net_jpountz_lz4_LZ4HIPJNI_LZ4HIP_1containerDecode(env, NULL, 0, 0, (jobject)body, 0, got, blk, 64, (jobject)dec, 32, need, (jintArray)szs, (jlongArray)inf);
+      CHECK(no_exc() && rc2 == 0);
+      { const jlong* I = (const jlong*)inf->data;
+        CHECK(I[0] == n && I[1] == got && I[2] == 1 && I[3] == (jlong)n * blk);
+        for (int i = 0; i < n; i++) CHECK(((jint*)szs->data)[i] == blk);
+        CHECK(memcmp(dec->data + 32, dsrc->data + 100, (size_t)n * blk) == 0); }
+      memset(body->data + got, 0, 4);                                   /* the end mark */
+      rc2 = Java_net_jpountz_lz4_LZ4HIPJNI_LZ4HIP_1containerDecode(env, NULL, 0, 0, (jobject)body, 0, got + 4, blk, 64, (jobject)dec, 32, need, (jintArray)szs, (jlongArray)inf);
+      CHECK(rc2 == 0 && ((jlong*)inf->data)[0] == n && ((jlong*)inf->data)[1] == got + 4 && ((jlong*)inf->data)[2] == 0);
+      rc2 = Java_net_jpountz_lz4_LZ4HIPJNI_LZ4HIP_1containerDecode(env, NULL, 0, 0, (jobject)body, 0, got - 7, blk, 64, (jobject)dec, 32, need, (jintArray)szs, (jlongArray)inf);
+      CHECK(rc2 == 0 && ((jlong*)inf->data)[0] == n - 1 && ((jlong*)inf->data)[2] == 2);
+      body->data[4 + 3] ^= 0x5A; body->data[4 + 9] ^= 0xA5;             /* block 0's payload */
+      rc2 = Java_net_jpountz_lz4_LZ4HIPJNI_LZ4HIP_1containerDecode(env, NULL, 0, 0, (jobject)body, 0, got, blk, 64, (jobject)dec, 32, need, (jintArray)szs, (jlongArray)inf);
+      CHECK(rc2 == 0 && ((jlong*)inf->data)[0] <= 1 && (((jlong*)inf->data)[2] == 5 || ((jlong*)inf->data)[0] == 0));
+      CHECK(Java_net_jpountz_lz4_LZ4HIPJNI_LZ4HIP_1containerDecode(env, NULL, 0, 0, (jobject)body, 0, got, blk, 64, (jobject)dec, 32, 10, (jintArray)szs, (jlongArray)inf) != 0 ||
+            ((jlong*)inf->data)[0] == 0);                               /* a destination that is too small is an error, not an overrun */
+      CHECK(no_exc() && szs->pins == 0 && inf->pins == 0 && nbk->pins == 0);
+      free(body->data); free(body); free(szs->data); free(szs); free(inf->data); free(inf); free(nbk->data); free(nbk); free(dec->data); free(dec); } }
 
   /* ---- 5. xxhash: one-shot (heap + direct), batch, streaming; known answers of SURVEY App. D ---- */
   memcpy(src->data + 7, README_IN, 14);

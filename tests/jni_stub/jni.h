@@ -6,7 +6,7 @@
 #define JNIEXPORT __attribute__((visibility("default")))
 #define JNICALL
 #define JNI_ABORT 2
-typedef int32_t jint; typedef int64_t jlong; typedef int8_t jbyte; typedef uint8_t jboolean;
+typedef int32_t jint; typedef int32_t jsize; typedef int64_t jlong; typedef int8_t jbyte; typedef uint8_t jboolean;
 typedef void* jobject; typedef jobject jclass; typedef jobject jstring; typedef jobject jarray;
 typedef jarray jbyteArray; typedef jarray jintArray; typedef jarray jlongArray;
 struct JNINativeInterface_;
@@ -23,5 +23,6 @@ struct JNINativeInterface_ {
   jint* (*GetIntArrayElements)(JNIEnv*, jintArray, jboolean*);
   void (*ReleaseLongArrayElements)(JNIEnv*, jlongArray, jlong*, jint);
   void (*ReleaseIntArrayElements)(JNIEnv*, jintArray, jint*, jint);
+  jint (*GetArrayLength)(JNIEnv*, jarray);
 };
 #endif
