@@ -75,6 +75,14 @@ def kernel_traffic(tr, world, *names):
     return int(sum(k[n] for n in names))
 
 
+def text_traffic(tr, world, n_blocks, leg, what):
+    """HBM bytes per launch of a real-text leg (profiles/traffic.json "text": PMC passes of tools/gpu_text_legs.py, which runs those
+    legs alone); None unless measured, at N = 1 and the bench's default batch"""
+    if world != 1 or n_blocks != 65536:
+        return None
+    return (((tr or {}).get("text") or {}).get(leg) or {}).get(what)
+
+
 def cpu_bench(args, env=None):
     """runs oracle/cpu_bench (the reference's liblz4 through dlopen, or the C port) and returns its JSON line"""
     from oracle import oracle as O
@@ -444,8 +452,9 @@ def main():
                                                "safe decompress, ratio %.3f; compressed bytes of 48 blocks vs the reference library" % (n, nbytes / csb),
                                    "unit": "GB/s", "verified": okb,
                                    "compress_GBps": round(world * nbytes / wc / 1e9, 3), "decompress_GBps": round(world * nbytes / wd / 1e9, 3),
-                                   "roofline_compress": roof("compress_fast_v2w_cu_kernel + compress_fast_ms_cu_kernel", nbytes + csb, tkc, None),
-                                   "roofline_decode": roof(decode_kernel_name(n), nbytes + csb, tkd, None)}
+                                   # (HBM bytes of these launches: PMC passes of the text legs by themselves, tools/gpu_text_legs.py)
+                                   "roofline_compress": roof("compress_fast_v2w_cu_kernel + compress_fast_ms_cu_kernel", nbytes + csb, tkc, text_traffic(tr, world, n, "real_book1", "compress")),
+                                   "roofline_decode": roof(decode_kernel_name(n), nbytes + csb, tkd, text_traffic(tr, world, n, "real_book1", "decode"))}
             ok = ok and okb
             if want_cpu:
                 def fb():
@@ -487,7 +496,7 @@ def main():
             extra["real_book1_4MiB"] = {"workload": "%d x 4 MiB blocks of book1 text per GPU, fast compress (byU32, packed entries, ten chains per CU), ratio %.3f; "
                                                     "compressed bytes of 3 blocks vs the reference library" % (nT, nT * bT / csT),
                                         "value": round(world * float(nT) * bT / wT / 1e9, 3), "unit": "GB/s", "verified": okT,
-                                        "roofline": roof("compress_fast_v2wp_cu_kernel", float(nT) * bT + csT, tkT, None)}
+                                        "roofline": roof("compress_fast_v2wp_cu_kernel", float(nT) * bT + csT, tkT, text_traffic(tr, world, n, "real_book1_4MiB", "compress") if nT == 2560 else None)}
             ok = ok and okT
             del sT, cT, BT, arT
             del bdev, offs
@@ -555,7 +564,7 @@ def main():
                                         "value": round(float(nS) * b3 / wS / 1e9, 3), "unit": "GB/s", "verified": okS,
                                         "predicted_8gpu_aggregate_GBps": round(8.0 * nS * b3 / wS / 1e9, 1),
                                         "note": "predicted aggregate = 8 x this GPU's rate (independent shards); not a multi-GPU measurement",
-                                        "roofline": roof(decode_kernel_name(nS, True, True), float(nS) * b3 + csS, tkS, None)}
+                                        "roofline": roof(decode_kernel_name(nS, True, True), float(nS) * b3 + csS, tkS, kernel_traffic(tr, world, decode_kernel_name(nS, True, True)))}
             extra["configs2_shard8_compress"] = {"workload": "the same 2048 x 4 MiB shard, LZ4_compress_default (byU32)",
                                                  "value": round(float(nS) * b3 / wSc / 1e9, 3), "unit": "GB/s", "verified": None,
                                                  "predicted_8gpu_aggregate_GBps": round(8.0 * nS * b3 / wSc / 1e9, 1),

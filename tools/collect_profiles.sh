@@ -21,12 +21,15 @@ db=$(find gpurun_out/prof_$tag -name "*.db" | head -1)
  echo "# command: rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline   (all configs; 1x MI355X)"
  python tools/rocprof_summary.py $db lz4hip) > gpurun_out/${tag}_bench_all_configs_kernel_trace.txt
 tools/traffic_passes.sh gpurun_out/traffic_$tag 2 > /dev/null
-python tools/traffic_json.py gpurun_out/traffic_$tag 65536 65536 "profiles/${tag}_traffic_pmc.txt (tools/traffic_passes.sh: separate rocprofv3 --pmc passes of bench.py, 1x MI355X)"
+tools/traffic_passes.sh gpurun_out/traffic_text_$tag 2 text > /dev/null     # the real-text legs by themselves (tools/gpu_text_legs.py)
+python tools/traffic_json.py gpurun_out/traffic_$tag 65536 65536 "profiles/${tag}_traffic_pmc.txt (tools/traffic_passes.sh: separate rocprofv3 --pmc passes of bench.py, 1x MI355X)" gpurun_out/traffic_text_$tag
 cp profiles/traffic.json gpurun_out/traffic_$tag.json
 (echo "# profiles/${tag}_traffic_pmc.txt"
  echo "# command: tools/traffic_passes.sh (one rocprofv3 --kernel-trace --pmc <set> run per counter set; bench.py --steps 2 --warmup 1 --no-cpu-baseline, all configs)"
- for t in gpurun_out/traffic_$tag/*/; do db=$(find $t -name "*.db" | head -1); python tools/rocprof_summary.py $db lz4hip | grep -v "^$"; done) > gpurun_out/${tag}_traffic_pmc.txt
-rm -rf gpurun_out/prof_$tag gpurun_out/traffic_$tag
+ for t in gpurun_out/traffic_$tag/*/; do db=$(find $t -name "*.db" | head -1); python tools/rocprof_summary.py $db lz4hip | grep -v "^$"; done
+ echo "# the real-text legs alone (tools/gpu_text_legs.py):"
+ for t in gpurun_out/traffic_text_$tag/*/; do db=$(find $t -name "*.db" | head -1); python tools/rocprof_summary.py $db lz4hip | grep -v "^$"; done) > gpurun_out/${tag}_traffic_pmc.txt
+rm -rf gpurun_out/prof_$tag gpurun_out/traffic_$tag gpurun_out/traffic_text_$tag
 # the bench line last: it quotes profiles/traffic.json, which the passes above have just rewritten
 python bench.py 2>&1 | tail -1 > gpurun_out/${tag}_bench_line.json
 cat gpurun_out/${tag}_bench_line.json

@@ -3,6 +3,7 @@
 usage: traffic_json.py <passes dir> <blocks_per_gpu> <block_bytes> <source tag>"""
 import glob, hashlib, json, os, sqlite3, sys
 d, n, blk, tag = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+text_dir = sys.argv[5] if len(sys.argv) > 5 else None   # passes of tools/gpu_text_legs.py (the real-text legs alone)
 vals = {}
 full = {}   # every lz4hip kernel by its full (template) name: "decode_kernel<8, true, 2, false>", ...
 def norm(k):
@@ -24,7 +25,9 @@ for db in glob.glob(os.path.join(d, "*", "pmc_results.db")):
     # (16384 x 4 MiB, the biggest by far): it is represented by its BIGGEST dispatch.
     # compress_fast_v2wp_cu_kernel (blocks of 65547 bytes .. 4 MiB) is launched with every fast compress and returns at once when the
     # batch has no such block: its real launch is the biggest one (compress_4MiB).
-    BIGGEST = ("decode_deep_kernel<8, true>", "decode_ring_kernel<4, 2048, true>", "compress_fast_v2wp_cu_kernel")
+    # decode_wave_kernel<8, 16384, ..> (a wavefront per block): the configs2_shard8 launch (2048 x 4 MiB) and small launches of 64 KiB
+    # blocks: its biggest dispatch is the shard
+    BIGGEST = ("decode_deep_kernel<8, true>", "decode_ring_kernel<4, 2048, true>", "compress_fast_v2wp_cu_kernel", "decode_wave_kernel<8, 16384")
     for (k, c), vs in rows.items():
         if any(h in k for h in HEADLINE_FIRST):
             vs = vs[:3]
@@ -64,5 +67,21 @@ out["kernels_read_bytes_by_request_size"] = {
     k: int(128 * c["TCC_EA0_RDREQ_128B_sum"] + 64 * c["TCC_EA0_RDREQ_64B_sum"] + 32 * c["TCC_EA0_RDREQ_32B_sum"])
     for k, c in full.items() if all(x in c for x in ("TCC_EA0_RDREQ_128B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_32B_sum"))}
 out["kernels"] = {k: int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024) for k, c in full.items() if "FETCH_SIZE" in c and "WRITE_SIZE" in c}
+if text_dir:
+    # the text legs' launches, from passes of their own command: every kernel by its BIGGEST dispatch (the five-pair and the packed
+    # kernel are both launched with every fast compress and the one that has no block of its kind returns at once)
+    tk = {}
+    for db in glob.glob(os.path.join(text_dir, "*", "pmc_results.db")):
+        con = sqlite3.connect(db)
+        for k, c, v in con.execute("select kernel_name, counter_name, value from counters_collection where kernel_name like '%%lz4hip%%'"):
+            e = tk.setdefault(norm(k), {})
+            e[c] = max(e.get(c, 0), v)
+    tb = {k: int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024) for k, c in tk.items() if "FETCH_SIZE" in c and "WRITE_SIZE" in c}
+    def pick(*subs):
+        vs = [v for k, v in tb.items() if any(s_ in k for s_ in subs)]
+        return int(sum(vs)) if vs else None
+    out["text"] = {"real_book1": {"compress": pick("compress_fast_v2w_cu_kernel", "compress_fast_ms_cu_kernel"), "decode": pick("decode_kernel<4, true, 0, true>")},
+                   "real_book1_4MiB": {"compress": pick("compress_fast_v2wp_cu_kernel")},
+                   "kernels": tb, "source": "tools/gpu_text_legs.py under tools/traffic_passes.sh <dir> 2 text"}
 json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json"), "w"), indent=1, sort_keys=True)
 print(json.dumps(out["kernels"]))
