@@ -430,6 +430,12 @@ struct BlockWaveDev : GroupDev<64, 0> {
   typedef GroupDev<64, 0> Base;
   typedef typename Base::LChunk LChunk;   // one dword
   static_assert(Base::LB == 4u, "a lane of the wave loop moves one dword");
+  // 256-byte windows of the stream a parallel trip discovers (lz4_decode_wave.h).  TWO (possible where KS >= 2048) were built and measured
+  // (gpurun_out/r05l-p, tools/wave_stats.py): 21.8 instead of 9.9 sequences per trip on BASELINE configs[2]'s blocks, and the same time per
+  // block (2048 x 4 MiB 30.7 -> 32.8 ms, 512 x 64 KiB App. F 0.70 -> 1.00 ms): a trip's cost is not fixed work to be spread -- the walk
+  // (13 instructions per start), the copy rounds (~220 each) and the discovery (190 per window) all grow with what a trip carries
+  // (1673 instead of 901 instructions).  One window; the two-window form stays in the source and in the simulator's tests.
+  static constexpr uint32_t kWaveWindows = 1u;
   static constexpr uint32_t kWaveLds = (uint32_t)KS + 16u + 16u + (uint32_t)KW + 32u;   // (32 tail: the first 16 ring bytes mirrored, plus a dword's reach)
   uint8_t* wsb = nullptr;   // stream ring
   uint8_t* wrb = nullptr;   // output ring, index 0
@@ -504,6 +510,12 @@ struct BlockWaveDev : GroupDev<64, 0> {
     v.w[0] = *Base::dwp(wrb + ((fw + l4) & ((uint32_t)KW - 1u)));
     return v;
   }
+#ifdef LZ4HIP_RING_DBG
+  __device__ __forceinline__ void wv_stats(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t e, uint32_t f, uint32_t h) const {
+    if (this->l == 0u) { atomicAdd(&g_ring_stat[0], a); atomicAdd(&g_ring_stat[1], b); atomicAdd(&g_ring_stat[2], c); atomicAdd(&g_ring_stat[3], d);
+                         atomicAdd(&g_ring_stat[4], e); atomicAdd(&g_ring_stat[5], f); atomicAdd(&g_ring_stat[6], h); atomicAdd(&g_ring_stat[7], 1ull); }
+  }
+#endif
   // ---- lane-parallel side (the parallel trips of lz4_decode_wave.h): per-lane values are plain scalars (SIMT) ----
   typedef uint32_t VU;
   typedef bool VB;
@@ -512,6 +524,8 @@ struct BlockWaveDev : GroupDev<64, 0> {
   __device__ __forceinline__ static uint64_t vballot(bool b) { return __builtin_amdgcn_ballot_w64(b); }
   __device__ __forceinline__ static uint32_t vreadlane(VU v, uint32_t i) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)i); }
   __device__ __forceinline__ static VU vwritelane(VU v, uint32_t s, uint32_t i) {
+    s = (uint32_t)__builtin_amdgcn_readfirstlane((int)s);   // (wave-uniform values the compiler happens to hold in a vector register reach the asm as one: folds away when they are scalar already)
+    i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
     asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(s), "s"(i) : "m0");
     return v;
   }

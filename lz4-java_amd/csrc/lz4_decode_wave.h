@@ -240,14 +240,14 @@ LZ4HIP_DEV bool wave_single_step(Grp& g, const uint8_t* dst, uint32_t& ip, uint3
 
 // entry: ip + 1536 <= iend, ip <= iend - 306, op <= oend - 606.  Leaves with ip / op at the first sequence it did not decode;
 // everything below op is in memory then.
-template <class Grp>
+template <class Grp, uint32_t NWIN>   // NWIN: 256-byte windows of the stream per trip (2 needs a stream ring of 2 KB)
 LZ4HIP_DEV void decode_wave_par_loop(Grp& g, const uint8_t* src, const int iend, uint8_t* dst, const int oend, int& ip_io, int& op_io, uint8_t* lds) {
   typedef typename Grp::LChunk LChunk;
   typedef typename Grp::VU VU;
   typedef typename Grp::VB VB;
   constexpr uint32_t STEP = 256u, WIN = 256u, TRIPMAX = 2048u;   // a trip's window of the stream; the most output a trip produces
-  constexpr uint32_t AHEAD = WIN + 256u;   // stream bytes a trip may read from ip on: a sequence that starts at window position <= 250 has its offset word at <= 250 + 2 + 255 and reads 4 bytes there; the copies' 80-byte reads start at <= 252
-                                           // (512: what a 1 KB stream ring always holds in front of ip with one refill step on its way)
+  constexpr uint32_t AHEAD = NWIN * 512u;  // stream bytes a trip may read from ip on: a sequence that starts at window position <= 250 has its offset word at <= 250 + 2 + 255 and reads 4 bytes there; the copies' 80-byte reads start at <= 252;
+                                           // a second window starts at <= 250 + 260.  (512: what a 1 KB stream ring always holds in front of ip with one refill step on its way; 1024 of a 2 KB ring's 1537)
   const uint32_t KW = g.wv_ring(), KS = g.wv_stream();
   uint32_t ip = (uint32_t)ip_io, op = (uint32_t)op_io;
   const uint32_t ilim = (uint32_t)iend - 306u, olim = (uint32_t)oend - 606u;
@@ -260,60 +260,105 @@ LZ4HIP_DEV void decode_wave_par_loop(Grp& g, const uint8_t* src, const int iend,
     g.rs_put(avail, a0); g.rs_put(avail + STEP, a1); g.rs_put(avail + 2u * STEP, a2); g.rs_put(avail + 3u * STEP, a3);
     avail += 4u * STEP;
   }
-  uint32_t fetched = avail;
-  LChunk rf = LChunk();
+  LChunk rf0 = LChunk(), rf1 = LChunk();   // the steps requested at the top of a trip; they go into the ring at its end
   uint32_t fl = (op + db) & ~(STEP - 1u);
   const VU lane = g.vlane();
   const VU p0 = lane * 4u;
+#ifdef LZ4HIP_RING_DBG   /* developer build: what the loop did (tools/wave_stats.py) */
+  uint32_t dbg_trips = 0, dbg_seqs = 0, dbg_rounds = 0, dbg_single = 0, dbg_hungry = 0, dbg_T = 0, dbg_two = 0;
+#endif
 
   for (;;) {
     if (!((ip <= ilim) & (op <= olim))) break;
     // ---- the stream ring holds what this trip may read ----
     if (LZ4HIP_UNLIKELY(ip + AHEAD > avail)) {
-      if (fetched != avail) { g.rs_put(fetched - STEP, rf); avail = fetched; }
-      while ((ip + AHEAD > avail) & (fetched + STEP <= (uint32_t)iend) & (fetched + STEP <= (ip & ~(STEP - 1u)) + KS)) {
-        g.rs_put(fetched, g.rs_fetch(src, fetched));
-        fetched += STEP; avail = fetched;
+#ifdef LZ4HIP_RING_DBG
+      dbg_hungry++;
+#endif
+      while ((ip + AHEAD > avail) & (avail + STEP <= (uint32_t)iend) & (avail + STEP <= (ip & ~(STEP - 1u)) + KS)) {
+        g.rs_put(avail, g.rs_fetch(src, avail));
+        avail += STEP;
       }
       if (ip + AHEAD > avail) break;            // (the end of the stream is near: the loops behind this one do the rest)
     }
-    // ---- 1. discovery: every byte of the window as if a token started there ----
+    // ---- stream refill: REQUESTED here, at the top of the trip, PUT into the ring at its end -- the loads are a whole trip old when
+    // they are waited for, and nothing is carried from trip to trip.  (Carried over -- requested in one trip, put in the next -- a
+    // 2 KB ring could not stay 1 KB ahead of a trip that consumes ~500 bytes: 67 % of the trips found it short and waited for a
+    // synchronous refill, tools/wave_stats.py.)  The ring keeps everything from ip & ~255 on: this trip's reads.  Up to two steps
+    // per trip: what a trip of two windows consumes ----
+    uint32_t nf = 0u;
+    if ((avail + STEP <= (uint32_t)iend) & (avail + STEP <= (ip & ~(STEP - 1u)) + KS)) {
+      rf0 = g.rs_fetch(src, avail);
+      nf = 1u;
+      if ((NWIN > 1u) & (avail + 2u * STEP <= (uint32_t)iend) & (avail + 2u * STEP <= (ip & ~(STEP - 1u)) + KS)) { rf1 = g.rs_fetch(src, avail + STEP); nf = 2u; }
+    }
+    // ---- 1 + 2. discovery and walk, for one window of the stream or (NWIN == 2, where the stream ring holds 1 KB in front of ip)
+    // for two in a row.  The product runs ONE: two carry 21.8 instead of 9.9 sequences per trip and take the same time per block
+    // (group_dev.h kWaveWindows).  posv: where sequence k starts, relative to ip; lanes [0, T0) come from the first window ----
     // (all reads are ALIGNED dwords funnelled in registers: five unaligned reads by 64 lanes kept the CU's LDS busy for ~400 cycles
     // per trip -- SQ_LDS_UNALIGNED_STALL was 80 % of SQ_LDS_IDX_ACTIVE and at 16 wavefronts per CU the LDS, not the wavefronts, set
     // the pace: 4096 x 4 MiB 110 ms, gpurun_out/r05g)
-    VU blo, bhi;
-    g.vs_win(ip, blo, bhi);                     // stream bytes [ip + 4 l, ip + 4 l + 8)
-    VU rec[4];
-    VU nxpack = VU(0u);
-#pragma unroll
-    for (uint32_t j = 0; j < 4u; j++) {
-      const VU w = j == 0u ? blo : ((blo >> (8 * (int)j)) | (bhi << (32 - 8 * (int)j)));   // bytes j, j + 1, ..
-      const VU tl = (w >> 4) & 15u, tm = w & 15u, e1 = (w >> 8) & 255u;
-      const VB l15 = tl == 15u;
-      const VU lit = tl + Grp::vsel(l15, e1, VU(0u));
-      const VU q = p0 + (j + 1u) + Grp::vsel(l15, VU(1u), VU(0u)) + lit;                     // window position of the offset word
-      const VU ow = g.vs_ld32(ip + q);
-      const VU e2 = (ow >> 16) & 255u;
-      const VB m15 = tm == 15u;
-      const VU mlx = tm + Grp::vsel(m15, e2, VU(0u));                                       // match length - 4
-      const VU nxt = q + 2u + Grp::vsel(m15, VU(1u), VU(0u));
-      // lengths of 255 and more are marked 255: "not for a trip" (that includes every run of two or more length bytes)
-      rec[j] = (ow & 0xFFFFu) | (Grp::vmin(lit, VU(255u)) << 16) | (Grp::vmin(mlx, VU(255u)) << 24);
-      nxpack = nxpack | (Grp::vsel(nxt <= 250u, nxt, VU(255u)) << (8 * (int)j));
-    }
-    // ---- 2. walk: the starts of the sequences in the window, the k-th to lane k ----
+    VU rec[NWIN][4];
     VU posv = VU(0u);
-    uint32_t T = 0u, s = 0u;
-    do {
-      posv = Grp::vwritelane(posv, s, T);
-      T++;
-      const uint32_t d = Grp::vreadlane(nxpack, s >> 2);
-      s = (d >> ((s & 3u) * 8u)) & 255u;
-    } while ((s != 255u) & (T < 64u));
-    // ---- 3. records, output positions, the first sequence that is not for this trip ----
+    uint32_t T = 0u, T0 = 0u, base1 = 0u;
+#pragma unroll
+    for (uint32_t wdw = 0; wdw < NWIN; wdw++) {
+      uint32_t wbase = 0u;                      // this window's start, relative to ip
+      if (wdw == 1u) {
+        // the second window starts behind the last sequence of the first: its true end, from its record (the walk only knows
+        // "beyond position 250"); none if that sequence is not simple, or the lanes are used up
+        const uint32_t sp = Grp::vreadlane(posv, T - 1u), sln = sp >> 2, sq = sp & 3u;
+        const uint32_t l0 = Grp::vreadlane(rec[0][0], sln), l1 = Grp::vreadlane(rec[0][1], sln), l2 = Grp::vreadlane(rec[0][2], sln), l3 = Grp::vreadlane(rec[0][3], sln);
+        const uint32_t lr = sq == 0u ? l0 : sq == 1u ? l1 : sq == 2u ? l2 : l3;
+        const uint32_t llit = (lr >> 16) & 255u, lmx = lr >> 24;
+        if (((lr & 0xFFFFu) == 0u) | (llit == 255u) | (lmx == 255u) | (T >= 48u)) break;
+        wbase = sp + 1u + (llit >= 15u ? 1u : 0u) + llit + 2u + (lmx >= 15u ? 1u : 0u);
+        base1 = wbase;
+      }
+      VU blo, bhi;
+      g.vs_win(ip + wbase, blo, bhi);           // stream bytes [ip + wbase + 4 l, + 8)
+      VU nxpack = VU(0u);
+#pragma unroll
+      for (uint32_t j = 0; j < 4u; j++) {
+        const VU w = j == 0u ? blo : ((blo >> (8 * (int)j)) | (bhi << (32 - 8 * (int)j)));   // bytes j, j + 1, ..
+        const VU tl = (w >> 4) & 15u, tm = w & 15u, e1 = (w >> 8) & 255u;
+        const VB l15 = tl == 15u;
+        const VU lit = tl + Grp::vsel(l15, e1, VU(0u));
+        const VU q = p0 + (j + 1u) + Grp::vsel(l15, VU(1u), VU(0u)) + lit;                   // window position of the offset word
+        const VU ow = g.vs_ld32(q + (ip + wbase));
+        const VU e2 = (ow >> 16) & 255u;
+        const VB m15 = tm == 15u;
+        const VU mlx = tm + Grp::vsel(m15, e2, VU(0u));                                     // match length - 4
+        const VU nxt = q + 2u + Grp::vsel(m15, VU(1u), VU(0u));
+        // lengths of 255 and more are marked 255: "not for a trip" (that includes every run of two or more length bytes)
+        rec[wdw][j] = (ow & 0xFFFFu) | (Grp::vmin(lit, VU(255u)) << 16) | (Grp::vmin(mlx, VU(255u)) << 24);
+        nxpack = nxpack | (Grp::vsel(nxt <= 250u, nxt, VU(255u)) << (8 * (int)j));
+      }
+      // the starts of the sequences in the window, the k-th to lane k
+      uint32_t s = 0u;
+      do {
+        posv = Grp::vwritelane(posv, s + wbase, T);
+        T++;
+        const uint32_t d = Grp::vreadlane(nxpack, s >> 2);
+        s = (d >> ((s & 3u) * 8u)) & 255u;
+      } while ((s != 255u) & (T < 64u));
+      if (wdw == 0u) T0 = T;
+    }
+    // ---- 3. records, output positions ----
     const VB act = lane < T;
-    const VU sl = posv >> 2, slot = posv & 3u;
-    const VU r = Grp::vsel(slot == 0u, Grp::vshfl(rec[0], sl), Grp::vsel(slot == 1u, Grp::vshfl(rec[1], sl), Grp::vsel(slot == 2u, Grp::vshfl(rec[2], sl), Grp::vshfl(rec[3], sl))));
+    VU r;
+    {
+      const VU sl = posv >> 2, slot = posv & 3u;
+      r = Grp::vsel(slot == 0u, Grp::vshfl(rec[0][0], sl), Grp::vsel(slot == 1u, Grp::vshfl(rec[0][1], sl), Grp::vsel(slot == 2u, Grp::vshfl(rec[0][2], sl), Grp::vshfl(rec[0][3], sl))));
+    }
+    if (NWIN > 1u) {
+      if (T > T0) {
+        const VU pr = posv - base1;
+        const VU sl = pr >> 2, slot = pr & 3u;
+        const VU r1 = Grp::vsel(slot == 0u, Grp::vshfl(rec[NWIN - 1u][0], sl), Grp::vsel(slot == 1u, Grp::vshfl(rec[NWIN - 1u][1], sl), Grp::vsel(slot == 2u, Grp::vshfl(rec[NWIN - 1u][2], sl), Grp::vshfl(rec[NWIN - 1u][3], sl))));
+        r = Grp::vsel(lane < T0, r, r1);
+      }
+    }
     const VU off = r & 0xFFFFu, lit = (r >> 16) & 255u, ml = (r >> 24) + 4u;
     const VB simple = (off != 0u) & (lit != 255u) & (ml != 259u);   // (tested here, once per real start, not at every speculative position)
     const VU tot = Grp::vsel(act, lit + ml, VU(0u));
@@ -321,53 +366,68 @@ LZ4HIP_DEV void decode_wave_par_loop(Grp& g, const uint8_t* src, const int iend,
     const VU o = ex + op;                       // where the sequence's output starts
     const VU mp = o + lit - off;                // where its match copies from (negative: invalid offset)
     const VU oe = o + tot;
-    // independent: the whole source lies below this trip's output.  held: the ring has the source and keeps it while the trip is
-    // written (the trip touches at most [op, bound): the ring loses what lies below bound - KW); a source the ring does not hold is
-    // FAR and comes from the block's flushed output in memory -- which has everything below the flusher's position (and below the
-    // loop's entry position)
+    const VU send = mp + ml;
+    // held: the ring has the source and keeps it while the trip is written (the trip touches at most [op, bound): the ring loses what
+    // lies below bound - KW); a source the ring does not hold is FAR and comes from the block's flushed output in memory -- which has
+    // everything below the flusher's position (and below the loop's entry position)
     const uint32_t oe_all = Grp::vreadlane(oe, T - 1u);
     const uint32_t bound = (oe_all - op < TRIPMAX ? oe_all : op + TRIPMAX) + 16u;
     const uint32_t memlim = fl > op0 + db ? fl - db : op0;
     const VB held = (mp >= VU(op0)) & ((mp + KW) >= VU(bound));
-    const VB ok = act & simple & (mp < VU(0x80000000u)) & ((mp + ml) <= VU(op)) & (held | ((mp + ml) <= VU(memlim))) &
-                  ((posv + ip) <= VU(ilim)) & (o <= VU(olim)) & ((oe - op) <= VU(TRIPMAX));
+    const VB okb = act & simple & (mp < VU(0x80000000u)) & (held | (send <= VU(memlim))) &
+                   ((posv + ip) <= VU(ilim)) & (o <= VU(olim)) & ((oe - op) <= VU(TRIPMAX));
     // (mp "negative" -- an offset that reaches in front of the block -- is a huge unsigned number: tested by itself, the sums may wrap)
-#ifdef LZ4HIP_WAVE_DBG   /* developer build of the simulator: why trips end (tests/hostsim) */
-    g.vnote(act, simple, mp < VU(0x80000000u), (mp + ml) <= VU(op), held | ((mp + ml) <= VU(memlim)), held, (oe - op) <= VU(TRIPMAX), ok);
+    // ---- 4. copies in DEPENDENCY ROUNDS, a lane per sequence, exact.  A round takes the sequences from lane `a` on whose whole
+    // source lies below the round's own output (the dependency rule); the first one whose source reaches into it starts the next
+    // round, behind this round's stores -- LDS operations of a wavefront execute in order.  A round that would be empty ends the
+    // trip: its first sequence reaches into its OWN output (or is not for a trip at all) ----
+    const VU lp = posv + ip + Grp::vsel(lit >= 15u, VU(2u), VU(1u));
+    uint32_t a = 0u;
+    for (;;) {
+      const uint32_t oa = Grp::vreadlane(o, a);
+      const uint64_t okm = Grp::vballot((okb & (send <= VU(oa))) | (lane < a));
+      const uint32_t Te = (uint32_t)__builtin_ctzll(~okm | (1ull << 63));   // (< 64: lane 63 is never needed)
+#ifdef LZ4HIP_WAVE_DBG   /* developer build of the simulator: why rounds end (tests/hostsim) */
+      g.vnote(act, simple, mp < VU(0x80000000u), (send <= VU(oa)) | (lane < a), held | (send <= VU(memlim)), held, (oe - op) <= VU(TRIPMAX), (okb & (send <= VU(oa))) | (lane < a));
 #endif
-    // ---- stream refill, HERE: the step requested a trip ago goes into the ring and the next one is requested.  Stores count in
-    // vmcnt on this part, so the wait for the requested step is a wait for the flusher's stores too: at the end of the trip (right
-    // behind them, or right in front of them) it cost 2048 x 4 MiB 32.0 ms against 30.1 ms here, where they are half a trip old
-    // (gpurun_out/r05i-k).  The ring keeps everything from ip & ~255 on: this trip's reads ----
-    if ((fetched + STEP <= (uint32_t)iend) & (fetched + STEP <= (ip & ~(STEP - 1u)) + KS)) {
-      if (fetched != avail) { g.rs_put(fetched - STEP, rf); avail = fetched; }
-      rf = g.rs_fetch(src, fetched);
-      fetched += STEP;
+      if (Te == a) break;
+      g.vcopy_seq(o + db, lp, lit, mp + db, ml, (lane >= a) & (lane < Te), dst, mp, !held);
+#ifdef LZ4HIP_RING_DBG
+      dbg_rounds++;
+#endif
+      a = Te;
+      if (a >= T) break;
     }
-    const uint64_t okm = Grp::vballot(ok);
-    const uint32_t Te = (uint32_t)__builtin_ctzll(~okm | (1ull << 63));   // leading sequences that are fine (< 64: lane 63 is never needed)
-    if (LZ4HIP_UNLIKELY(Te == 0u)) {
+#ifdef LZ4HIP_RING_DBG
+    dbg_trips++; dbg_seqs += a; dbg_T += T; dbg_single += a == 0u ? 1u : 0u; dbg_two += T > T0 ? 1u : 0u;
+#endif
+    if (LZ4HIP_UNLIKELY(a == 0u)) {
       if (!wave_single_step(g, dst, ip, op, op0, fl, db, ilim, olim)) break;
     } else {
-      // ---- 4. copies: a lane per sequence, exact ----
-      const VB go = lane < Te;
-      const VU lp = posv + ip + Grp::vsel(lit >= 15u, VU(2u), VU(1u));
-      g.vcopy_seq(o + db, lp, lit, mp + db, ml, go, dst, mp, !held);
-      const uint32_t outb = Grp::vreadlane(oe, Te - 1u) - op;
+      const uint32_t outb = Grp::vreadlane(oe, a - 1u) - op;
       uint32_t used;
-      if (Te < T) used = Grp::vreadlane(posv, Te);
-      else {                                    // every start of the window was taken: the next token lies behind the last sequence
-        const uint32_t lr = Grp::vreadlane(r, Te - 1u), lpv = Grp::vreadlane(posv, Te - 1u);
+      if (a < T) used = Grp::vreadlane(posv, a);
+      else {                                    // every start was taken: the next token lies behind the last sequence
+        const uint32_t lr = Grp::vreadlane(r, a - 1u), lpv = Grp::vreadlane(posv, a - 1u);
         const uint32_t llit = (lr >> 16) & 255u, lmx = lr >> 24;
         used = lpv + 1u + (llit >= 15u ? 1u : 0u) + llit + 2u + (lmx >= 15u ? 1u : 0u);
       }
       ip += used; op += outb;
+    }
+    // ---- the requested steps into the ring (in front of the flusher's stores: stores count in vmcnt on this part) ----
+    if (nf != 0u) {
+      g.rs_put(avail, rf0);
+      if (nf > 1u) g.rs_put(avail + STEP, rf1);
+      avail += nf * STEP;
     }
     // ---- flusher: whole aligned steps below op ----
     while (op + db - fl >= STEP) { g.wv_store(dst, fl, g.wv_read_al(fl), op0 + db, 0xFFFFFFFFu); fl += STEP; }
   }
   while (op + db - fl >= STEP) { g.wv_store(dst, fl, g.wv_read_al(fl), op0 + db, 0xFFFFFFFFu); fl += STEP; }
   if (op + db != fl) g.wv_store(dst, fl, g.wv_read_al(fl), op0 + db, op + db);
+#ifdef LZ4HIP_RING_DBG
+  g.wv_stats(dbg_trips, dbg_seqs, dbg_rounds, dbg_single, dbg_hungry, dbg_T, dbg_two);
+#endif
   ip_io = (int)ip; op_io = (int)op;
 }
 

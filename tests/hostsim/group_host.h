@@ -282,6 +282,7 @@ struct GroupHost {
   // stream ring (kWs bytes + 16 tail) and the output ring (16 pad | kWv bytes | 16 tail) in "LDS" with the device backend's layout,
   // mirror rule and per-lane index arithmetic; every call is one instruction (all lanes' loads, then all lanes' stores); an index
   // outside the wavefront's LDS bytes counts as oob.  rs_fetch / rs_put / rs_ld64 above serve this ring too (rsb = wsb, kRs = kWs).
+  static constexpr uint32_t kWaveWindows = 2u;   // (the simulator runs the two-window form also with the 1 KB stream ring: it is the superset; see wv_begin)
   bool wave_mode = false;
   uint32_t kWv = 8192u, kWs = 2048u;
   std::vector<uint8_t> wv_mem;

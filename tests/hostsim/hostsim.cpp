@@ -208,7 +208,9 @@ int sim_decompress(const uint8_t* src, int src_size, uint8_t* dst, int out_size,
   if (wave_ks1k) g.kWs = 1024u;
   int r;
   const bool wave_par = (gl0 & 0x800000) != 0;   // bit 23: the parallel wave loop (several sequences of the block per trip)
-  if (wave && wave_par) r = safe ? lz4hip::decode_block<hostsim::GroupHost, true, 5>(g, src, src_size, dst, out_size, g.stg_buf)
+  if (wave && wave_par && wave_ks1k) r = safe ? lz4hip::decode_block<hostsim::GroupHost, true, 6>(g, src, src_size, dst, out_size, g.stg_buf)
+                                              : lz4hip::decode_block<hostsim::GroupHost, false, 6>(g, src, src_size, dst, out_size, g.stg_buf);
+  else if (wave && wave_par) r = safe ? lz4hip::decode_block<hostsim::GroupHost, true, 5>(g, src, src_size, dst, out_size, g.stg_buf)
                                  : lz4hip::decode_block<hostsim::GroupHost, false, 5>(g, src, src_size, dst, out_size, g.stg_buf);
   else if (wave) r = safe ? lz4hip::decode_block<hostsim::GroupHost, true, 4>(g, src, src_size, dst, out_size, g.stg_buf)
                      : lz4hip::decode_block<hostsim::GroupHost, false, 4>(g, src, src_size, dst, out_size, g.stg_buf);
