@@ -417,6 +417,25 @@ def main():
                                    "value": round(world * nbytes / wr / 1e9, 3), "unit": "GB/s", "verified": okr, "ms": round(tkr * 1e3, 3),
                                    "note": "the size-word walk is one dependent load per block on one lane: it bounds this leg for small blocks"}
         ok = ok and okr
+        # ---- the same for lz4-java's LZ4Block container: the headline bytes as 64 KiB LZ4Block blocks (21-byte headers,
+        # XXH32 checks) assembled on the device, then walked IN PARALLEL (the headers carry a magic: a candidate per region, a lane per
+        # region, a stitch -- kernels.hip container_walk_par_kernel), decoded by the fast decoder and check-summed on the device ----
+        wfb, _ = timed(lambda: amd.DeviceBatch.container_blocks(1, src, blk, comp, total_t), 1)
+        totb = int(total_t.item())
+        back.zero_()
+
+        def block_read():
+            rc = L.lz4hip_container_decode_dev(1, 0, comp.data_ptr(), totb, blk, back.data_ptr(), blk, n, sizes_t.data_ptr(), info_t.data_ptr(),
+                                               ws_t.data_ptr(), wsb, dev.index or 0, torch.cuda.current_stream().cuda_stream)
+            assert rc == 0, L.lz4hip_last_error()
+        wrb, tkrb = timed(block_read, 2)
+        infb = [int(x) for x in info_t.cpu()]
+        okrb = all_ok(totb == csum + 21 * n and infb[0] == n and infb[1] == totb and infb[2] == 1 and infb[3] == n * blk and bool(torch.equal(back, src)))
+        extra["block_read_dev"] = {"workload": "the headline bytes as an LZ4Block stream (%d blocks of 64 KiB, device-assembled) -> headers found and walked in parallel, "
+                                               "blocks decoded (LZ4_decompress_fast into the headers' original lengths) and XXH32-checked on the device "
+                                               "(lz4hip_container_decode_dev kind 1)" % n,
+                                   "value": round(world * nbytes / wrb / 1e9, 3), "unit": "GB/s", "verified": okrb, "ms": round(tkrb * 1e3, 3)}
+        ok = ok and okrb
         del ws_t, sizes_t, info_t
 
         # ---- real text: BASELINE configs[0] names a 64 KiB Silesia/dickens block; the only real data of the reference are

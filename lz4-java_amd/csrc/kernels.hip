@@ -686,7 +686,8 @@ struct ContainerRead {   // arrays of n_max entries in the workspace
 };
 __device__ __forceinline__ uint32_t rd32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
 __global__ __launch_bounds__(64) void container_walk_kernel(int kind, int block_checksum, const uint8_t* body, uint64_t body_bytes, uint32_t max_block,
-                                                            uint64_t slot_bytes, uint32_t n_max, ContainerRead c) {
+                                                            uint64_t slot_bytes, uint32_t n_max, ContainerRead c, const uint32_t* par_ok) {
+  if (par_ok && *par_ok != 0u) return;   // (the parallel walk of an LZ4Block stream, below, has done it)
   // every entry gets a value (the decode launch covers all n_max slots): blocks that are not walked decode nothing
   for (uint32_t i = threadIdx.x; i < n_max; i += 64u) { c.src_off[i] = 0; c.src_len[i] = 0; c.dst_off[i] = (uint64_t)i * slot_bytes; c.dst_cap[i] = 0; c.out[i] = 0;
                                                         c.pay_off[i] = 0; c.pay_len[i] = 0; c.end_off[i] = 0; c.stored[i] = 0; c.hashes[i] = 0; c.meta[i] = 0; }
@@ -747,6 +748,153 @@ __global__ __launch_bounds__(64) void container_walk_kernel(int kind, int block_
   if (k == n_max && p == body_bytes) why = CR_MORE;   // (every slot used and nothing left: not "more follows")
   c.walk[0] = k; c.walk[1] = why; c.walk[2] = (uint32_t)p; c.walk[3] = (uint32_t)(p >> 32);
 }
+// ---- LZ4Block streams: the walk in PARALLEL (round 5; the round-4 verdict: the one-lane walk costs 6x the decode of the same blocks -- one
+// dependent DRAM load per block, 36.7 ms for 65536 x 64 KiB against 6.1 ms).  An LZ4 Frame has no marker in front of a block, an LZ4Block
+// header starts with the 8-byte magic "LZ4Block" (LZ4BlockOutputStream.java:39): the body is cut into up to 1024 REGIONS,
+//   K0 container_find_kernel: a wavefront per region finds the region's first structurally valid header (coalesced scan, ballot);
+//   K1 container_walk_par_kernel (one workgroup, a lane per region): every lane walks the chain from its region's candidate to the
+//      region's end, COUNTING; one thread stitches the segments in stream order -- the chain position that arrives in a region must BE
+//      that region's first candidate (it then is a header of the true chain, by induction from offset 0), a region the chain jumps over
+//      lies inside a payload and is skipped --; then the lanes walk once more and fill the batch arrays from their block index on.
+// The stop reason, the consumed position and every array entry are the serial walk's (same rules in the same order, container_walk_kernel
+// above): tests compare the two.  Whatever the stitch cannot vouch for -- a damaged header on the chain, a magic inside a payload in
+// front of a region's true header, a cut tail -- sets *par_ok = 0 and the serial walk, launched behind, does the whole body.
+// ------------------------------------------------------------------------------------------------
+#define LZ4HIP_WALK_LANES 1024u
+#define LZ4HIP_WALK_NONE 0xFFFFFFFFFFFFFFFFull
+// the structural rules of an LZ4Block header (LZ4BlockInputStream.java:200-222), as container_walk_kernel applies them
+__device__ __forceinline__ bool lz4block_header_bad(const uint8_t* h, int32_t& clen, int32_t& olen, uint32_t& check, uint32_t& method) {
+  const char* magic = "LZ4Block";
+  bool bad = false;
+  for (int i = 0; i < 8; i++) bad |= h[i] != (uint8_t)magic[i];
+  const uint32_t token = h[8], level = 10u + (token & 0x0Fu);
+  method = token & 0xF0u;
+  bad |= method != 0x10u && method != 0x20u;
+  clen = (int32_t)rd32(h + 9); olen = (int32_t)rd32(h + 13); check = rd32(h + 17);
+  bad |= olen > (int32_t)(1u << level) || olen < 0 || clen < 0 || (olen == 0 && clen != 0) || (olen != 0 && clen == 0) || (method == 0x10u && olen != clen);
+  return bad;
+}
+__global__ __launch_bounds__(256) void container_find_kernel(const uint8_t* body, uint64_t body_bytes, uint64_t region, uint32_t lanes, uint64_t* first) {
+  const uint32_t w = (blockIdx.x * 256u + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+  if (w >= lanes) return;
+  const uint64_t lo = (uint64_t)w * region, hi = (w + 1u == lanes) ? body_bytes : lo + region;   // candidates p: lo <= p < hi, p + 21 <= body_bytes
+  uint64_t found = LZ4HIP_WALK_NONE;
+  for (uint64_t base = lo; base < hi; base += 1024u) {
+    const uint64_t q = base + lane * 16u;
+    uint64_t mine = LZ4HIP_WALK_NONE;
+    if (q < hi && q + 21u <= body_bytes) {
+      // 16 candidate positions q .. q + 15: the 8 bytes at each against the magic (bytes read: [q, q + 23) where they exist)
+      uint8_t b[24];
+      const uint64_t avail = body_bytes - q < 24u ? body_bytes - q : 24u;
+      if (avail == 24u) { __builtin_memcpy(b, body + q, 24); } else { for (uint32_t i = 0; i < 24u; i++) b[i] = i < avail ? body[q + i] : 0; }
+      for (uint32_t j = 0; j < 16u; j++) {
+        if (q + j >= hi || q + j + 21u > body_bytes) break;
+        if (b[j] == 'L' && b[j + 1] == 'Z' && b[j + 2] == '4' && b[j + 3] == 'B' && b[j + 4] == 'l' && b[j + 5] == 'o' && b[j + 6] == 'c' && b[j + 7] == 'k') {
+          int32_t clen, olen; uint32_t check, method;
+          if (!lz4block_header_bad(body + q + j, clen, olen, check, method)) { mine = q + j; break; }
+        }
+      }
+    }
+    const uint64_t hit = __builtin_amdgcn_ballot_w64(mine != LZ4HIP_WALK_NONE);
+    if (hit) {
+      const int src = __builtin_ctzll(hit);
+      found = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), src) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, src);
+      break;
+    }
+  }
+  if (lane == 0) first[w] = found;
+}
+// one lane's walk of its region: from p on, headers by the serial walk's rules; COUNT blocks (fill == false) or write their entries from
+// block index k0 on, at most `limit` of them (fill == true).  Ends at the region's end `hi` (hand-over: why stays CR_SLOTS), at the end of
+// the body (CR_MORE) or at the first header that stops the serial walk (its reason).  Returns the blocks taken; p = where it ended.
+__device__ __forceinline__ uint32_t lz4block_walk_region(const uint8_t* body, uint64_t body_bytes, uint64_t slot_bytes, uint64_t& p, uint64_t hi, bool last,
+                                                         uint32_t& why, bool fill, uint32_t k0, uint32_t limit, const ContainerRead& c) {
+  uint32_t k = 0;
+  why = CR_SLOTS;
+  while (k < limit) {
+    if (p == body_bytes) { why = CR_MORE; break; }
+    if (!last && p >= hi) break;
+    if (p + 21u > body_bytes) { why = CR_TRUNCATED; break; }
+    int32_t clen, olen; uint32_t check, method;
+    if (lz4block_header_bad(body + p, clen, olen, check, method)) { why = CR_CORRUPT; break; }
+    if (olen == 0) {
+      if (check != 0u) { why = CR_CORRUPT; break; }
+      p += 21u; why = CR_END; break;
+    }
+    if ((uint64_t)olen > slot_bytes) { why = CR_BLOCK_TOO_BIG; break; }
+    if (p + 21u + (uint64_t)clen > body_bytes) { why = CR_TRUNCATED; break; }
+    if (fill) {
+      const uint32_t b = k0 + k;
+      const bool raw = method == 0x10u;
+      c.pay_off[b] = p + 21u; c.pay_len[b] = clen;
+      c.src_off[b] = p + 21u; c.src_len[b] = raw ? 0 : clen;
+      c.dst_cap[b] = raw ? 0 : olen;
+      c.meta[b] = (raw ? 1 : 0) | (olen << 1);
+      c.stored[b] = check;
+      c.end_off[b] = p + 21u + (uint64_t)clen;
+    }
+    p += 21u + (uint64_t)clen;
+    k++;
+  }
+  return k;
+}
+__global__ __launch_bounds__(1024) void container_walk_par_kernel(const uint8_t* body, uint64_t body_bytes, uint64_t slot_bytes, uint32_t n_max, uint64_t region,
+                                                                  uint32_t lanes, const uint64_t* first, ContainerRead c, uint32_t* par_ok) {
+  __shared__ uint32_t s_cnt[LZ4HIP_WALK_LANES], s_why[LZ4HIP_WALK_LANES], s_base[LZ4HIP_WALK_LANES], s_limit[LZ4HIP_WALK_LANES];
+  __shared__ uint64_t s_end[LZ4HIP_WALK_LANES];
+  __shared__ uint32_t s_ok, s_total, s_stop_why, s_stop_lane;
+  __shared__ uint64_t s_stop_pos;
+  const uint32_t t = threadIdx.x;
+  // every entry gets a value (the decode launch covers all n_max slots): blocks that are not walked decode nothing
+  for (uint32_t i = t; i < n_max; i += LZ4HIP_WALK_LANES) { c.src_off[i] = 0; c.src_len[i] = 0; c.dst_off[i] = (uint64_t)i * slot_bytes; c.dst_cap[i] = 0; c.out[i] = 0;
+                                                            c.pay_off[i] = 0; c.pay_len[i] = 0; c.end_off[i] = 0; c.stored[i] = 0; c.hashes[i] = 0; c.meta[i] = 0; }
+  const uint64_t lo = (uint64_t)t * region, hi = lo + region;
+  const bool last = t + 1u == lanes;
+  if (t < lanes) {
+    uint64_t p = first[t];
+    uint32_t why = CR_SLOTS, k = 0;
+    if (p != LZ4HIP_WALK_NONE) k = lz4block_walk_region(body, body_bytes, slot_bytes, p, hi, last, why, false, 0u, 0xFFFFFFFFu, c);
+    s_cnt[t] = k; s_why[t] = why; s_end[t] = p; s_limit[t] = 0u;
+  }
+  __syncthreads();
+  if (t == 0) {
+    // the stitch: cur = where the true chain stands; it starts at offset 0
+    uint64_t cur = 0;
+    uint32_t k = 0, ok = 1u, why = CR_SLOTS, stop_lane = 0xFFFFFFFFu;
+    if (body_bytes == 0) { why = CR_MORE; }
+    else for (uint32_t i = 0; i < lanes; i++) {
+      const uint64_t rhi = (i + 1u == lanes) ? LZ4HIP_WALK_NONE : (uint64_t)(i + 1u) * region;
+      if (cur >= rhi) continue;                              // the chain jumps over this region: it lies inside a payload
+      if (first[i] != cur) { ok = 0u; break; }               // (no candidate where the chain arrives, or a magic in front of it: the serial walk decides)
+      s_base[i] = k;
+      if (k + s_cnt[i] >= n_max) {                           // the slots run out inside this lane (or exactly at its end)
+        s_limit[i] = n_max - k; stop_lane = i; why = CR_SLOTS; k = n_max; break;
+      }
+      s_limit[i] = s_cnt[i];
+      k += s_cnt[i]; cur = s_end[i];
+      if (s_why[i] != CR_SLOTS) { why = s_why[i]; stop_lane = i; break; }
+    }
+    // (a chain that ran through every lane ends with the last lane's reason: CR_MORE at the end of the body or a stop)
+    s_ok = ok; s_total = k; s_stop_why = why; s_stop_lane = stop_lane; s_stop_pos = cur;
+  }
+  __syncthreads();
+  if (s_ok == 0u) { if (t == 0) *par_ok = 0u; return; }
+  if (t < lanes && s_limit[t] != 0u) {
+    uint64_t p = first[t];
+    uint32_t why;
+    (void)lz4block_walk_region(body, body_bytes, slot_bytes, p, hi, last, why, true, s_base[t], s_limit[t], c);
+    if (t == s_stop_lane && s_stop_why == CR_SLOTS) s_stop_pos = p;   // the slots ran out in this lane: the walk stands behind its last block
+  }
+  __syncthreads();
+  if (t == 0) {
+    uint32_t why = s_stop_why;
+    const uint64_t p = s_stop_pos;
+    if (s_total == n_max && p == body_bytes) why = CR_MORE;   // (every slot used and nothing left: not "more follows")
+    c.walk[0] = s_total; c.walk[1] = why; c.walk[2] = (uint32_t)p; c.walk[3] = (uint32_t)(p >> 32);
+    *par_ok = 1u;
+  }
+}
+
 // raw blocks: payload -> slot (one workgroup per block); also the length array of the LZ4Block checksum pass
 __global__ __launch_bounds__(256) void container_raw_kernel(int kind, const uint8_t* body, uint8_t* dst, ContainerRead c, int32_t* hash_len) {
   const uint32_t b = blockIdx.x;
@@ -801,7 +949,7 @@ __global__ __launch_bounds__(1024) void container_verdict_kernel(int kind, int b
     info[4] = (unsigned long long)code;
   }
 }
-size_t container_read_ws_bytes(uint32_t n_max) { return (size_t)n_max * (4u * 8u + 8u * 4u) + 64u; }
+size_t container_read_ws_bytes(uint32_t n_max) { return (size_t)n_max * (4u * 8u + 8u * 4u) + 64u + 16u + LZ4HIP_WALK_LANES * 8u; }   // (+ the parallel walk's candidate per region)
 int launch_container_read(int kind, int block_checksum, const uint8_t* body, uint64_t body_bytes, uint32_t max_block, uint8_t* dst, uint64_t slot_bytes,
                           uint32_t n_max, int32_t* sizes, unsigned long long* info, void* ws, void* stream) {
   if (n_max == 0) return 0;
@@ -813,7 +961,18 @@ int launch_container_read(int kind, int block_checksum, const uint8_t* body, uin
   c.stored = (uint32_t*)(c.pay_len + n_max); c.hashes = c.stored + n_max; c.meta = (int32_t*)(c.hashes + n_max);
   int32_t* hash_len = c.meta + n_max;
   c.walk = (uint32_t*)(hash_len + n_max);
-  hipLaunchKernelGGL(container_walk_kernel, dim3(1), dim3(64), 0, st, kind, block_checksum, body, body_bytes, max_block, slot_bytes, n_max, c);
+  uint32_t* par_ok = nullptr;
+  if (kind == 1 && body_bytes >= 65536u) {   // LZ4Block streams: the walk in parallel (smaller bodies: the serial walk is a few loads)
+    uint64_t* first = (uint64_t*)(((uintptr_t)(c.walk + 16) + 7u) & ~(uintptr_t)7u);
+    par_ok = c.walk + 9;
+    uint32_t lanes = (uint32_t)(body_bytes / 16384u < LZ4HIP_WALK_LANES ? body_bytes / 16384u : LZ4HIP_WALK_LANES);
+    if (lanes == 0u) lanes = 1u;
+    const uint64_t region = ((body_bytes + lanes - 1u) / lanes + 1023u) & ~1023ull;
+    lanes = (uint32_t)((body_bytes + region - 1u) / region);
+    hipLaunchKernelGGL(container_find_kernel, dim3((lanes + 3u) / 4u), dim3(256), 0, st, body, body_bytes, region, lanes, first);
+    hipLaunchKernelGGL(container_walk_par_kernel, dim3(1), dim3(LZ4HIP_WALK_LANES), 0, st, body, body_bytes, slot_bytes, n_max, region, lanes, first, c, par_ok);
+  }
+  hipLaunchKernelGGL(container_walk_kernel, dim3(1), dim3(64), 0, st, kind, block_checksum, body, body_bytes, max_block, slot_bytes, n_max, c, par_ok);
   int e;
   if (kind == 0 && block_checksum && (e = launch_xxh32(body, c.pay_off, c.pay_len, 0u, c.hashes, n_max, stream)) != 0) return e;
   BatchArgs a{body, c.src_off, c.src_len, dst, c.dst_off, c.dst_cap, c.out, n_max};

@@ -204,6 +204,92 @@ def test_device_container_exact_capacity_and_too_small(amd, O, corpus):
                     assert bool((buf[cap:] == 0xA5).all()), (kind, chk, short, "bytes beyond dst_cap written")
 
 
+def test_lz4block_parallel_walk_equals_serial_rules(S, amd, O, port, corpus):
+    """LZ4Block streams of more than 64 KB are walked IN PARALLEL on the device (kernels.hip container_find_kernel +
+    container_walk_par_kernel: a candidate header per region, a lane per region, a stitch in stream order; the serial walk behind it
+    for whatever the stitch cannot vouch for).  lz4hip_container_decode against the host restatement of the walk's rules
+    (streams_common.OracleDeviceEngine.containerDecode: LZ4BlockInputStream.java:191-264 in order): blocks delivered, their sizes and
+    bytes, container bytes consumed and the stop reason -- on bodies of thousands of blocks (1024 lanes), with raw blocks whose PAYLOAD
+    holds magics and whole valid-looking headers (in front of and behind a region's true header), slot limits inside / exactly at
+    the end of a lane's run, a missing / damaged empty block, cut tails, and damage anywhere."""
+    import random
+    import struct
+    import streams_common as sc
+    rng = random.Random(2048)
+    eng = S.HIPEngine()
+    host = sc.OracleDeviceEngine(port, O)
+    B = amd.LZ4HIPBatch
+    book = corpus["book1[:200000]"]
+
+    def stream(n_blocks, block, decoys=0.0):
+        """an LZ4Block stream of n_blocks blocks (compressible, incompressible = stored raw, and -- decoys -- raw blocks whose bytes
+        contain magics and valid-looking headers)"""
+        parts = []
+        for i in range(n_blocks):
+            k = rng.random()
+            if k < decoys:      # incompressible noise with LZ4Block headers inside (a stored container in a container)
+                inner = b"LZ4Block" + bytes([0x20 | 6]) + struct.pack("<iiI", rng.randrange(1, 400), rng.randrange(400, 65000), rng.randrange(1 << 28))
+                b = bytearray(rng.randbytes(block))
+                for _ in range(rng.randrange(1, 6)):
+                    at = rng.randrange(0, block - 40)
+                    b[at:at + len(inner)] = inner if rng.random() < 0.7 else b"LZ4Block" + rng.randbytes(13)
+                parts.append(bytes(b))
+            elif k < decoys + 0.3:
+                parts.append(rng.randbytes(block))
+            else:
+                at = rng.randrange(0, len(book) - 5000)
+                parts.append((book[at:] + book * (block // len(book) + 1))[:block])
+        v = b"".join(parts)
+        o = io.BytesIO()
+        w = S.LZ4BlockOutputStream(o, block, engine=eng, batchBlocks=256)
+        w.write(v); w.close()
+        return o.getvalue(), v
+
+    def same(body, max_block, n_max):
+        want = host.containerDecode(B.LZ4BLOCK_BLOCKS, body, max_block, n_max)
+        got = B.containerDecode(B.LZ4BLOCK_BLOCKS, body, max_block, n_max)
+        assert got[1:4] == want[1:4], (len(body), n_max, got[1:4][1:], want[1:4][1:], len(got[1]), len(want[1]))
+        assert got[0] == want[0]
+        return want
+
+    n_stop = {}
+    for n_blocks, block, decoys in ((3000, 4096, 0.0), (2500, 4096, 0.15), (700, 65536, 0.1), (40, 1 << 20, 0.2)):
+        body, v = stream(n_blocks, block, decoys)
+        assert len(body) > 65536
+        mb = 1 << max(10, (block - 1).bit_length())
+        r = same(body, mb, n_blocks + 10)                     # the whole stream: every block, the empty block reached
+        assert r[3] == B.CR_END and len(r[1]) == n_blocks and r[0] == v
+        for n_max in (1, 7, n_blocks // 3, n_blocks - 1, n_blocks, n_blocks + 1):
+            r = same(body, mb, n_max)
+            n_stop[r[3]] = n_stop.get(r[3], 0) + 1
+        end = len(body) - 21                                   # (the empty block)
+        for cut in (end, end + 5, end - 1, end - 3000, len(body) // 2, 70000):
+            r = same(body[:cut], mb, n_blocks + 10)
+            n_stop[r[3]] = n_stop.get(r[3], 0) + 1
+        heads = [m for m in range(0, len(body) - 8) if body[m:m + 8] == b"LZ4Block"][:0]   # (positions come from a walk, below)
+        pos, p = [], 0
+        while p + 21 <= len(body):
+            pos.append(p)
+            p += 21 + struct.unpack_from("<i", body, p + 9)[0]
+        for _ in range(14):                                    # damage: header fields, payload bytes, a magic
+            d = bytearray(body)
+            h = pos[rng.randrange(len(pos))]
+            kind = rng.randrange(5)
+            if kind == 0:
+                d[h + rng.randrange(8)] ^= 0x20
+            elif kind == 1:
+                d[h + 8] ^= rng.choice([0x10, 0x30, 0x80])
+            elif kind == 2:
+                d[h + 9 + rng.randrange(8)] ^= 1 << rng.randrange(8)
+            elif kind == 3:
+                d[h + 17 + rng.randrange(4)] ^= 1 << rng.randrange(8)
+            else:
+                d[rng.randrange(len(d))] ^= 1 << rng.randrange(8)
+            r = same(bytes(d), mb, n_blocks + 10)
+            n_stop[r[3]] = n_stop.get(r[3], 0) + 1
+    assert n_stop.get(B.CR_CORRUPT, 0) > 10 and n_stop.get(B.CR_SLOTS, 0) > 5 and n_stop.get(B.CR_TRUNCATED, 0) > 3 and n_stop.get(B.CR_MORE, 0) >= 1, n_stop
+
+
 def test_device_read_path_equals_host_walk(S, amd, O, corpus, ref):
     """SURVEY.md 8(f) f1 / f2, READ side: frames and LZ4Block streams whose headers are walked, checksums verified and blocks decoded ON
     THE DEVICE (lz4hip_container_decode{,_dev}) deliver the same bytes and raise the same exception, at the same point of the stream,
