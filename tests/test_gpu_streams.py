@@ -290,6 +290,75 @@ def test_lz4block_parallel_walk_equals_serial_rules(S, amd, O, port, corpus):
     assert n_stop.get(B.CR_CORRUPT, 0) > 10 and n_stop.get(B.CR_SLOTS, 0) > 5 and n_stop.get(B.CR_TRUNCATED, 0) > 3 and n_stop.get(B.CR_MORE, 0) >= 1, n_stop
 
 
+def test_frame_parallel_walk_equals_serial_rules(S, amd, O, port, corpus):
+    """LZ4 Frame bodies have no marker in front of a block; the device walks them in parallel all the same: a region's candidate is a
+    position whose chain of size words holds for three (five: blocks over 256 KB) blocks, and the stitch accepts it only if the true
+    chain from offset 0 lands on it (else the serial walk does the body).  lz4hip_container_decode against the host restatement of
+    LZ4FrameInputStream.java:258-322: blocks delivered, sizes, bytes, consumed, stop reason and liblz4's code -- bodies of thousands of
+    blocks, with and without block checksums, raw blocks, an end mark / none, slot limits, cut tails, damaged size words, payloads and
+    checksums, and payloads made of small little-endian integers (every position a plausible size word: the serial walk's case)."""
+    import random
+    import struct
+    import streams_common as sc
+    rng = random.Random(4096)
+    host = sc.OracleDeviceEngine(port, O)
+    B = amd.LZ4HIPBatch
+    book = corpus["book1[:200000]"]
+    n_stop = {}
+
+    def same(body, max_block, n_max, cks):
+        want = host.containerDecode(B.FRAME_BLOCKS, body, max_block, n_max, cks)
+        got = B.containerDecode(B.FRAME_BLOCKS, body, max_block, n_max, cks)
+        assert got[1:] == want[1:], (len(body), n_max, cks, got[2:], want[2:], len(got[1]), len(want[1]))
+        assert got[0] == want[0]
+        n_stop[want[3]] = n_stop.get(want[3], 0) + 1
+        return want
+
+    for n_blocks, block, cks, kind in ((3000, 4096, False, "mixed"), (2000, 4096, True, "mixed"), (600, 65536, True, "mixed"), (300, 65536, False, "ints"),
+                                       (24, 1 << 20, False, "mixed")):
+        parts = []
+        for i in range(n_blocks):
+            k = rng.random()
+            if kind == "ints":          # raw blocks full of small integers: every aligned position looks like a size word
+                parts.append(b"".join(struct.pack("<I", rng.randrange(1, 3000)) for _ in range(block // 4)))
+            elif k < 0.3:
+                parts.append(rng.randbytes(block))
+            else:
+                at = rng.randrange(0, len(book) - 5000)
+                parts.append((book[at:] + book * (block // len(book) + 1))[:block])
+        v = b"".join(parts)
+        body = B.containerBlocks(B.FRAME_BLOCKS, v, block, cks)
+        assert len(body) > 65536
+        r = same(body + b"\0\0\0\0", block, n_blocks + 10, cks)     # with the end mark
+        assert r[3] == B.CR_END and len(r[1]) == n_blocks and r[0] == v
+        r = same(body, block, n_blocks + 10, cks)                       # the body ends at a block boundary
+        assert r[3] == B.CR_MORE and len(r[1]) == n_blocks
+        for n_max in (1, 5, n_blocks // 2, n_blocks - 1, n_blocks):
+            same(body, block, n_max, cks)
+        for cut in (len(body) - 1, len(body) - 3, len(body) - block // 3, len(body) // 2, 70001):
+            same(body[:cut], block, n_blocks + 10, cks)
+        pos, p = [], 0
+        while p + 4 <= len(body):
+            pos.append(p)
+            p += 4 + (struct.unpack_from("<I", body, p)[0] & 0x7FFFFFFF) + (4 if cks else 0)
+        for _ in range(12):                                             # damage: a size word, a payload byte, a checksum
+            d = bytearray(body)
+            h = pos[rng.randrange(len(pos))]
+            k = rng.randrange(4)
+            if k == 0:
+                d[h + rng.randrange(4)] ^= 1 << rng.randrange(8)
+            elif k == 1:
+                d[h:h + 4] = struct.pack("<I", rng.choice([0, block + 1, 0x7FFFFFFF, 1]))
+            elif k == 2 and cks:
+                e = h + 4 + (struct.unpack_from("<I", body, h)[0] & 0x7FFFFFFF)
+                d[e + rng.randrange(4)] ^= 1 << rng.randrange(8)
+            else:
+                d[rng.randrange(len(d))] ^= 1 << rng.randrange(8)
+            same(bytes(d), block, n_blocks + 10, cks)
+    assert n_stop.get(B.CR_SLOTS, 0) > 5 and n_stop.get(B.CR_TRUNCATED, 0) > 5 and n_stop.get(B.CR_END, 0) >= 5 and \
+        n_stop.get(B.CR_BLOCK_TOO_BIG, 0) + n_stop.get(B.CR_DECODE, 0) + n_stop.get(B.CR_BLOCK_CHECKSUM, 0) > 5, n_stop
+
+
 def test_device_read_path_equals_host_walk(S, amd, O, corpus, ref):
     """SURVEY.md 8(f) f1 / f2, READ side: frames and LZ4Block streams whose headers are walked, checksums verified and blocks decoded ON
     THE DEVICE (lz4hip_container_decode{,_dev}) deliver the same bytes and raise the same exception, at the same point of the stream,
