@@ -66,6 +66,26 @@ struct BatchEngine {
     o.resize((size_t)got);
     return o;
   }
+  // rounds 4 / 5: the READ side on the device (lz4hip_container_decode: the size words / LZ4Block headers of a run of blocks walked,
+  // checksums verified, blocks decoded there; what LZ4FrameInputStream.readBlock / LZ4BlockInputStream.refill do block by block).
+  // hostWalk = true keeps the readers' host walk around the batch launches (rounds 1-3) -- same bytes, same exceptions either way
+  bool hostWalk = false;
+  enum { CR_END = 0, CR_MORE = 1, CR_TRUNCATED = 2, CR_BLOCK_TOO_BIG = 3, CR_BLOCK_CHECKSUM = 4, CR_DECODE = 5, CR_CORRUPT = 6, CR_SLOTS = 7 };
+  struct ContainerRun { bytes decoded; std::vector<int32_t> sizes; uint64_t consumed = 0; int why = CR_MORE; int64_t code = 0; };
+  ContainerRun containerDecode(int kind, const uint8_t* body, size_t len, uint32_t maxBlock, uint32_t nMax, bool blockChecksum) const {
+    ContainerRun r;
+    static const uint8_t dummy = 0;
+    uint32_t nb = 0;
+    uint64_t need = 0;   // the destination by what the body holds (a host-side walk of the headers), not by nMax x maxBlock
+    chk(lz4hip_container_decode_bound(kind, blockChecksum ? 1 : 0, len ? body : &dummy, len, maxBlock, nMax, &nb, &need));
+    r.decoded.resize(need ? (size_t)need : 1u);
+    r.sizes.assign(nMax, 0);
+    uint64_t info[5] = {0, 0, 0, 0, 0};
+    chk(lz4hip_container_decode(kind, blockChecksum ? 1 : 0, len ? body : &dummy, len, maxBlock, nMax, r.decoded.data(), r.decoded.size(), r.sizes.data(), info));
+    r.sizes.resize((size_t)info[0]);
+    r.consumed = info[1]; r.why = (int)info[2]; r.decoded.resize((size_t)info[3]); r.code = (int64_t)info[4];
+    return r;
+  }
   uint32_t xxh32_one(const uint8_t* buf, size_t n, uint32_t seed) const {
     static const uint8_t dummy = 0;
     return xxh32(n ? buf : &dummy, {0}, {(int32_t)n}, seed)[0];
@@ -89,6 +109,43 @@ inline size_t readUpTo(std::istream& in, uint8_t* p, size_t n) {
   }
   return got;
 }
+// the readers' input: an istream plus the bytes the device read path took from it and did not consume (they are read again first)
+class PushbackReader {
+ public:
+  explicit PushbackReader(std::istream& in) : in_(in) {}
+  size_t readUpTo(uint8_t* p, size_t n) {
+    size_t got = std::min(n, back_.size());
+    std::copy(back_.begin(), back_.begin() + (std::ptrdiff_t)got, p);
+    back_.erase(back_.begin(), back_.begin() + (std::ptrdiff_t)got);
+    if (got < n) got += detail::readUpTo(in_, p + got, n - got);
+    return got;
+  }
+  // up to `want` bytes, in pieces: a reader that asks for a whole batch of maximum-size blocks does not allocate them for a short stream
+  bytes readChunk(size_t want) {
+    bytes c;
+    while (c.size() < want) {
+      const size_t piece = std::min<size_t>(want - c.size(), (size_t)4 << 20), at = c.size();
+      c.resize(at + piece);
+      const size_t got = readUpTo(c.data() + at, piece);
+      c.resize(at + got);
+      if (got < piece) break;
+    }
+    return c;
+  }
+  void unread(const uint8_t* p, size_t n) { back_.insert(back_.begin(), p, p + n); }
+  bool seekable() { in_.clear(in_.rdstate() & ~std::ios::eofbit); return in_.tellg() != std::istream::pos_type(-1); }
+  // the container ended and the caller reads on behind it: the surplus goes back to the stream (the reference's readers consume exactly
+  // the container: LZ4FrameInputStream.java:258-322, LZ4BlockInputStream.java:191-264).  Only for seekable inputs.
+  void giveBack() {
+    if (back_.empty()) return;
+    in_.clear();
+    in_.seekg(-(std::istream::off_type)back_.size(), std::ios::cur);
+    back_.clear();
+  }
+ private:
+  std::istream& in_;
+  std::deque<uint8_t> back_;
+};
 // compress data[i*blockSize ..] for all i in one launch
 struct Compressed { bytes dst; int bound; std::vector<int32_t> lens, sizes; };
 inline Compressed compressBlocks(const BatchEngine& e, const bytes& data, int blockSize) {
@@ -236,7 +293,7 @@ class LZ4FrameOutputStream {
 class LZ4FrameInputStream {
  public:
   explicit LZ4FrameInputStream(std::istream& in, bool readSingleFrame = false, BatchEngine engine = BatchEngine(), size_t batchBlocks = 64)
-      : in_(in), e_(engine), single_(readSingleFrame), batch_(batchBlocks ? batchBlocks : 1) {}
+      : r_(in), e_(engine), single_(readSingleFrame), batch_(batchBlocks ? batchBlocks : 1) {}
   // up to n bytes; 0 at the end of the stream
   size_t read(uint8_t* p, size_t n) {
     if (n == 0 || !fill()) return 0;
@@ -263,11 +320,11 @@ class LZ4FrameInputStream {
   bool isExpectedContentSizeDefined() { return getExpectedContentSize() >= 0; }
 
  private:
-  void readFully(uint8_t* p, size_t n) { if (detail::readUpTo(in_, p, n) < n) throw IOException(frame::PREMATURE_EOS); }
+  void readFully(uint8_t* p, size_t n) { if (r_.readUpTo(p, n) < n) throw IOException(frame::PREMATURE_EOS); }
   bool nextFrameInfo() {  // LZ4FrameInputStream.java:124-160
     for (;;) {
       uint8_t h[4];
-      const size_t got = detail::readUpTo(in_, h, 4);
+      const size_t got = r_.readUpTo(h, 4);
       if (got == 0 && headerRead_) return false;  // clean end between frames
       if (got < 4) throw IOException(frame::PREMATURE_EOS);
       const uint32_t magic = detail::getLE32(h);
@@ -305,7 +362,59 @@ class LZ4FrameInputStream {
     inFrame_ = true;
   }
   bool bit(int b) const { return (flgBits_ >> b) & 1; }
+  // behind the end mark (LZ4FrameInputStream.java:264-276): content checksum, content size
+  void endMark() {
+    try {
+      if (bit(frame::CONTENT_CHECKSUM)) {
+        uint8_t w4[4];
+        readFully(w4, 4);
+        if (detail::getLE32(w4) != (uint32_t)content().getValue()) throw IOException("Content checksum mismatch");
+      }
+      if (bit(frame::CONTENT_SIZE) && expectedContentSize_ != totalContentSize_) throw IOException("Size check mismatch");
+    } catch (const IOException& e) { pending_ = e.what(); return; }
+    frameFinished_ = true;
+  }
+  // readBlock for a run of blocks ON THE DEVICE (BatchEngine::containerDecode): one chunk of container bytes goes over, the decoded
+  // blocks and a stop reason come back; what the device did not consume is read again.  Same checks in the same order, same messages;
+  // a defect in block k surfaces after the bytes of the blocks before it
+  void readBlocksDevice() {
+    const bool bc = bit(frame::BLOCK_CHECKSUM);
+    const size_t want = batch_ * ((size_t)maxBlockSize_ + 8u) + 4u;
+    const bytes chunk = r_.readChunk(want);
+    const bool atEof = chunk.size() < want;
+    const BatchEngine::ContainerRun run = e_.containerDecode(0, chunk.data(), chunk.size(), (uint32_t)maxBlockSize_, (uint32_t)batch_, bc);
+    const uint8_t* rest = chunk.data() + run.consumed;
+    const size_t nrest = chunk.size() - (size_t)run.consumed;
+    if (!run.decoded.empty()) {
+      ready_.insert(ready_.end(), run.decoded.begin(), run.decoded.end());
+      totalContentSize_ += (int64_t)run.decoded.size();
+      if (bit(frame::CONTENT_CHECKSUM)) content().update(run.decoded.data(), run.decoded.size());  // one update per batch
+    }
+    r_.unread(rest, nrest);
+    uint8_t w4[4];
+    switch (run.why) {
+      case BatchEngine::CR_END: endMark(); break;
+      case BatchEngine::CR_BLOCK_TOO_BIG:
+        (void)r_.readUpTo(w4, 4);
+        pending_ = "Block size " + std::to_string(detail::getLE32(rest) & ~frame::INCOMPRESSIBLE_MASK) + " exceeded max: " + std::to_string(maxBlockSize_);
+        break;
+      case BatchEngine::CR_BLOCK_CHECKSUM: pending_ = frame::BLOCK_HASH_MISMATCH; break;
+      case BatchEngine::CR_DECODE: pending_ = "Error decoding offset " + std::to_string(-run.code) + " of input buffer"; break;
+      case BatchEngine::CR_TRUNCATED:
+      case BatchEngine::CR_MORE:
+        if (atEof) { bytes drop(nrest); (void)r_.readUpTo(drop.data(), nrest); pending_ = frame::PREMATURE_EOS; }
+        break;   // (else: the next call goes on from the bytes handed back)
+      default: break;
+    }
+  }
   void readBlocks() {  // readBlock (:258-322) for up to batch_ blocks
+    // (the device path takes a whole chunk from the stream: with readSingleFrame the caller reads on behind the frame, so it needs a
+    // stream that can take the surplus back; any other gets the host walk, which consumes exactly the frame)
+    if (!e_.hostWalk && (!single_ || r_.seekable())) {
+      readBlocksDevice();
+      if (single_ && frameFinished_) r_.giveBack();
+      return;
+    }
     struct Blk { bool compressed; bytes payload; uint32_t stored; };
     std::vector<Blk> blocks;
     bool endMark = false;
@@ -367,17 +476,7 @@ class LZ4FrameInputStream {
       if (!badExc.empty()) { pending_ = badExc; return; }
     }
     if (!exc.empty()) { pending_ = exc; return; }
-    if (endMark) {
-      try {
-        if (bit(frame::CONTENT_CHECKSUM)) {
-          uint8_t w4[4];
-          readFully(w4, 4);
-          if (detail::getLE32(w4) != (uint32_t)content().getValue()) throw IOException("Content checksum mismatch");
-        }
-        if (bit(frame::CONTENT_SIZE) && expectedContentSize_ != totalContentSize_) throw IOException("Size check mismatch");
-      } catch (const IOException& e) { pending_ = e.what(); return; }
-      frameFinished_ = true;
-    }
+    if (endMark) this->endMark();
   }
   bool fill() {  // false at the end of the stream
     while (ready_.empty()) {
@@ -391,7 +490,7 @@ class LZ4FrameInputStream {
     }
     return true;
   }
-  std::istream& in_;
+  detail::PushbackReader r_;
   BatchEngine e_;
   bool single_;
   size_t batch_;
@@ -499,7 +598,7 @@ class LZ4BlockInputStream {
  public:
   explicit LZ4BlockInputStream(std::istream& in, bool stopOnEmptyBlock = true, BatchEngine engine = BatchEngine(), size_t batchBlocks = 256,
                                blockstream::Checksum checksum = blockstream::Checksum())
-      : in_(in), e_(engine), stopOnEmpty_(stopOnEmptyBlock), batch_(batchBlocks ? batchBlocks : 1), checksum_(std::move(checksum)) {}
+      : r_(in), e_(engine), stopOnEmpty_(stopOnEmptyBlock), batch_(batchBlocks ? batchBlocks : 1), checksum_(std::move(checksum)) {}
   size_t read(uint8_t* p, size_t n) {
     if (n == 0 || !fill()) return 0;
     const size_t k = std::min(n, ready_.size());
@@ -524,14 +623,53 @@ class LZ4BlockInputStream {
 
  private:
   static constexpr const char* CORRUPTED = "Stream is corrupted";
+  // refill for a run of blocks ON THE DEVICE (BatchEngine::containerDecode): headers walked with the reference's rules, LZ4 blocks
+  // through the fast decoder (its return value must be the header's compressed length), raw ones copied, the checksums of the decoded
+  // bytes compared -- every defect is "Stream is corrupted", delivered after the blocks before it.  false: this run is for the host
+  // path (the stream does not start with a header; a block bigger than the first header announced; a header whose compressedLen
+  // exceeds the chunk although more input follows -- asking the device again with the same bytes would never end)
+  bool refillDevice() {
+    uint8_t head[blockstream::HEADER_LENGTH];
+    const size_t hgot = r_.readUpTo(head, sizeof head);
+    r_.unread(head, hgot);
+    if (hgot < sizeof head || memcmp(head, blockstream::magic(), 8) != 0) return false;
+    const uint32_t maxBlock = 1u << (blockstream::COMPRESSION_LEVEL_BASE + (head[8] & 0x0F));
+    const size_t want = batch_ * ((size_t)maxBlock + sizeof head) + sizeof head;
+    const bytes chunk = r_.readChunk(want);
+    const bool atEof = chunk.size() < want;
+    const BatchEngine::ContainerRun run = e_.containerDecode(1, chunk.data(), chunk.size(), maxBlock, (uint32_t)batch_, false);
+    if (run.why == BatchEngine::CR_BLOCK_TOO_BIG ||
+        (run.consumed == 0 && run.decoded.empty() && (run.why == BatchEngine::CR_TRUNCATED || run.why == BatchEngine::CR_MORE) && !atEof)) {
+      r_.unread(chunk.data(), chunk.size());
+      return false;
+    }
+    const size_t nrest = chunk.size() - (size_t)run.consumed;
+    ready_.insert(ready_.end(), run.decoded.begin(), run.decoded.end());
+    r_.unread(chunk.data() + run.consumed, nrest);
+    if (run.why == BatchEngine::CR_END) { if (stopOnEmpty_) finished_ = true; }
+    else if (run.why == BatchEngine::CR_CORRUPT) { pending_ = CORRUPTED; pendingEof_ = false; }
+    else if ((run.why == BatchEngine::CR_TRUNCATED || run.why == BatchEngine::CR_MORE) && atEof) {
+      bytes drop(nrest);
+      (void)r_.readUpTo(drop.data(), nrest);
+      if (nrest < sizeof head && !stopOnEmpty_) finished_ = true;   // (:192-199: the stream may end at -- or inside -- a header)
+      else { pending_ = "Stream ended prematurely"; pendingEof_ = true; }
+    }
+    return true;
+  }
   void refill() {  // LZ4BlockInputStream.java:191-264, for up to batch_ blocks
+    // (stopOnEmptyBlock: the caller reads on behind the empty block, so the device path -- which takes whole chunks from the stream --
+    // needs one that can take the surplus back)
+    if (!checksum_ && !e_.hostWalk && (!stopOnEmpty_ || r_.seekable()) && refillDevice()) {
+      if (stopOnEmpty_ && finished_) r_.giveBack();
+      return;
+    }
     struct Blk { int method; bytes payload; int32_t olen; uint32_t check; };
     std::vector<Blk> blocks;
     std::string exc;
     bool eof = false, fin = false;
     while (blocks.size() < batch_) {
       uint8_t head[blockstream::HEADER_LENGTH];
-      if (detail::readUpTo(in_, head, sizeof head) < sizeof head) {
+      if (r_.readUpTo(head, sizeof head) < sizeof head) {
         if (!stopOnEmpty_) fin = true; else { exc = "Stream ended prematurely"; eof = true; }
         break;
       }
@@ -550,8 +688,8 @@ class LZ4BlockInputStream {
           fin = true;
           break;
         }
-        Blk b{method, bytes((size_t)clen), olen, check};
-        if (detail::readUpTo(in_, b.payload.data(), (size_t)clen) < (size_t)clen) { exc = "Stream ended prematurely"; eof = true; break; }
+        Blk b{method, r_.readChunk((size_t)clen), olen, check};   // (in pieces: a damaged compressedLen of 2 GB allocates what the stream holds, not 2 GB)
+        if (b.payload.size() < (size_t)clen) { exc = "Stream ended prematurely"; eof = true; break; }
         blocks.push_back(std::move(b));
       } catch (const IOException& e) { exc = e.what(); break; }
     }
@@ -613,7 +751,7 @@ class LZ4BlockInputStream {
     }
     return true;
   }
-  std::istream& in_;
+  detail::PushbackReader r_;
   BatchEngine e_;
   bool stopOnEmpty_;
   size_t batch_;

@@ -117,6 +117,76 @@ int main(int argc, char** argv) {
       { std::istringstream s(sink.str().substr(0, sink.str().size() - 1)); LZ4BlockInputStream in(s); CHECK(thrown([&] { in.readAll(); }) == "Stream ended prematurely"); }
       CHECK(thrown([&] { std::ostringstream o; LZ4BlockOutputStream f(o, 63); }).find("blockSize must be >= 64") != std::string::npos);
     }
+    // ---- rounds 4 / 5: the READ side on the device (BatchEngine::containerDecode; the default) against the host walk (hostWalk = true):
+    // the same bytes and the same exception, at the same point of the stream -- intact streams and the same streams damaged / cut;
+    // a frame / a block stream followed by other bytes leaves the input right behind it; an LZ4Block header whose compressedLen
+    // exceeds the reader's chunk in the middle of a long stream ends in the reference's exception, not in a loop ----
+    {
+      BatchEngine hw; hw.hostWalk = true;
+      auto drainF = [&](const std::string& st, const BatchEngine& e, bool single, size_t batch, std::string& exc) {
+        std::istringstream s(st);
+        LZ4FrameInputStream in(s, single, e, batch);
+        bytes got, buf(50000);
+        exc.clear();
+        try { for (size_t k; (k = in.read(buf.data(), buf.size())) != 0;) got.insert(got.end(), buf.begin(), buf.begin() + (std::ptrdiff_t)k); }
+        catch (const std::exception& x) { exc = x.what(); }
+        return got;
+      };
+      auto drainB = [&](const std::string& st, const BatchEngine& e, size_t batch, std::string& exc) {
+        std::istringstream s(st);
+        LZ4BlockInputStream in(s, true, e, batch);
+        bytes got, buf(50000);
+        exc.clear();
+        try { for (size_t k; (k = in.read(buf.data(), buf.size())) != 0;) got.insert(got.end(), buf.begin(), buf.begin() + (std::ptrdiff_t)k); }
+        catch (const std::exception& x) { exc = x.what(); }
+        return got;
+      };
+      std::ostringstream bs;
+      { LZ4BlockOutputStream f(bs, 1 << 12, BatchEngine(), false, 64); f.write(data.data(), data.size()); }
+      const std::string blk = bs.str();
+      uint32_t rs = 99;
+      auto rnd = [&](size_t n) { rs = rs * 1664525u + 1013904223u; return (size_t)(rs >> 8) % n; };
+      int n_err = 0;
+      for (int t = 0; t < 40; t++) {
+        std::string f = all_frame, b = blk;
+        if (t) {
+          if (t % 4 == 0) { f.resize(1 + rnd(f.size() - 1)); b.resize(1 + rnd(b.size() - 1)); }
+          else { f[rnd(f.size())] ^= (char)(1 << rnd(8)); b[rnd(b.size())] ^= (char)(1 << rnd(8)); }
+        }
+        std::string e1, e2;
+        const bytes g1 = drainF(f, BatchEngine(), false, 3, e1), g2 = drainF(f, hw, false, 3, e2);
+        CHECK(g1 == g2 && e1 == e2);
+        const bytes h1 = drainB(b, BatchEngine(), 5, e1), h2 = drainB(b, hw, 5, e2);
+        CHECK(h1 == h2 && e1 == e2);
+        if (t == 0) CHECK(g1 == data && h1 == data && e1.empty());
+        n_err += !e1.empty();
+      }
+      CHECK(n_err > 10);
+      {   // a single frame / a block stream embedded in another protocol
+        const std::string tail = "TRAILER-TRAILER-TRAILER";
+        std::istringstream s(all_frame + tail);
+        LZ4FrameInputStream in(s, true, BatchEngine(), 4);
+        CHECK(in.readAll() == data);
+        std::string left((std::istreambuf_iterator<char>(s)), std::istreambuf_iterator<char>());
+        CHECK(left == tail);
+        std::istringstream s2(blk + tail);
+        LZ4BlockInputStream in2(s2, true, BatchEngine(), 16);
+        CHECK(in2.readAll() == data);
+        std::string left2((std::istreambuf_iterator<char>(s2)), std::istreambuf_iterator<char>());
+        CHECK(left2 == tail);
+      }
+      {   // compressedLen of block 5: + 1 GiB (one flipped bit), and 0x7FFFFFF0
+        size_t h = 0;
+        for (int k = 0; k < 5; k++) h += 21u + detail::getLE32((const uint8_t*)blk.data() + h + 9);
+        for (int v = 0; v < 2; v++) {
+          std::string b = blk + std::string(300000, '\0');
+          if (v == 0) b[h + 12] ^= 0x40; else { b[h + 9] = (char)0xF0; b[h + 10] = b[h + 11] = (char)0xFF; b[h + 12] = 0x7F; }
+          std::string e1, e2;
+          const bytes g1 = drainB(b, BatchEngine(), 4, e1), g2 = drainB(b, hw, 4, e2);
+          CHECK(!e1.empty() && e1 == e2 && g1 == g2 && g1.size() >= 4u * 4096u);
+        }
+      }
+    }
     // ---- WithLength ----
     {
       const std::vector<bytes> bufs = {bytes(), bytes(data.begin(), data.begin() + 13), bytes(data.begin() + 1000, data.begin() + 70000), bytes(5000, 7)};
