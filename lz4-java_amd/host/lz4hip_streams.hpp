@@ -133,7 +133,9 @@ class PushbackReader {
     return c;
   }
   void unread(const uint8_t* p, size_t n) { back_.insert(back_.begin(), p, p + n); }
-  bool seekable() { in_.clear(in_.rdstate() & ~std::ios::eofbit); return in_.tellg() != std::istream::pos_type(-1); }
+  // (a read that reached the end of the stream leaves eofbit AND failbit set: both are cleared for the probe -- a chunk that was cut
+  // short by the end of the input is the usual case here, not an error)
+  bool seekable() { in_.clear(); return in_.tellg() != std::istream::pos_type(-1); }
   // the container ended and the caller reads on behind it: the surplus goes back to the stream (the reference's readers consume exactly
   // the container: LZ4FrameInputStream.java:258-322, LZ4BlockInputStream.java:191-264).  Only for seekable inputs.
   void giveBack() {
