@@ -58,8 +58,10 @@ int lz4hip_device_count(void);            /* devices the engine is initialised o
 const char* lz4hip_last_error(void);      /* thread-local description of the last failure       */
 int lz4hip_version(void);
 /* tuning knobs (not part of the reference API): "decode_lanes" = lanes of a wavefront sharing one
- * block in the decoder (0 = default by batch size, 4/8/16/32/64; 1 with the ring loop: a lane per block); "decode_pipe" = 3 / 2 / 1 / 0 / -1
- * (default by batch size; 3 = the ring loop of lz4_decode_ring.h: compressed stream and recent output in LDS rings -- "decode_ring" = bytes of
+ * block in the decoder (0 = default by batch size, 4/8/16/32/64; 1 with the ring loop: a lane per block); "decode_pipe" = 5 / 4 / 3 / 2 / 1 / 0 / -1
+ * (default by batch size; 5 / 4 = the wave loops of lz4_decode_wave.h: a WAVEFRONT per block, stream and recent output in LDS rings --
+ * "decode_ring" = bytes of the output ring, 0 (by batch size) / 8192 / 16384 / 32768 / 65536 --, 5: several sequences of the block per
+ * trip, the default for launches of up to 16 blocks per compute unit; 4: one sequence per trip; 3 = the ring loop of lz4_decode_ring.h: compressed stream and recent output in LDS rings -- "decode_ring" = bytes of
  * its output ring, 0 / 256 / 512 / 1024 / 2048 / 4096 --, the default for batches of 12288..40959 big blocks, chosen on the device): the
  * software-pipelined interior loops of the decoder (faster when the batch is too small to fill the GPU; 2 = the deep loop: the
  * compressed stream staged in LDS, two slots -- the match source of one sequence on its way while the next sequence is parsed and
