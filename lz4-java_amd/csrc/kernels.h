@@ -55,9 +55,6 @@ int launch_container_read(int kind, int block_checksum, const uint8_t* body, uin
 // pipe: 1 = pipelined interior loop (lz4_decode_core.h PIPE), 0 = plain, -1 = default for the batch size
 // stage: 1 = the plain interior loop writes through LDS staging (whole-line output), 0 / -1 = off
 // pipe 3: the ring loop (lz4_decode_ring.h); ring = bytes of its output ring (512 / 1024 / 2048 / 4096; 0 = default for the lanes)
-// pipe 4 / 5: the wave loops (lz4_decode_wave.h): a wavefront per block; 4 = one sequence per trip, 5 = several; ring = bytes of the output ring
-// (8192 / 16384 / 32768 / 65536 <-> 16 / 8 / 4 / 1-2 wavefronts per CU; 0 = by batch size).  With every knob at its default a launch of up to
-// 16 blocks per CU gets pipe 5
 // route_word: one device uint32_t of scratch (or nullptr): with every knob at its default, batches of 12288 .. 40959 blocks are routed
 // between the deep loop and the ring loop on the device by the blocks' compressed sizes (decode_route_kernel)
 int launch_decompress(const BatchArgs& a, bool safe, int lanes_per_block, int pipe, int stage, int ring, void* stream, uint32_t* route_word = nullptr);
