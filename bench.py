@@ -67,6 +67,48 @@ def measured_traffic(n_blocks, block):
     return None
 
 
+def live_traffic(args, timeout_s=300):
+    """HBM bytes per launch of the headline's two kernels, MEASURED BY THIS RUN: two short child runs of this same file (headline launches
+    only, --warmup 1 --steps 2) under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- separate passes, KiB -> bytes,
+    FETCH_SIZE doubled: MI355X_MICROARCH.md's HBM section -- before the parent touches the GPU.  Returns ({kernel: bytes}, note); an empty
+    dict and the reason when rocprofv3 is missing, this process is itself being profiled, or a pass fails: the committed passes
+    (profiles/traffic.json) are what the line carries then."""
+    import shutil, sqlite3, subprocess, tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return {}, "no rocprofv3 on this box"
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return {}, "this run is itself under a profiler"
+    vals = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="lz4hip_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extra-configs", "--no-live-traffic",
+                   "--blocks", str(args.blocks), "--block-size", str(args.block_size), "--litmax", str(args.litmax), "--win", str(args.win),
+                   "--decode-lanes", str(args.decode_lanes)]
+            r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
+            dbs = [os.path.join(w, f) for w, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
+            if r.returncode != 0 or not dbs:
+                return {}, "the %s pass failed (rc %d)" % (counter, r.returncode)
+            per = {}
+            con = sqlite3.connect(dbs[0])
+            for k, c, v in con.execute("select kernel_name, counter_name, value from counters_collection where kernel_name like '%lz4hip%'"):
+                if c == counter:
+                    per.setdefault(k.split("(")[0].replace("void ", "").replace("lz4hip::", "").strip(), []).append(v)
+            con.close()
+            for k, vs in per.items():
+                vs = sorted(vs)
+                vals.setdefault(k, {})[counter] = vs[len(vs) // 2] if len(vs) % 2 else 0.5 * (vs[len(vs) // 2 - 1] + vs[len(vs) // 2])
+        except Exception as e:   # a time-out, an unreadable database: the committed passes stand in
+            return {}, "the %s pass: %s" % (counter, type(e).__name__)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    out = {k: int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024) for k, c in vals.items() if "FETCH_SIZE" in c and "WRITE_SIZE" in c}
+    return out, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes made by this run (two child runs of the headline launches, median over their launches)"
+
+
 def kernel_traffic(tr, world, *names):
     """HBM bytes per launch of the named kernels (summed) from the same PMC passes; None unless every one was measured, at N = 1"""
     k = (tr or {}).get("kernels") or {}
@@ -174,10 +216,14 @@ def main():
     ap.add_argument("--decode-lanes", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the configs[2..4] / decompress_fast sub-objects")
+    ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from profiles/traffic.json only (no PMC child runs)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         relaunch(args.gpus)
+    live, live_note = {}, None
+    if args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_live_traffic:
+        live, live_note = live_traffic(args)   # before this process takes memory on the GPU
 
     import torch
     import torch.distributed as dist
@@ -682,12 +728,18 @@ def main():
             "verified": ok,
             "compress_GBps": round(nbytes / t_c / 1e9, 3), "decompress_GBps": round(nbytes / t_d / 1e9, 3),
             # compress: reads N, writes C (1 + 1/ratio B/B); decompress: reads C, writes N
-            "roofline": roof("compress_fast_v2w_cu_kernel", nbytes + csum, t_c, kernel_traffic(tr, world, "compress_fast_v2w_cu_kernel")),
-            "roofline_decode": roof(decode_kernel_name(n), nbytes + csum, t_d, kernel_traffic(tr, world, decode_kernel_name(n))),
+            "roofline": roof("compress_fast_v2w_cu_kernel", nbytes + csum, t_c, live.get("compress_fast_v2w_cu_kernel") or kernel_traffic(tr, world, "compress_fast_v2w_cu_kernel")),
+            "roofline_decode": roof(decode_kernel_name(n), nbytes + csum, t_d, live.get(decode_kernel_name(n)) or kernel_traffic(tr, world, decode_kernel_name(n))),
         }
         if tr:
             out["traffic_source"] = tr.get("source")
             out["traffic_stale"] = tr.get("kernel_source_hash") != kernel_source_hash()   # true: kernels changed since the PMC passes
+        if live_note:
+            # the headline's two `traffic` values are this run's own PMC passes when they worked; the other legs' come from the committed file
+            hk = ("compress_fast_v2w_cu_kernel", decode_kernel_name(n))
+            out["traffic_live"] = {"headline": bool(live.get(hk[0]) and live.get(hk[1])), "note": live_note,
+                                   "bytes_per_launch": {k: live.get(k) for k in hk},
+                                   "committed_file": {k: kernel_traffic(tr, world, k) for k in hk}}
         if extra:
             out["configs"] = extra
         if want_cpu:

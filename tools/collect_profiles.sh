@@ -6,19 +6,19 @@ tag=$1
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 # headline launches only (--no-extra-configs): the per-kernel averages of this trace are the ones bench.py's HIP events must agree with
-timeout 400 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$tag -o kt -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extra-configs > gpurun_out/prof_$tag.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$tag -o kt -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-live-traffic --no-extra-configs > gpurun_out/prof_$tag.log 2>&1
 db=$(find gpurun_out/prof_$tag -name "*.db" | head -1)
 (echo "# profiles/${tag}_bench_kernel_trace.txt"
- echo "# command: rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extra-configs   (1x MI355X; summary by tools/rocprof_summary.py)"
+ echo "# command: rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-live-traffic --no-extra-configs   (1x MI355X; summary by tools/rocprof_summary.py)"
  python tools/rocprof_summary.py $db
  echo "# the line that run printed:"
  tail -1 gpurun_out/prof_$tag.log) > gpurun_out/${tag}_bench_kernel_trace.txt
 # the whole default command (all configs): one trace
 rm -rf gpurun_out/prof_$tag
-timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$tag -o kt -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline > gpurun_out/prof_$tag.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$tag -o kt -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-live-traffic > gpurun_out/prof_$tag.log 2>&1
 db=$(find gpurun_out/prof_$tag -name "*.db" | head -1)
 (echo "# profiles/${tag}_bench_all_configs_kernel_trace.txt"
- echo "# command: rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline   (all configs; 1x MI355X)"
+ echo "# command: rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-live-traffic   (all configs; 1x MI355X)"
  python tools/rocprof_summary.py $db lz4hip) > gpurun_out/${tag}_bench_all_configs_kernel_trace.txt
 tools/traffic_passes.sh gpurun_out/traffic_$tag 2 > /dev/null
 tools/traffic_passes.sh gpurun_out/traffic_text_$tag 2 text > /dev/null     # the real-text legs by themselves (tools/gpu_text_legs.py)

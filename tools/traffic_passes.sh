@@ -3,7 +3,7 @@
 # under-reports wide coalesced reads by 2x on gfx950).  usage: tools/traffic_passes.sh <outdir> <steps>
 out=$1; steps=${2:-2}
 # third argument "text": the passes run tools/gpu_text_legs.py (the real-text legs alone) instead of bench.py
-cmd="python bench.py --steps $steps --warmup 1 --no-cpu-baseline"
+cmd="python bench.py --steps $steps --warmup 1 --no-cpu-baseline --no-live-traffic"
 [ "$3" = "text" ] && cmd="python tools/gpu_text_legs.py"
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p $out
