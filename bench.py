@@ -221,9 +221,6 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         relaunch(args.gpus)
-    live, live_note = {}, None
-    if args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_live_traffic:
-        live, live_note = live_traffic(args)   # before this process takes memory on the GPU
 
     import torch
     import torch.distributed as dist
@@ -235,6 +232,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    live, live_note = {}, None
+    if args.gpus == 1 and world == 1 and not args.no_live_traffic:
+        # (behind `import torch` -- a fresh box pages the image in once, for the children too -- and before this process has a context on the GPU)
+        live, live_note = live_traffic(args, timeout_s=180)
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
     if torch.cuda.device_count() < (local_rank + 1):
