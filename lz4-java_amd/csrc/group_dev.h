@@ -529,6 +529,31 @@ struct BlockWaveDev : GroupDev<64, 0> {
     asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(s), "s"(i) : "m0");
     return v;
   }
+  // The walk of a trip (lz4_decode_wave.h): nx holds, a byte per window position (four per lane), where the sequence that starts
+  // there is followed by the next one (255: not in this window).  From position 0: the k-th start goes to lane T + k of posv, T counts
+  // them (at most 64 lanes).  By hand: the compiler's loop is 15 instructions a hop, six of them the two-part loop condition; this
+  // one is 12 -- a window of text is ~58 hops
+  __device__ __forceinline__ static void vwalk(VU nx, VU& posv, uint32_t& T) {
+    uint32_t s = 0u, t1, t2;
+    T = (uint32_t)__builtin_amdgcn_readfirstlane((int)T);
+    asm volatile(
+        "L_walk_%=:\n"
+        "  s_mov_b32 m0, %[T]\n"
+        "  s_lshr_b32 %[t1], %[s], 2\n"
+        "  v_writelane_b32 %[pv], %[s], m0\n"
+        "  s_lshl_b32 %[t2], %[s], 3\n"
+        "  v_readlane_b32 %[s], %[nx], %[t1]\n"
+        "  s_add_u32 %[T], %[T], 1\n"
+        "  s_lshr_b32 %[s], %[s], %[t2]\n"
+        "  s_and_b32 %[s], %[s], 0xff\n"
+        "  s_cmp_lt_u32 %[T], 64\n"
+        "  s_cselect_b32 %[t1], %[s], 0xff\n"
+        "  s_cmpk_lg_u32 %[t1], 0xff\n"
+        "  s_cbranch_scc1 L_walk_%=\n"
+        : [pv] "+v"(posv), [T] "+s"(T), [s] "+s"(s), [t1] "=&s"(t1), [t2] "=&s"(t2)
+        : [nx] "v"(nx)
+        : "m0", "scc");
+  }
   __device__ __forceinline__ static VU vshfl(VU v, VU srcl) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(srcl << 2), (int)v); }
   __device__ __forceinline__ static VU vexcl_scan(VU a) {   // exclusive prefix sum across the wavefront: row_shr DPP adds + row_bcast15/31
     int x = (int)a;
@@ -635,26 +660,26 @@ struct BlockWaveDev : GroupDev<64, 0> {
     c += len & 2u;
     if (len & 1u) a[c] = (uint8_t)r.e;
   }
-  // far: the match source of this lane is not in the ring: it is mem[mpos, mpos + lenm) (the block's flushed output; 80 bytes from
-  // mpos on are readable).  The far lanes of a trip have their loads in flight together, behind the ring reads of the others
-  __device__ __forceinline__ void vcopy_seq(VU dw, VU sp, VU lenl, VU sw, VU lenm, bool go, const uint8_t* mem, VU mpos, bool far) {
+  // One RUN per lane (lz4_decode_wave.h: even lanes the literals of a sequence, odd lanes its match): len bytes to ring coordinates
+  // dw, from the stream ring at stream position sp (from_stream) or from the output ring at ring coordinates sp.
+  // far: the match source of this lane is not in the ring: it is mem[mpos, mpos + len) (the block's flushed output; 80 bytes from
+  // mpos on are readable).  The far lanes of a round have their loads in flight together, behind the ring reads of the others
+  __device__ __forceinline__ void vcopy_run(VU dw, bool from_stream, VU sp, VU len, bool go, const uint8_t* mem, VU mpos, bool far) {
     const uint32_t x = dw & ((uint32_t)KW - 1u);
-    const bool odd = go && ((lenl > 64u) || (lenm > 64u) || (x < 16u) || (x + lenl + lenm + 16u > (uint32_t)KW));
+    const bool odd = go && ((len > 64u) || (x < 16u) || (x + len + 16u > (uint32_t)KW));
     const bool gf = go && far;
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(odd) == 0ull, 1)) {
       if (go) {
-        const Run16 rl = vrun_load(wsb, (uint32_t)KS - 1u, sp, lenl);
-        Run16 rm = vrun_load(wrb, (uint32_t)KW - 1u, sw, lenm);
+        Run16 r = vrun_load(from_stream ? wsb : wrb, from_stream ? (uint32_t)KS - 1u : (uint32_t)KW - 1u, sp, len);
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(gf) != 0ull, 0)) {
-          if (gf) rm = vrun_load(mem, 0xFFFFFFFFu, mpos, lenm);
+          if (gf) r = vrun_load(mem, 0xFFFFFFFFu, mpos, len);
         }
-        vrun_store(dw, lenl, rl);
-        vrun_store(dw + lenl, lenm, rm);
+        vrun_store(dw, len, r);
       }
     } else {
-      vcopy<0>(dw, nullptr, sp, lenl, go);
-      vcopy<1>(dw + lenl, nullptr, sw, lenm, go && !far);
-      if (__builtin_amdgcn_ballot_w64(gf) != 0ull) vcopy<2>(dw + lenl, mem, mpos, lenm, gf);
+      vcopy<0>(dw, nullptr, sp, len, go && from_stream);
+      vcopy<1>(dw, nullptr, sp, len, go && !from_stream && !far);
+      if (__builtin_amdgcn_ballot_w64(gf) != 0ull) vcopy<2>(dw, mem, mpos, len, gf);
     }
   }
   // the step at ring coordinates fw (a multiple of 256) to memory: its bytes inside [lo, hi) (ring coordinates), nothing else

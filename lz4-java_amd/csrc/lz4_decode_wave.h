@@ -264,6 +264,7 @@ LZ4HIP_DEV void decode_wave_par_loop(Grp& g, const uint8_t* src, const int iend,
   uint32_t fl = (op + db) & ~(STEP - 1u);
   const VU lane = g.vlane();
   const VU p0 = lane * 4u;
+  uint32_t wild = op;                          // end of what one-sequence steps have written into the ring (see `bound`)
 #ifdef LZ4HIP_RING_DBG   /* developer build: what the loop did (tools/wave_stats.py) */
   uint32_t dbg_trips = 0, dbg_seqs = 0, dbg_rounds = 0, dbg_single = 0, dbg_hungry = 0, dbg_T = 0, dbg_two = 0;
 #endif
@@ -335,84 +336,108 @@ LZ4HIP_DEV void decode_wave_par_loop(Grp& g, const uint8_t* src, const int iend,
         nxpack = nxpack | (Grp::vsel(nxt <= 250u, nxt, VU(255u)) << (8 * (int)j));
       }
       // the starts of the sequences in the window, the k-th to lane k
-      uint32_t s = 0u;
-      do {
-        posv = Grp::vwritelane(posv, s + wbase, T);
-        T++;
-        const uint32_t d = Grp::vreadlane(nxpack, s >> 2);
-        s = (d >> ((s & 3u) * 8u)) & 255u;
-      } while ((s != 255u) & (T < 64u));
+      if (wdw == 0u) Grp::vwalk(nxpack, posv, T);
+      else {
+        uint32_t s = 0u;
+        do {
+          posv = Grp::vwritelane(posv, s + wbase, T);
+          T++;
+          const uint32_t d = Grp::vreadlane(nxpack, s >> 2);
+          s = (d >> ((s & 3u) * 8u)) & 255u;
+        } while ((s != 255u) & (T < 64u));
+      }
       if (wdw == 0u) T0 = T;
     }
-    // ---- 3. records, output positions ----
-    const VB act = lane < T;
-    VU r;
-    {
-      const VU sl = posv >> 2, slot = posv & 3u;
-      r = Grp::vsel(slot == 0u, Grp::vshfl(rec[0][0], sl), Grp::vsel(slot == 1u, Grp::vshfl(rec[0][1], sl), Grp::vsel(slot == 2u, Grp::vshfl(rec[0][2], sl), Grp::vshfl(rec[0][3], sl))));
-    }
-    if (NWIN > 1u) {
-      if (T > T0) {
-        const VU pr = posv - base1;
-        const VU sl = pr >> 2, slot = pr & 3u;
-        const VU r1 = Grp::vsel(slot == 0u, Grp::vshfl(rec[NWIN - 1u][0], sl), Grp::vsel(slot == 1u, Grp::vshfl(rec[NWIN - 1u][1], sl), Grp::vsel(slot == 2u, Grp::vshfl(rec[NWIN - 1u][2], sl), Grp::vshfl(rec[NWIN - 1u][3], sl))));
-        r = Grp::vsel(lane < T0, r, r1);
-      }
-    }
-    const VU off = r & 0xFFFFu, lit = (r >> 16) & 255u, ml = (r >> 24) + 4u;
-    const VB simple = (off != 0u) & (lit != 255u) & (ml != 259u);   // (tested here, once per real start, not at every speculative position)
-    const VU tot = Grp::vsel(act, lit + ml, VU(0u));
-    const VU ex = Grp::vexcl_scan(tot);
-    const VU o = ex + op;                       // where the sequence's output starts
-    const VU mp = o + lit - off;                // where its match copies from (negative: invalid offset)
-    const VU oe = o + tot;
-    const VU send = mp + ml;
-    // held: the ring has the source and keeps it while the trip is written (the trip touches at most [op, bound): the ring loses what
-    // lies below bound - KW); a source the ring does not hold is FAR and comes from the block's flushed output in memory -- which has
-    // everything below the flusher's position (and below the loop's entry position)
-    const uint32_t oe_all = Grp::vreadlane(oe, T - 1u);
-    const uint32_t bound = (oe_all - op < TRIPMAX ? oe_all : op + TRIPMAX) + 16u;
-    const uint32_t memlim = fl > op0 + db ? fl - db : op0;
-    const VB held = (mp >= VU(op0)) & ((mp + KW) >= VU(bound));
-    const VB okb = act & simple & (mp < VU(0x80000000u)) & (held | (send <= VU(memlim))) &
-                   ((posv + ip) <= VU(ilim)) & (o <= VU(olim)) & ((oe - op) <= VU(TRIPMAX));
-    // (mp "negative" -- an offset that reaches in front of the block -- is a huge unsigned number: tested by itself, the sums may wrap)
-    // ---- 4. copies in DEPENDENCY ROUNDS, a lane per sequence, exact.  A round takes the sequences from lane `a` on whose whole
-    // source lies below the round's own output (the dependency rule); the first one whose source reaches into it starts the next
-    // round, behind this round's stores -- LDS operations of a wavefront execute in order.  A round that would be empty ends the
-    // trip: its first sequence reaches into its OWN output (or is not for a trip at all) ----
-    const VU lp = posv + ip + Grp::vsel(lit >= 15u, VU(2u), VU(1u));
-    uint32_t a = 0u;
+    // ---- 3. records, output positions: A LANE PER RUN -- lane 2k the literals of a sequence, lane 2k + 1 its match.  (A lane per
+    // sequence copied two runs, 16 reads and 16 predicated stores a round: ~220 instructions of a trip of ~900 that is bound by
+    // instruction issue.  With a lane per run the same bytes move with half the instructions, the prefix sum of the run lengths is
+    // every run's output position, and a match may read its own sequence's literals: they belong to the round before its own.)
+    // The wavefront holds 31 sequences that way: a window with more of them (text: up to 64) is taken in PASSES of 31, each pass from
+    // the sequence the pass before it ended with -- discovery and walk are paid once per window ----
+    const VB isM = (lane & 1u) != 0u;
+    uint32_t tk = 0u, opc = op, lrec = 0u;      // sequences taken by this trip, the output position behind them, the last one's record
     for (;;) {
-      const uint32_t oa = Grp::vreadlane(o, a);
-      const uint64_t okm = Grp::vballot((okb & (send <= VU(oa))) | (lane < a));
-      const uint32_t Te = (uint32_t)__builtin_ctzll(~okm | (1ull << 63));   // (< 64: lane 63 is never needed)
+      const uint32_t np = T - tk < 31u ? T - tk : 31u;   // (31: the rounds' ballot keeps lane 63 out)
+      const VU sq = (lane >> 1) + tk;           // this lane's sequence
+      const VU pv = Grp::vshfl(posv, sq);       // where it starts, relative to ip
+      const VB act = lane < 2u * np;
+      VU r;
+      {
+        const VU sl = pv >> 2, slot = pv & 3u;
+        r = Grp::vsel(slot == 0u, Grp::vshfl(rec[0][0], sl), Grp::vsel(slot == 1u, Grp::vshfl(rec[0][1], sl), Grp::vsel(slot == 2u, Grp::vshfl(rec[0][2], sl), Grp::vshfl(rec[0][3], sl))));
+      }
+      if (NWIN > 1u) {
+        if (T > T0) {
+          const VU pr = pv - base1;
+          const VU sl = pr >> 2, slot = pr & 3u;
+          const VU r1 = Grp::vsel(slot == 0u, Grp::vshfl(rec[NWIN - 1u][0], sl), Grp::vsel(slot == 1u, Grp::vshfl(rec[NWIN - 1u][1], sl), Grp::vsel(slot == 2u, Grp::vshfl(rec[NWIN - 1u][2], sl), Grp::vshfl(rec[NWIN - 1u][3], sl))));
+          r = Grp::vsel(sq < T0, r, r1);
+        }
+      }
+      const VU off = r & 0xFFFFu, lit = (r >> 16) & 255u, ml = (r >> 24) + 4u;
+      const VB simple = (off != 0u) & (lit != 255u) & (ml != 259u);   // (tested here, once per real start, not at every speculative position)
+      const VU len = Grp::vsel(isM, ml, lit);   // this lane's run
+      const VU tot = Grp::vsel(act, len, VU(0u));
+      const VU ex = Grp::vexcl_scan(tot);
+      const VU o = ex + opc;                    // where the run's output starts
+      const VU mp = o - off;                    // match lanes: where the match copies from (negative: invalid offset)
+      const VU oe = o + tot;
+      const VU send = mp + ml;
+      // held: the ring has the source and keeps it while the pass is written (it touches at most [opc, bound): the ring loses what
+      // lies below bound - KW); a source the ring does not hold is FAR and comes from the block's flushed output in memory -- which
+      // has everything below the flusher's position (and below the loop's entry position)
+      const uint32_t oe_all = Grp::vreadlane(oe, 2u * np - 1u);
+      const uint32_t tb = (oe_all - op < TRIPMAX ? oe_all : op + TRIPMAX) + 16u;
+      const uint32_t bound = (int32_t)(wild - tb) > 0 ? wild : tb;   // (... or what a one-sequence step before this trip has touched: its pieces are a whole step wide)
+      const uint32_t memlim = fl > op0 + db ? fl - db : op0;
+      const VB held = (mp >= VU(op0)) & ((mp + KW) >= VU(bound));
+      const VB okb = act & simple & (!isM | ((mp < VU(0x80000000u)) & (held | (send <= VU(memlim))))) &
+                     ((pv + ip) <= VU(ilim)) & (o <= VU(olim)) & ((oe - op) <= VU(TRIPMAX));
+      // (mp "negative" -- an offset that reaches in front of the block -- is a huge unsigned number: tested by itself, the sums may wrap)
+      // ---- 4. copies in DEPENDENCY ROUNDS, a lane per run, exact.  A round takes the runs from lane `a` on; a literal run has no
+      // dependency, a match is taken when its whole source lies below the round's own output.  The first match whose source reaches
+      // into it starts the next round, behind this round's stores -- LDS operations of a wavefront execute in order.  A round that
+      // would be empty ends the trip: its first run is a match that reaches into its OWN output (or is not for a trip at all) ----
+      const VU lp = pv + ip + Grp::vsel(lit >= 15u, VU(2u), VU(1u));
+      const VU spv = Grp::vsel(isM, mp + db, lp);   // the run's source: ring coordinates of the match source / stream position of the literals
+      uint32_t a = 0u;
+      for (;;) {
+        const uint32_t oa = Grp::vreadlane(o, a);
+        const uint64_t okm = Grp::vballot((okb & (!isM | (send <= VU(oa)))) | (lane < a));
+        const uint32_t Te = (uint32_t)__builtin_ctzll(~okm | (1ull << 63));   // (< 64: a pass uses lanes 0 .. 61)
 #ifdef LZ4HIP_WAVE_DBG   /* developer build of the simulator: why rounds end (tests/hostsim) */
-      g.vnote(act, simple, mp < VU(0x80000000u), (send <= VU(oa)) | (lane < a), held | (send <= VU(memlim)), held, (oe - op) <= VU(TRIPMAX), (okb & (send <= VU(oa))) | (lane < a));
+        g.vnote(act, simple, !isM | (mp < VU(0x80000000u)), !isM | (send <= VU(oa)) | (lane < a), !isM | held | (send <= VU(memlim)), !isM | held, (oe - op) <= VU(TRIPMAX), (okb & (!isM | (send <= VU(oa)))) | (lane < a));
 #endif
-      if (Te == a) break;
-      g.vcopy_seq(o + db, lp, lit, mp + db, ml, (lane >= a) & (lane < Te), dst, mp, !held);
+        if (Te == a) break;
+        g.vcopy_run(o + db, !isM, spv, len, (lane >= a) & (lane < Te), dst, mp, isM & !held);
 #ifdef LZ4HIP_RING_DBG
-      dbg_rounds++;
+        dbg_rounds++;
 #endif
-      a = Te;
-      if (a >= T) break;
+        a = Te;
+        if (a >= 2u * np) break;
+      }
+      a &= ~1u;                                 // (literals whose match was not taken are written again by whoever takes the sequence: the same bytes)
+      if (a == 0u) break;
+      tk += a >> 1;
+      opc = Grp::vreadlane(oe, a - 1u);
+      lrec = Grp::vreadlane(r, a - 1u);
+      if ((a < 2u * np) | (tk >= T)) break;     // the pass ended early, or the window is done
     }
 #ifdef LZ4HIP_RING_DBG
-    dbg_trips++; dbg_seqs += a; dbg_T += T; dbg_single += a == 0u ? 1u : 0u; dbg_two += T > T0 ? 1u : 0u;
+    dbg_trips++; dbg_seqs += tk; dbg_T += T; dbg_single += tk == 0u ? 1u : 0u; dbg_two += T > T0 ? 1u : 0u;
 #endif
-    if (LZ4HIP_UNLIKELY(a == 0u)) {
+    if (LZ4HIP_UNLIKELY(tk == 0u)) {
       if (!wave_single_step(g, dst, ip, op, op0, fl, db, ilim, olim)) break;
+      wild = op + STEP;                         // its wave-wide pieces end up to a step behind the sequence: the ring has lost what lies KW below that
     } else {
-      const uint32_t outb = Grp::vreadlane(oe, a - 1u) - op;
       uint32_t used;
-      if (a < T) used = Grp::vreadlane(posv, a);
+      if (tk < T) used = Grp::vreadlane(posv, tk);
       else {                                    // every start was taken: the next token lies behind the last sequence
-        const uint32_t lr = Grp::vreadlane(r, a - 1u), lpv = Grp::vreadlane(posv, a - 1u);
-        const uint32_t llit = (lr >> 16) & 255u, lmx = lr >> 24;
+        const uint32_t lpv = Grp::vreadlane(posv, tk - 1u);
+        const uint32_t llit = (lrec >> 16) & 255u, lmx = lrec >> 24;
         used = lpv + 1u + (llit >= 15u ? 1u : 0u) + llit + 2u + (lmx >= 15u ? 1u : 0u);
       }
-      ip += used; op += outb;
+      ip += used; op = opc;
     }
     // ---- the requested steps into the ring (in front of the flusher's stores: stores count in vmcnt on this part) ----
     if (nf != 0u) {

@@ -146,3 +146,31 @@ def lz4_seq(lit, ml, off, rng):
     tok = (min(lit, 15) << 4) | min(ml - 4, 15)
     s = bytes([tok]) + (ext(lit - 15) if lit >= 15 else b"") + rng.randbytes(lit) + bytes([off & 255, off >> 8])
     return s + (ext(ml - 4 - 15) if ml - 4 >= 15 else b"")
+
+
+def wild_piece_stream(kw, rng):
+    """A hand-assembled valid block that aims at one hazard of the parallel wave loop: a sequence only the one-sequence step takes
+    (a match that overlaps its own output) writes wave-wide pieces -- up to a step (256 bytes) beyond its end -- into the output ring,
+    i.e. over the ring bytes that hold the output KW bytes earlier; a short trip right behind it whose matches lie KW - 16 .. KW - 300
+    bytes back must not take those bytes from the ring.  (Found by the fuzz test in round 5: the trip's rule for "the ring still holds
+    the source" looked at the trip's own output only.)"""
+    seq = lz4_seq
+    c, n = bytearray(), 0
+    def add(lit, ml, off):
+        nonlocal n
+        c.extend(seq(lit, ml, off, rng)); n += lit + ml
+    while n < kw + 600:                                   # history: short simple sequences, sources near by
+        lit = rng.randrange(0, 20); add(lit, rng.randrange(4, 20), rng.randrange(1, min(n + lit, 2000) + 1) if n + lit else 1) if n + lit else add(5, 4, 3)
+    for d in list(range(16, 320, 7)) * 2:
+        add(rng.randrange(3, 9), rng.randrange(6, 12), rng.randrange(1, 5))      # overlaps its own output: the one-sequence step
+        # a trip of little output (the rule compares a source's position with the END of everything the trip has found: 3 bytes of
+        # stream for 4 of output keep that near): sources just inside the ring's reach
+        for _ in range(rng.choice([3, 40])):
+            lit = rng.choice([0, 0, 0, 1])
+            add(lit, rng.randrange(4, 6), kw - d - rng.randrange(0, 4))
+        for _ in range(rng.randrange(0, 3)):
+            lit = rng.randrange(0, 20); add(lit, rng.randrange(4, 20), rng.randrange(1, 2000))
+    for _ in range(400):                                  # far from the end of the stream: the loop stays in charge throughout
+        lit = rng.randrange(0, 20); add(lit, rng.randrange(4, 20), rng.randrange(1, 2000))
+    c.extend(bytes([0xF0, 1]) + rng.randbytes(16))        # last literals (the last match starts more than 12 bytes in front of the end)
+    return bytes(c), n + 16

@@ -338,13 +338,22 @@ struct GroupHost {
   // ---- lane-parallel side (the parallel trips): per-lane values are 64-element vectors, every call is one instruction ----
   typedef V<uint32_t> VU;
   typedef V<bool> VB;
-  static inline uint64_t par_trips = 0, par_seqs = 0, par_single = 0, par_far = 0;
+  static inline uint64_t par_trips = 0, par_seqs = 0, par_single = 0, par_far = 0, par_rounds = 0, par_windows = 0;
   static VU vlane() { VU r; for (int i = 0; i < 64; i++) r.v[i] = (uint32_t)i; return r; }
   static VU vsel(const VB& c, const VU& a, const VU& b) { VU r; for (int i = 0; i < 64; i++) r.v[i] = c.v[i] ? a.v[i] : b.v[i]; return r; }
   static uint64_t vballot(const VB& b) { uint64_t m = 0; for (int i = 0; i < 64; i++) if (b.v[i]) m |= 1ull << i; return m; }
   static uint32_t vreadlane(const VU& v, uint32_t i) { return v.v[i & 63u]; }
   static VU vwritelane(const VU& v, uint32_t s, uint32_t i) { VU r = v; r.v[i & 63u] = s; return r; }
   static VU vshfl(const VU& v, const VU& srcl) { VU r; for (int i = 0; i < 64; i++) r.v[i] = v.v[srcl.v[i] & 63u]; return r; }
+  static void vwalk(const VU& nx, VU& posv, uint32_t& T) {   // (group_dev.h vwalk: hand-written there)
+    uint32_t s = 0u;
+    do {
+      posv = vwritelane(posv, s, T);
+      T++;
+      const uint32_t d = vreadlane(nx, s >> 2);
+      s = (d >> ((s & 3u) * 8u)) & 255u;
+    } while ((s != 255u) & (T < 64u));
+  }
   static VU vexcl_scan(const VU& a) { par_trips++; VU r; uint32_t acc = 0; for (int l = 0; l < 64; l++) { r.v[l] = acc; acc += a.v[l]; } return r; }
   static inline uint64_t why[8] = {0};
   void vnote(const VB& act, const VB& a, const VB& b, const VB& c, const VB& d, const VB& e, const VB& f, const VB& ok) {
@@ -354,6 +363,7 @@ struct GroupHost {
   }
   static VU vmin(const VU& a, const VU& b) { VU r; for (int l = 0; l < 64; l++) r.v[l] = a.v[l] < b.v[l] ? a.v[l] : b.v[l]; return r; }
   void vs_win(uint32_t ip, VU& lo, VU& hi) {   // (the device reads the three aligned dwords at ((ip & ~3) + 4 l) & mask)
+    par_windows++;
     for (int l = 0; l < 64; l++) {
       const uint32_t a = ((ip & ~3u) + 4u * (uint32_t)l) & (kWs - 1u);
       uint8_t b[12] = {0};
@@ -401,40 +411,37 @@ struct GroupHost {
       for (int l = 0; l < 64; l++) if (m.v[l]) c.v[l] += n;
     }
   }
-  // both copies of a trip (group_dev.h vcopy_seq): the usual trip reads EVERYTHING (literals and match sources of all lanes) before
-  // it stores anything, and stores no mirror copies -- the rule that decides it is the device's
-  void vcopy_seq(const VU& dw, const VU& sp, const VU& lenl, const VU& sw, const VU& lenm, const VB& go, const uint8_t* mem, const VU& mpos, const VB& far) {
-    for (int l = 0; l < 64; l++) { par_seqs += go.v[l] ? 1u : 0u; par_far += (go.v[l] && far.v[l]) ? 1u : 0u; }
+  // one run per lane (group_dev.h vcopy_run): the usual round reads EVERYTHING (the sources of all its lanes) before it stores
+  // anything, and stores no mirror copies -- the rule that decides it is the device's
+  void vcopy_run(const VU& dw, const VB& from_stream, const VU& sp, const VU& len, const VB& go, const uint8_t* mem, const VU& mpos, const VB& far) {
+    par_rounds++;
+    for (int l = 0; l < 64; l++) { par_seqs += (go.v[l] && !from_stream.v[l]) ? 1u : 0u; par_far += (go.v[l] && far.v[l]) ? 1u : 0u; }
     bool odd = false;
     for (int l = 0; l < 64; l++) {
       const uint32_t x = dw.v[l] & (kWv - 1u);
-      odd |= go.v[l] && (lenl.v[l] > 64u || lenm.v[l] > 64u || x < 16u || x + lenl.v[l] + lenm.v[l] + 16u > kWv);
+      odd |= go.v[l] && (len.v[l] > 64u || x < 16u || x + len.v[l] + 16u > kWv);
     }
-    VB gr, gf;
-    for (int l = 0; l < 64; l++) { gr.v[l] = go.v[l] && !far.v[l]; gf.v[l] = go.v[l] && far.v[l]; }
-    if (odd) { vcopy(0, dw, sp, lenl, go); vcopy(1, dw + lenl, sw, lenm, gr); vcopy(2, dw + lenl, mpos, lenm, gf, mem); return; }
-    static uint8_t bl[64][80], bm[64][80];
+    VB gs, gr, gf;
+    for (int l = 0; l < 64; l++) { gs.v[l] = go.v[l] && from_stream.v[l]; gr.v[l] = go.v[l] && !from_stream.v[l] && !far.v[l]; gf.v[l] = go.v[l] && far.v[l]; }
+    if (odd) { vcopy(0, dw, sp, len, gs); vcopy(1, dw, sp, len, gr); vcopy(2, dw, mpos, len, gf, mem); return; }
+    static uint8_t bf[64][80];
     for (int l = 0; l < 64; l++) {
       if (!go.v[l]) continue;
-      // (the device reads 64 + 15 bytes from each source whatever the lengths: every index it forms must lie in the LDS bytes /
-      // the block's slot)
-      for (uint32_t c = 0; c < 64u; c += 16u) { const uint8_t* q = wsb + ((sp.v[l] + c) & (kWs - 1u)); if (rl_ok(q, 16)) memcpy(bl[l] + c, q, 16); }
-      for (uint32_t c = 0; c < 64u; c += 16u) { const uint8_t* q = wrb + ((sw.v[l] + c) & (kWv - 1u)); if (rl_ok(q, 16)) memcpy(bm[l] + c, q, 16); }
-      auto tail = [&](const uint8_t* base, uint32_t mask, uint32_t s0, uint32_t len, uint8_t* out, bool is_mem) {
-        uint32_t c = len & ~15u;
-        for (uint32_t n = 8u; n >= 1u; n >>= 1) { const uint8_t* q = base + ((s0 + c) & mask); if ((is_mem ? rd_ok(q, n) : rl_ok(q, n)) && (len & n)) memcpy(out + c, q, n); c += len & n; }
+      // (the device reads 64 + 15 bytes from the source whatever the length: every index it forms must lie in the LDS bytes / the block's slot)
+      const uint8_t* base = from_stream.v[l] ? wsb : wrb;
+      const uint32_t mask = from_stream.v[l] ? kWs - 1u : kWv - 1u;
+      auto run = [&](const uint8_t* b, uint32_t m, uint32_t s0, bool is_mem) {
+        for (uint32_t c = 0; c < 64u; c += 16u) { const uint8_t* q = b + ((s0 + c) & m); if (is_mem ? rd_ok(q, 16) : rl_ok(q, 16)) memcpy(bf[l] + c, q, 16); }
+        uint32_t c = len.v[l] & ~15u;
+        for (uint32_t n = 8u; n >= 1u; n >>= 1) { const uint8_t* q = b + ((s0 + c) & m); if ((is_mem ? rd_ok(q, n) : rl_ok(q, n)) && (len.v[l] & n)) memcpy(bf[l] + c, q, n); c += len.v[l] & n; }
       };
-      tail(wsb, kWs - 1u, sp.v[l], lenl.v[l], bl[l], false);
-      tail(wrb, kWv - 1u, sw.v[l], lenm.v[l], bm[l], false);
-      if (far.v[l]) {
-        for (uint32_t c = 0; c < 64u; c += 16u) { const uint8_t* q = mem + mpos.v[l] + c; if (rd_ok(q, 16)) memcpy(bm[l] + c, q, 16); }
-        tail(mem, 0xFFFFFFFFu, mpos.v[l], lenm.v[l], bm[l], true);
-      }
+      run(base, mask, sp.v[l], false);
+      if (far.v[l]) run(mem, 0xFFFFFFFFu, mpos.v[l], true);
     }
     for (int l = 0; l < 64; l++) {
       if (!go.v[l]) continue;
       uint8_t* a = wrb + (dw.v[l] & (kWv - 1u));
-      if (rl_ok(a, lenl.v[l] + lenm.v[l])) { memcpy(a, bl[l], lenl.v[l]); memcpy(a + lenl.v[l], bm[l], lenm.v[l]); }
+      if (rl_ok(a, len.v[l])) memcpy(a, bf[l], len.v[l]);
     }
   }
   LChunk wv_read_al(uint32_t fw) {

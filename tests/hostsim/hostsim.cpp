@@ -186,6 +186,7 @@ void sim_ring_stats(unsigned long long* out3) { out3[0] = hostsim::GroupHost::ri
 unsigned long long sim_ring_trips() { return hostsim::GroupHost::ring_trips; }   // offset words the ring loop has parsed so far
 void sim_wave_why(unsigned long long* out8) { for (int i = 0; i < 8; i++) out8[i] = hostsim::GroupHost::why[i]; }
 void sim_wave_par_stats(unsigned long long* out3) { out3[0] = hostsim::GroupHost::par_trips; out3[1] = hostsim::GroupHost::par_seqs; out3[2] = hostsim::GroupHost::par_far; }
+void sim_wave_par_rounds(unsigned long long* out2) { out2[0] = hostsim::GroupHost::par_rounds; out2[1] = hostsim::GroupHost::par_windows; }
 void sim_wave_stats(unsigned long long* out4) { out4[0] = hostsim::GroupHost::wave_trips; out4[1] = hostsim::GroupHost::wave_entries; out4[2] = hostsim::GroupHost::wave_far; out4[3] = hostsim::GroupHost::wave_mirror; }
 unsigned long long sim_deep_trips() { return hostsim::GroupHost::deep_trips; }   // offset words the deep decoder loop has parsed so far
 

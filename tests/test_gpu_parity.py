@@ -333,6 +333,30 @@ def test_deep_decoder_loop_long_streams(amd, ref, O, corpus):
         amd.set_option("decode_lanes", 0); amd.set_option("decode_pipe", -1); amd.set_option("decode_stage", -1); amd.set_option("decode_ring", 0)
 
 
+def test_wave_par_trip_behind_a_one_sequence_step(amd, ref):
+    """conftest.wild_piece_stream on the device (the CPU suite runs it in the lane simulator, where the hazard was found): a trip of the
+    parallel wave loop right behind a sequence its one-sequence step took, match sources at the edge of what the output ring still
+    holds -- the step's wave-wide pieces have overwritten ring bytes the trip's own rule would still trust.  Every ring size."""
+    from conftest import wild_piece_stream
+    rng = random.Random(606)
+    cases = []
+    for log in (13, 14, 15, 16):
+        for _ in range(4):
+            cases.append(wild_piece_stream(1 << log, rng))
+    streams = [c for c, _ in cases]
+    caps = [n for _, n in cases]
+    want = [ref.decompress_safe_raw(c, n) for c, n in cases]
+    assert all(r == n for (r, _), n in zip(want, caps))
+    try:
+        for pipe, ring in ((5, 0), (5, 8192), (5, 16384), (5, 32768), (5, 65536), (4, 8192), (4, 65536)):
+            amd.set_option("decode_lanes", 64); amd.set_option("decode_pipe", pipe); amd.set_option("decode_stage", 0); amd.set_option("decode_ring", ring)
+            res = gpu_decode_safe_many(amd, streams, caps)
+            for k, ((r, d), (er, ed)) in enumerate(zip(res, want)):
+                assert r == er and d[:er] == ed[:er], (pipe, ring, k, r, er, next((i for i in range(min(r, er)) if d[i] != ed[i]), None))
+    finally:
+        amd.set_option("decode_lanes", 0); amd.set_option("decode_pipe", -1); amd.set_option("decode_stage", -1); amd.set_option("decode_ring", 0)
+
+
 def test_concurrent_callers(amd, ref, corpus):
     """instances are shared singletons and must be thread-safe (LZ4Compressor.java:25): 32 threads hammer the single-block and
     batch entry points (ctypes releases the GIL across the calls) and every result must equal the reference's"""

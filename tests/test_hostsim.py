@@ -478,6 +478,22 @@ def test_wave_decoder_small_and_fuzz(sim, ref, O, corpus, par):
         assert r3 == r4 and (r3 < 0 or d3[:cap] == d4[:cap]), ("fast", mode, len(v), cap, scap, r3, r4)
 
 
+def test_wave_par_trip_behind_a_one_sequence_step(sim, ref, O):
+    """conftest.wild_piece_stream: the parallel wave loop right behind a sequence of its one-sequence step, sources at the edge of what
+    the ring still holds -- every ring size, both stream rings"""
+    from conftest import wild_piece_stream
+    rng = random.Random(505)
+    for log in (12, 13, 14, 15, 16):
+        for rep in range(3):
+            c, n = wild_piece_stream(1 << log, rng)
+            want_r, want = ref.decompress_safe_raw(c, n)
+            assert want_r == n
+            for lg in sorted({log, 13, 16}):
+                for ks1k in (False, True):
+                    r, d = sim_decode(sim, c, n, 1, wave_flag(lg, ks1k, True), shift=rng.choice([0, 3, 64, 131]))
+                    assert r == n and d[:n] == want, (log, rep, lg, ks1k, r, n, next((i for i in range(min(r, n)) if d[i] != want[i]), None))
+
+
 def test_decode_core_malformed_vectors(sim, golden):
     for v in golden["malformed"]:
         vec = bytes.fromhex(v["hex"])
