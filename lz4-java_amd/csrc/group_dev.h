@@ -435,7 +435,10 @@ struct BlockWaveDev : GroupDev<64, 0> {
   // block (2048 x 4 MiB 30.7 -> 32.8 ms, 512 x 64 KiB App. F 0.70 -> 1.00 ms): a trip's cost is not fixed work to be spread -- the walk
   // (13 instructions per start), the copy rounds (~220 each) and the discovery (190 per window) all grow with what a trip carries
   // (1673 instead of 901 instructions).  One window; the two-window form stays in the source and in the simulator's tests.
-  static constexpr uint32_t kWaveWindows = 1u;
+#ifndef LZ4HIP_WAVE_WINDOWS
+#define LZ4HIP_WAVE_WINDOWS 1   /* developer A/B builds: 2 */
+#endif
+  static constexpr uint32_t kWaveWindows = LZ4HIP_WAVE_WINDOWS;
   static constexpr uint32_t kWaveLds = (uint32_t)KS + 16u + 16u + (uint32_t)KW + 32u;   // (32 tail: the first 16 ring bytes mirrored, plus a dword's reach)
   uint8_t* wsb = nullptr;   // stream ring
   uint8_t* wrb = nullptr;   // output ring, index 0
@@ -596,9 +599,26 @@ struct BlockWaveDev : GroupDev<64, 0> {
   // EXACT lane-per-sequence copy of len bytes (lanes with go) from the stream ring (FROM_STREAM) or the output ring (source in ring
   // coordinates) to ring coordinates dw: 16 bytes at a time while 16 are left, then 8 / 4 / 2 / 1.  Nothing outside [dw, dw + len)
   // is written; sources and destinations of different lanes do not overlap (the caller's dependency rule)
-  template <class T> __device__ __forceinline__ void vstep(const uint8_t* sb, uint32_t sm, VU dw, VU sp, VU c, bool m) {
+  // A load from the block's flushed output (a FAR match source) that the compiler does not see as a memory operation, waited for
+  // on the spot.  Why: the copies sit inside the trip's pass and round loops, and with a vector memory load anywhere in a loop the
+  // compiler puts s_waitcnt vmcnt(0) at the loop's head -- where it waits for the stream refill requested at the top of the trip
+  // and for the flusher's stores of the trip before (stores count in vmcnt on this part).  Measured with a build that had no far
+  // loads in the loops at all (gpurun_out/r05y2): 2048 x 4 MiB 27.0 -> 22.6 ms, 4096: 37.2 -> 32.6.
+  template <class T> __device__ __forceinline__ static T vld_mem(const uint8_t* p) {
+    typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+    typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+    T r;
+    if constexpr (sizeof(T) == 16) { u4v t; asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(t) : "v"(p) : "memory"); __builtin_memcpy(&r, &t, 16); }
+    else if constexpr (sizeof(T) == 8) { u2v t; asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(t) : "v"(p) : "memory"); __builtin_memcpy(&r, &t, 8); }
+    else if constexpr (sizeof(T) == 4) { uint32_t t; asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(t) : "v"(p) : "memory"); __builtin_memcpy(&r, &t, 4); }
+    else if constexpr (sizeof(T) == 2) { uint32_t t; asm volatile("global_load_ushort %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(t) : "v"(p) : "memory"); r = (T)t; }
+    else { uint32_t t; asm volatile("global_load_ubyte %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(t) : "v"(p) : "memory"); r = (T)t; }
+    return r;
+  }
+  template <class T, bool MEM = false> __device__ __forceinline__ void vstep(const uint8_t* sb, uint32_t sm, VU dw, VU sp, VU c, bool m) {
     T v = T();
-    if (m) v = *(const T*)(sb + ((sp + c) & sm));
+    if constexpr (MEM) { if (m) v = vld_mem<T>(sb + (sp + c)); }
+    else { if (m) v = *(const T*)(sb + ((sp + c) & sm)); }
     vput<T>(dw + c, v, m);
   }
   // SRC 0: the stream ring, 1: the output ring (sp in ring coordinates), 2: memory (sb + sp is the source; [sb + sp, + len) is readable)
@@ -608,20 +628,20 @@ struct BlockWaveDev : GroupDev<64, 0> {
     for (uint32_t c = 0u;; c += 16u) {
       const bool m = go && (c + 16u <= len);
       if (__builtin_amdgcn_ballot_w64(m) == 0ull) break;
-      vstep<u4a>(sb, sm, dw, sp, c, m);
+      vstep<u4a, SRC == 2>(sb, sm, dw, sp, c, m);
     }
     uint32_t c = len & ~15u;
     bool m = go && ((len & 8u) != 0u);
-    vstep<u2a>(sb, sm, dw, sp, c, m);
+    vstep<u2a, SRC == 2>(sb, sm, dw, sp, c, m);
     c += m ? 8u : 0u;
     m = go && ((len & 4u) != 0u);
-    vstep<u1a>(sb, sm, dw, sp, c, m);
+    vstep<u1a, SRC == 2>(sb, sm, dw, sp, c, m);
     c += m ? 4u : 0u;
     m = go && ((len & 2u) != 0u);
-    vstep<h1a>(sb, sm, dw, sp, c, m);
+    vstep<h1a, SRC == 2>(sb, sm, dw, sp, c, m);
     c += m ? 2u : 0u;
     m = go && ((len & 1u) != 0u);
-    vstep<uint8_t>(sb, sm, dw, sp, c, m);
+    vstep<uint8_t, SRC == 2>(sb, sm, dw, sp, c, m);
   }
   // Both copies of a trip: literals (stream position sp, lenl bytes) to ring coordinates dw, the match (source sw, lenm bytes) behind
   // them.  The usual trip -- every active length <= 64, no destination at the ring's ends -- issues ALL its reads (4 x 16 bytes and
@@ -643,6 +663,39 @@ struct BlockWaveDev : GroupDev<64, 0> {
     r.d = *(const h1a*)(sb + ((sp + c) & sm));
     c += len & 2u;
     r.e = *(sb + ((sp + c) & sm));
+    return r;
+  }
+  // the same run from the block's flushed output (a far source): eight loads in flight together, one wait, none of it visible to
+  // the compiler as a memory operation (see vld_mem)
+  __device__ __forceinline__ static Run16 vrun_load_mem(const uint8_t* p, VU len) {
+    typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+    typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+    u4v a0, a1, a2, a3; u2v b; uint32_t c, d, e;
+    uint32_t o = len & ~15u;
+    const uint8_t* pb = p + o;
+    o += len & 8u;
+    const uint8_t* pc = p + o;
+    o += len & 4u;
+    const uint8_t* pd = p + o;
+    o += len & 2u;
+    const uint8_t* pe = p + o;
+    asm volatile(
+        "global_load_dwordx4 %0, %8, off\n\t"
+        "global_load_dwordx4 %1, %8, off offset:16\n\t"
+        "global_load_dwordx4 %2, %8, off offset:32\n\t"
+        "global_load_dwordx4 %3, %8, off offset:48\n\t"
+        "global_load_dwordx2 %4, %9, off\n\t"
+        "global_load_dword %5, %10, off\n\t"
+        "global_load_ushort %6, %11, off\n\t"
+        "global_load_ubyte %7, %12, off\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(b), "=&v"(c), "=&v"(d), "=&v"(e)
+        : "v"(p), "v"(pb), "v"(pc), "v"(pd), "v"(pe)
+        : "memory");
+    Run16 r;
+    __builtin_memcpy(&r.a0, &a0, 16); __builtin_memcpy(&r.a1, &a1, 16); __builtin_memcpy(&r.a2, &a2, 16); __builtin_memcpy(&r.a3, &a3, 16);
+    __builtin_memcpy(&r.b, &b, 8);
+    r.c = c; r.d = d; r.e = e;
     return r;
   }
   __device__ __forceinline__ void vrun_store(VU dw, VU len, const Run16& r) {   // (no destination at the ring's ends: no mirror stores)
@@ -672,7 +725,7 @@ struct BlockWaveDev : GroupDev<64, 0> {
       if (go) {
         Run16 r = vrun_load(from_stream ? wsb : wrb, from_stream ? (uint32_t)KS - 1u : (uint32_t)KW - 1u, sp, len);
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(gf) != 0ull, 0)) {
-          if (gf) r = vrun_load(mem, 0xFFFFFFFFu, mpos, len);
+          if (gf) r = vrun_load_mem(mem + mpos, len);
         }
         vrun_store(dw, len, r);
       }
