@@ -725,14 +725,21 @@ struct BlockWaveDev : GroupDev<64, 0> {
       if (go) {
         Run16 r = vrun_load(from_stream ? wsb : wrb, from_stream ? (uint32_t)KS - 1u : (uint32_t)KW - 1u, sp, len);
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(gf) != 0ull, 0)) {
-          if (gf) r = vrun_load_mem(mem + mpos, len);
+          // (the rare branches take their operands through an empty asm: what is computed from them -- 64-bit addresses here, ring
+          // masks and mirror tests below -- is computed IN the branch; the compiler otherwise hoists ~55 instructions of it in front
+          // of the round loop, where every pass pays for them)
+          VU mp2 = mpos, ln2 = len;
+          asm volatile("" : "+v"(mp2), "+v"(ln2));
+          if (gf) r = vrun_load_mem(mem + mp2, ln2);
         }
         vrun_store(dw, len, r);
       }
     } else {
-      vcopy<0>(dw, nullptr, sp, len, go && from_stream);
-      vcopy<1>(dw, nullptr, sp, len, go && !from_stream && !far);
-      if (__builtin_amdgcn_ballot_w64(gf) != 0ull) vcopy<2>(dw, mem, mpos, len, gf);
+      VU dw2 = dw, sp2 = sp, ln2 = len, mp2 = mpos;
+      asm volatile("" : "+v"(dw2), "+v"(sp2), "+v"(ln2), "+v"(mp2));
+      vcopy<0>(dw2, nullptr, sp2, ln2, go && from_stream);
+      vcopy<1>(dw2, nullptr, sp2, ln2, go && !from_stream && !far);
+      if (__builtin_amdgcn_ballot_w64(gf) != 0ull) vcopy<2>(dw2, mem, mp2, ln2, gf);
     }
   }
   // the step at ring coordinates fw (a multiple of 256) to memory: its bytes inside [lo, hi) (ring coordinates), nothing else
