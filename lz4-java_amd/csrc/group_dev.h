@@ -539,23 +539,44 @@ struct BlockWaveDev : GroupDev<64, 0> {
   __device__ __forceinline__ static void vwalk(VU nx, VU& posv, uint32_t& T) {
     uint32_t s = 0u, t1, t2;
     T = (uint32_t)__builtin_amdgcn_readfirstlane((int)T);
-    asm volatile(
-        "L_walk_%=:\n"
-        "  s_mov_b32 m0, %[T]\n"
-        "  s_lshr_b32 %[t1], %[s], 2\n"
-        "  v_writelane_b32 %[pv], %[s], m0\n"
-        "  s_lshl_b32 %[t2], %[s], 3\n"
-        "  v_readlane_b32 %[s], %[nx], %[t1]\n"
-        "  s_add_u32 %[T], %[T], 1\n"
-        "  s_lshr_b32 %[s], %[s], %[t2]\n"
+    // Four hops at a time without a test in between: position 255's "next" is 255 (nothing that starts at 248 .. 255 is followed by a
+    // start inside the window), so hops past the last start stay there and write 255; the count is then the first lane that holds
+    // 255.  While fewer than 61 lanes are taken; the last ones hop one at a time with both tests.  8 instructions a hop + 4 per four.
+#define LZ4HIP_WALK_HOP \
+        "  s_mov_b32 m0, %[T]\n" \
+        "  s_lshr_b32 %[t1], %[s], 2\n" \
+        "  v_writelane_b32 %[pv], %[s], m0\n" \
+        "  s_lshl_b32 %[t2], %[s], 3\n" \
+        "  v_readlane_b32 %[s], %[nx], %[t1]\n" \
+        "  s_add_u32 %[T], %[T], 1\n" \
+        "  s_lshr_b32 %[s], %[s], %[t2]\n" \
         "  s_and_b32 %[s], %[s], 0xff\n"
+    asm volatile(
+        "  s_cmp_gt_u32 %[T], 60\n"
+        "  s_cbranch_scc1 L_walkchk_%=\n"
+        "L_walk4_%=:\n"
+        LZ4HIP_WALK_HOP LZ4HIP_WALK_HOP LZ4HIP_WALK_HOP LZ4HIP_WALK_HOP
+        "  s_cmpk_eq_u32 %[s], 0xff\n"
+        "  s_cbranch_scc1 L_walkend_%=\n"
+        "  s_cmp_le_u32 %[T], 60\n"
+        "  s_cbranch_scc1 L_walk4_%=\n"
+        "L_walkchk_%=:\n"
+        "  s_cmp_lt_u32 %[T], 64\n"
+        "  s_cbranch_scc0 L_walkend_%=\n"
+        "L_walk1_%=:\n"
+        LZ4HIP_WALK_HOP
         "  s_cmp_lt_u32 %[T], 64\n"
         "  s_cselect_b32 %[t1], %[s], 0xff\n"
         "  s_cmpk_lg_u32 %[t1], 0xff\n"
-        "  s_cbranch_scc1 L_walk_%=\n"
+        "  s_cbranch_scc1 L_walk1_%=\n"
+        "L_walkend_%=:\n"
+        "  v_cmp_eq_u32_e32 vcc, 0xff, %[pv]\n"
+        "  s_ff1_i32_b64 %[t1], vcc\n"
+        "  s_min_u32 %[T], %[T], %[t1]\n"
         : [pv] "+v"(posv), [T] "+s"(T), [s] "+s"(s), [t1] "=&s"(t1), [t2] "=&s"(t2)
         : [nx] "v"(nx)
-        : "m0", "scc");
+        : "m0", "scc", "vcc");
+#undef LZ4HIP_WALK_HOP
   }
   __device__ __forceinline__ static VU vshfl(VU v, VU srcl) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(srcl << 2), (int)v); }
   __device__ __forceinline__ static VU vexcl_scan(VU a) {   // exclusive prefix sum across the wavefront: row_shr DPP adds + row_bcast15/31

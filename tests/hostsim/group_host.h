@@ -345,14 +345,21 @@ struct GroupHost {
   static uint32_t vreadlane(const VU& v, uint32_t i) { return v.v[i & 63u]; }
   static VU vwritelane(const VU& v, uint32_t s, uint32_t i) { VU r = v; r.v[i & 63u] = s; return r; }
   static VU vshfl(const VU& v, const VU& srcl) { VU r; for (int i = 0; i < 64; i++) r.v[i] = v.v[srcl.v[i] & 63u]; return r; }
-  static void vwalk(const VU& nx, VU& posv, uint32_t& T) {   // (group_dev.h vwalk: hand-written there)
+  static void vwalk(const VU& nx, VU& posv, uint32_t& T) {   // (group_dev.h vwalk, hand-written there: the same hops in the same groups)
     uint32_t s = 0u;
-    do {
+    auto hop = [&]() {
       posv = vwritelane(posv, s, T);
       T++;
       const uint32_t d = vreadlane(nx, s >> 2);
       s = (d >> ((s & 3u) * 8u)) & 255u;
-    } while ((s != 255u) & (T < 64u));
+    };
+    bool done = false;
+    while (T <= 60u) {
+      hop(); hop(); hop(); hop();
+      if (s == 255u) { done = true; break; }
+    }
+    if (!done) while ((s != 255u) & (T < 64u)) hop();
+    for (uint32_t k = 0; k < 64u; k++) if (posv.v[k] == 255u) { if (k < T) T = k; break; }
   }
   static VU vexcl_scan(const VU& a) { par_trips++; VU r; uint32_t acc = 0; for (int l = 0; l < 64; l++) { r.v[l] = acc; acc += a.v[l]; } return r; }
   static inline uint64_t why[8] = {0};
