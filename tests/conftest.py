@@ -174,3 +174,35 @@ def wild_piece_stream(kw, rng):
         lit = rng.randrange(0, 20); add(lit, rng.randrange(4, 20), rng.randrange(1, 2000))
     c.extend(bytes([0xF0, 1]) + rng.randbytes(16))        # last literals (the last match starts more than 12 bytes in front of the end)
     return bytes(c), n + 16
+
+
+def ring_edge_stream(rng, n_target=90000):
+    """A hand-assembled valid block of short sequences whose match distances cluster around the sizes of the wave loops' output rings
+    (4 .. 64 KB, +- 320 bytes) -- "the ring still holds it" against "it comes from flushed memory" is decided there --, mixed with
+    matches that overlap their own output (the one-sequence step and its wave-wide pieces), long literal runs and long matches (the
+    slow copies, trips that end early) and plain sequences.  Returns (stream, decoded size)."""
+    c, n = bytearray(), 0
+    def add(lit, ml, off):
+        nonlocal n
+        off = max(1, min(off, n + lit, 65535))
+        c.extend(lz4_seq(lit, ml, off, rng)); n += lit + ml
+    add(12, 4, 5)
+    while n < n_target:
+        k = rng.random()
+        if k < 0.55:
+            if rng.random() < 0.5:
+                off = rng.choice([4096, 8192, 16384, 32768, 65536]) + rng.randrange(-320, 321)
+            else:
+                off = rng.randrange(1, 2000)
+            for _ in range(rng.choice([1, 1, 2, 5, 30])):
+                add(rng.randrange(0, 7), rng.randrange(4, 9), off + rng.randrange(-3, 4))
+        elif k < 0.65:
+            add(rng.randrange(0, 10), rng.randrange(4, 41), rng.randrange(1, 9))
+        elif k < 0.70:
+            add(rng.randrange(15, 300), rng.randrange(4, 20), rng.randrange(1, 65536))
+        elif k < 0.75:
+            add(rng.randrange(0, 10), rng.randrange(20, 600), rng.randrange(1, 65536))
+        else:
+            add(rng.randrange(0, 31), rng.randrange(4, 31), rng.randrange(1, 65536))
+    c.extend(bytes([0xF0, 1]) + rng.randbytes(16))
+    return bytes(c), n + 16

@@ -357,6 +357,27 @@ def test_wave_par_trip_behind_a_one_sequence_step(amd, ref):
         amd.set_option("decode_lanes", 0); amd.set_option("decode_pipe", -1); amd.set_option("decode_stage", -1); amd.set_option("decode_ring", 0)
 
 
+def test_wave_loops_ring_edge_streams(amd, ref):
+    """conftest.ring_edge_stream on the device: 24 hand-assembled blocks whose match distances cluster around every ring size, with
+    one-sequence steps, slow copies and early trip ends in between -- both wave loops, every ring (the CPU suite runs the same
+    generator in the lane simulator)"""
+    from conftest import ring_edge_stream
+    rng = random.Random(8118)
+    cases = [ring_edge_stream(rng, rng.choice([20000, 90000, 150000])) for _ in range(24)]
+    streams = [c for c, _ in cases]
+    caps = [n for _, n in cases]
+    want = [ref.decompress_safe_raw(c, n) for c, n in cases]
+    assert all(r == n for (r, _), n in zip(want, caps))
+    try:
+        for pipe, ring in ((5, 0), (5, 8192), (5, 16384), (5, 32768), (5, 65536), (4, 0), (4, 8192), (4, 32768)):
+            amd.set_option("decode_lanes", 64); amd.set_option("decode_pipe", pipe); amd.set_option("decode_stage", 0); amd.set_option("decode_ring", ring)
+            res = gpu_decode_safe_many(amd, streams, caps)
+            for k, ((r, d), (er, ed)) in enumerate(zip(res, want)):
+                assert r == er and d[:er] == ed[:er], (pipe, ring, k, r, er, next((i for i in range(min(max(r, 0), er)) if d[i] != ed[i]), None))
+    finally:
+        amd.set_option("decode_lanes", 0); amd.set_option("decode_pipe", -1); amd.set_option("decode_stage", -1); amd.set_option("decode_ring", 0)
+
+
 def test_concurrent_callers(amd, ref, corpus):
     """instances are shared singletons and must be thread-safe (LZ4Compressor.java:25): 32 threads hammer the single-block and
     batch entry points (ctypes releases the GIL across the calls) and every result must equal the reference's"""

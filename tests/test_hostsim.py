@@ -494,6 +494,21 @@ def test_wave_par_trip_behind_a_one_sequence_step(sim, ref, O):
                     assert r == n and d[:n] == want, (log, rep, lg, ks1k, r, n, next((i for i in range(min(r, n)) if d[i] != want[i]), None))
 
 
+def test_wave_loops_ring_edge_streams(sim, ref):
+    """conftest.ring_edge_stream through both wave loops at every ring size: distances at the edge of what a ring holds, one-sequence
+    steps between short trips, slow copies, early trip ends"""
+    from conftest import ring_edge_stream
+    rng = random.Random(7117)
+    for rep in range(6):
+        c, n = ring_edge_stream(rng, rng.choice([20000, 90000, 150000]))
+        want_r, want = ref.decompress_safe_raw(c, n)
+        assert want_r == n
+        for log in (12, 13, 14, 15, 16):
+            for par in (True, False) if log in (13, 16) else (True,):
+                r, d = sim_decode(sim, c, n, 1, wave_flag(log, rng.random() < 0.5, par), shift=rng.choice([0, 3, 64, 131, 255]))
+                assert r == n and d[:n] == want, (rep, log, par, r, n, next((i for i in range(min(max(r, 0), n)) if d[i] != want[i]), None))
+
+
 def test_decode_core_malformed_vectors(sim, golden):
     for v in golden["malformed"]:
         vec = bytes.fromhex(v["hex"])
