@@ -431,10 +431,10 @@ struct BlockWaveDev : GroupDev<64, 0> {
   typedef typename Base::LChunk LChunk;   // one dword
   static_assert(Base::LB == 4u, "a lane of the wave loop moves one dword");
   // 256-byte windows of the stream a parallel trip discovers (lz4_decode_wave.h).  TWO (possible where KS >= 2048) were built and measured
-  // (gpurun_out/r05l-p, tools/wave_stats.py): 21.8 instead of 9.9 sequences per trip on BASELINE configs[2]'s blocks, and the same time per
-  // block (2048 x 4 MiB 30.7 -> 32.8 ms, 512 x 64 KiB App. F 0.70 -> 1.00 ms): a trip's cost is not fixed work to be spread -- the walk
-  // (13 instructions per start), the copy rounds (~220 each) and the discovery (190 per window) all grow with what a trip carries
-  // (1673 instead of 901 instructions).  One window; the two-window form stays in the source and in the simulator's tests.
+  // twice (profiles/r05_wave_notes.txt sections 2 and 4): 21.8 instead of 9.9 sequences per trip on BASELINE configs[2]'s blocks, and never
+  // faster (2048 x 4 MiB 30.7 -> 32.8 ms with the first version of the trip, 26.9 -> 29.1 ms with a lane per run; 2048 x 64 KiB App. F
+  // 0.84 -> 1.25 ms): a trip's cost is not fixed work to be spread -- walk, rounds and discovery all grow with what a trip carries.  One
+  // window; the two-window form stays in the source (developer builds) and in the simulator's tests.
 #ifndef LZ4HIP_WAVE_WINDOWS
 #define LZ4HIP_WAVE_WINDOWS 1   /* developer A/B builds: 2 */
 #endif
@@ -617,9 +617,6 @@ struct BlockWaveDev : GroupDev<64, 0> {
       if (m & (t < 32u)) *(T*)(a + KW) = v;
     }
   }
-  // EXACT lane-per-sequence copy of len bytes (lanes with go) from the stream ring (FROM_STREAM) or the output ring (source in ring
-  // coordinates) to ring coordinates dw: 16 bytes at a time while 16 are left, then 8 / 4 / 2 / 1.  Nothing outside [dw, dw + len)
-  // is written; sources and destinations of different lanes do not overlap (the caller's dependency rule)
   // A load from the block's flushed output (a FAR match source) that the compiler does not see as a memory operation, waited for
   // on the spot.  Why: the copies sit inside the trip's pass and round loops, and with a vector memory load anywhere in a loop the
   // compiler puts s_waitcnt vmcnt(0) at the loop's head -- where it waits for the stream refill requested at the top of the trip
@@ -636,6 +633,10 @@ struct BlockWaveDev : GroupDev<64, 0> {
     else { uint32_t t; asm volatile("global_load_ubyte %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(t) : "v"(p) : "memory"); r = (T)t; }
     return r;
   }
+  // EXACT lane-per-run copy, the slow form (a destination at the ring's ends, a run of more than 64 bytes): len bytes (lanes with go)
+  // from the stream ring, the output ring (source in ring coordinates) or memory to ring coordinates dw, 16 bytes at a time while 16 are
+  // left, then 8 / 4 / 2 / 1, every step with its mirror store.  Nothing outside [dw, dw + len) is written; sources and destinations of
+  // different lanes do not overlap (the caller's dependency rule)
   template <class T, bool MEM = false> __device__ __forceinline__ void vstep(const uint8_t* sb, uint32_t sm, VU dw, VU sp, VU c, bool m) {
     T v = T();
     if constexpr (MEM) { if (m) v = vld_mem<T>(sb + (sp + c)); }
@@ -664,11 +665,10 @@ struct BlockWaveDev : GroupDev<64, 0> {
     m = go && ((len & 1u) != 0u);
     vstep<uint8_t, SRC == 2>(sb, sm, dw, sp, c, m);
   }
-  // Both copies of a trip: literals (stream position sp, lenl bytes) to ring coordinates dw, the match (source sw, lenm bytes) behind
-  // them.  The usual trip -- every active length <= 64, no destination at the ring's ends -- issues ALL its reads (4 x 16 bytes and
-  // an 8 / 4 / 2 / 1 cascade per copy, only the active lanes: an unaligned LDS access costs a cycle per lane) in front of ONE wait
-  // and then the predicated stores; the step-by-step form above waited for the LDS once per step (14 round trips per trip, 43 % of
-  // the wavefront's cycles: profiles/r05_wave_notes.txt)
+  // The usual round -- every active run <= 64 bytes, no destination at the ring's ends -- issues ALL its reads (4 x 16 bytes and an
+  // 8 / 4 / 2 / 1 cascade per run, only the active lanes: an unaligned LDS access costs a cycle per lane) in front of ONE wait and
+  // then the predicated stores; the step-by-step form above waits for the LDS once per step (14 round trips per trip, 43 % of the
+  // wavefront's cycles when it was the only form: profiles/r05_wave_notes.txt)
   struct Run16 { u4a a0, a1, a2, a3; u2a b; uint32_t c; uint32_t d; uint32_t e; };
   __device__ __forceinline__ static Run16 vrun_load(const uint8_t* sb, uint32_t sm, VU sp, VU len) {
     Run16 r;

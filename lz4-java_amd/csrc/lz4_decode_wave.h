@@ -179,17 +179,17 @@ LZ4HIP_DEV void decode_wave_loop(Grp& g, const uint8_t* src, const int iend, uin
 //     (token, literal-length byte, the offset word and match-length byte behind the literals: aligned dword reads, funnelled)
 //     into a record {offset, literal length, match length} and the window position of the NEXT token (255: none / not simple);
 //  2. WALK: the four next-positions of a lane are one dword, so the chain 0 -> next(0) -> ... is a scalar walk of v_readlane's
-//     (~7 instructions per sequence, no memory); the k-th start goes to lane k (v_writelane);
-//  3. RECORDS: lane k fetches the record of its start from the lane that decoded it (ds_bpermute), an exclusive prefix sum (DPP)
-//     of literal + match lengths gives every sequence its output position, and one ballot finds the first sequence that is not for
-//     this trip: invalid offset, not simple, or -- the dependency rule -- a match source that reaches into THIS TRIP'S OWN OUTPUT
-//     (a source the ring no longer holds is read from the block's flushed output in memory, all such lanes of a trip together).  The trip ends in front of it; as the first sequence of the next trip its source lies
-//     below that trip's output (or it is handed to the one-sequence step below);
-//  4. COPIES, a lane per sequence, exact: literals stream ring -> output ring, matches output ring -> output ring, 16 bytes at a
-//     time and an 8 / 4 / 2 / 1 cascade for the rest -- no byte outside a sequence's own output is written, so the lanes need no
-//     order between them.
-// What a trip cannot take as its FIRST sequence (a match that overlaps its own output or reaches into its own literals, a far
-// source, literal runs over 255 / matches over 259 bytes) is decoded by `wave_single_step` -- the one-sequence trip above without
+//     (8 instructions per sequence, no memory: group_dev.h vwalk, written by hand); the k-th start goes to lane k (v_writelane);
+//  3. RECORDS, A LANE PER RUN: lane 2k takes the literals of the k-th sequence, lane 2k + 1 its match.  Both fetch the record of
+//     their start from the lane that decoded it (ds_bpermute); the exclusive prefix sum (DPP) of the run lengths is every run's output
+//     position; one ballot finds the first run that is not for this round: invalid offset, not simple, or -- the dependency rule -- a
+//     match whose source reaches into THIS ROUND'S OWN OUTPUT (a source the ring no longer holds is read from the block's flushed
+//     output in memory).  The next round starts there, behind this round's stores; a round that would be empty ends the trip, and its
+//     first sequence is handed to the one-sequence step below;
+//  4. COPIES, exact: literals stream ring -> output ring, matches output ring -> output ring, 16 bytes at a time and an 8 / 4 / 2 / 1
+//     cascade for the rest -- no byte outside a run's own output is written, so the lanes need no order between them.
+// What a trip cannot take as its FIRST sequence (a match that overlaps its own output, literal runs over 255 / matches over 259
+// bytes) is decoded by `wave_single_step` -- the one-sequence trip above without
 // its pipelining; what that cannot take either leaves the loop for the exact code of decode_block.
 // ================================================================================================================================
 

@@ -411,7 +411,7 @@ def test_wave_decoder_loop(sim, ref, O, corpus, par):
     the C restatement's bounded fast decoder.  Every access outside the block's slots or the wavefront's LDS bytes, every
     unaligned store by lanes 1.., every mirror store the device's wave-uniform pre-test would have skipped counts as a failure.
     par: the PARALLEL loop -- every sequence that starts in a 256-byte window of the stream per trip (speculative lane-parallel
-    discovery, scalar walk, records by lane shuffle, prefix-summed output positions, the dependency rule, exact lane-per-sequence
+    discovery, scalar walk, records by lane shuffle, prefix-summed output positions, the dependency rule, exact lane-per-run
     copies), with the one-sequence step for what a trip cannot start with."""
     rng = random.Random(20250924)
     from conftest import deep_decoder_cases
