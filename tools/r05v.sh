@@ -7,3 +7,4 @@ out=gpurun_out/r05v; mkdir -p $out
 timeout 600 python tools/gpu_small_batches.py 300 > $out/small_batches.log 2>&1
 timeout 900 python tools/gpu_fuzz.py 6000 77 > $out/gpu_fuzz.log 2>&1
 cat $out/fuzz_wave.log; tail -3 $out/small_batches.log; tail -6 $out/gpu_fuzz.log
+timeout 280 python tools/gpu_ring_edge.py 400 11 2>&1 | tail -1 >> $out/fuzz_wave.log
