@@ -525,6 +525,7 @@ struct BlockWaveDev : GroupDev<64, 0> {
   __device__ __forceinline__ VU vlane() const { return this->l; }
   __device__ __forceinline__ static VU vsel(bool c, VU a, VU b) { return c ? a : b; }
   __device__ __forceinline__ static uint64_t vballot(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+  __device__ __forceinline__ static bool vlanes(uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }   // per-lane predicate from a wave-uniform lane mask (the SGPR pair IS the mask: no vector instruction)
   __device__ __forceinline__ static uint32_t vreadlane(VU v, uint32_t i) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)i); }
   __device__ __forceinline__ static VU vwritelane(VU v, uint32_t s, uint32_t i) {
     s = (uint32_t)__builtin_amdgcn_readfirstlane((int)s);   // (wave-uniform values the compiler happens to hold in a vector register reach the asm as one: folds away when they are scalar already)
@@ -736,31 +737,37 @@ struct BlockWaveDev : GroupDev<64, 0> {
   }
   // One RUN per lane (lz4_decode_wave.h: even lanes the literals of a sequence, odd lanes its match): len bytes to ring coordinates
   // dw, from the stream ring at stream position sp (from_stream) or from the output ring at ring coordinates sp.
-  // far: the match source of this lane is not in the ring: it is mem[mpos, mpos + len) (the block's flushed output; 80 bytes from
-  // mpos on are readable).  The far lanes of a round have their loads in flight together, behind the ring reads of the others
-  __device__ __forceinline__ void vcopy_run(VU dw, bool from_stream, VU sp, VU len, bool go, const uint8_t* mem, VU mpos, bool far) {
+  // The lanes of the round, the far ones and the "odd" ones come as wave-uniform LANE MASKS (gom; farm, oddm: computed once per pass
+  // by the caller): the round's tests are scalar ANDs, its predicates SGPR pairs -- a ballot of a bool the compiler holds as a mask
+  // costs a v_cndmask + v_cmp each time.
+  // far: the match source of the lane is not in the ring: it is mem[mpos, mpos + len) (the block's flushed output; 80 bytes from mpos
+  // on are readable).  The far lanes of a round have their loads in flight together, behind the ring reads of the others
+  __device__ __forceinline__ uint64_t vodd_mask(VU dw, VU len) const {   // lanes whose run cannot take the usual round: longer than 64 bytes, or a destination at the ring's ends
     const uint32_t x = dw & ((uint32_t)KW - 1u);
-    const bool odd = go && ((len > 64u) || (x < 16u) || (x + len + 16u > (uint32_t)KW));
-    const bool gf = go && far;
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(odd) == 0ull, 1)) {
-      if (go) {
+    return __builtin_amdgcn_ballot_w64((len > 64u) || (x < 16u) || (x + len + 16u > (uint32_t)KW));
+  }
+  __device__ __forceinline__ void vcopy_run(VU dw, bool from_stream, VU sp, VU len, uint64_t gom, const uint8_t* mem, VU mpos, uint64_t farm, uint64_t oddm) {
+    const uint64_t gfm = gom & farm;
+    if (__builtin_expect((oddm & gom) == 0ull, 1)) {
+      if (vlanes(gom)) {
         Run16 r = vrun_load(from_stream ? wsb : wrb, from_stream ? (uint32_t)KS - 1u : (uint32_t)KW - 1u, sp, len);
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(gf) != 0ull, 0)) {
+        if (__builtin_expect(gfm != 0ull, 0)) {
           // (the rare branches take their operands through an empty asm: what is computed from them -- 64-bit addresses here, ring
           // masks and mirror tests below -- is computed IN the branch; the compiler otherwise hoists ~55 instructions of it in front
           // of the round loop, where every pass pays for them)
           VU mp2 = mpos, ln2 = len;
           asm volatile("" : "+v"(mp2), "+v"(ln2));
-          if (gf) r = vrun_load_mem(mem + mp2, ln2);
+          if (vlanes(gfm)) r = vrun_load_mem(mem + mp2, ln2);
         }
         vrun_store(dw, len, r);
       }
     } else {
       VU dw2 = dw, sp2 = sp, ln2 = len, mp2 = mpos;
       asm volatile("" : "+v"(dw2), "+v"(sp2), "+v"(ln2), "+v"(mp2));
+      const bool go = vlanes(gom), far = vlanes(farm);
       vcopy<0>(dw2, nullptr, sp2, ln2, go && from_stream);
       vcopy<1>(dw2, nullptr, sp2, ln2, go && !from_stream && !far);
-      if (__builtin_amdgcn_ballot_w64(gf) != 0ull) vcopy<2>(dw2, mem, mp2, ln2, gf);
+      if (gfm != 0ull) vcopy<2>(dw2, mem, mp2, ln2, go && far);
     }
   }
   // the step at ring coordinates fw (a multiple of 256) to memory: its bytes inside [lo, hi) (ring coordinates), nothing else

@@ -400,16 +400,20 @@ LZ4HIP_DEV void decode_wave_par_loop(Grp& g, const uint8_t* src, const int iend,
       // would be empty ends the trip: its first run is a match that reaches into its OWN output (or is not for a trip at all) ----
       const VU lp = pv + ip + Grp::vsel(lit >= 15u, VU(2u), VU(1u));
       const VU spv = Grp::vsel(isM, mp + db, lp);   // the run's source: ring coordinates of the match source / stream position of the literals
+      // (the round's lane sets are wave-uniform MASKS, combined with scalar instructions: one vector compare per round)
+      const uint64_t okbm = Grp::vballot(okb), farm = Grp::vballot(isM & !held), oddm = g.vodd_mask(o + db, len);
+      constexpr uint64_t litm = 0x5555555555555555ull;                        // the even lanes: literal runs
       uint32_t a = 0u;
       for (;;) {
         const uint32_t oa = Grp::vreadlane(o, a);
-        const uint64_t okm = Grp::vballot((okb & (!isM | (send <= VU(oa)))) | (lane < a));
+        const uint64_t below = (1ull << a) - 1ull;                            // the lanes the rounds before this one took (a <= 62)
+        const uint64_t okm = (okbm & (litm | Grp::vballot(send <= VU(oa)))) | below;
         const uint32_t Te = (uint32_t)__builtin_ctzll(~okm | (1ull << 63));   // (< 64: a pass uses lanes 0 .. 61)
 #ifdef LZ4HIP_WAVE_DBG   /* developer build of the simulator: why rounds end (tests/hostsim) */
         g.vnote(act, simple, !isM | (mp < VU(0x80000000u)), !isM | (send <= VU(oa)) | (lane < a), !isM | held | (send <= VU(memlim)), !isM | held, (oe - op) <= VU(TRIPMAX), (okb & (!isM | (send <= VU(oa)))) | (lane < a));
 #endif
         if (Te == a) break;
-        g.vcopy_run(o + db, !isM, spv, len, (lane >= a) & (lane < Te), dst, mp, isM & !held);
+        g.vcopy_run(o + db, !isM, spv, len, ((1ull << Te) - 1ull) & ~below, dst, mp, farm, oddm);
 #ifdef LZ4HIP_RING_DBG
         dbg_rounds++;
 #endif

@@ -341,6 +341,7 @@ struct GroupHost {
   static inline uint64_t par_trips = 0, par_seqs = 0, par_single = 0, par_far = 0, par_rounds = 0, par_windows = 0;
   static VU vlane() { VU r; for (int i = 0; i < 64; i++) r.v[i] = (uint32_t)i; return r; }
   static VU vsel(const VB& c, const VU& a, const VU& b) { VU r; for (int i = 0; i < 64; i++) r.v[i] = c.v[i] ? a.v[i] : b.v[i]; return r; }
+  static VB vlanes(uint64_t m) { VB r; for (int i = 0; i < 64; i++) r.v[i] = (m >> i) & 1u; return r; }
   static uint64_t vballot(const VB& b) { uint64_t m = 0; for (int i = 0; i < 64; i++) if (b.v[i]) m |= 1ull << i; return m; }
   static uint32_t vreadlane(const VU& v, uint32_t i) { return v.v[i & 63u]; }
   static VU vwritelane(const VU& v, uint32_t s, uint32_t i) { VU r = v; r.v[i & 63u] = s; return r; }
@@ -420,7 +421,14 @@ struct GroupHost {
   }
   // one run per lane (group_dev.h vcopy_run): the usual round reads EVERYTHING (the sources of all its lanes) before it stores
   // anything, and stores no mirror copies -- the rule that decides it is the device's
-  void vcopy_run(const VU& dw, const VB& from_stream, const VU& sp, const VU& len, const VB& go, const uint8_t* mem, const VU& mpos, const VB& far) {
+  uint64_t vodd_mask(const VU& dw, const VU& len) const {
+    uint64_t m = 0;
+    for (int l = 0; l < 64; l++) { const uint32_t x = dw.v[l] & (kWv - 1u); if (len.v[l] > 64u || x < 16u || x + len.v[l] + 16u > kWv) m |= 1ull << l; }
+    return m;
+  }
+  void vcopy_run(const VU& dw, const VB& from_stream, const VU& sp, const VU& len, uint64_t gom, const uint8_t* mem, const VU& mpos, uint64_t farm, uint64_t oddm) {
+    const VB go = vlanes(gom), far = vlanes(farm);
+    if (oddm != vodd_mask(dw, len)) oob = true;   // (the caller's mask must be the rule below)
     par_rounds++;
     for (int l = 0; l < 64; l++) { par_seqs += (go.v[l] && !from_stream.v[l]) ? 1u : 0u; par_far += (go.v[l] && far.v[l]) ? 1u : 0u; }
     bool odd = false;
