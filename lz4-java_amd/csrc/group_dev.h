@@ -739,7 +739,7 @@ struct BlockWaveDev : GroupDev<64, 0> {
   // on are readable).  The far lanes of a round have their loads in flight together, behind the ring reads of the others
   __device__ __forceinline__ uint64_t vodd_mask(VU dw, VU len) const {   // lanes whose run cannot take the usual round: longer than 64 bytes, or a destination at the ring's ends
     const uint32_t x = dw & ((uint32_t)KW - 1u);
-    return __builtin_amdgcn_ballot_w64((len > 64u) || (x < 16u) || (x + len + 16u > (uint32_t)KW));
+    return __builtin_amdgcn_ballot_w64(len > 64u) | __builtin_amdgcn_ballot_w64(x < 16u) | __builtin_amdgcn_ballot_w64(x + len + 16u > (uint32_t)KW);   // (a ballot per comparison: see lz4_decode_wave.h)
   }
   __device__ __forceinline__ void vcopy_run(VU dw, bool from_stream, VU sp, VU len, uint64_t gom, const uint8_t* mem, VU mpos, uint64_t farm, uint64_t oddm) {
     const uint64_t gfm = gom & farm;

@@ -326,7 +326,8 @@ LZ4HIP_DEV void decode_wave_par_loop(Grp& g, const uint8_t* src, const int iend,
       const uint32_t np = T - tk < 31u ? T - tk : 31u;   // (31: the rounds' ballot keeps lane 63 out)
       const VU sq = (lane >> 1) + tk;           // this lane's sequence
       const VU pv = Grp::vshfl(posv, sq);       // where it starts, relative to ip
-      const VB act = lane < 2u * np;
+      const uint64_t actm = (1ull << (2u * np)) - 1ull;                        // (np <= 31)
+      const VB act = Grp::vlanes(actm);
       // the sequence's header: its first bytes out of the window registers (two lane shuffles + a funnel), the offset word and the
       // match-length byte behind its literals from the stream ring
       const VU sl = pv >> 2;
@@ -340,7 +341,9 @@ LZ4HIP_DEV void decode_wave_par_loop(Grp& g, const uint8_t* src, const int iend,
       const VB m15 = tm == 15u;
       const VU mlx = tm + Grp::vsel(m15, e2, VU(0u)), ml = mlx + 4u;
       const VU endp = (lp - ip) + lit + Grp::vsel(m15, VU(3u), VU(2u));          // where the next token lies, relative to ip
-      const VB simple = (off != 0u) & (lit < 255u) & (mlx < 255u);              // lengths of 255 and more (every run of two or more length bytes) are not for a trip
+      // (lane sets are kept as wave-uniform MASKS -- a ballot per comparison, combined with scalar instructions: a ballot of a compound
+      // bool costs the compiler a v_cndmask + v_cmp on top of the same scalar work)
+      const uint64_t simplem = Grp::vballot(off != 0u) & Grp::vballot(lit < 255u) & Grp::vballot(mlx < 255u);   // lengths of 255 and more (every run of two or more length bytes) are not for a trip
       const VU len = Grp::vsel(isM, ml, lit);   // this lane's run
       const VU tot = Grp::vsel(act, len, VU(0u));
       const VU ex = Grp::vexcl_scan(tot);
@@ -355,9 +358,11 @@ LZ4HIP_DEV void decode_wave_par_loop(Grp& g, const uint8_t* src, const int iend,
       const uint32_t tb = (oe_all - op < TRIPMAX ? oe_all : op + TRIPMAX) + 16u;
       const uint32_t bound = (int32_t)(wild - tb) > 0 ? wild : tb;   // (... or what a one-sequence step before this trip has touched: its pieces are a whole step wide)
       const uint32_t memlim = fl > op0 + db ? fl - db : op0;
-      const VB held = (mp >= VU(op0)) & ((mp + KW) >= VU(bound));
-      const VB okb = act & simple & (!isM | ((mp < VU(0x80000000u)) & (held | (send <= VU(memlim))))) &
-                     ((pv + ip) <= VU(ilim)) & (o <= VU(olim)) & ((oe - op) <= VU(TRIPMAX));
+      constexpr uint64_t litm = 0x5555555555555555ull;                        // the even lanes: literal runs
+      const uint64_t heldm = Grp::vballot(mp >= VU(op0)) & Grp::vballot((mp + KW) >= VU(bound));
+      const uint64_t srcm = Grp::vballot(mp < VU(0x80000000u)) & (heldm | Grp::vballot(send <= VU(memlim)));   // match lanes: the source is valid and can be had
+      const uint64_t okbm = actm & simplem & (litm | srcm) & Grp::vballot((pv + ip) <= VU(ilim)) & Grp::vballot(o <= VU(olim)) & Grp::vballot((oe - op) <= VU(TRIPMAX));
+      const uint64_t farm = ~litm & ~heldm;
       // (mp "negative" -- an offset that reaches in front of the block -- is a huge unsigned number: tested by itself, the sums may wrap)
       // ---- 4. copies in DEPENDENCY ROUNDS, a lane per run, exact.  A round takes the runs from lane `a` on; a literal run has no
       // dependency, a match is taken when its whole source lies below the round's own output.  The first match whose source reaches
@@ -365,8 +370,7 @@ LZ4HIP_DEV void decode_wave_par_loop(Grp& g, const uint8_t* src, const int iend,
       // would be empty ends the trip: its first run is a match that reaches into its OWN output (or is not for a trip at all) ----
       const VU spv = Grp::vsel(isM, mp + db, lp);   // the run's source: ring coordinates of the match source / stream position of the literals
       // (the round's lane sets are wave-uniform MASKS, combined with scalar instructions: one vector compare per round)
-      const uint64_t okbm = Grp::vballot(okb), farm = Grp::vballot(isM & !held), oddm = g.vodd_mask(o + db, len);
-      constexpr uint64_t litm = 0x5555555555555555ull;                        // the even lanes: literal runs
+      const uint64_t oddm = g.vodd_mask(o + db, len);
       uint32_t a = 0u;
       for (;;) {
         const uint32_t oa = Grp::vreadlane(o, a);
@@ -374,7 +378,7 @@ LZ4HIP_DEV void decode_wave_par_loop(Grp& g, const uint8_t* src, const int iend,
         const uint64_t okm = (okbm & (litm | Grp::vballot(send <= VU(oa)))) | below;
         const uint32_t Te = (uint32_t)__builtin_ctzll(~okm | (1ull << 63));   // (< 64: a pass uses lanes 0 .. 61)
 #ifdef LZ4HIP_WAVE_DBG   /* developer build of the simulator: why rounds end (tests/hostsim) */
-        g.vnote(act, simple, !isM | (mp < VU(0x80000000u)), !isM | (send <= VU(oa)) | (lane < a), !isM | held | (send <= VU(memlim)), !isM | held, (oe - op) <= VU(TRIPMAX), (okb & (!isM | (send <= VU(oa)))) | (lane < a));
+        g.vnote(act, Grp::vlanes(simplem), !isM | (mp < VU(0x80000000u)), !isM | (send <= VU(oa)) | (lane < a), Grp::vlanes(litm | heldm) | (send <= VU(memlim)), Grp::vlanes(litm | heldm), (oe - op) <= VU(TRIPMAX), Grp::vlanes(okm));
 #endif
         if (Te == a) break;
         g.vcopy_run(o + db, !isM, spv, len, ((1ull << Te) - 1ull) & ~below, dst, mp, farm, oddm);
