@@ -86,3 +86,23 @@ def test_bench_relaunch_command(monkeypatch):
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
     assert seen["env"].get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
+
+
+def test_bench_live_traffic_falls_back_without_a_gpu(monkeypatch):
+    """bench.py measures the headline's HBM traffic itself with two short rocprofv3 --pmc child runs; where that cannot work -- no
+    rocprofv3, a run that is itself being profiled, a pass that fails (here: no GPU) -- it returns nothing and the reason, and the
+    line carries the committed passes (profiles/traffic.json) instead.  Never an exception, never a hang."""
+    import argparse
+    import bench
+    a = argparse.Namespace(blocks=64, block_size=65536, litmax=38, win=65535, decode_lanes=0)
+    got, note = bench.live_traffic(a, timeout_s=120)
+    assert got == {} and isinstance(note, str) and note
+    monkeypatch.setenv("ROCPROFILER_FAKE", "1")        # "this run is itself under a profiler"
+    got, note = bench.live_traffic(a, timeout_s=5)
+    assert got == {} and "profiler" in note
+    monkeypatch.delenv("ROCPROFILER_FAKE")
+    import shutil
+    monkeypatch.setattr(shutil, "which", lambda *_: None)
+    monkeypatch.setattr(bench.os.path, "exists", lambda p_: False if "rocprofv3" in str(p_) else os.path.lexists(p_))
+    got, note = bench.live_traffic(a, timeout_s=5)
+    assert got == {} and "rocprofv3" in note
