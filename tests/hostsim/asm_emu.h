@@ -46,7 +46,9 @@ struct AsmEmu {
     static const std::map<std::string, std::string> m = {
         {"ip", "s104"}, {"php", "s105"}, {"pfe", "s106"}, {"pc", "s107"}, {"code", "s108"}, {"lim", "s109"}, {"n", "s110"}, {"ntop", "s111"},
         {"kmul", "s112"}, {"plo", "s113"}, {"src", "s[114:115]"}, {"pfa", "v200"}, {"pms", "v201"}, {"pml", "v202"}, {"pof", "v203"},
-        {"tbl", "v204"}, {"lane", "v205"}, {"j4", "v206"}, {"j16", "v207"}};
+        {"tbl", "v204"}, {"lane", "v205"}, {"j4", "v206"}, {"j16", "v207"},
+        // the walk of the parallel wave decoder (lz4-java_amd/csrc/group_dev.h vwalk)
+        {"T", "s116"}, {"s", "s117"}, {"t1", "s118"}, {"t2", "s119"}, {"pv", "v208"}, {"nx", "v209"}};
     return m;
   }
 
@@ -288,6 +290,12 @@ struct AsmEmu {
       else if (op == "s_brev_b32") { uint32_t a = (uint32_t)rd_s(o[1], false), r = 0; for (int b = 0; b < 32; b++) r |= ((a >> b) & 1u) << (31 - b); wr_s(o[0], r, false); }
       else if (op == "s_cselect_b32") wr_s(o[0], scc ? rd_s(o[1], false) : rd_s(o[2], false), false);
       else if (op == "s_cmp_gt_u32" || op == "s_cmpk_gt_u32") scc = (uint32_t)rd_s(o[0], false) > (uint32_t)rd_s(o[1], false);
+      else if (op == "s_cmp_le_u32") scc = (uint32_t)rd_s(o[0], false) <= (uint32_t)rd_s(o[1], false);
+      else if (op == "s_cmpk_eq_u32") scc = (uint32_t)rd_s(o[0], false) == (uint32_t)rd_s(o[1], false);
+      else if (op == "s_cmpk_lg_u32") scc = (uint32_t)rd_s(o[0], false) != (uint32_t)rd_s(o[1], false);
+      else if (op == "s_lshr_b32") { const uint32_t r = (uint32_t)rd_s(o[1], false) >> ((uint32_t)rd_s(o[2], false) & 31u); wr_s(o[0], r, false); scc = r != 0; }
+      else if (op == "s_lshl_b32") { const uint32_t r = (uint32_t)rd_s(o[1], false) << ((uint32_t)rd_s(o[2], false) & 31u); wr_s(o[0], r, false); scc = r != 0; }
+      else if (op == "s_min_u32") { const uint32_t a = (uint32_t)rd_s(o[1], false), b = (uint32_t)rd_s(o[2], false); wr_s(o[0], a < b ? a : b, false); scc = a < b; }
       else if (op == "s_cmp_ge_u32") scc = (uint32_t)rd_s(o[0], false) >= (uint32_t)rd_s(o[1], false);
       else if (op == "s_cmp_lt_u32") scc = (uint32_t)rd_s(o[0], false) < (uint32_t)rd_s(o[1], false);
       else if (op == "s_cmp_eq_u32") scc = (uint32_t)rd_s(o[0], false) == (uint32_t)rd_s(o[1], false);

@@ -107,3 +107,25 @@ int sim_asm_compress(const uint8_t* src, int n, uint8_t* dst, int cap, int kind,
 }
 
 }  // extern "C"
+
+// ---- the hand-written walk of the parallel wave decoder (lz4-java_amd/csrc/group_dev.h vwalk): its TEXT in the interpreter ----
+// nx: the packed next-position bytes of a window (four per lane); out: posv (64 lanes) and the count.  Returns 0, or -1 when the
+// interpreter stopped on something it does not know.
+extern "C" int sim_wave_walk_asm(const uint32_t* nx, uint32_t t_in, uint32_t* posv_out, uint32_t* t_out) {
+  static hostsim::AsmEmu* emu = nullptr;
+  if (!emu) {
+    emu = new hostsim::AsmEmu();
+    if (!emu->load(kWaveWalkAsm)) { fprintf(stderr, "asm_emu (walk): %s\n", emu->error.c_str()); return -1; }
+  }
+  hostsim::AsmEmu& e = *emu;
+  uint64_t poison = 0x9E3779B97F4A7C15ull ^ nx[0];
+  for (int r = 0; r < 256; r++) for (int l = 0; l < 64; l++) { poison = poison * 6364136223846793005ull + 1442695040888963407ull; e.v[r][l] = (uint32_t)(poison >> 32); }
+  for (int r = 0; r < 128; r++) { poison = poison * 6364136223846793005ull + 1442695040888963407ull; e.s[r] = (uint32_t)(poison >> 32); }
+  e.vcc = poison; e.scc = (poison >> 7) & 1u; e.m0 = (uint32_t)(poison >> 9); e.exec = ~0ull;
+  e.s[116] = t_in; e.s[117] = 0u;                       // T, s (the statement's "+s" operands: the caller's values)
+  for (int l = 0; l < 64; l++) { e.v[208][l] = 0u; e.v[209][l] = nx[l]; }   // posv starts at zero (lz4_decode_wave.h), nx
+  if (!e.run()) { fprintf(stderr, "asm_emu (walk): %s\n", e.error.c_str()); return -1; }
+  for (int l = 0; l < 64; l++) posv_out[l] = e.v[208][l];
+  *t_out = e.s[116];
+  return 0;
+}

@@ -795,3 +795,35 @@ def test_asm_loop_retry_path_with_narrow_fingerprints(ref, O, corpus):
             assert r == a[0] and (r <= 0 or b == a[1]), (k, len(v), cap, r, a[0])
             calls += st[0]; parked += st[2]
     assert parked > 50000
+
+
+def test_wave_walk_asm_text_in_the_interpreter(asmsim):
+    """The hand-written walk of the parallel wave decoder (lz4-java_amd/csrc/group_dev.h vwalk: four hops per end test, position 255
+    its own successor, the count = the first lane that holds 255) -- its TEXT, extracted from the preprocessed device header, run by
+    the ISA interpreter against the plain definition of the walk (and thereby against its C++ twin of the lane simulator, which hops
+    in the same groups): random next-position tables of every density, chains that fill all 64 lanes, chains that end at once."""
+    asmsim.sim_wave_walk_asm.restype = C.c_int
+    asmsim.sim_wave_walk_asm.argtypes = [C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    rng = random.Random(31337)
+    for trial in range(3000):
+        # a window's next-position bytes: a start at p is followed by one at p + 3 .. p + gap (255 beyond position 250), and -- the
+        # property the grouped hops rely on -- nothing that starts at 248 .. 255 has a successor inside the window
+        gap = rng.choice([3, 4, 6, 10, 30, 80, 300])
+        nxt = [255] * 256
+        for p_ in range(256):
+            q = p_ + rng.randrange(3, gap + 1)
+            nxt[p_] = q if q <= 250 else 255
+        if trial % 50 == 0:
+            nxt[0] = 255                                            # a window with a single start
+        if trial % 50 == 1:
+            for p_ in range(0, 250, 3): nxt[p_] = p_ + 3 if p_ + 3 <= 250 else 255   # 84 starts: the lanes run out
+        nx = (C.c_uint32 * 64)(*[nxt[4 * l] | (nxt[4 * l + 1] << 8) | (nxt[4 * l + 2] << 16) | (nxt[4 * l + 3] << 24) for l in range(64)])
+        posv, t = (C.c_uint32 * 64)(), C.c_uint32(0)
+        assert asmsim.sim_wave_walk_asm(nx, 0, posv, C.byref(t)) == 0
+        want, s_ = [], 0
+        while True:
+            want.append(s_)
+            s_ = nxt[s_]
+            if s_ == 255 or len(want) == 64:
+                break
+        assert t.value == len(want) and list(posv[:t.value]) == want, (trial, gap, t.value, len(want), list(posv[:8]), want[:8])
