@@ -88,7 +88,20 @@ def live_traffic(args, timeout_s=300):
                    "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extra-configs", "--no-live-traffic",
                    "--blocks", str(args.blocks), "--block-size", str(args.block_size), "--litmax", str(args.litmax), "--win", str(args.win),
                    "--decode-lanes", str(args.decode_lanes)]
-            r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
+            # (its own process group: a pass that runs into the time-out is killed WITH the bench child rocprofv3 started -- nothing of it
+            # may still be on the GPU when the parent measures)
+            proc = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                proc.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                import signal
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                proc.wait()
+                raise
+            r = proc
             dbs = [os.path.join(w, f) for w, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
             if r.returncode != 0 or not dbs:
                 return {}, "the %s pass failed (rc %d)" % (counter, r.returncode)
