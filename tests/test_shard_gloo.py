@@ -106,6 +106,21 @@ def test_bench_live_traffic_falls_back_without_a_gpu(monkeypatch):
     monkeypatch.setattr(bench.os.path, "exists", lambda p_: False if "rocprofv3" in str(p_) else os.path.lexists(p_))
     got, note = bench.live_traffic(a, timeout_s=5)
     assert got == {} and "rocprofv3" in note
+    monkeypatch.undo()
+    # a pass that hangs: killed with its whole process group when the time is up
+    import stat, tempfile, time
+    with tempfile.TemporaryDirectory() as d:
+        fake = os.path.join(d, "rocprofv3")
+        open(fake, "w").write("#!/bin/bash\nsleep 300 &\necho $! > %s/grandchild.pid\nwait\n" % d)
+        os.chmod(fake, os.stat(fake).st_mode | stat.S_IXUSR)
+        monkeypatch.setattr(shutil, "which", lambda *_: fake)
+        t0 = time.time()
+        got, note = bench.live_traffic(a, timeout_s=2)
+        assert got == {} and "TimeoutExpired" in note and time.time() - t0 < 30
+        pid = int(open(os.path.join(d, "grandchild.pid")).read())
+        time.sleep(0.5)
+        alive = os.path.exists("/proc/%d" % pid) and "sleep" in open("/proc/%d/cmdline" % pid).read()
+        assert not alive, "the hanging pass's grandchild survived the time-out"
 
 
 def test_bench_names_the_decoder_the_library_routes_to():
