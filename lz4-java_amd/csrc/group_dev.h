@@ -430,15 +430,9 @@ struct BlockWaveDev : GroupDev<64, 0> {
   typedef GroupDev<64, 0> Base;
   typedef typename Base::LChunk LChunk;   // one dword
   static_assert(Base::LB == 4u, "a lane of the wave loop moves one dword");
-  // 256-byte windows of the stream a parallel trip discovers (lz4_decode_wave.h).  TWO (possible where KS >= 2048) were built and measured
-  // twice (profiles/r05_wave_notes.txt sections 2 and 4): 21.8 instead of 9.9 sequences per trip on BASELINE configs[2]'s blocks, and never
-  // faster (2048 x 4 MiB 30.7 -> 32.8 ms with the first version of the trip, 26.9 -> 29.1 ms with a lane per run; 2048 x 64 KiB App. F
-  // 0.84 -> 1.25 ms): a trip's cost is not fixed work to be spread -- walk, rounds and discovery all grow with what a trip carries.  One
-  // window; the two-window form stays in the source (developer builds) and in the simulator's tests.
-#ifndef LZ4HIP_WAVE_WINDOWS
-#define LZ4HIP_WAVE_WINDOWS 1   /* developer A/B builds: 2 */
-#endif
-  static constexpr uint32_t kWaveWindows = LZ4HIP_WAVE_WINDOWS;
+  // (A trip discovers ONE 256-byte window of the stream.  Two windows per trip were built and measured twice -- profiles/r05_wave_notes.txt
+  // sections 2 and 4: 21.8 instead of 9.9 sequences per trip on BASELINE configs[2]'s blocks and never faster, 2048 x 4 MiB 26.9 -> 29.1 ms
+  // -- and taken out of the source when the discovery was cut down to what the walk needs.)
   static constexpr uint32_t kWaveLds = (uint32_t)KS + 16u + 16u + (uint32_t)KW + 32u;   // (32 tail: the first 16 ring bytes mirrored, plus a dword's reach)
   uint8_t* wsb = nullptr;   // stream ring
   uint8_t* wrb = nullptr;   // output ring, index 0
@@ -591,6 +585,7 @@ struct BlockWaveDev : GroupDev<64, 0> {
     return (uint32_t)x - a;
   }
   __device__ __forceinline__ static VU vmin(VU a, VU b) { return a < b ? a : b; }
+  __device__ __forceinline__ static VU valignbyte(VU hi, VU lo, VU sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }   // bytes [sh, sh + 4) of {hi, lo}, sh = 0 .. 3
   // the trip's window: stream bytes [ip + 4 l, ip + 4 l + 8) of lane l, from three ALIGNED dwords (ip is wave-uniform)
   __device__ __forceinline__ void vs_win(uint32_t ip, VU& lo, VU& hi) const {
     const uint32_t* q = Base::dwp(wsb + (((ip & ~3u) + l4) & ((uint32_t)KS - 1u)));
@@ -744,7 +739,7 @@ struct BlockWaveDev : GroupDev<64, 0> {
   // on are readable).  The far lanes of a round have their loads in flight together, behind the ring reads of the others
   __device__ __forceinline__ uint64_t vodd_mask(VU dw, VU len) const {   // lanes whose run cannot take the usual round: longer than 64 bytes, or a destination at the ring's ends
     const uint32_t x = dw & ((uint32_t)KW - 1u);
-    return __builtin_amdgcn_ballot_w64((len > 64u) || (x < 16u) || (x + len + 16u > (uint32_t)KW));
+    return __builtin_amdgcn_ballot_w64(len > 64u) | __builtin_amdgcn_ballot_w64(x < 16u) | __builtin_amdgcn_ballot_w64(x + len + 16u > (uint32_t)KW);   // (a ballot per comparison: see lz4_decode_wave.h)
   }
   __device__ __forceinline__ void vcopy_run(VU dw, bool from_stream, VU sp, VU len, uint64_t gom, const uint8_t* mem, VU mpos, uint64_t farm, uint64_t oddm) {
     const uint64_t gfm = gom & farm;

@@ -128,7 +128,7 @@ LZ4HIP_DEV int decode_block(Grp& g, const uint8_t* src, int src_size, uint8_t* d
       if (ip + 1024 <= iend && ip <= iend - 306 && op <= oend - 606) decode_wave_loop(g, src, iend, dst, oend, ip, op, stage);
     }
     if constexpr (PIPE == 5 || PIPE == 6) {   // the parallel wave loop: several sequences of the block per trip (6: one window of the stream per trip whatever the backend's ring -- the simulator's way to the form a 1 KB stream ring runs)
-      if (ip + 1536 <= iend && ip <= iend - 306 && op <= oend - 606) decode_wave_par_loop<Grp, PIPE == 6 ? 1u : Grp::kWaveWindows>(g, src, iend, dst, oend, ip, op, stage);
+      if (ip + 1536 <= iend && ip <= iend - 306 && op <= oend - 606) decode_wave_par_loop<Grp>(g, src, iend, dst, oend, ip, op, stage);
     }
     if ((PIPE == 1 || (PIPE == 2 && ip + 2048 > iend) || (PIPE == 3 && ip + 320 > iend) || (PIPE == 4 && ip + 1024 > iend) || ((PIPE == 5 || PIPE == 6) && ip + 1536 > iend)) && ip <= iend - 306 && op <= oend - 606) {   // (2 .. 5: only the tail of the stream)
       // ---- the same loop, software-pipelined.  A wavefront's memory operations retire in order, so a wait for a load also

@@ -240,14 +240,14 @@ LZ4HIP_DEV bool wave_single_step(Grp& g, const uint8_t* dst, uint32_t& ip, uint3
 
 // entry: ip + 1536 <= iend, ip <= iend - 306, op <= oend - 606.  Leaves with ip / op at the first sequence it did not decode;
 // everything below op is in memory then.
-template <class Grp, uint32_t NWIN>   // NWIN: 256-byte windows of the stream per trip (2 needs a stream ring of 2 KB)
+template <class Grp>
 LZ4HIP_DEV void decode_wave_par_loop(Grp& g, const uint8_t* src, const int iend, uint8_t* dst, const int oend, int& ip_io, int& op_io, uint8_t* lds) {
   typedef typename Grp::LChunk LChunk;
   typedef typename Grp::VU VU;
   typedef typename Grp::VB VB;
   constexpr uint32_t STEP = 256u, WIN = 256u, TRIPMAX = 2048u;   // a trip's window of the stream; the most output a trip produces
-  constexpr uint32_t AHEAD = NWIN * 512u;  // stream bytes a trip may read from ip on: a sequence that starts at window position <= 250 has its offset word at <= 250 + 2 + 255 and reads 4 bytes there; the copies' 80-byte reads start at <= 252;
-                                           // a second window starts at <= 250 + 260.  (512: what a 1 KB stream ring always holds in front of ip with one refill step on its way; 1024 of a 2 KB ring's 1537)
+  constexpr uint32_t AHEAD = 512u;         // stream bytes a trip may read from ip on: a sequence that starts at window position <= 250 has its offset word at <= 250 + 2 + 255 and reads 4 bytes there; the copies' 80-byte reads start at <= 252
+                                           // (512: what a 1 KB stream ring always holds in front of ip with one refill step on its way)
   const uint32_t KW = g.wv_ring(), KS = g.wv_stream();
   uint32_t ip = (uint32_t)ip_io, op = (uint32_t)op_io;
   const uint32_t ilim = (uint32_t)iend - 306u, olim = (uint32_t)oend - 606u;
@@ -260,13 +260,13 @@ LZ4HIP_DEV void decode_wave_par_loop(Grp& g, const uint8_t* src, const int iend,
     g.rs_put(avail, a0); g.rs_put(avail + STEP, a1); g.rs_put(avail + 2u * STEP, a2); g.rs_put(avail + 3u * STEP, a3);
     avail += 4u * STEP;
   }
-  LChunk rf0 = LChunk(), rf1 = LChunk();   // the steps requested at the top of a trip; they go into the ring at its end
+  LChunk rf0 = LChunk();                   // the step requested at the top of a trip; it goes into the ring at its end
   uint32_t fl = (op + db) & ~(STEP - 1u);
   const VU lane = g.vlane();
   const VU p0 = lane * 4u;
   uint32_t wild = op;                          // end of what one-sequence steps have written into the ring (see `bound`)
 #ifdef LZ4HIP_RING_DBG   /* developer build: what the loop did (tools/wave_stats.py) */
-  uint32_t dbg_trips = 0, dbg_seqs = 0, dbg_rounds = 0, dbg_single = 0, dbg_hungry = 0, dbg_T = 0, dbg_two = 0;
+  uint32_t dbg_trips = 0, dbg_seqs = 0, dbg_rounds = 0, dbg_single = 0, dbg_hungry = 0, dbg_T = 0;
 #endif
 
   for (;;) {
@@ -283,70 +283,36 @@ LZ4HIP_DEV void decode_wave_par_loop(Grp& g, const uint8_t* src, const int iend,
       if (ip + AHEAD > avail) break;            // (the end of the stream is near: the loops behind this one do the rest)
     }
     // ---- stream refill: REQUESTED here, at the top of the trip, PUT into the ring at its end -- the loads are a whole trip old when
-    // they are waited for, and nothing is carried from trip to trip.  (Carried over -- requested in one trip, put in the next -- a
-    // 2 KB ring could not stay 1 KB ahead of a trip that consumes ~500 bytes: 67 % of the trips found it short and waited for a
-    // synchronous refill, tools/wave_stats.py.)  The ring keeps everything from ip & ~255 on: this trip's reads.  Up to two steps
-    // per trip: what a trip of two windows consumes ----
+    // they are waited for, and nothing is carried from trip to trip.  The ring keeps everything from ip & ~255 on: this trip's
+    // reads.  One step per trip: what a window consumes (a trip that consumes more finds the ring short and takes the refill above) ----
     uint32_t nf = 0u;
     if ((avail + STEP <= (uint32_t)iend) & (avail + STEP <= (ip & ~(STEP - 1u)) + KS)) {
       rf0 = g.rs_fetch(src, avail);
       nf = 1u;
-      if ((NWIN > 1u) & (avail + 2u * STEP <= (uint32_t)iend) & (avail + 2u * STEP <= (ip & ~(STEP - 1u)) + KS)) { rf1 = g.rs_fetch(src, avail + STEP); nf = 2u; }
     }
-    // ---- 1 + 2. discovery and walk, for one window of the stream or (NWIN == 2, where the stream ring holds 1 KB in front of ip)
-    // for two in a row.  The product runs ONE: two carry 21.8 instead of 9.9 sequences per trip and take the same time per block
-    // (group_dev.h kWaveWindows).  posv: where sequence k starts, relative to ip; lanes [0, T0) come from the first window ----
-    // (all reads are ALIGNED dwords funnelled in registers: five unaligned reads by 64 lanes kept the CU's LDS busy for ~400 cycles
-    // per trip -- SQ_LDS_UNALIGNED_STALL was 80 % of SQ_LDS_IDX_ACTIVE and at 16 wavefronts per CU the LDS, not the wavefronts, set
-    // the pace: 4096 x 4 MiB 110 ms, gpurun_out/r05g)
-    VU rec[NWIN][4];
+    // ---- 1 + 2. discovery and walk.  The speculative part decodes only what the WALK needs: where a sequence that starts at window
+    // position p would be followed by the next one -- token, literal-length byte: all inside the window registers, no LDS access;
+    // the offset word and the match-length byte behind the literals are fetched in step 3, for the real starts only (a quarter of the
+    // instructions, and 2 instead of 8 LDS reads per lane: this was 125 instructions per window).  posv: where sequence k starts,
+    // relative to ip.  (The window is read as ALIGNED dwords funnelled in registers: five unaligned reads by 64 lanes kept the CU's
+    // LDS busy for ~400 cycles per trip -- SQ_LDS_UNALIGNED_STALL was 80 % of SQ_LDS_IDX_ACTIVE and at 16 wavefronts per CU the LDS,
+    // not the wavefronts, set the pace: 4096 x 4 MiB 110 ms, gpurun_out/r05g) ----
     VU posv = VU(0u);
-    uint32_t T = 0u, T0 = 0u, base1 = 0u;
-#pragma unroll
-    for (uint32_t wdw = 0; wdw < NWIN; wdw++) {
-      uint32_t wbase = 0u;                      // this window's start, relative to ip
-      if (wdw == 1u) {
-        // the second window starts behind the last sequence of the first: its true end, from its record (the walk only knows
-        // "beyond position 250"); none if that sequence is not simple, or the lanes are used up
-        const uint32_t sp = Grp::vreadlane(posv, T - 1u), sln = sp >> 2, sq = sp & 3u;
-        const uint32_t l0 = Grp::vreadlane(rec[0][0], sln), l1 = Grp::vreadlane(rec[0][1], sln), l2 = Grp::vreadlane(rec[0][2], sln), l3 = Grp::vreadlane(rec[0][3], sln);
-        const uint32_t lr = sq == 0u ? l0 : sq == 1u ? l1 : sq == 2u ? l2 : l3;
-        const uint32_t llit = (lr >> 16) & 255u, lmx = lr >> 24;
-        if (((lr & 0xFFFFu) == 0u) | (llit == 255u) | (lmx == 255u) | (T >= 48u)) break;
-        wbase = sp + 1u + (llit >= 15u ? 1u : 0u) + llit + 2u + (lmx >= 15u ? 1u : 0u);
-        base1 = wbase;
-      }
-      VU blo, bhi;
-      g.vs_win(ip + wbase, blo, bhi);           // stream bytes [ip + wbase + 4 l, + 8)
+    uint32_t T = 0u;
+    VU blo, bhi;
+    g.vs_win(ip, blo, bhi);                     // stream bytes [ip + 4 l, + 8)
+    {
       VU nxpack = VU(0u);
 #pragma unroll
       for (uint32_t j = 0; j < 4u; j++) {
         const VU w = j == 0u ? blo : ((blo >> (8 * (int)j)) | (bhi << (32 - 8 * (int)j)));   // bytes j, j + 1, ..
-        const VU tl = (w >> 4) & 15u, tm = w & 15u, e1 = (w >> 8) & 255u;
+        const VU tl = (w >> 4) & 15u, e1 = (w >> 8) & 255u;
         const VB l15 = tl == 15u;
-        const VU lit = tl + Grp::vsel(l15, e1, VU(0u));
-        const VU q = p0 + (j + 1u) + Grp::vsel(l15, VU(1u), VU(0u)) + lit;                   // window position of the offset word
-        const VU ow = g.vs_ld32(q + (ip + wbase));
-        const VU e2 = (ow >> 16) & 255u;
-        const VB m15 = tm == 15u;
-        const VU mlx = tm + Grp::vsel(m15, e2, VU(0u));                                     // match length - 4
-        const VU nxt = q + 2u + Grp::vsel(m15, VU(1u), VU(0u));
-        // lengths of 255 and more are marked 255: "not for a trip" (that includes every run of two or more length bytes)
-        rec[wdw][j] = (ow & 0xFFFFu) | (Grp::vmin(lit, VU(255u)) << 16) | (Grp::vmin(mlx, VU(255u)) << 24);
+        // (a run of two or more length bytes makes this wrong -- and the sequence "not simple" in step 3: the trip ends in front of it)
+        const VU nxt = p0 + (j + 3u) + Grp::vsel(l15, VU(1u), VU(0u)) + tl + Grp::vsel(l15, e1, VU(0u)) + Grp::vsel((w & 15u) == 15u, VU(1u), VU(0u));
         nxpack = nxpack | (Grp::vsel(nxt <= 250u, nxt, VU(255u)) << (8 * (int)j));
       }
-      // the starts of the sequences in the window, the k-th to lane k
-      if (wdw == 0u) Grp::vwalk(nxpack, posv, T);
-      else {
-        uint32_t s = 0u;
-        do {
-          posv = Grp::vwritelane(posv, s + wbase, T);
-          T++;
-          const uint32_t d = Grp::vreadlane(nxpack, s >> 2);
-          s = (d >> ((s & 3u) * 8u)) & 255u;
-        } while ((s != 255u) & (T < 64u));
-      }
-      if (wdw == 0u) T0 = T;
+      Grp::vwalk(nxpack, posv, T);              // the starts of the sequences in the window, the k-th to lane k
     }
     // ---- 3. records, output positions: A LANE PER RUN -- lane 2k the literals of a sequence, lane 2k + 1 its match.  (A lane per
     // sequence copied two runs, 16 reads and 16 predicated stores a round: ~220 instructions of a trip of ~900 that is bound by
@@ -355,27 +321,29 @@ LZ4HIP_DEV void decode_wave_par_loop(Grp& g, const uint8_t* src, const int iend,
     // The wavefront holds 31 sequences that way: a window with more of them (text: up to 64) is taken in PASSES of 31, each pass from
     // the sequence the pass before it ended with -- discovery and walk are paid once per window ----
     const VB isM = (lane & 1u) != 0u;
-    uint32_t tk = 0u, opc = op, lrec = 0u;      // sequences taken by this trip, the output position behind them, the last one's record
+    uint32_t tk = 0u, opc = op, lend = 0u;      // sequences taken by this trip, the output position behind them, where the last one ends in the stream
     for (;;) {
       const uint32_t np = T - tk < 31u ? T - tk : 31u;   // (31: the rounds' ballot keeps lane 63 out)
       const VU sq = (lane >> 1) + tk;           // this lane's sequence
       const VU pv = Grp::vshfl(posv, sq);       // where it starts, relative to ip
-      const VB act = lane < 2u * np;
-      VU r;
-      {
-        const VU sl = pv >> 2, slot = pv & 3u;
-        r = Grp::vsel(slot == 0u, Grp::vshfl(rec[0][0], sl), Grp::vsel(slot == 1u, Grp::vshfl(rec[0][1], sl), Grp::vsel(slot == 2u, Grp::vshfl(rec[0][2], sl), Grp::vshfl(rec[0][3], sl))));
-      }
-      if (NWIN > 1u) {
-        if (T > T0) {
-          const VU pr = pv - base1;
-          const VU sl = pr >> 2, slot = pr & 3u;
-          const VU r1 = Grp::vsel(slot == 0u, Grp::vshfl(rec[NWIN - 1u][0], sl), Grp::vsel(slot == 1u, Grp::vshfl(rec[NWIN - 1u][1], sl), Grp::vsel(slot == 2u, Grp::vshfl(rec[NWIN - 1u][2], sl), Grp::vshfl(rec[NWIN - 1u][3], sl))));
-          r = Grp::vsel(sq < T0, r, r1);
-        }
-      }
-      const VU off = r & 0xFFFFu, lit = (r >> 16) & 255u, ml = (r >> 24) + 4u;
-      const VB simple = (off != 0u) & (lit != 255u) & (ml != 259u);   // (tested here, once per real start, not at every speculative position)
+      const uint64_t actm = (1ull << (2u * np)) - 1ull;                        // (np <= 31)
+      const VB act = Grp::vlanes(actm);
+      // the sequence's header: its first bytes out of the window registers (two lane shuffles + a funnel), the offset word and the
+      // match-length byte behind its literals from the stream ring
+      const VU sl = pv >> 2;
+      const VU hw = Grp::valignbyte(Grp::vshfl(bhi, sl), Grp::vshfl(blo, sl), pv & 3u);
+      const VU tl = (hw >> 4) & 15u, tm = hw & 15u, e1 = (hw >> 8) & 255u;
+      const VB l15 = tl == 15u;
+      const VU lit = tl + Grp::vsel(l15, e1, VU(0u));
+      const VU lp = pv + ip + Grp::vsel(l15, VU(2u), VU(1u));                   // stream position of the literals
+      const VU ow = g.vs_ld32(lp + lit);
+      const VU off = ow & 0xFFFFu, e2 = (ow >> 16) & 255u;
+      const VB m15 = tm == 15u;
+      const VU mlx = tm + Grp::vsel(m15, e2, VU(0u)), ml = mlx + 4u;
+      const VU endp = (lp - ip) + lit + Grp::vsel(m15, VU(3u), VU(2u));          // where the next token lies, relative to ip
+      // (lane sets are kept as wave-uniform MASKS -- a ballot per comparison, combined with scalar instructions: a ballot of a compound
+      // bool costs the compiler a v_cndmask + v_cmp on top of the same scalar work)
+      const uint64_t simplem = Grp::vballot(off != 0u) & Grp::vballot(lit < 255u) & Grp::vballot(mlx < 255u);   // lengths of 255 and more (every run of two or more length bytes) are not for a trip
       const VU len = Grp::vsel(isM, ml, lit);   // this lane's run
       const VU tot = Grp::vsel(act, len, VU(0u));
       const VU ex = Grp::vexcl_scan(tot);
@@ -390,19 +358,19 @@ LZ4HIP_DEV void decode_wave_par_loop(Grp& g, const uint8_t* src, const int iend,
       const uint32_t tb = (oe_all - op < TRIPMAX ? oe_all : op + TRIPMAX) + 16u;
       const uint32_t bound = (int32_t)(wild - tb) > 0 ? wild : tb;   // (... or what a one-sequence step before this trip has touched: its pieces are a whole step wide)
       const uint32_t memlim = fl > op0 + db ? fl - db : op0;
-      const VB held = (mp >= VU(op0)) & ((mp + KW) >= VU(bound));
-      const VB okb = act & simple & (!isM | ((mp < VU(0x80000000u)) & (held | (send <= VU(memlim))))) &
-                     ((pv + ip) <= VU(ilim)) & (o <= VU(olim)) & ((oe - op) <= VU(TRIPMAX));
+      constexpr uint64_t litm = 0x5555555555555555ull;                        // the even lanes: literal runs
+      const uint64_t heldm = Grp::vballot(mp >= VU(op0)) & Grp::vballot((mp + KW) >= VU(bound));
+      const uint64_t srcm = Grp::vballot(mp < VU(0x80000000u)) & (heldm | Grp::vballot(send <= VU(memlim)));   // match lanes: the source is valid and can be had
+      const uint64_t okbm = actm & simplem & (litm | srcm) & Grp::vballot((pv + ip) <= VU(ilim)) & Grp::vballot(o <= VU(olim)) & Grp::vballot((oe - op) <= VU(TRIPMAX));
+      const uint64_t farm = ~litm & ~heldm;
       // (mp "negative" -- an offset that reaches in front of the block -- is a huge unsigned number: tested by itself, the sums may wrap)
       // ---- 4. copies in DEPENDENCY ROUNDS, a lane per run, exact.  A round takes the runs from lane `a` on; a literal run has no
       // dependency, a match is taken when its whole source lies below the round's own output.  The first match whose source reaches
       // into it starts the next round, behind this round's stores -- LDS operations of a wavefront execute in order.  A round that
       // would be empty ends the trip: its first run is a match that reaches into its OWN output (or is not for a trip at all) ----
-      const VU lp = pv + ip + Grp::vsel(lit >= 15u, VU(2u), VU(1u));
       const VU spv = Grp::vsel(isM, mp + db, lp);   // the run's source: ring coordinates of the match source / stream position of the literals
       // (the round's lane sets are wave-uniform MASKS, combined with scalar instructions: one vector compare per round)
-      const uint64_t okbm = Grp::vballot(okb), farm = Grp::vballot(isM & !held), oddm = g.vodd_mask(o + db, len);
-      constexpr uint64_t litm = 0x5555555555555555ull;                        // the even lanes: literal runs
+      const uint64_t oddm = g.vodd_mask(o + db, len);
       uint32_t a = 0u;
       for (;;) {
         const uint32_t oa = Grp::vreadlane(o, a);
@@ -410,7 +378,7 @@ LZ4HIP_DEV void decode_wave_par_loop(Grp& g, const uint8_t* src, const int iend,
         const uint64_t okm = (okbm & (litm | Grp::vballot(send <= VU(oa)))) | below;
         const uint32_t Te = (uint32_t)__builtin_ctzll(~okm | (1ull << 63));   // (< 64: a pass uses lanes 0 .. 61)
 #ifdef LZ4HIP_WAVE_DBG   /* developer build of the simulator: why rounds end (tests/hostsim) */
-        g.vnote(act, simple, !isM | (mp < VU(0x80000000u)), !isM | (send <= VU(oa)) | (lane < a), !isM | held | (send <= VU(memlim)), !isM | held, (oe - op) <= VU(TRIPMAX), (okb & (!isM | (send <= VU(oa)))) | (lane < a));
+        g.vnote(act, Grp::vlanes(simplem), !isM | (mp < VU(0x80000000u)), !isM | (send <= VU(oa)) | (lane < a), Grp::vlanes(litm | heldm) | (send <= VU(memlim)), Grp::vlanes(litm | heldm), (oe - op) <= VU(TRIPMAX), Grp::vlanes(okm));
 #endif
         if (Te == a) break;
         g.vcopy_run(o + db, !isM, spv, len, ((1ull << Te) - 1ull) & ~below, dst, mp, farm, oddm);
@@ -424,30 +392,23 @@ LZ4HIP_DEV void decode_wave_par_loop(Grp& g, const uint8_t* src, const int iend,
       if (a == 0u) break;
       tk += a >> 1;
       opc = Grp::vreadlane(oe, a - 1u);
-      lrec = Grp::vreadlane(r, a - 1u);
+      lend = Grp::vreadlane(endp, a - 1u);
       if ((a < 2u * np) | (tk >= T)) break;     // the pass ended early, or the window is done
     }
 #ifdef LZ4HIP_RING_DBG
-    dbg_trips++; dbg_seqs += tk; dbg_T += T; dbg_single += tk == 0u ? 1u : 0u; dbg_two += T > T0 ? 1u : 0u;
+    dbg_trips++; dbg_seqs += tk; dbg_T += T; dbg_single += tk == 0u ? 1u : 0u;
 #endif
     if (LZ4HIP_UNLIKELY(tk == 0u)) {
       if (!wave_single_step(g, dst, ip, op, op0, fl, db, ilim, olim)) break;
       wild = op + STEP;                         // its wave-wide pieces end up to a step behind the sequence: the ring has lost what lies KW below that
     } else {
-      uint32_t used;
-      if (tk < T) used = Grp::vreadlane(posv, tk);
-      else {                                    // every start was taken: the next token lies behind the last sequence
-        const uint32_t lpv = Grp::vreadlane(posv, tk - 1u);
-        const uint32_t llit = (lrec >> 16) & 255u, lmx = lrec >> 24;
-        used = lpv + 1u + (llit >= 15u ? 1u : 0u) + llit + 2u + (lmx >= 15u ? 1u : 0u);
-      }
-      ip += used; op = opc;
+      ip += tk < T ? Grp::vreadlane(posv, tk) : lend;   // (every start was taken: the next token lies behind the last sequence)
+      op = opc;
     }
     // ---- the requested steps into the ring (in front of the flusher's stores: stores count in vmcnt on this part) ----
     if (nf != 0u) {
       g.rs_put(avail, rf0);
-      if (nf > 1u) g.rs_put(avail + STEP, rf1);
-      avail += nf * STEP;
+      avail += STEP;
     }
     // ---- flusher: whole aligned steps below op ----
     while (op + db - fl >= STEP) { g.wv_store(dst, fl, g.wv_read_al(fl), op0 + db, 0xFFFFFFFFu); fl += STEP; }
@@ -455,7 +416,7 @@ LZ4HIP_DEV void decode_wave_par_loop(Grp& g, const uint8_t* src, const int iend,
   while (op + db - fl >= STEP) { g.wv_store(dst, fl, g.wv_read_al(fl), op0 + db, 0xFFFFFFFFu); fl += STEP; }
   if (op + db != fl) g.wv_store(dst, fl, g.wv_read_al(fl), op0 + db, op + db);
 #ifdef LZ4HIP_RING_DBG
-  g.wv_stats(dbg_trips, dbg_seqs, dbg_rounds, dbg_single, dbg_hungry, dbg_T, dbg_two);
+  g.wv_stats(dbg_trips, dbg_seqs, dbg_rounds, dbg_single, dbg_hungry, dbg_T, 0u);
 #endif
   ip_io = (int)ip; op_io = (int)op;
 }

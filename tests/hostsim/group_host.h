@@ -282,7 +282,6 @@ struct GroupHost {
   // stream ring (kWs bytes + 16 tail) and the output ring (16 pad | kWv bytes | 16 tail) in "LDS" with the device backend's layout,
   // mirror rule and per-lane index arithmetic; every call is one instruction (all lanes' loads, then all lanes' stores); an index
   // outside the wavefront's LDS bytes counts as oob.  rs_fetch / rs_put / rs_ld64 above serve this ring too (rsb = wsb, kRs = kWs).
-  static constexpr uint32_t kWaveWindows = 2u;   // (the simulator runs the two-window form also with the 1 KB stream ring: it is the superset; see wv_begin)
   bool wave_mode = false;
   uint32_t kWv = 8192u, kWs = 2048u;
   std::vector<uint8_t> wv_mem;
@@ -341,6 +340,7 @@ struct GroupHost {
   static inline uint64_t par_trips = 0, par_seqs = 0, par_single = 0, par_far = 0, par_rounds = 0, par_windows = 0;
   static VU vlane() { VU r; for (int i = 0; i < 64; i++) r.v[i] = (uint32_t)i; return r; }
   static VU vsel(const VB& c, const VU& a, const VU& b) { VU r; for (int i = 0; i < 64; i++) r.v[i] = c.v[i] ? a.v[i] : b.v[i]; return r; }
+  static VU valignbyte(const VU& hi, const VU& lo, const VU& sh) { VU r; for (int l = 0; l < 64; l++) { const uint64_t x = ((uint64_t)hi.v[l] << 32) | lo.v[l]; r.v[l] = (uint32_t)(x >> (8u * (sh.v[l] & 3u))); } return r; }
   static VB vlanes(uint64_t m) { VB r; for (int i = 0; i < 64; i++) r.v[i] = (m >> i) & 1u; return r; }
   static uint64_t vballot(const VB& b) { uint64_t m = 0; for (int i = 0; i < 64; i++) if (b.v[i]) m |= 1ull << i; return m; }
   static uint32_t vreadlane(const VU& v, uint32_t i) { return v.v[i & 63u]; }
