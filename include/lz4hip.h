@@ -214,7 +214,8 @@ int lz4hip_container_blocks_dev(int kind, int flags, int level, const uint8_t* s
  * block when it was reached), stop reason, decoded bytes of the delivered blocks, liblz4's code when a decode failed }.
  * Stop reasons follow the readers' own order of checks per block; the first block that fails ends the run:
  *   0 end mark (frame) / empty block (LZ4Block) reached     1 body ended at a block boundary     7 all n_max slots used, more follows
- *   2 body ended inside a block ("Stream ended prematurely")   3 frame: "Block size %s exceeded max"  (or a slot too small)
+ *   2 body ended inside a block ("Stream ended prematurely")   3 frame: "Block size %s exceeded max"  (or a slot too small;
+ *     LZ4Block: an original length above slot_bytes or -- when max_block is not 0 -- above max_block: not a stream error)
  *   4 frame: block checksum mismatch     5 frame: the block does not decode (LZ4Exception)     6 LZ4Block: "Stream is corrupted"
  * ws = device scratch of lz4hip_container_decode_workspace_bytes(n_max) bytes.                                               */
 size_t lz4hip_container_decode_workspace_bytes(uint32_t n_max);
@@ -230,7 +231,11 @@ int lz4hip_container_decode(int kind, int flags, const uint8_t* body, uint64_t b
  * whole blocks of the first n_max that body holds, *dst_bytes = the most their decoded forms can need (frame: max_block per
  * compressed block, the stored size of a raw one; LZ4Block: the headers' original lengths) -- so that a 100-byte frame asks for one
  * block's worth of destination, not n_max x max_block (the readers of LZ4FrameInputStream.java:258-322 / LZ4BlockInputStream.java:
- * 191-264 allocate one block at a time).  lz4hip_container_decode sizes its own device slots the same way.                      */
+ * 191-264 allocate one block at a time).  The walk stops where the device walk stops, and nothing it stops at sizes anything: an
+ * LZ4Block header whose original length exceeds max_block (stop reason 3: the readers take their host path), a payload cut short
+ * (2), a header that announces more than 255 x compressedLen + 64 bytes -- more than LZ4 can decode from that many (6, "Stream is
+ * corrupted", said by the walk itself).  lz4hip_container_decode sizes its own device slots the same way: a few KB of hostile
+ * headers cannot make it allocate gigabytes.                                                                                   */
 int lz4hip_container_decode_bound(int kind, int flags, const uint8_t* body, uint64_t body_bytes, uint32_t max_block, uint32_t n_max,
                                   uint32_t* n_blocks, uint64_t* dst_bytes);
 

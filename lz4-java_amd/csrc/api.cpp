@@ -893,10 +893,19 @@ static void container_prewalk(int kind, int flags, const uint8_t* body, uint64_t
       const uint32_t method = h[8] & 0xF0u, level = 10u + (h[8] & 0x0Fu);
       const int32_t clen = (int32_t)rd32(h + 9), olen = (int32_t)rd32(h + 13);
       if ((method != 0x10u && method != 0x20u) || olen > (int32_t)(1u << level) || olen <= 0 || clen <= 0 || (method == 0x10u && olen != clen)) break;
+      // (round-5 advisor) the device walk stops at a block bigger than the caller's max_block (CR_BLOCK_TOO_BIG: the readers take the
+      // host walk, which allocates one block at a time like LZ4BlockInputStream.java:236-253), at a block whose payload is cut short
+      // (CR_TRUNCATED) and at a header that announces more than its compressed bytes can decode to -- clen bytes of LZ4 are at most
+      // 255 x clen bytes (CR_CORRUPT: the reference's decompressor would fail on it) -- in that order, and none of the three sizes a
+      // slot.  Without these rules 256 headers {level nibble 15, olen 32 MiB, clen 1} -- 5 KB of input -- sized 8 GiB of device slots
+      // and 8 GiB of destination before block 0 was found corrupt
+      if ((uint64_t)olen > max_block) break;
       bound = (uint64_t)olen;
       need = 21ull + (uint64_t)clen;
+      if (p + need > body_bytes) break;
+      if (method == 0x20u && bound > 255ull * (uint64_t)clen + 64u) break;
     }
-    if (bound > smax) smax = bound;             // (also for a block whose payload is cut short: the device walk looks at it)
+    if (bound > smax) smax = bound;             // (frames: also for a block whose payload is cut short: the device walk looks at it)
     if (p + need > body_bytes) break;
     total += bound; p += need; k++;
   }

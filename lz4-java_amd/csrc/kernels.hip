@@ -732,8 +732,12 @@ __global__ __launch_bounds__(64) void container_walk_kernel(int kind, int block_
         if (check != 0u) { why = CR_CORRUPT; break; }
         p += 21u; why = CR_END; break;
       }
-      if ((uint64_t)olen > slot_bytes) { why = CR_BLOCK_TOO_BIG; break; }      // (the caller's slots are too small: not a stream error)
+      if (max_block != 0u && (uint32_t)olen > max_block) { why = CR_BLOCK_TOO_BIG; break; }   // (a block bigger than the caller allows: not a stream error, the readers take the host walk)
       if (p + 21u + (uint64_t)clen > body_bytes) { why = CR_TRUNCATED; break; }
+      // clen bytes of LZ4 decode to at most 255 x clen bytes: a header that announces more cannot decode (the reference reads the payload,
+      // fails in the decompressor and says "Stream is corrupted", :236-253) -- said here, so that nobody has to size a slot by it
+      if (method == 0x20u && (uint64_t)olen > 255ull * (uint64_t)clen + 64u) { why = CR_CORRUPT; break; }
+      if ((uint64_t)olen > slot_bytes) { why = CR_BLOCK_TOO_BIG; break; }      // (the caller's slots are too small: not a stream error)
       const bool raw = method == 0x10u;
       c.pay_off[k] = p + 21u; c.pay_len[k] = clen;
       c.src_off[k] = p + 21u; c.src_len[k] = raw ? 0 : clen;                   // (fast decoder: src_len = readable bytes of the slot)
@@ -871,8 +875,10 @@ __device__ __forceinline__ uint32_t lz4block_walk_region(int kind, uint32_t max_
       if (check != 0u) { why = CR_CORRUPT; break; }
       p += 21u; why = CR_END; break;
     }
-    if ((uint64_t)olen > slot_bytes) { why = CR_BLOCK_TOO_BIG; break; }
+    if (max_block != 0u && (uint32_t)olen > max_block) { why = CR_BLOCK_TOO_BIG; break; }
     if (p + 21u + (uint64_t)clen > body_bytes) { why = CR_TRUNCATED; break; }
+    if (method == 0x20u && (uint64_t)olen > 255ull * (uint64_t)clen + 64u) { why = CR_CORRUPT; break; }   // (cannot decode: container_walk_kernel)
+    if ((uint64_t)olen > slot_bytes) { why = CR_BLOCK_TOO_BIG; break; }
     if (fill) {
       const uint32_t b = k0 + k;
       const bool raw = method == 0x10u;

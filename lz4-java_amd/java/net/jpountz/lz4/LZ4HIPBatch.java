@@ -118,7 +118,10 @@ public final class LZ4HIPBatch {
     if (!src.isDirect()) {
       throw new IllegalArgumentException("LZ4HIPBatch needs direct ByteBuffers");
     }
-    if (srcOff < 0 || len < 0 || srcOff + len > src.capacity()) {
+    if (blocks == null) {
+      throw new NullPointerException("blocks");
+    }
+    if (srcOff < 0 || len < 0 || srcOff + len > src.capacity() || blocks.length < 1) {
       throw new ArrayIndexOutOfBoundsException();
     }
     final long r = LZ4HIPJNI.LZ4HIP_containerDecodeBound(kind, blockChecksum ? 1 : 0, src, srcOff, len, maxBlock, nMax, blocks);

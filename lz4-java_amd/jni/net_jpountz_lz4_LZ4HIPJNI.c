@@ -194,6 +194,7 @@ JNIEXPORT jint JNICALL Java_net_jpountz_lz4_LZ4HIPJNI_LZ4HIP_1containerDecode(JN
   const uint8_t* s = (const uint8_t*)(*env)->GetDirectBufferAddress(env, src);
   uint8_t* d = (uint8_t*)(*env)->GetDirectBufferAddress(env, dest);
   if (s == NULL || d == NULL || srcOff < 0 || len < 0 || destOff < 0 || destCap < 0 || maxBlock <= 0 || nMax <= 0) return LZ4HIP_E_ARG;
+  if (sizes == NULL || info == NULL) return LZ4HIP_E_ARG;   /* (GetArrayLength of a null reference crashes a real JVM: round-5 advisor) */
   if ((*env)->GetArrayLength(env, sizes) < nMax || (*env)->GetArrayLength(env, info) < 5) return LZ4HIP_E_ARG;
   jint* sz = (*env)->GetIntArrayElements(env, sizes, NULL);
   jlong* inf = (*env)->GetLongArrayElements(env, info, NULL);
@@ -210,7 +211,7 @@ JNIEXPORT jlong JNICALL Java_net_jpountz_lz4_LZ4HIPJNI_LZ4HIP_1containerDecodeBo
     jlong len, jint maxBlock, jint nMax, jintArray blocks) {
   (void)cls;
   const uint8_t* s = (const uint8_t*)(*env)->GetDirectBufferAddress(env, src);
-  if (s == NULL || srcOff < 0 || len < 0 || (*env)->GetArrayLength(env, blocks) < 1) return (jlong)LZ4HIP_E_ARG;
+  if (s == NULL || srcOff < 0 || len < 0 || blocks == NULL || (*env)->GetArrayLength(env, blocks) < 1) return (jlong)LZ4HIP_E_ARG;
   uint32_t nb = 0;
   uint64_t need = 0;
   const int rc = lz4hip_container_decode_bound(kind, flags, s + srcOff, (uint64_t)len, (uint32_t)maxBlock, (uint32_t)nMax, &nb, &need);

@@ -238,6 +238,10 @@ int main(int argc, char** argv) {
       CHECK(rc2 == 0 && ((jlong*)inf->data)[0] == 0 && ((jlong*)inf->data)[1] == 0 && ((jlong*)inf->data)[2] == 5 && ((jlong*)inf->data)[4] < 0);   /* nothing delivered, "the block does not decode", liblz4's negative code */
       CHECK(Java_net_jpountz_lz4_LZ4HIPJNI_LZ4HIP_1containerDecode(env, NULL, 0, 0, (jobject)body, 0, got, blk, 64, (jobject)dec, 32, 10, (jintArray)szs, (jlongArray)inf) != 0 ||
             ((jlong*)inf->data)[0] == 0);                               /* a destination that is too small is an error, not an overrun */
+      /* null array references (round-5 advisor: GetArrayLength of null crashes a real JVM -- and this fake one): an argument error, no call into the env */
+      CHECK(Java_net_jpountz_lz4_LZ4HIPJNI_LZ4HIP_1containerDecodeBound(env, NULL, 0, 0, (jobject)body, 0, got, blk, 64, NULL) < 0);
+      CHECK(Java_net_jpountz_lz4_LZ4HIPJNI_LZ4HIP_1containerDecode(env, NULL, 0, 0, (jobject)body, 0, got, blk, 64, (jobject)dec, 32, need, NULL, (jlongArray)inf) != 0);
+      CHECK(Java_net_jpountz_lz4_LZ4HIPJNI_LZ4HIP_1containerDecode(env, NULL, 0, 0, (jobject)body, 0, got, blk, 64, (jobject)dec, 32, need, (jintArray)szs, NULL) != 0);
       CHECK(no_exc() && szs->pins == 0 && inf->pins == 0 && nbk->pins == 0);
       free(body->data); free(body); free(szs->data); free(szs); free(inf->data); free(inf); free(nbk->data); free(nbk); free(dec->data); free(dec); } }
 

@@ -124,6 +124,8 @@ class OracleDeviceEngine(OracleEngine):
                     why = self.CR_BLOCK_TOO_BIG; break
                 if p + 21 + clen > n:
                     why = self.CR_TRUNCATED; break
+                if method == 0x20 and olen > 255 * clen + 64:   # (cannot decode: clen bytes of LZ4 are at most 255 x clen bytes; the device says so without sizing a slot by it)
+                    why = self.CR_CORRUPT; break
                 blocks.append(dict(raw=method == 0x10, pay=body[p + 21:p + 21 + clen], cap=olen, stored=check, end=p + 21 + clen))
                 p += 21 + clen
         if len(blocks) == nMax and p == n:

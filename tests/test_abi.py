@@ -81,6 +81,14 @@ def test_container_decode_bound_is_a_host_walk(amd):
     assert bound(1, 0, bs, 1 << 16, 256) == (2, 1030)                      # stops at the empty block
     assert bound(1, 0, hdr(0x20, 15, 0x7FFFFFF0, 1 << 25), 1 << 25, 256) == (0, 0)   # one header, a huge compressedLen: nothing to allocate
     assert bound(1, 0, b"LZ4Blocc" + bs[8:], 1 << 16, 256) == (0, 0)       # damaged magic
+    # round-5 advisor: 5 KB of hostile headers {level nibble 15, original length 32 MiB, compressedLen 1} sized 8 GiB of device slots and
+    # of destination before block 0 was found corrupt.  One compressed byte decodes to at most 255 bytes: the walk stops at such a header
+    # (the device: "Stream is corrupted" without decoding) and it sizes nothing
+    hostile = (hdr(0x20, 15, 1, 1 << 25) + b"\0") * 256
+    assert bound(1, 0, hostile, 1 << 25, 257) == (0, 0)
+    assert bound(1, 0, bs[:71] + hostile, 1 << 25, 257) == (1, 1000)
+    # ... and a block bigger than the caller's max_block is where the walk stops (the device: stop reason 3, the readers' host path)
+    assert bound(1, 0, bs[:71] + hdr(0x20, 15, 100, 1 << 20) + bytes(100), 1 << 16, 256) == (1, 1000)
     nb, need = C.c_uint32(0), C.c_uint64(0)
     assert l.lz4hip_container_decode_bound(2, 0, None, 0, 65536, 1, C.byref(nb), C.byref(need)) != 0      # kind
     assert l.lz4hip_container_decode_bound(0, 0, None, 0, 65536, 0, C.byref(nb), C.byref(need)) != 0      # n_max
