@@ -1121,7 +1121,7 @@ int lz4hip_set_option(const char* name, int value) {
     return LZ4HIP_OK;
   }
   if (name && strcmp(name, "decode_pipe") == 0) {
-    if (value < -1 || value > 5) return fail(LZ4HIP_E_ARG, "decode_pipe must be -1 .. 5");
+    if (value < -1 || value > 7 || value == 6) return fail(LZ4HIP_E_ARG, "decode_pipe must be -1 .. 5 or 7");
     g_decode_pipe = value;
     return LZ4HIP_OK;
   }

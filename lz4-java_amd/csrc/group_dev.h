@@ -765,6 +765,48 @@ struct BlockWaveDev : GroupDev<64, 0> {
       if (gfm != 0ull) vcopy<2>(dw2, mem, mp2, ln2, go && far);
     }
   }
+  // ---- the pair loop's mailbox (lz4_decode_pair.h: a PARSER and a COPIER wavefront per block): behind the wavefront's rings,
+  // kMailSlots messages of 64 lanes x 8 bytes and 16 control words.  Ordering between the two wavefronts rests on the LDS itself --
+  // it executes a wavefront's instructions in order, each as a whole -- so a post is a store behind the data it publishes and a peek
+  // a load in front of the data it guards; the empty asm statements hold the COMPILER to that order (volatile alone orders only
+  // volatile accesses).  No fence: a workgroup-scope release would make the parser wait for its stream refill -- a load from
+  // memory that is meant to be in flight for a whole trip -- at every message ----
+  static constexpr uint32_t kMailSlots = 3u, kMailSlotBytes = 512u, kMailBytes = kMailSlots * kMailSlotBytes + 64u;
+  static constexpr uint32_t kPairLds = kWaveLds + kMailBytes;
+  // (the mailbox is addressed as LDS -- address space 3 -- explicitly: through the generic pointer the volatile accesses came out as
+  // flat_load / flat_store with system-scope cache bits)
+  typedef __attribute__((address_space(3))) uint8_t* lds8p;
+  typedef __attribute__((address_space(3))) volatile uint32_t* lds32vp;
+  typedef uint32_t u2v8 __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(3))) u2v8* lds64p;
+  lds8p pmb = nullptr;
+  __device__ __forceinline__ void pm_begin(uint8_t* lds) { pmb = (lds8p)(lds + kWaveLds); }
+  __device__ __forceinline__ void wv_begin_db(uint8_t* lds, uint32_t db) { wsb = lds; wrb = lds + KS + 32; wdb = db; }   // (the parser: it has no destination pointer, only its low byte)
+  __device__ __forceinline__ uint32_t pm_peek(uint32_t i) const {
+    asm volatile("" ::: "memory");
+    const uint32_t v = *(lds32vp)(pmb + kMailSlots * kMailSlotBytes + 4u * i);
+    asm volatile("" ::: "memory");
+    return uni(v);
+  }
+  __device__ __forceinline__ void pm_post(uint32_t i, uint32_t v) {
+    asm volatile("" ::: "memory");
+    if (this->l == 0u) *(lds32vp)(pmb + kMailSlots * kMailSlotBytes + 4u * i) = v;
+    asm volatile("" ::: "memory");
+  }
+  __device__ __forceinline__ void pm_put(uint32_t slot, uint32_t w0, uint32_t w1) {
+    u2v8 t; t.x = w0; t.y = w1;
+    *(lds64p)(pmb + slot * kMailSlotBytes + 2u * l4) = t;
+  }
+  __device__ __forceinline__ void pm_get(uint32_t slot, uint32_t& w0, uint32_t& w1) const {
+    const u2v8 t = *(lds64p)(pmb + slot * kMailSlotBytes + 2u * l4);
+    w0 = t.x; w1 = t.y;
+  }
+  __device__ __forceinline__ static void pm_nap() { __builtin_amdgcn_s_sleep(1); }    // a message is a few hundred cycles away
+  __device__ __forceinline__ static void pm_idle() { __builtin_amdgcn_s_sleep(8); }   // between entries: the copier is in decode_block's exact code, or between blocks
+  __device__ __forceinline__ static const uint8_t* pm_ptr(uint32_t lo, uint32_t hi) {   // (through address space 1: a pointer rebuilt from integers is otherwise a FLAT pointer)
+    typedef __attribute__((address_space(1))) const uint8_t* G;
+    return (const uint8_t*)(G)(((uint64_t)hi << 32) | lo);
+  }
   // the step at ring coordinates fw (a multiple of 256) to memory: its bytes inside [lo, hi) (ring coordinates), nothing else
   __device__ __forceinline__ void wv_store(uint8_t* dst, uint32_t fw, const LChunk& c, uint32_t lo, uint32_t hi) const {
     uint8_t* p = dst + (intptr_t)(int32_t)(fw + l4 - wdb);

@@ -1114,6 +1114,35 @@ __global__ __launch_bounds__(64 * W) void decode_wave_kernel(BatchArgs a, const 
     if (g.l == 0) a.out[b] = r;
   }
 }
+// the pair loop's kernel (lz4_decode_pair.h): TWO WAVEFRONTS PER BLOCK -- wavefront 2p of the workgroup is the COPIER of pair p (it
+// runs decode_block: rings, copies, flusher, the exact code for what the loops leave), wavefront 2p + 1 its PARSER (it runs ahead
+// in the compressed stream and posts what to copy through a mailbox in LDS).  Consecutive wavefronts of a workgroup go to different
+// SIMDs, so the two halves of a block issue side by side.  One workgroup per CU as above; W pairs, W = 1 .. 8 (8 pairs = 16
+// wavefronts = the 1024 threads a workgroup can have: launches of up to 8 blocks per CU; more blocks per CU keep decode_wave_kernel).
+template <int W, int KW, int KS, bool SAFE>
+__global__ __launch_bounds__(128 * W) void decode_pair_kernel(BatchArgs a, const uint32_t* route, uint32_t want) {
+  if (route && *route != want) return;   // (the launch was routed to another decoder: launch_decompress)
+  typedef BlockWaveDev<KW, KS> G;
+  static_assert(G::kMailSlots == PAIR_SLOTS && G::kMailSlotBytes == PAIR_SLOT_BYTES && G::kMailBytes >= PAIR_MAIL_BYTES, "mailbox layout");
+  __shared__ __attribute__((aligned(16))) uint8_t pair_mem[W * G::kPairLds];
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t pair = wave >> 1;
+  uint8_t* lds = pair_mem + pair * G::kPairLds;
+  if ((wave & 1u) == 0u && (threadIdx.x & 63u) < PAIR_CTL_WORDS) ((uint32_t*)(lds + G::kWaveLds + PAIR_SLOTS * PAIR_SLOT_BYTES))[threadIdx.x & 63u] = 0u;
+  __syncthreads();                       // (the only barrier: the control words are zero before any parser looks at them)
+  if (wave & 1u) {
+    G g;
+    pair_parser_service(g, lds);
+    return;
+  }
+  for (uint32_t b = blockIdx.x * W + pair; b < a.n; b += gridDim.x * W) {
+    G g;
+    const int r = decode_block<G, SAFE, 7, false>(g, a.src + a.src_off[b], a.src_len[b], a.dst + a.dst_off[b], a.dst_cap[b], lds);
+    if (g.l == 0) a.out[b] = r;
+  }
+  G g;
+  pair_parser_quit(g, lds);
+}
 static uint32_t device_cus() {   // compute units of the current device (cached per device)
   static std::atomic<uint32_t> cus[64];
   int d = 0;
@@ -1139,6 +1168,27 @@ static int launch_decode_wave_w(const BatchArgs& a, bool safe, bool par, hipStre
     else hipLaunchKernelGGL((decode_wave_kernel<W, KW, KS, false, 4>), dim3(grid), dim3(64 * W), 0, st, a, route, want);
   }
   return (int)hipGetLastError();
+}
+template <int W, int KW, int KS>
+static int launch_decode_pair_w(const BatchArgs& a, bool safe, hipStream_t st, const uint32_t* route, uint32_t want) {
+  const uint32_t wgs = (a.n + W - 1u) / W, cus = device_cus();
+  const uint32_t grid = wgs < cus ? wgs : cus;
+  if (safe) hipLaunchKernelGGL((decode_pair_kernel<W, KW, KS, true>), dim3(grid), dim3(128 * W), 0, st, a, route, want);
+  else hipLaunchKernelGGL((decode_pair_kernel<W, KW, KS, false>), dim3(grid), dim3(128 * W), 0, st, a, route, want);
+  return (int)hipGetLastError();
+}
+// the pair loop: ring = bytes of the output ring (16384 / 32768 / 65536; 0 = the largest that lets the batch spread over all CUs)
+static int launch_decode_pair(const BatchArgs& a, bool safe, int ring, hipStream_t st, const uint32_t* route = nullptr, uint32_t want = 0) {
+  if (ring == 0) {
+    const uint32_t cus = device_cus();
+    ring = a.n <= 2u * cus ? 65536 : a.n <= 4u * cus ? 32768 : 16384;
+  }
+  switch (ring) {
+    case 65536: return a.n <= device_cus() ? launch_decode_pair_w<1, 65536, 2048>(a, safe, st, route, want) : launch_decode_pair_w<2, 65536, 2048>(a, safe, st, route, want);
+    case 32768: return launch_decode_pair_w<4, 32768, 2048>(a, safe, st, route, want);
+    case 16384: return launch_decode_pair_w<8, 16384, 2048>(a, safe, st, route, want);
+    default: return (int)hipErrorInvalidValue;
+  }
 }
 // ring: bytes of the output ring (8192 / 16384 / 32768 / 65536; 0 = the largest that lets the batch spread over all CUs)
 static int launch_decode_wave(const BatchArgs& a, bool safe, bool par, int ring, hipStream_t st, const uint32_t* route = nullptr, uint32_t want = 0) {
@@ -1200,6 +1250,7 @@ int ring_stats_fetch(unsigned long long* out8) {   // developer build: reads and
 int launch_decompress(const BatchArgs& a, bool safe, int lanes_per_block, int pipe, int stage, int ring, void* stream, uint32_t* route_word) {
   if (a.n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
+  if (pipe == 7) return launch_decode_pair(a, safe, ring, st);   // the pair loop: two wavefronts per block (lz4_decode_pair.h)
   if (pipe == 4 || pipe == 5) return launch_decode_wave(a, safe, pipe == 5, ring, st);   // the wave loops: a wavefront per block (lanes_per_block is 64 by construction); 5: several sequences per trip
   if (pipe == 3) {   // the ring loop: lanes 4 / 8 / 16, output ring 512 .. 4096 bytes (0 = 512 with 4 lanes, 4096 otherwise)
     const int gl = lanes_per_block == 0 ? 4 : lanes_per_block;

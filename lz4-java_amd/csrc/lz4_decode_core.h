@@ -39,6 +39,7 @@
 #include "lz4_decode_deep.h"
 #include "lz4_decode_ring.h"
 #include "lz4_decode_wave.h"
+#include "lz4_decode_pair.h"
 namespace lz4hip {
 
 // SAFE: LZ4_decompress_safe(src, dst, src_size, out_size) -> decoded size or negative.
@@ -54,6 +55,8 @@ namespace lz4hip {
 //       4 = the wave loop of lz4_decode_wave.h (ONE WAVEFRONT PER BLOCK, Grp = BlockWaveDev: stream ring and an output ring of 8 .. 64 KB
 //       in LDS at `stage`, wave-uniform parse, one LDS round trip per sequence): launches of few blocks.
 //       5 = the parallel wave loop (same file, same rings): every sequence that starts in a 256-byte window of the stream per trip.
+//       7 = the pair loop of lz4_decode_pair.h (TWO WAVEFRONTS PER BLOCK: the caller is the copier, `stage` = the pair's LDS: the rings of 4 / 5 and a mailbox; a second wavefront
+//       runs pair_parser_service on the same LDS).
 // STAGE: the interior loop writes through an LDS staging buffer (`stage`, Grp::kStage bytes for this block) and output leaves
 //        it as whole 128-byte lines (group_dev.h st_*).
 template <class Grp, bool SAFE, int PIPE = 0, bool STAGE = false>
@@ -130,7 +133,10 @@ LZ4HIP_DEV int decode_block(Grp& g, const uint8_t* src, int src_size, uint8_t* d
     if constexpr (PIPE == 5 || PIPE == 6) {   // the parallel wave loop: several sequences of the block per trip (6: one window of the stream per trip whatever the backend's ring -- the simulator's way to the form a 1 KB stream ring runs)
       if (ip + 1536 <= iend && ip <= iend - 306 && op <= oend - 606) decode_wave_par_loop<Grp>(g, src, iend, dst, oend, ip, op, stage);
     }
-    if ((PIPE == 1 || (PIPE == 2 && ip + 2048 > iend) || (PIPE == 3 && ip + 320 > iend) || (PIPE == 4 && ip + 1024 > iend) || ((PIPE == 5 || PIPE == 6) && ip + 1536 > iend)) && ip <= iend - 306 && op <= oend - 606) {   // (2 .. 5: only the tail of the stream)
+    if constexpr (PIPE == 7) {   // the pair loop (lz4_decode_pair.h): this wavefront copies, its partner wavefront parses the stream a trip or two ahead
+      if (ip + 1536 <= iend && ip <= iend - 306 && op <= oend - 606) decode_pair_loop<Grp>(g, src, iend, dst, oend, ip, op, stage);
+    }
+    if ((PIPE == 1 || (PIPE == 2 && ip + 2048 > iend) || (PIPE == 3 && ip + 320 > iend) || (PIPE == 4 && ip + 1024 > iend) || ((PIPE == 5 || PIPE == 6 || PIPE == 7) && ip + 1536 > iend)) && ip <= iend - 306 && op <= oend - 606) {   // (2 .. 7: only the tail of the stream)
       // ---- the same loop, software-pipelined.  A wavefront's memory operations retire in order, so a wait for a load also
       // waits for every OLDER store.  Here (a) the next sequence's offset word is requested as soon as this sequence's header
       // is parsed, (b) a "simple" sequence (literals and match take one step each, match source entirely before the

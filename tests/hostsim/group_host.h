@@ -6,6 +6,8 @@
 #pragma once
 #include <stdint.h>
 #include <string.h>
+#include <atomic>
+#include <thread>
 #include <vector>
 #include "wave_host.h"
 
@@ -201,7 +203,8 @@ struct GroupHost {
   uint8_t ring_mem[1024 + 32 + 8192 + 96 + 64];
   uint8_t* rsb = nullptr; uint8_t* rgb = nullptr;
   uint32_t dbase = 0;
-  static inline uint64_t ring_trips = 0, ring_entries = 0, ring_repl = 0, ring_flush = 0;   // (statistics for the tests)
+  static inline std::atomic<uint64_t> ring_trips{0};   // (rs_ld64: both wavefronts of a pair bump it)
+  static inline uint64_t ring_entries = 0, ring_repl = 0, ring_flush = 0;   // (statistics for the tests)
   uint32_t ring_bytes() const { return kRing; }
   uint32_t ring_step() const { return lb() * (uint32_t)GL; }
   uint32_t ring_piece() const { return GL == 1 ? 16u : lb() * (uint32_t)GL - 4u; }
@@ -211,6 +214,7 @@ struct GroupHost {
   uint32_t rs_tail() const { return lb() < 16u ? 16u : lb(); }
   uint32_t ring_lds() const { return kRs + rs_tail() + kRing + 3u * lb() + (GL == 1 ? 32u : 0u); }
   bool rl_ok(const uint8_t* p, uint32_t k) {
+    if (wave_mode && pair_lds) { if (p < pair_lds || p + k > pair_lds + (kWs + 32u + kWv + 32u)) { oob = true; return false; } return true; }
     if (wave_mode) { if (p < wv_mem.data() || p + k > wv_mem.data() + wv_mem.size()) { oob = true; return false; } return true; }
     if (p < ring_mem || p + k > ring_mem + ring_lds()) { oob = true; return false; } return true;
   }
@@ -295,10 +299,45 @@ struct GroupHost {
   void wv_begin(uint8_t*, const uint8_t* dst) {
     wave_entries++;
     wave_mode = true;
-    wv_mem.assign(kWs + 32u + kWv + 32u, 0xEE);
-    wsb = wv_mem.data(); wrb = wsb + kWs + 32u; wdb = (uint32_t)(uintptr_t)dst & 255u;
+    if (pair_lds) {   // the pair loop: both wavefronts' backends work on the one block of "LDS" the harness made (the copier enters while the parser is idle: the rings may be poisoned, the mailbox behind them may not)
+      memset(pair_lds, 0xEE, kWs + 32u + kWv + 32u);
+      wsb = pair_lds;
+    } else {
+      wv_mem.assign(kWs + 32u + kWv + 32u, 0xEE);
+      wsb = wv_mem.data();
+    }
+    wrb = wsb + kWs + 32u; wdb = (uint32_t)(uintptr_t)dst & 255u;
     rsb = wsb; kRs = kWs;
   }
+  // ---- the pair loop (lz4_decode_pair.h): a parser and a copier wavefront per block = two of these backends, each on its own host
+  // thread, over ONE block of "LDS" (rings + mailbox).  The mailbox's control words are acquire / release atomics -- what the device
+  // gets from the LDS executing a wavefront's instructions in order; every peek / post naps at random so that the interleavings vary ----
+  static constexpr uint32_t kMailSlots = 3u, kMailSlotBytes = 512u, kMailBytes = kMailSlots * kMailSlotBytes + 64u;
+  uint8_t* pair_lds = nullptr;
+  uint8_t* pmb = nullptr;
+  uint64_t nap_rng = 0x2545F4914F6CDD1Dull;
+  uint32_t pair_lds_bytes() const { return kWs + 32u + kWv + 32u + kMailBytes; }
+  void wv_begin_db(uint8_t*, uint32_t db) { wave_mode = true; wsb = pair_lds; wrb = wsb + kWs + 32u; wdb = db; rsb = wsb; kRs = kWs; }
+  void pm_begin(uint8_t*) { pmb = pair_lds + kWs + 32u + kWv + 32u; }
+  std::atomic<uint32_t>* pm_ctl(uint32_t i) { return reinterpret_cast<std::atomic<uint32_t>*>(pmb + kMailSlots * kMailSlotBytes + 4u * i); }
+  void pm_jitter(uint32_t one_in) {
+    nap_rng ^= nap_rng << 13; nap_rng ^= nap_rng >> 7; nap_rng ^= nap_rng << 17;
+    if (nap_rng % one_in == 0u) std::this_thread::yield();
+  }
+  uint32_t pm_peek(uint32_t i) { pm_jitter(16); return pm_ctl(i)->load(std::memory_order_acquire); }
+  void pm_post(uint32_t i, uint32_t v) { pm_jitter(8); pm_ctl(i)->store(v, std::memory_order_release); pm_jitter(8); }
+  void pm_put(uint32_t slot, const V<uint32_t>& w0, const V<uint32_t>& w1) {
+    if (slot >= kMailSlots) { oob = true; return; }
+    for (int l = 0; l < 64; l++) { memcpy(pmb + slot * kMailSlotBytes + 8u * l, &w0.v[l], 4); memcpy(pmb + slot * kMailSlotBytes + 8u * l + 4u, &w1.v[l], 4); }
+  }
+  void pm_get(uint32_t slot, V<uint32_t>& w0, V<uint32_t>& w1) {
+    if (slot >= kMailSlots) { oob = true; return; }
+    for (int l = 0; l < 64; l++) { memcpy(&w0.v[l], pmb + slot * kMailSlotBytes + 8u * l, 4); memcpy(&w1.v[l], pmb + slot * kMailSlotBytes + 8u * l + 4u, 4); }
+  }
+  void pm_nap() { pair_naps++; std::this_thread::yield(); }
+  void pm_idle() { std::this_thread::yield(); }
+  static const uint8_t* pm_ptr(uint32_t lo, uint32_t hi) { return (const uint8_t*)(uintptr_t)(((uint64_t)hi << 32) | lo); }
+  static inline std::atomic<uint64_t> pair_naps{0}, pair_entries{0};
   struct WPiece { uint8_t b[64][4]; uint32_t dl[64]; };
   uint32_t wv_delta(int l, uint32_t w) const { return l == 0 ? 0u : 4u * (uint32_t)l - (w & 3u); }
   WPiece wv_get(uint8_t* base, uint32_t mask, uint32_t sp, uint32_t w) {
@@ -428,7 +467,7 @@ struct GroupHost {
   }
   void vcopy_run(const VU& dw, const VB& from_stream, const VU& sp, const VU& len, uint64_t gom, const uint8_t* mem, const VU& mpos, uint64_t farm, uint64_t oddm) {
     const VB go = vlanes(gom), far = vlanes(farm);
-    if (oddm != vodd_mask(dw, len)) oob = true;   // (the caller's mask must be the rule below)
+    if ((oddm ^ vodd_mask(dw, len)) & gom) oob = true;   // (the caller's mask must be the rule below, for the lanes of the round: the pair loop's copier gets the mask from the parser, and lanes 62 / 63 of its message are header words)
     par_rounds++;
     for (int l = 0; l < 64; l++) { par_seqs += (go.v[l] && !from_stream.v[l]) ? 1u : 0u; par_far += (go.v[l] && far.v[l]) ? 1u : 0u; }
     bool odd = false;

@@ -188,6 +188,7 @@ void sim_wave_why(unsigned long long* out8) { for (int i = 0; i < 8; i++) out8[i
 void sim_wave_par_stats(unsigned long long* out3) { out3[0] = hostsim::GroupHost::par_trips; out3[1] = hostsim::GroupHost::par_seqs; out3[2] = hostsim::GroupHost::par_far; }
 void sim_wave_par_rounds(unsigned long long* out2) { out2[0] = hostsim::GroupHost::par_rounds; out2[1] = hostsim::GroupHost::par_windows; }
 void sim_wave_stats(unsigned long long* out4) { out4[0] = hostsim::GroupHost::wave_trips; out4[1] = hostsim::GroupHost::wave_entries; out4[2] = hostsim::GroupHost::wave_far; out4[3] = hostsim::GroupHost::wave_mirror; }
+unsigned long long sim_pair_naps() { return hostsim::GroupHost::pair_naps.load(); }
 unsigned long long sim_deep_trips() { return hostsim::GroupHost::deep_trips; }   // offset words the deep decoder loop has parsed so far
 
 // safe != 0: (src_size = compressed length) -> decoded size; safe == 0: (src_size = readable
@@ -209,6 +210,22 @@ int sim_decompress(const uint8_t* src, int src_size, uint8_t* dst, int out_size,
   if (wave_ks1k) g.kWs = 1024u;
   int r;
   const bool wave_par = (gl0 & 0x800000) != 0;   // bit 23: the parallel wave loop (several sequences of the block per trip)
+  if (wave && (gl0 & 0x1000000) != 0) {          // bit 24: the PAIR loop (lz4_decode_pair.h): a copier and a parser wavefront = two host threads over one block of "LDS"
+    hostsim::GroupHost gp(gl, src, src_size, dst, out_size);
+    gp.kWv = g.kWv; gp.kWs = g.kWs;
+    std::vector<uint64_t> lds((g.pair_lds_bytes() + 7u) / 8u, 0xEEEEEEEEEEEEEEEEull);
+    g.pair_lds = gp.pair_lds = (uint8_t*)lds.data();
+    memset(g.pair_lds + g.pair_lds_bytes() - 64u, 0, 64);   // the control words (the kernel zeroes them in front of its barrier)
+    static std::atomic<uint64_t> seed{0x9E3779B97F4A7C15ull};
+    g.nap_rng = seed.fetch_add(0xD1B54A32D192ED03ull) | 1u; gp.nap_rng = g.nap_rng * 0x2545F4914F6CDD1Dull | 1u;
+    std::thread parser([&] { lz4hip::pair_parser_service(gp, gp.pair_lds); });
+    r = safe ? lz4hip::decode_block<hostsim::GroupHost, true, 7>(g, src, src_size, dst, out_size, g.pair_lds)
+             : lz4hip::decode_block<hostsim::GroupHost, false, 7>(g, src, src_size, dst, out_size, g.pair_lds);
+    lz4hip::pair_parser_quit(g, g.pair_lds);
+    parser.join();
+    if (g.oob || gp.oob) return -1000000;
+    return r;
+  }
   if (wave && wave_par && wave_ks1k) r = safe ? lz4hip::decode_block<hostsim::GroupHost, true, 6>(g, src, src_size, dst, out_size, g.stg_buf)
                                               : lz4hip::decode_block<hostsim::GroupHost, false, 6>(g, src, src_size, dst, out_size, g.stg_buf);
   else if (wave && wave_par) r = safe ? lz4hip::decode_block<hostsim::GroupHost, true, 5>(g, src, src_size, dst, out_size, g.stg_buf)
