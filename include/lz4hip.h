@@ -57,24 +57,32 @@ void lz4hip_shutdown(void);
 int lz4hip_device_count(void);            /* devices the engine is initialised on (0 if none)   */
 const char* lz4hip_last_error(void);      /* thread-local description of the last failure       */
 int lz4hip_version(void);
-/* tuning knobs (not part of the reference API): "decode_lanes" = lanes of a wavefront sharing one
- * block in the decoder (0 = default by batch size, 4/8/16/32/64; 1 with the ring loop: a lane per block); "decode_pipe" = 5 / 4 / 3 / 2 / 1 / 0 / -1
- * (default by batch size; 5 / 4 = the wave loops of lz4_decode_wave.h: a WAVEFRONT per block, stream and recent output in LDS rings --
- * "decode_ring" = bytes of the output ring, 0 (by batch size) / 8192 / 16384 / 32768 / 65536 --, 5: several sequences of the block per
- * trip, the default for launches of up to 16 blocks per compute unit; 4: one sequence per trip; 3 = the ring loop of lz4_decode_ring.h: compressed stream and recent output in LDS rings -- "decode_ring" = bytes of
- * its output ring, 0 / 256 / 512 / 1024 / 2048 / 4096 --, the default for batches of 12288..40959 big blocks, chosen on the device): the
- * software-pipelined interior loops of the decoder (faster when the batch is too small to fill the GPU; 2 = the deep loop: the
- * compressed stream staged in LDS, two slots -- the match source of one sequence on its way while the next sequence is parsed and
- * requested; 1 = the two-trip loop); "decode_stage" =
- * 1 / 0 / -1 (default by batch size): the decoder's interior loop writes through an LDS staging buffer so that output
- * reaches memory as whole 128-byte lines (faster when the batch is bandwidth-bound); "compress_core" = 5 (default: adaptive two-pass -- blocks of long
- * sequences are finished by the lean core (lz4_fast_v2_core.h), whose parked hits a partner wavefront writes out, blocks of
- * short sequences by the window-parallel core), 3 (lean core only) or 1 (window-parallel core only);
- * "compress_switch" = routing threshold of the adaptive schemes in bytes per sequence (default 16); "compress_pack" = 1 (default) / 0:
- * blocks of 65547 bytes .. 4 MiB are compressed with 32-bit table entries on eight match-finder chains per CU instead of five
- * (0: every block on the five-chain kernel).  The knobs are
- * process-wide atomics read once per launch; every setting produces the same bytes.                                       */
+/* tuning knobs (not part of the reference API; process-wide atomics read once per launch; every setting produces the same bytes).
+ * Which decoder a launch of n blocks gets with every knob at its default (CU = compute units of the device, 256 on an MI355X):
+ *   n <= 4 CU    the pair loop (lz4_decode_pair.h): TWO wavefronts per block, a parser and a copier
+ *   n <= 16 CU   the parallel wave loop (lz4_decode_wave.h): a wavefront per block, several sequences of it per trip
+ *   more         chosen ON THE DEVICE from a sample of the batch (decode_route_kernel): streams of "decode_route_dense" or more sequences
+ *                per 256 bytes (text) -> the wave loop; 12288 .. 40959 blocks averaging >= 512 KiB compressed -> the ring loop
+ *                (lz4_decode_ring.h); otherwise the deep loop (lz4_decode_deep.h) below 40960 blocks, the 4-lane staged loop from there on
+ * "decode_pipe" = -1 (the table above) or one loop for every launch: 7 = pair loop, 5 = parallel wave loop, 4 = wave loop with one
+ *   sequence per trip, 3 = ring loop, 2 = deep loop, 1 = two-trip pipelined loop, 0 = plain loop;
+ * "decode_ring" = bytes of the output ring in LDS: 0 (by batch size) / 8192 / 16384 / 32768 / 65536 with decode_pipe 4 / 5,
+ *   0 / 16384 / 32768 / 65536 with 7, 0 / 256 / 512 / 1024 / 2048 / 4096 with 3 (which ones: by "decode_lanes");
+ * "decode_lanes" = lanes of a wavefront sharing one block in the lane-group loops (0 = by batch size, 4 / 8 / 16 / 32 / 64; 1 with the ring
+ *   loop: a lane per block); a combination no kernel exists for makes the next decode call fail with LZ4HIP_E_ARG and a message that names it;
+ * "decode_stage" = 1 / 0 / -1 (by batch size): the plain loop writes through an LDS staging buffer so that output reaches memory as
+ *   whole 128-byte lines (faster when the batch is bandwidth-bound);
+ * "decode_route_dense" = 0 .. 255 (default 44): the density from which the device-side route sends a batch to the wave loop; 0 = never;
+ * "compress_core" = 5 (default: adaptive two-pass -- blocks of long sequences are finished by the lean core (lz4_fast_v2_core.h), whose
+ *   parked hits a partner wavefront writes out, blocks of short sequences by the window-parallel core), 3 (lean core only) or 1
+ *   (window-parallel core only); "compress_switch" = routing threshold of the adaptive scheme in bytes per sequence (default 16);
+ * "compress_pack" = 1 (default) / 0: blocks of 65547 bytes .. 4 MiB are compressed with 32-bit table entries on ten match-finder chains
+ *   per CU instead of five (0: every block on the five-chain kernel).                                                           */
 int lz4hip_set_option(const char* name, int value);
+/* diagnostic: what the device-side route of the first device's last routed decode launch decided -- out4 = { route (0 lane-group
+ * default, 1 ring loop, 2 wave loop), hops counted by the sampler, stream bytes it walked, average compressed size of 64 blocks };
+ * synchronises the device                                                                                                      */
+int lz4hip_last_decode_route(uint32_t* out4);
 
 /* == LZ4_compressBound (LZ4JNI.c:237): n + n/255 + 16, 0 if n < 0 or n > 0x7E000000            */
 int lz4hip_compress_bound(int n);

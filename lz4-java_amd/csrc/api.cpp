@@ -150,10 +150,28 @@ int launch_fast(const lz4hip::BatchArgs& a, hipStream_t st) {
   return le;
 }
 
+// the decode knobs are process-wide and set one at a time: a combination no kernel exists for is said here, by name (round-5 advisor: it
+// used to surface as a bare "kernel launch: invalid value")
+const char* decode_knobs_error(int lanes, int pipe, int ring) {
+  const bool wave_ring = ring == 0 || ring == 8192 || ring == 16384 || ring == 32768 || ring == 65536;
+  if (pipe == 4 || pipe == 5) return wave_ring ? nullptr : "decode_pipe 4 / 5 (the wave loops) take decode_ring 0, 8192, 16384, 32768 or 65536";
+  if (pipe == 7) return (wave_ring && ring != 8192) ? nullptr : "decode_pipe 7 (the pair loop) takes decode_ring 0, 16384, 32768 or 65536";
+  if (pipe == 3) {
+    const int gl = lanes == 0 ? 4 : lanes;
+    const int kw = ring ? ring : (gl == 1 ? 256 : gl == 4 ? 512 : 4096);
+    const bool ok = (gl == 1 && (kw == 256 || kw == 512)) || (gl == 4 && (kw == 512 || kw == 1024 || kw == 2048)) ||
+                    (gl == 8 && (kw == 512 || kw == 1024 || kw == 2048 || kw == 4096)) || (gl == 16 && (kw == 2048 || kw == 4096));
+    return ok ? nullptr : "decode_pipe 3 (the ring loop) takes decode_lanes 1 (decode_ring 256 / 512), 4 (512 .. 2048), 8 (512 .. 4096) or 16 (2048 / 4096)";
+  }
+  if (lanes == 1) return "decode_lanes 1 exists for decode_pipe 3 (the ring loop) only";
+  return nullptr;
+}
+
 int launch_decode(const lz4hip::BatchArgs& a, bool safe, hipStream_t st) {
+  if (const char* why = decode_knobs_error(g_decode_lanes.load(), g_decode_pipe.load(), g_decode_ring.load())) return fail(LZ4HIP_E_ARG, why);
   // (a word of scratch for the device-side choice between the deep and the ring loop: only batches of 12288 .. 40959 blocks use it)
   uint32_t* route = nullptr;
-  if (a.n >= 12288u && a.n < 40960u && hipMallocAsync((void**)&route, sizeof(uint32_t), st) != hipSuccess) route = nullptr;
+  if (a.n > 16u * cu_count() && hipMallocAsync((void**)&route, sizeof(uint32_t), st) != hipSuccess) route = nullptr;
   const int e = lz4hip::launch_decompress(a, safe, g_decode_lanes.load(), g_decode_pipe.load(), g_decode_stage.load(), g_decode_ring.load(), st, route);
   if (route) (void)hipFreeAsync(route, st);
   return e;
@@ -167,6 +185,7 @@ int launch_op(Op op, const lz4hip::BatchArgs& a, hipStream_t st) {
     case OP_DECODE_FAST: e = launch_decode(a, false, st); break;
     case OP_COMPRESS_HC: return fail(LZ4HIP_E_ARG, "internal: HC goes through dev_hc");
   }
+  if (e == LZ4HIP_E_ARG) return e;        // (decode_knobs_error: the message is set)
   if (e != 0) return fail(LZ4HIP_E_HIP, "kernel launch", (hipError_t)e);
   return LZ4HIP_OK;
 }
@@ -1114,6 +1133,17 @@ namespace lz4hip { int ring_stats_fetch(unsigned long long* out8); }
 extern "C" {
 __attribute__((visibility("default"))) int lz4hip_dbg_ring_stats(unsigned long long* out8) { return lz4hip::ring_stats_fetch(out8); }
 #endif
+int lz4hip_last_decode_route(uint32_t* out4) {
+  int rc = ensure_init();
+  if (rc) return fail(rc, "no HIP device: liblz4hip has no CPU fallback");
+  if (!out4) return fail(LZ4HIP_E_ARG, "null pointer argument");
+  int ord;
+  if (ordinal(0, &ord)) return fail(LZ4HIP_E_NO_DEVICE, "no device");
+  DeviceGuard g(ord);
+  const int e = lz4hip::last_decode_route(out4);
+  if (e) return fail(LZ4HIP_E_HIP, "hipMemcpyFromSymbol", (hipError_t)e);
+  return LZ4HIP_OK;
+}
 int lz4hip_set_option(const char* name, int value) {
   if (name && strcmp(name, "decode_stage") == 0) {
     if (value < -1 || value > 1) return fail(LZ4HIP_E_ARG, "decode_stage must be -1, 0 or 1");
@@ -1123,6 +1153,11 @@ int lz4hip_set_option(const char* name, int value) {
   if (name && strcmp(name, "decode_pipe") == 0) {
     if (value < -1 || value > 7 || value == 6) return fail(LZ4HIP_E_ARG, "decode_pipe must be -1 .. 5 or 7");
     g_decode_pipe = value;
+    return LZ4HIP_OK;
+  }
+  if (name && strcmp(name, "decode_route_dense") == 0) {   // sequences per 256 bytes of compressed stream from which a batch of more than 16 blocks per CU goes to the wave kernel; 0: never
+    if (value < 0 || value > 255) return fail(LZ4HIP_E_ARG, "decode_route_dense must be 0 .. 255");
+    lz4hip::set_route_dense(value);
     return LZ4HIP_OK;
   }
   if (name && strcmp(name, "decode_ring") == 0) {

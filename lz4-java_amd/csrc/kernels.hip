@@ -1044,7 +1044,8 @@ int launch_container_read(int kind, int block_checksum, const uint8_t* body, uin
 // decode
 // ------------------------------------------------------------------------------------------------
 template <int GL, bool SAFE, int PIPE, bool STAGE>
-__global__ __launch_bounds__(256) void decode_kernel(BatchArgs a) {
+__global__ __launch_bounds__(256) void decode_kernel(BatchArgs a, const uint32_t* route, uint32_t want) {
+  if (route && *route != want) return;   // (the launch was routed to another decoder: launch_decompress)
   // STAGE: one staging buffer per block of the workgroup (group_dev.h st_*): 256/GL x 576 bytes; PIPE 2: the block's window of
   // the compressed stream (group_dev.h sr_*): 256/GL x (kStream + 16) bytes
   constexpr uint32_t kPer = PIPE == 2 ? GroupDev<GL>::kStreamLds : GroupDev<GL>::kStage;
@@ -1143,6 +1144,11 @@ __global__ __launch_bounds__(128 * W) void decode_pair_kernel(BatchArgs a, const
   G g;
   pair_parser_quit(g, lds);
 }
+#ifndef LZ4HIP_ROUTE_DENSE
+#define LZ4HIP_ROUTE_DENSE 44   /* sequences per 256 bytes of stream from which a batch of more than 16 blocks per CU goes to the wave kernel (decode_route_kernel below) */
+#endif
+static std::atomic<int> g_route_dense{LZ4HIP_ROUTE_DENSE};   // "decode_route_dense": 0 = no density route
+void set_route_dense(int v) { g_route_dense.store(v, std::memory_order_relaxed); }
 static uint32_t device_cus() {   // compute units of the current device (cached per device)
   static std::atomic<uint32_t> cus[64];
   int d = 0;
@@ -1205,16 +1211,103 @@ static int launch_decode_wave(const BatchArgs& a, bool safe, bool par, int ring,
   }
 }
 
-// Which decoder a mid-sized batch gets is decided ON THE DEVICE from the blocks' compressed sizes (the launch is asynchronous and
-// its arguments live in device memory): *route = 1 when a sample of the blocks averages at least `big` compressed bytes -- big
-// blocks with (typically) a short match window, where the ring loop with a 2 KiB output ring wins (BASELINE configs[2]: 847 vs 808-835
-// GB/s, and a fabric traffic of 2.x instead of 3.75x the algorithmic bytes) -- else 0: the deep loop (64 KiB-class blocks: the ring
-// loop loses there below 40960 blocks, 70 vs 103 GB/s on text).  Both kernels are launched; the one that is not meant returns at once.
-__global__ __launch_bounds__(64) void decode_route_kernel(const int32_t* src_len, uint32_t n, uint32_t big, uint32_t* route) {
-  const uint32_t step = n > 64u ? n / 64u : 1u, i = threadIdx.x * step;
-  uint32_t v = (i < n && src_len[i] > 0) ? (uint32_t)src_len[i] : 0u, c = i < n ? 1u : 0u;
-  for (int d = 32; d >= 1; d >>= 1) { v += (uint32_t)__shfl_xor((int)v, d, 64); c += (uint32_t)__shfl_xor((int)c, d, 64); }
-  if (threadIdx.x == 0) *route = (c && v / c >= big) ? 1u : 0u;
+// Which decoder a batch of more than 16 blocks per CU gets is decided ON THE DEVICE (the launch is asynchronous and its arguments live
+// in device memory): every candidate kernel is launched with the route word and the value it answers to; the ones that are not
+// meant return at once.  *route =
+//   1  the ring loop (lz4_decode_ring.h, 4 lanes, 2 KiB ring): a sample of the blocks averages at least `big` compressed bytes -- big
+//      blocks with (typically) a short match window (BASELINE configs[2]: 847 vs 808-835 GB/s and a fabric traffic of 2.x instead of
+//      3.75x the algorithmic bytes); only asked for batches of 12288 .. 40959 blocks (`big` = 0: never);
+//   2  the wave kernel (lz4_decode_wave.h, a wavefront per block, W = 16): the streams are DENSE -- `dense` or more sequences per 256
+//      bytes of stream.  The lane-group loops decode ~21 G sequences/s whatever the data (a match source is a memory request: text at
+//      6 output bytes per sequence is 128 GB/s where App. F data at 34 are 708), the wave kernel 10 .. 23 G/s growing with the
+//      sequences a 256-byte window holds, its output window on chip: on text it wins at EVERY batch size (65536 blocks: 142 vs 128
+//      GB/s, 8192: 140 vs 60), on everything else it loses up to 2x (profiles/r05_wave_notes.txt section 5);
+//   0  the lane-group default of the batch size (deep loop below 40960 blocks, 4-lane staged loop from there on).
+// Round 5 sampled the HEAD of 16 streams with one lane each and took the route out again: a block's head is not its body (a text
+// stream runs 16 compressed bytes per sequence in its first 512 bytes -- no history yet -- and 4.2 overall).  This sampler reads the
+// MIDDLE of the streams and needs no parse from the start for it: the walk of the wave loop (speculative next-token positions for
+// every byte of a window, then the chain from the window's first byte) started at an ARBITRARY byte falls in with the true token
+// chain within a few sequences -- chains that meet stay together -- and until it does it hops through literal bytes at about the
+// data's own pace.  32 blocks spread over the batch, 1 KB from the middle of each, the first 256-byte window thrown away, hops per
+// byte of the rest: Calgary book1 58 .. 69 sequences per 256 bytes (true: 61), App. F 9 .. 21 (15), 4 MiB App. F blocks 9 .. 16 (14),
+// geo 4 .. 30 (7), pic 1 .. 44 (32) per SAMPLE; the route takes the sum over the 32.  One workgroup of 16 wavefronts, two blocks
+// each, both 1 KB loads in flight together: ~10 us in front of launches of >= 0.9 ms.
+__device__ uint32_t g_last_route[4];
+__global__ __launch_bounds__(1024) void decode_route_kernel(const uint8_t* src, const uint64_t* src_off, const int32_t* src_len, uint32_t n, uint32_t big, uint32_t dense,
+                                                            uint32_t* route) {
+  typedef BlockWaveDev<8192, 1024> G;   // (its hand-written walk: a static function of registers)
+  constexpr uint32_t SPAN = 1024u, NS = 2u;
+  __shared__ __attribute__((aligned(16))) uint8_t win[16][NS][SPAN + 32];
+  __shared__ uint32_t acc[16][2];
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
+  // ---- the blocks' sizes: 64 of them, wavefront 0 (the ring loop's criterion, unchanged) ----
+  uint32_t avg = 0u;
+  if (wave == 0u) {
+    const uint32_t step = n > 64u ? n / 64u : 1u, i = lane * step;
+    uint32_t v = (i < n && src_len[i] > 0) ? (uint32_t)src_len[i] : 0u, c = i < n ? 1u : 0u;
+    for (int d = 32; d >= 1; d >>= 1) { v += (uint32_t)__shfl_xor((int)v, d, 64); c += (uint32_t)__shfl_xor((int)c, d, 64); }
+    avg = c ? v / c : 0u;
+  }
+  // ---- the streams' density: wavefront w samples blocks (2 w + k) n / 32 + n / 64, k = 0, 1 ----
+  uint32_t start[NS], have[NS];
+#pragma unroll
+  for (uint32_t k = 0; k < NS; k++) {
+    const uint64_t bi = ((uint64_t)(NS * wave + k) * n) / (16u * NS) + n / (32u * NS);
+    const uint32_t b = bi < n ? (uint32_t)bi : n - 1u;
+    const int32_t len = uniform_i32(src_len[b]);
+    have[k] = len >= 4096 ? 1u : 0u;              // (shorter streams are not sampled: their decode time is not in their interior loops)
+    start[k] = have[k] ? (((uint32_t)len >> 1) & ~3u) : 0u;
+    if (have[k]) {
+      const uint8_t* p = uniform_ptr(src + src_off[b]) + start[k];
+      // (byte loads assembled into dwords would be 16 instructions; the streams lie at any address, so: unaligned dword loads)
+      uint32_t w[4];
+#pragma unroll
+      for (uint32_t j = 0; j < 4u; j++) __builtin_memcpy(&w[j], p + j * 256u + 4u * lane, 4);
+      uint32_t tail = 0u;
+      if (lane < 8u) __builtin_memcpy(&tail, p + SPAN + 4u * lane, 4);
+#pragma unroll
+      for (uint32_t j = 0; j < 4u; j++) *(uint32_t*)&win[wave][k][j * 256u + 4u * lane] = w[j];
+      if (lane < 8u) *(uint32_t*)&win[wave][k][SPAN + 4u * lane] = tail;
+    }
+  }
+  uint32_t seqs = 0u, bytes = 0u;
+#pragma unroll
+  for (uint32_t k = 0; k < NS; k++) {
+    if (!have[k]) continue;
+    uint32_t ip = 0u;                             // relative to start[k]
+    for (uint32_t wdw = 0; wdw < 4u && ip + 264u <= SPAN + 32u; wdw++) {
+      const uint32_t* q = (const uint32_t*)&win[wave][k][(ip & ~3u) + 4u * lane];
+      const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], sh = ip & 3u;
+      const uint32_t blo = __builtin_amdgcn_alignbyte(d1, d0, sh), bhi = __builtin_amdgcn_alignbyte(d2, d1, sh);
+      uint32_t nxpack = 0u;
+#pragma unroll
+      for (uint32_t j = 0; j < 4u; j++) {         // (lz4_decode_wave.h step 1: where a token at window byte 4 l + j would be followed by the next)
+        const uint32_t w = j == 0u ? blo : ((blo >> (8u * j)) | (bhi << (32u - 8u * j)));
+        const uint32_t tl = (w >> 4) & 15u, e1 = (w >> 8) & 255u;
+        const uint32_t nxt = 4u * lane + (j + 3u) + (tl == 15u ? 1u + e1 : 0u) + tl + ((w & 15u) == 15u ? 1u : 0u);
+        nxpack |= (nxt <= 250u ? nxt : 255u) << (8u * j);
+      }
+      uint32_t posv = 0u, T = 0u;
+      G::vwalk(nxpack, posv, T);
+      const uint32_t last = T > 1u ? (uint32_t)__builtin_amdgcn_readlane((int)posv, (int)(T - 1u)) : 256u;   // the last start is where the next window begins
+      const uint32_t hops = T > 1u ? T - 1u : 1u;
+      if (wdw != 0u) { seqs += hops; bytes += last; }
+      ip += last;
+    }
+  }
+  if (lane == 0u) { acc[wave][0] = seqs; acc[wave][1] = bytes; }
+  __syncthreads();
+  if (threadIdx.x == 0u) {
+    uint32_t ts = 0u, tb = 0u;
+    for (uint32_t w = 0; w < 16u; w++) { ts += acc[w][0]; tb += acc[w][1]; }
+    const bool is_big = big != 0u && avg >= big;
+    const bool is_dense = dense != 0u && tb >= 2048u && (uint64_t)ts * 256u >= (uint64_t)dense * tb;   // (at least a few windows were sampled)
+    *route = is_big ? 1u : is_dense ? 2u : 0u;
+    g_last_route[0] = is_big ? 1u : is_dense ? 2u : 0u; g_last_route[1] = ts; g_last_route[2] = tb; g_last_route[3] = avg;   // (diagnostic: last_decode_route)
+  }
+}
+int last_decode_route(uint32_t* out4) {   // what the last routed decode launch of this device decided: {route, sampled hops, sampled stream bytes, average compressed size}
+  return (int)hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_last_route), 4 * sizeof(uint32_t));
 }
 
 template <int GL>
@@ -1222,19 +1315,19 @@ static int launch_decode_gl(const BatchArgs& a, bool safe, int pipe, bool stage,
   const uint32_t per_wg = 256u / GL;
   const uint32_t grid = (a.n + per_wg - 1u) / per_wg;
   if (stage) {   // (staging belongs to the plain loop)
-    if (safe) hipLaunchKernelGGL((decode_kernel<GL, true, 0, true>), dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((decode_kernel<GL, false, 0, true>), dim3(grid), dim3(256), 0, st, a);
+    if (safe) hipLaunchKernelGGL((decode_kernel<GL, true, 0, true>), dim3(grid), dim3(256), 0, st, a, route, 0u);
+    else hipLaunchKernelGGL((decode_kernel<GL, false, 0, true>), dim3(grid), dim3(256), 0, st, a, route, 0u);
   } else if (pipe == 2 && GL <= 16) {   // (the deep loop works in 64-byte steps: groups of up to 16 lanes)
     if constexpr (GL <= 16) {
       if (safe) hipLaunchKernelGGL((decode_deep_kernel<GL, true>), dim3(grid), dim3(256), 0, st, a, route, 0u);
       else hipLaunchKernelGGL((decode_deep_kernel<GL, false>), dim3(grid), dim3(256), 0, st, a, route, 0u);
     }
   } else if (safe) {
-    if (pipe) hipLaunchKernelGGL((decode_kernel<GL, true, 1, false>), dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((decode_kernel<GL, true, 0, false>), dim3(grid), dim3(256), 0, st, a);
+    if (pipe) hipLaunchKernelGGL((decode_kernel<GL, true, 1, false>), dim3(grid), dim3(256), 0, st, a, route, 0u);
+    else hipLaunchKernelGGL((decode_kernel<GL, true, 0, false>), dim3(grid), dim3(256), 0, st, a, route, 0u);
   } else {
-    if (pipe) hipLaunchKernelGGL((decode_kernel<GL, false, 1, false>), dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((decode_kernel<GL, false, 0, false>), dim3(grid), dim3(256), 0, st, a);
+    if (pipe) hipLaunchKernelGGL((decode_kernel<GL, false, 1, false>), dim3(grid), dim3(256), 0, st, a, route, 0u);
+    else hipLaunchKernelGGL((decode_kernel<GL, false, 0, false>), dim3(grid), dim3(256), 0, st, a, route, 0u);
   }
   return (int)hipGetLastError();
 }
@@ -1284,6 +1377,11 @@ int launch_decompress(const BatchArgs& a, bool safe, int lanes_per_block, int pi
   // trip (lz4_decode_wave.h, decode_pipe 5).  Against the lane-group loops below (GB/s of output, gpurun_out/r05j): 4 MiB blocks 256:
   // 17 -> 45, 2048: 135 -> 285, 4096: 272 -> 403 (8192: 519 -> 404, so not beyond 16 per CU); 64 KiB App. F 512: 31 -> 50, 2048: 120 -> 146,
   // 4096: 213 -> 232; 64 KiB text 512: 4.2 -> 16.1, 2048: 16.4 -> 49.6, 4096: 30.7 -> 66.4; one 64 KiB block 0.71 -> 0.43 ms.
+  // Round 6: up to FOUR blocks per CU a block gets TWO wavefronts -- a parser and a copier (lz4_decode_pair.h, decode_pipe 7): with at most
+  // one wavefront per SIMD the trip's two halves run side by side (4 MiB blocks 256: 69 -> 93 GB/s, 1024: 258 -> 293; one 64 KiB block
+  // 0.286 -> 0.223 ms).  From eight blocks per CU on the SIMDs are saturated by one wavefront per block (two per SIMD, each issuing 52 % of
+  // its cycles) and the second wavefront's messages are pure overhead (2048 x 4 MiB: 432 -> 393): profiles/r06_pair_notes.txt.
+  if (auto_lanes && pipe < 0 && stage < 0 && a.n <= 4u * device_cus()) return launch_decode_pair(a, safe, 0, st);
   if (auto_lanes && pipe < 0 && stage < 0 && a.n <= 16u * device_cus()) return launch_decode_wave(a, safe, true, 0, st);
   if (auto_lanes) lanes_per_block = a.n >= 40960u ? 4 : 8;
   const int p = pipe < 0 ? ((a.n < 40960u && lanes_per_block >= 8) ? (lanes_per_block <= 16 ? 2 : 1) : 0) : pipe;
@@ -1291,12 +1389,17 @@ int launch_decompress(const BatchArgs& a, bool safe, int lanes_per_block, int pi
   // (text 106 -> 111); below that the pipelined loop wins (16384 blocks: 424 vs 289 staged vs 304 plain; 32768: 545 vs 447;
   // 49152: 508 vs 597)
   const bool sg = !p && (stage < 0 ? a.n >= 40960u : stage != 0);
-  if (auto_lanes && pipe < 0 && stage < 0 && route_word && a.n >= 12288u && a.n < 40960u) {
-    // every default in place and a batch that fills the GPU with the ring loop's 16 blocks per wavefront (8192 x 4 MiB: 422 vs 544
-    // GB/s for the deep loop; 16384: 847 vs 815): deep loop or ring loop, decided from the blocks' sizes
-    hipLaunchKernelGGL(decode_route_kernel, dim3(1), dim3(64), 0, st, a.src_len, a.n, 512u << 10, route_word);
-    int e = launch_decode_gl<8>(a, safe, 2, false, st, route_word);
-    if (e == 0) e = launch_decode_ring<4, 2048>(a, safe, st, route_word, 1u);
+  if (auto_lanes && pipe < 0 && stage < 0 && route_word) {
+    // every default in place and more than 16 blocks per CU: the decoder is chosen on the device (decode_route_kernel above) -- by the
+    // blocks' sizes between the deep loop and the ring loop (batches that fill the GPU with the ring loop's 16 blocks per wavefront,
+    // 12288 .. 40959 blocks: 8192 x 4 MiB 422 vs 544 GB/s for the deep loop; 16384: 847 vs 815), and by the streams' sequence density
+    // between either of them and the wave kernel
+    const bool ring_size = a.n >= 12288u && a.n < 40960u;
+    hipLaunchKernelGGL(decode_route_kernel, dim3(1), dim3(1024), 0, st, a.src, a.src_off, a.src_len, a.n, ring_size ? 512u << 10 : 0u,
+                       (uint32_t)g_route_dense.load(std::memory_order_relaxed), route_word);
+    int e = a.n >= 40960u ? launch_decode_gl<4>(a, safe, 0, true, st, route_word) : launch_decode_gl<8>(a, safe, 2, false, st, route_word);
+    if (e == 0 && ring_size) e = launch_decode_ring<4, 2048>(a, safe, st, route_word, 1u);
+    if (e == 0) e = launch_decode_wave(a, safe, true, 8192, st, route_word, 2u);
     return e;
   }
   switch (lanes_per_block) {

@@ -144,7 +144,8 @@ def test_decode_fuzz_bit_exact(amd, ref, O, corpus):
                                      (4, 2, 0, 0), (8, 2, 0, 0), (16, 2, 0, 0),     # pipe 2: the deep interior loop (lz4_decode_deep.h)
                                      (1, 3, 0, 256), (1, 3, 0, 512), (4, 3, 0, 512), (4, 3, 0, 1024), (4, 3, 0, 2048), (8, 3, 0, 512), (8, 3, 0, 4096), (16, 3, 0, 4096),   # pipe 3: the ring loop (lz4_decode_ring.h); (4, 3, 2048) is the routed default of 12288..40959 big blocks
                                      (64, 4, 0, 0), (64, 4, 0, 8192), (64, 4, 0, 16384), (64, 4, 0, 32768), (64, 4, 0, 65536),   # pipe 4: the wave loop (lz4_decode_wave.h), a wavefront per block
-                                     (64, 5, 0, 0), (64, 5, 0, 8192), (64, 5, 0, 16384), (64, 5, 0, 32768), (64, 5, 0, 65536)):   # pipe 5: its parallel form, several sequences of the block per trip
+                                     (64, 5, 0, 0), (64, 5, 0, 8192), (64, 5, 0, 16384), (64, 5, 0, 32768), (64, 5, 0, 65536),   # pipe 5: its parallel form, several sequences of the block per trip
+                                     (64, 7, 0, 0), (64, 7, 0, 16384), (64, 7, 0, 32768), (64, 7, 0, 65536)):   # pipe 7: the pair loop (lz4_decode_pair.h), a parser and a copier wavefront per block
         amd.set_option("decode_lanes", lanes)
         amd.set_option("decode_pipe", pipe)
         amd.set_option("decode_stage", stage)
@@ -298,7 +299,8 @@ def test_decode_variants_at_odd_offsets(amd, ref, corpus):
     for lanes, pipe, stage, ring in ((4, 0, 1, 0), (8, 0, 1, 0), (16, 0, 1, 0), (64, 0, 1, 0), (4, 0, 0, 0), (8, 1, 0, 0), (16, 1, 0, 0), (4, 2, 0, 0), (8, 2, 0, 0), (16, 2, 0, 0),
                                      (1, 3, 0, 0), (4, 3, 0, 0), (4, 3, 0, 2048), (8, 3, 0, 0), (16, 3, 0, 0),   # (3: the ring loop flushes address-aligned steps)
                                      (64, 4, 0, 0), (64, 4, 0, 8192), (64, 4, 0, 16384), (64, 4, 0, 65536),   # (4: the wave loop flushes 256-byte steps, its first and last byte-exactly)
-                                     (64, 5, 0, 0), (64, 5, 0, 8192), (64, 5, 0, 16384), (64, 5, 0, 65536)):
+                                     (64, 5, 0, 0), (64, 5, 0, 8192), (64, 5, 0, 16384), (64, 5, 0, 65536),
+                                     (64, 7, 0, 0), (64, 7, 0, 16384), (64, 7, 0, 65536)):                      # (7: the pair loop, the same flusher in its copier wavefront)
         amd.set_option("decode_lanes", lanes); amd.set_option("decode_pipe", pipe); amd.set_option("decode_stage", stage); amd.set_option("decode_ring", ring)
         dst = bytearray(b"\xC3" * total)
         out = amd.LZ4HIPBatch.decompressSafe(bytes(src), so, [len(c) for c in comp], dst, dst_off, [len(b) for b in blocks])
@@ -324,7 +326,8 @@ def test_deep_decoder_loop_long_streams(amd, ref, O, corpus):
     try:
         for lanes, pipe, ring in ((4, 2, 0), (8, 2, 0), (16, 2, 0), (1, 3, 256), (1, 3, 512), (4, 3, 512), (4, 3, 1024), (4, 3, 2048), (8, 3, 512), (8, 3, 2048), (8, 3, 4096), (16, 3, 2048), (16, 3, 4096),
                                   (64, 4, 0), (64, 4, 8192), (64, 4, 16384), (64, 4, 32768), (64, 4, 65536),
-                                  (64, 5, 0), (64, 5, 8192), (64, 5, 16384), (64, 5, 32768), (64, 5, 65536)):
+                                  (64, 5, 0), (64, 5, 8192), (64, 5, 16384), (64, 5, 32768), (64, 5, 65536),
+                                  (64, 7, 0), (64, 7, 16384), (64, 7, 32768), (64, 7, 65536)):
             amd.set_option("decode_lanes", lanes); amd.set_option("decode_pipe", pipe); amd.set_option("decode_stage", 0); amd.set_option("decode_ring", ring)
             res = gpu_decode_safe_many(amd, streams, caps)
             for k, ((r, d), (er, ed)) in enumerate(zip(res, want)):
@@ -348,7 +351,7 @@ def test_wave_par_trip_behind_a_one_sequence_step(amd, ref):
     want = [ref.decompress_safe_raw(c, n) for c, n in cases]
     assert all(r == n for (r, _), n in zip(want, caps))
     try:
-        for pipe, ring in ((5, 0), (5, 8192), (5, 16384), (5, 32768), (5, 65536), (4, 8192), (4, 65536)):
+        for pipe, ring in ((5, 0), (5, 8192), (5, 16384), (5, 32768), (5, 65536), (4, 8192), (4, 65536), (7, 0), (7, 16384), (7, 32768), (7, 65536)):
             amd.set_option("decode_lanes", 64); amd.set_option("decode_pipe", pipe); amd.set_option("decode_stage", 0); amd.set_option("decode_ring", ring)
             res = gpu_decode_safe_many(amd, streams, caps)
             for k, ((r, d), (er, ed)) in enumerate(zip(res, want)):
@@ -369,13 +372,29 @@ def test_wave_loops_ring_edge_streams(amd, ref):
     want = [ref.decompress_safe_raw(c, n) for c, n in cases]
     assert all(r == n for (r, _), n in zip(want, caps))
     try:
-        for pipe, ring in ((5, 0), (5, 8192), (5, 16384), (5, 32768), (5, 65536), (4, 0), (4, 8192), (4, 32768)):
+        for pipe, ring in ((5, 0), (5, 8192), (5, 16384), (5, 32768), (5, 65536), (4, 0), (4, 8192), (4, 32768), (7, 0), (7, 16384), (7, 32768), (7, 65536)):
             amd.set_option("decode_lanes", 64); amd.set_option("decode_pipe", pipe); amd.set_option("decode_stage", 0); amd.set_option("decode_ring", ring)
             res = gpu_decode_safe_many(amd, streams, caps)
             for k, ((r, d), (er, ed)) in enumerate(zip(res, want)):
                 assert r == er and d[:er] == ed[:er], (pipe, ring, k, r, er, next((i for i in range(min(max(r, 0), er)) if d[i] != ed[i]), None))
     finally:
         amd.set_option("decode_lanes", 0); amd.set_option("decode_pipe", -1); amd.set_option("decode_stage", -1); amd.set_option("decode_ring", 0)
+
+
+def test_decode_knobs_that_no_kernel_exists_for_are_named(amd, ref):
+    """round-5 advisor: the decode knobs are set one at a time, and a combination without a kernel (a ring-loop ring with a wave loop,
+    a wave ring with the pair loop) surfaced as a bare 'kernel launch: invalid value'.  Now an argument error that names the knobs."""
+    c = ref.compress_fast(bytes(5000))
+    try:
+        for lanes, pipe, ring, word in ((64, 5, 2048, "decode_pipe 4 / 5"), (64, 7, 8192, "decode_pipe 7"), (16, 3, 512, "decode_pipe 3"), (1, 2, 0, "decode_lanes 1")):
+            amd.set_option("decode_lanes", lanes); amd.set_option("decode_pipe", pipe); amd.set_option("decode_ring", ring)
+            with pytest.raises(amd.LZ4HIPError) as ei:
+                amd.LZ4HIPBatch.decompressSafe(c, [0], [len(c)], bytearray(5000), [0], [5000])
+            assert word in str(ei.value) and "status -3" in str(ei.value), str(ei.value)
+    finally:
+        amd.set_option("decode_lanes", 0); amd.set_option("decode_pipe", -1); amd.set_option("decode_stage", -1); amd.set_option("decode_ring", 0)
+    r = amd.LZ4HIPBatch.decompressSafe(c, [0], [len(c)], bytearray(5000), [0], [5000])
+    assert list(r) == [5000]
 
 
 def test_concurrent_callers(amd, ref, corpus):

@@ -95,7 +95,8 @@ def test_cfg3_reference_compressed_4MiB_blocks_every_decoder_variant(amd, ref, O
                                          (4, 2, 0, 0), (8, 2, 0, 0), (16, 2, 0, 0),
                                          (4, 3, 0, 2048), (8, 3, 0, 2048), (8, 3, 0, 4096), (16, 3, 0, 4096),          # the ring loop; (4, 3, 2048) is what a routed batch of 12288..40959 such blocks gets
                                          (64, 4, 0, 0), (64, 4, 0, 8192), (64, 4, 0, 16384), (64, 4, 0, 32768),      # the wave loop: a wavefront per block
-                                         (64, 5, 0, 0), (64, 5, 0, 8192), (64, 5, 0, 16384), (64, 5, 0, 32768)):     # ... several sequences of the block per trip
+                                         (64, 5, 0, 0), (64, 5, 0, 8192), (64, 5, 0, 16384), (64, 5, 0, 32768),      # ... several sequences of the block per trip
+                                         (64, 7, 0, 0), (64, 7, 0, 16384), (64, 7, 0, 32768)):                       # the pair loop: two wavefronts per block
             amd.set_option("decode_lanes", lanes); amd.set_option("decode_pipe", pipe); amd.set_option("decode_stage", stage); amd.set_option("decode_ring", ring)
             back.zero_()
             amd.DeviceBatch.decompress_safe(dcomp, co, cl, back, B["so"], B["sl"], B["dlen"])
@@ -150,6 +151,7 @@ def test_routed_batch_of_big_blocks_vs_reference(amd, ref):
     back = torch.zeros(n * blk, dtype=torch.uint8, device=dev)
     amd.DeviceBatch.decompress_safe(comp, B["co"], cl, back, B["so"], dc, B["dlen"])
     torch.cuda.synchronize()
+    assert amd.last_decode_route()[0] == 1, amd.last_decode_route()       # the ring loop it was
     dlen = B["dlen"].cpu().numpy()
     for i in bad:
         er, ed = ref.decompress_safe_raw(streams[i], int(caps[i]))
@@ -160,6 +162,91 @@ def test_routed_batch_of_big_blocks_vs_reference(amd, ref):
     assert (dlen[ok] == blk).all()
     okt = torch.from_numpy(ok).to(dev)
     assert torch.equal(back.view(n, blk)[okt], src.view(n, blk)[okt])
+
+
+def test_batches_routed_by_sequence_density_vs_reference(amd, ref, corpus):
+    """More than 16 blocks per CU and every knob at its default: decode_route_kernel samples the MIDDLE of 32 streams (the wave loop's
+    speculative walk from an arbitrary byte: it falls in with the true token chain within a few sequences) and sends batches of dense
+    streams -- text: ~60 sequences per 256 bytes -- to the wave kernel, everything else (App. F ~15, a bitmap ~30, geophysical data ~7)
+    to the lane-group loop of the batch size.  For text, App. F, bitmap and geophysical batches below and above 40960 blocks: the route
+    taken, sizes and bytes against the source, a sample of damaged / reference-compressed streams against LZ4_decompress_safe
+    (LZ4JNI.c:216); and the same bytes with the density route forced on (decode_route_dense 1) and off (0)."""
+    import numpy as np
+    import torch
+    dev = torch.device("cuda:0")
+    blk = 65536
+    cap = amd.maxCompressedLength(blk)
+    book = np.frombuffer(corpus["book1[:200000]"], dtype=np.uint8)
+    rng = random.Random(4406)
+
+    def make(kind, n):
+        src = torch.empty(n * blk, dtype=torch.uint8, device=dev)
+        if kind == "appf":
+            amd.DeviceBatch.gen_blocks(src, blk, blk, n, first_idx=9 << 24)
+        elif kind == "book":
+            bdev = torch.from_numpy(book.copy()).to(dev)
+            offs = torch.arange(n, dtype=torch.int64, device=dev) * 7919 % (len(book) - blk)
+            ar = torch.arange(blk, dtype=torch.int64, device=dev)
+            for c0 in range(0, n, 1024):
+                c1 = min(n, c0 + 1024)
+                src[c0 * blk:c1 * blk] = bdev[(offs[c0:c1, None] + ar[None, :]).reshape(-1)]
+        else:
+            b = np.frombuffer(corpus[kind + "[:65536]"], dtype=np.uint8)
+            src = torch.from_numpy(b.copy()).to(dev).repeat(n)
+        return src
+
+    try:
+        for kind, n, want_route in (("book", 6144, 2), ("appf", 6144, 0), ("pic", 5000, 0), ("geo", 5000, 0), ("book", 45056, 2), ("appf", 45056, 0), ("book", 20000, 2)):
+            src = make(kind, n)
+            comp = torch.empty(n * cap, dtype=torch.uint8, device=dev)
+            B = _batch(torch, dev, n, blk, cap)
+            amd.DeviceBatch.compress_fast(src, B["so"], B["sl"], comp, B["co"], B["cc"], B["clen"])
+            torch.cuda.synchronize()
+            clen = B["clen"].cpu().numpy().copy()
+            sample = rng.sample(range(n), 24)
+            good, bad = sample[:8], sample[8:]
+            streams = {i: comp[i * cap:i * cap + int(clen[i])].cpu().numpy().tobytes() for i in sample}
+            for i in good:
+                assert streams[i] == ref.compress_fast(src[i * blk:(i + 1) * blk].cpu().numpy().tobytes()), (kind, i)   # the reference library's own bytes
+            caps = np.full(n, blk, dtype=np.int32)
+            for k, i in enumerate(bad):
+                c = bytearray(streams[i])
+                if k % 3 == 0:
+                    for _ in range(rng.randrange(1, 4)):
+                        c[rng.randrange(len(c))] = rng.randrange(256)
+                    comp[i * cap:i * cap + len(c)] = torch.from_numpy(np.frombuffer(bytes(c), dtype=np.uint8).copy()).to(dev)
+                elif k % 3 == 1:
+                    clen[i] = rng.randrange(len(c) // 3, len(c)); c = c[:clen[i]]
+                else:
+                    caps[i] = blk - rng.randrange(1, 5000)
+                streams[i] = bytes(c)
+            cl = torch.from_numpy(clen).to(dev)
+            dc = torch.from_numpy(caps).to(dev)
+            want = {i: ref.decompress_safe_raw(streams[i], int(caps[i])) for i in bad}
+            ok = np.ones(n, dtype=bool); ok[bad] = False
+            okt = torch.from_numpy(ok).to(dev)
+            for dense in (-1, 1, 0):                          # the default, "everything is dense", "nothing is"
+                if dense >= 0:
+                    amd.set_option("decode_route_dense", dense)
+                back = torch.zeros(n * blk, dtype=torch.uint8, device=dev)
+                amd.DeviceBatch.decompress_safe(comp, B["co"], cl, back, B["so"], dc, B["dlen"])
+                torch.cuda.synchronize()
+                route = amd.last_decode_route()
+                assert route[0] == (want_route if dense < 0 else 2 if dense == 1 else 0), (kind, n, dense, route)
+                dlen = B["dlen"].cpu().numpy()
+                for i in bad:
+                    er, ed = want[i]
+                    assert int(dlen[i]) == er, (kind, n, dense, i, int(dlen[i]), er)
+                    if er >= 0:
+                        assert back[i * blk:i * blk + er].cpu().numpy().tobytes() == ed[:er], (kind, n, dense, i)
+                assert (dlen[ok] == blk).all()
+                assert torch.equal(back.view(n, blk)[okt], src.view(n, blk)[okt]), (kind, n, dense)
+                del back
+            amd.set_option("decode_route_dense", 44)
+            del src, comp
+            torch.cuda.empty_cache()
+    finally:
+        amd.set_option("decode_route_dense", 44)
 
 
 def test_cfg4_256_blocks_hc9_every_block_vs_reference(amd, ref):
