@@ -174,6 +174,19 @@ def decode_kernel_name(n_blocks, safe=True, big_blocks=False):
     return "decode_deep_kernel<8, %s>" % s   # the deep interior loop, csrc/lz4_decode_deep.h
 
 
+def routed_decoder(amd, dev_index, n_blocks, safe=True):
+    """the decoder a launch of more than 16 blocks per CU really ran: decode_route_kernel's decision for the device's last routed launch
+    (lz4hip_last_decode_route: 0 = the lane-group default of the batch size, 1 = ring loop, 2 = wave kernel) as a kernel name, and the
+    sampled sequence density behind it"""
+    s = "true" if safe else "false"
+    if n_blocks <= 16 * 256:
+        return decode_kernel_name(n_blocks, safe), None
+    route, hops, nbytes, _avg, near, offs = amd.last_decode_route(dev_index)
+    name = "decode_wave_kernel<16, 8192, 1024, %s, 5>" % s if route == 2 else "decode_ring_kernel<4, 2048, %s>" % s if route == 1 else decode_kernel_name(n_blocks, safe)
+    return name, {"route": route, "sampled_sequences_per_256B": round(256.0 * hops / nbytes, 1) if nbytes else None,
+                  "sampled_offsets_within_6KB": round(near / offs, 3) if offs else None}
+
+
 def spread(r, *keys):
     """best-of-N / median-of-N of the named rates of a cpu_bench line (1.0 = every repetition the same; the harness repeats whole
     passes for >= CPU_BENCH_MIN_MS (300; headline 1000) per repetition on a persistent pinned thread pool, oracle/cpu_bench.c)"""
@@ -251,6 +264,8 @@ def main():
     if args.gpus == 1 and world == 1 and not args.no_live_traffic:
         # (behind `import torch` -- a fresh box pages the image in once, for the children too -- and before this process has a context on the GPU)
         live, live_note = live_traffic(args, timeout_s=180)
+        if not live:
+            print("bench.py: headline traffic from profiles/traffic.json (%s)" % live_note, file=sys.stderr, flush=True)
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
     if torch.cuda.device_count() < (local_rank + 1):
@@ -354,6 +369,8 @@ def main():
     csum = int(clen.sum().item())
     t_c = sum(e[0].elapsed_time(e[1]) for e in evs) / args.steps * 1e-3   # s per compress launch (HIP events on the launch stream)
     t_d = sum(e[2].elapsed_time(e[3]) for e in evs) / args.steps * 1e-3
+    t_g = sum(e[1].elapsed_time(e[2]) for e in evs) / args.steps * 1e-3   # the size all-gather as the launch stream sees it (0 at N = 1: no collective)
+    dev_index = dev.index or 0
     ok = all_ok(ok)
     nbytes = float(n) * blk
 
@@ -529,13 +546,26 @@ def main():
                     want = chk.compress_fast(book[int(offs[i]):int(offs[i]) + blk].tobytes())
                     okb = okb and cl[i] == len(want) and comp[i * cap:i * cap + cl[i]].cpu().numpy().tobytes() == want
             okb = all_ok(okb)
+            dk_name, dk_route = routed_decoder(amd, dev_index, n)
+            # the same text in smaller launches: which decoder each gets (pair loop / wave loop / routed by density) and what it delivers
+            by_n = {}
+            for nb_ in (2048, 8192, 16384):
+                if nb_ >= n:
+                    continue
+                back[:nb_ * blk].zero_()
+                wq, tq = timed(lambda: amd.DeviceBatch.decompress_safe(comp, co[:nb_], clen[:nb_], back, so[:nb_], sl[:nb_], dlen[:nb_]), 3)
+                kq, rq = routed_decoder(amd, dev_index, nb_)
+                okq = all_ok(bool(torch.equal(back[:nb_ * blk], src[:nb_ * blk])))
+                by_n[str(nb_)] = {"decompress_GBps": round(world * float(nb_) * blk / wq / 1e9, 3), "ms_per_launch": round(tq * 1e3, 4), "kernel": kq, "route": rq, "verified": okq}
+                okb = okb and okq
             extra["real_book1"] = {"workload": "%d x 64 KiB slices of Calgary book1 per GPU (stand-in for configs[0]'s Silesia/dickens block), fast compress + "
                                                "safe decompress, ratio %.3f; compressed bytes of 48 blocks vs the reference library" % (n, nbytes / csb),
                                    "unit": "GB/s", "verified": okb,
                                    "compress_GBps": round(world * nbytes / wc / 1e9, 3), "decompress_GBps": round(world * nbytes / wd / 1e9, 3),
                                    # (HBM bytes of these launches: PMC passes of the text legs by themselves, tools/gpu_text_legs.py)
                                    "roofline_compress": roof("compress_fast_v2w_cu_kernel + compress_fast_ms_cu_kernel", nbytes + csb, tkc, text_traffic(tr, world, n, "real_book1", "compress")),
-                                   "roofline_decode": roof(decode_kernel_name(n), nbytes + csb, tkd, text_traffic(tr, world, n, "real_book1", "decode"))}
+                                   "roofline_decode": roof(dk_name, nbytes + csb, tkd, text_traffic(tr, world, n, "real_book1", "decode")),
+                                   "decode_route": dk_route, "decode_by_blocks_per_launch": by_n}
             ok = ok and okb
             if want_cpu:
                 def fb():
@@ -610,10 +640,11 @@ def main():
         ok3 = all_ok(bool(torch.equal(bk3, s3)))
         # its bytes decode back to the input AND a sample of the blocks equals the reference library's output byte for byte
         ref3 = None
+        k3_name, k3_route = routed_decoder(amd, dev_index, n3)
         from oracle import oracle as O
+        cl3 = B3["clen"].cpu().tolist()
         if O.ref_path():
             chk = O.ref()
-            cl3 = B3["clen"].cpu().tolist()
             ref3 = 0
             for i in sorted(set([0, n3 - 1] + list(range(0, n3, max(1, n3 // 6)))))[:8]:
                 want = chk.compress_fast(s3[i * b3:(i + 1) * b3].cpu().numpy().tobytes())
@@ -625,9 +656,18 @@ def main():
         extra["configs2_decode_4MiB"] = {"workload": "%d x 4 MiB blocks per GPU in one launch (BASELINE configs[2]: 16384 blocks in all, sharded over the ranks), "
                                                      "App.F win 4096, LZ4_decompress_safe of fast-compressed blocks, ratio %.3f" % (n3, n3 * b3 / cs3),
                                          "value": round(world * float(n3) * b3 / wall / 1e9, 3), "unit": "GB/s", "verified": ok3,
-                                         "roofline": roof(decode_kernel_name(n3, True, True), float(n3) * b3 + cs3, tk,
-                                                          kernel_traffic(tr, world, decode_kernel_name(n3, True, True)) if n3 == (tr.get("configs2_blocks") or 16384) else None)}
+                                         "kernel_ran": k3_name, "route": k3_route,
+                                         "roofline": roof(k3_name, float(n3) * b3 + cs3, tk,
+                                                          kernel_traffic(tr, world, k3_name) if n3 == (tr.get("configs2_blocks") or 16384) else None)}
         ok = ok and ok3
+        # what the one-GPU shard legs of the committed N = 1 line predicted for this rank count (profiles/shard_prediction.json, written from
+        # the line by tools/collect_profiles.sh): beside the measured figure, so that a shortfall at N > 1 can be told from the line alone
+        try:
+            pred = json.load(open(os.path.join(ROOT, "profiles", "shard_prediction.json")))
+            extra["configs2_decode_4MiB"]["predicted_per_gpu_GBps"] = (pred.get("configs2_decode_per_gpu_GBps") or {}).get(str(world))
+            extra["configs2_decode_4MiB"]["prediction_source"] = pred.get("source")
+        except Exception:
+            pass
         # ---- the 8-GPU shard of configs[2] ON THIS GPU: `--gpus 8` gives every rank 16384 / 8 = 2048 blocks (n3 above) and the ranks
         # exchange no data, so one GPU running 2048 blocks IS what each of eight would run; x 8 is the PREDICTED aggregate, not a
         # measurement of eight GPUs.  (Round-4 verdict: the lane-group decoders take 63 ms for a launch of 4 MiB blocks whether it
@@ -639,18 +679,68 @@ def main():
             wS, tkS = timed(lambda: amd.DeviceBatch.decompress_safe(c3, B3["co"][:nS], B3["clen"][:nS], bkS, B3["so"][:nS], B3["sl"][:nS], B3["dlen"][:nS]), 3)
             okS = all_ok(bool(torch.equal(bkS, s3[:nS * b3])))
             csS = int(B3["clen"][:nS].sum().item())
-            wSc, tkSc = timed(lambda: amd.DeviceBatch.compress_fast(s3, B3["so"][:nS], B3["sl"][:nS], c3, B3["co"][:nS], B3["cc"][:nS], B3["clen"][:nS]), 2)
+            # ... and on streams that ARE the reference library's bytes: 64 of the shard's blocks compressed by liblz4 on the host, every
+            # one decoded 32 times into 2048 distinct slots (the same launch shape, the same kernel)
+            refS = None
+            if O.ref_path():
+                import concurrent.futures as cf
+                import numpy as np
+                chk = O.ref()
+                hostb = [s3[i * b3:(i + 1) * b3].cpu().numpy().tobytes() for i in range(64)]
+                with cf.ThreadPoolExecutor(cores) as ex:          # (ctypes releases the GIL in the call)
+                    rstreams = list(ex.map(chk.compress_fast, hostb))
+                okref = all(len(r_) == cl3[i] and c3[i * cap3:i * cap3 + cl3[i]].cpu().numpy().tobytes() == r_ for i, r_ in enumerate(rstreams[:8]))   # (the engine's bytes for these blocks are the same bytes)
+                offs_h, p_ = [], 0
+                for r_ in rstreams:
+                    offs_h.append(p_); p_ += len(r_) + 5
+                packed = torch.from_numpy(np.frombuffer(b"".join(r_ + b"\0" * 5 for r_ in rstreams), dtype=np.uint8).copy()).to(dev)
+                coR = torch.tensor([offs_h[i % 64] for i in range(nS)], dtype=i64, device=dev)
+                clR = torch.tensor([len(rstreams[i % 64]) for i in range(nS)], dtype=i32, device=dev)
+                bkS.zero_()
+                wR, tkR = timed(lambda: amd.DeviceBatch.decompress_safe(packed, coR, clR, bkS, B3["so"][:nS], B3["sl"][:nS], B3["dlen"][:nS]), 3)
+                okR = bool(torch.equal(B3["dlen"][:nS], B3["sl"][:nS]))
+                v64 = s3[:64 * b3].view(64, b3)
+                for j in range(nS // 64):
+                    okR = okR and bool(torch.equal(bkS[j * 64 * b3:(j + 1) * 64 * b3].view(64, b3), v64))
+                okR = all_ok(okR and okref)
+                refS = {"value": round(float(nS) * b3 / wR / 1e9, 3), "unit": "GB/s", "verified": okR, "streams": 64,
+                        "what": "64 blocks of the shard compressed by the reference library on the host (LZ4_compress_default), each decoded into 32 of the 2048 slots"}
+                okS = okS and okR
+                del packed, coR, clR
             extra["configs2_shard8"] = {"workload": "2048 x 4 MiB blocks in one launch: what EACH rank of `--gpus 8` decodes of BASELINE configs[2] (16384 blocks "
                                                     "sharded over 8 GPUs, no data exchanged), measured on one GPU; LZ4_decompress_safe",
                                         "value": round(float(nS) * b3 / wS / 1e9, 3), "unit": "GB/s", "verified": okS,
                                         "predicted_8gpu_aggregate_GBps": round(8.0 * nS * b3 / wS / 1e9, 1),
                                         "note": "predicted aggregate = 8 x this GPU's rate (independent shards); not a multi-GPU measurement",
+                                        "reference_compressed_streams": refS,
                                         "roofline": roof(decode_kernel_name(nS, True, True), float(nS) * b3 + csS, tkS, kernel_traffic(tr, world, decode_kernel_name(nS, True, True)))}
+            # the shards of 2 and 4 ranks as well (8192 / 4096 blocks per launch): the prediction bench.py --gpus N prints beside its measurement
+            shards = {"8": round(float(nS) * b3 / wS / 1e9, 3), "1": extra["configs2_decode_4MiB"]["value"]}
+            for wv_, nb_ in ((2, 8192), (4, 4096)):
+                if nb_ > n3:
+                    continue
+                bkq = bk3[:nb_ * b3]
+                bkq.zero_()
+                wq, tq = timed(lambda: amd.DeviceBatch.decompress_safe(c3, B3["co"][:nb_], B3["clen"][:nb_], bkq, B3["so"][:nb_], B3["sl"][:nb_], B3["dlen"][:nb_]), 2)
+                okq = all_ok(bool(torch.equal(bkq, s3[:nb_ * b3])))
+                okS = okS and okq
+                shards[str(wv_)] = round(float(nb_) * b3 / wq / 1e9, 3)
+                extra["configs2_shard%d" % wv_] = {"workload": "%d x 4 MiB blocks in one launch: the shard of each of %d ranks" % (nb_, wv_), "value": shards[str(wv_)], "unit": "GB/s",
+                                                   "verified": okq, "kernel": routed_decoder(amd, dev_index, nb_)[0], "predicted_aggregate_GBps": round(wv_ * shards[str(wv_)], 1)}
+            extra["configs2_shards_per_gpu_GBps"] = shards
+            wSc, tkSc = timed(lambda: amd.DeviceBatch.compress_fast(s3, B3["so"][:nS], B3["sl"][:nS], c3, B3["co"][:nS], B3["cc"][:nS], B3["clen"][:nS]), 2)
+            # (deterministic: the same sizes as the full launch wrote, and 8 blocks' bytes against the reference library once more)
+            okSc = B3["clen"][:nS].cpu().tolist() == cl3[:nS]
+            if O.ref_path():
+                for i in sorted(set([0, nS - 1] + list(range(0, nS, nS // 6))))[:8]:
+                    okSc = okSc and c3[i * cap3:i * cap3 + cl3[i]].cpu().numpy().tobytes() == O.ref().compress_fast(s3[i * b3:(i + 1) * b3].cpu().numpy().tobytes())
+            okSc = all_ok(okSc)
             extra["configs2_shard8_compress"] = {"workload": "the same 2048 x 4 MiB shard, LZ4_compress_default (byU32)",
-                                                 "value": round(float(nS) * b3 / wSc / 1e9, 3), "unit": "GB/s", "verified": None,
+                                                 "value": round(float(nS) * b3 / wSc / 1e9, 3), "unit": "GB/s", "verified": okSc,
+                                                 "blocks_vs_reference": 8 if O.ref_path() else 0,
                                                  "predicted_8gpu_aggregate_GBps": round(8.0 * nS * b3 / wSc / 1e9, 1),
-                                                 "roofline": roof("compress_fast_v2wp_cu_kernel", float(nS) * b3 + csS, tkSc, None)}
-            ok = ok and okS
+                                                 "roofline": roof("compress_fast_v2wp_cu_kernel", float(nS) * b3 + csS, tkSc, kernel_traffic(tr, world, "compress_fast_v2wp_cu_kernel@shard8"))}
+            ok = ok and okS and okSc
         if want_cpu:
             def f3():
                 r = cpu_bench([min(256, 2 * cores), b3, cores, 3, 1 << 24, args.litmax, 4096])
@@ -729,6 +819,15 @@ def main():
             extra["configs4_xxhash_4KiB"]["cpu_baseline"] = cpu_entry(f5)
         del s4
 
+    # ---- N > 1: every rank's own figures on rank 0's line (a shortfall is attributable to the decoder, the launcher or RCCL from the line alone) ----
+    per_rank = None
+    if world > 1:
+        c2 = (extra.get("configs2_decode_4MiB") or {})
+        mine = torch.tensor([t_c * 1e3, t_g * 1e3, t_d * 1e3, float(c2.get("value") or 0.0) / world, float((c2.get("route") or {}).get("route") or 0)], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": r_, "compress_ms": round(float(v_[0]), 3), "gather_ms": round(float(v_[1]), 4), "decompress_ms": round(float(v_[2]), 3),
+                     "configs2_decode_GBps_this_rank_clock": round(float(v_[3]), 3), "configs2_route": int(v_[4])} for r_, v_ in enumerate(allr)]
     if rank == 0:
         ratio = nbytes / csum
         value = world * nbytes * args.steps / dt / 1e9
@@ -747,6 +846,9 @@ def main():
             "roofline": roof("compress_fast_v2w_cu_kernel", nbytes + csum, t_c, live.get("compress_fast_v2w_cu_kernel") or kernel_traffic(tr, world, "compress_fast_v2w_cu_kernel")),
             "roofline_decode": roof(decode_kernel_name(n), nbytes + csum, t_d, live.get(decode_kernel_name(n)) or kernel_traffic(tr, world, decode_kernel_name(n))),
         }
+        out["gather_ms"] = round(t_g * 1e3, 4)     # the int32 size all-gather per step (HIP events on the launch stream; no collective at N = 1)
+        if per_rank is not None:
+            out["per_rank"] = per_rank
         if tr:
             out["traffic_source"] = tr.get("source")
             out["traffic_stale"] = tr.get("kernel_source_hash") != kernel_source_hash()   # true: kernels changed since the PMC passes
@@ -776,6 +878,12 @@ def main():
                                        "roundtrip_GBps": round(r1["roundtrip_GBps"], 4)},
                         "lib": r["_lib"]}
             out["cpu_baseline"] = cpu_entry(f1)
+            try:   # the single-call path side by side: one 64 KiB block on one host core against one launch on the device
+                one = out["cpu_baseline"]["one_thread"]["decompress_safe_GBps"]
+                out["cpu_baseline"]["one_thread"]["us_per_64KiB_block_decode"] = round(blk / one / 1e3, 2)
+                out["configs"]["decode_small_launches"]["launches"]["1"]["host_one_thread_us_per_block"] = round(blk / one / 1e3, 2)
+            except Exception:
+                pass
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

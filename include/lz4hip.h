@@ -79,10 +79,10 @@ int lz4hip_version(void);
  * "compress_pack" = 1 (default) / 0: blocks of 65547 bytes .. 4 MiB are compressed with 32-bit table entries on ten match-finder chains
  *   per CU instead of five (0: every block on the five-chain kernel).                                                           */
 int lz4hip_set_option(const char* name, int value);
-/* diagnostic: what the device-side route of the first device's last routed decode launch decided -- out4 = { route (0 lane-group
- * default, 1 ring loop, 2 wave loop), hops counted by the sampler, stream bytes it walked, average compressed size of 64 blocks };
- * synchronises the device                                                                                                      */
-int lz4hip_last_decode_route(uint32_t* out4);
+/* diagnostic: what the device-side route of a device's last routed decode launch decided (device = index as in the _dev calls) -- out6
+ * = { route (0 lane-group default, 1 ring loop, 2 wave loop), hops counted by the sampler, stream bytes it walked, average compressed
+ * size of 64 blocks, sampled match offsets within 6 KB, sampled match offsets }; synchronises the device                        */
+int lz4hip_last_decode_route(int device, uint32_t* out6);
 
 /* == LZ4_compressBound (LZ4JNI.c:237): n + n/255 + 16, 0 if n < 0 or n > 0x7E000000            */
 int lz4hip_compress_bound(int n);

@@ -43,7 +43,7 @@ C_ABI = {
     "lz4hip_last_error": (C.c_char_p, []),
     "lz4hip_version": (C.c_int, []),
     "lz4hip_set_option": (C.c_int, [C.c_char_p, C.c_int]),
-    "lz4hip_last_decode_route": (C.c_int, [C.POINTER(C.c_uint32)]),
+    "lz4hip_last_decode_route": (C.c_int, [C.c_int, C.POINTER(C.c_uint32)]),
     "lz4hip_compress_bound": (C.c_int, [C.c_int]),
     "lz4hip_compress_fast_batch": (C.c_int, [C.c_void_p, _u64p, _i32p, C.c_void_p, _u64p, _i32p, _i32p, C.c_uint32]),
     "lz4hip_compress_hc_batch": (C.c_int, [C.c_void_p, _u64p, _i32p, C.c_void_p, _u64p, _i32p, _i32p, C.c_uint32, C.c_int]),
@@ -732,9 +732,10 @@ def set_option(name, value):
     _chk(lib().lz4hip_set_option(name.encode(), value))
 
 
-def last_decode_route():
-    """diagnostic: (route, sampled hops, sampled stream bytes, average compressed size) of the last decode launch that was routed on
-    the device (more than 16 blocks per compute unit, every knob at its default); route 0 = lane-group default, 1 = ring loop, 2 = wave loop"""
-    out = (C.c_uint32 * 4)()
-    _chk(lib().lz4hip_last_decode_route(out))
+def last_decode_route(device=0):
+    """diagnostic: (route, sampled hops, sampled stream bytes, average compressed size, sampled offsets within 6 KB, sampled offsets) of
+    the last decode launch that was routed on the device (more than 16 blocks per compute unit, every knob at its default); route 0 =
+    lane-group default, 1 = ring loop, 2 = wave loop"""
+    out = (C.c_uint32 * 6)()
+    _chk(lib().lz4hip_last_decode_route(device, out))
     return tuple(int(x) for x in out)

@@ -495,6 +495,7 @@ int host_shard(Op op, int level, int ord, const uint8_t* src, const uint64_t* sr
       case OP_DECODE_FAST: le = launch_decode(a, false, s.st); break;
       case OP_COMPRESS_HC: le = lz4hip::launch_compress_hc(a, level, s.d_ws.p, sb, s.st); break;
     }
+    if (le == LZ4HIP_E_ARG) { *err = lz4hip_last_error(); rc = le; break; }   // (a decode knob combination without a kernel: launch_decode has said which, on this thread)
     if (le) { rc = bad("kernel launch", (hipError_t)le); break; }
     s.packed = (op == OP_COMPRESS_FAST || op == OP_COMPRESS_HC);
     // the sizes travel first; compress ops: the finisher fetches exactly the packed bytes once it has them
@@ -1133,14 +1134,14 @@ namespace lz4hip { int ring_stats_fetch(unsigned long long* out8); }
 extern "C" {
 __attribute__((visibility("default"))) int lz4hip_dbg_ring_stats(unsigned long long* out8) { return lz4hip::ring_stats_fetch(out8); }
 #endif
-int lz4hip_last_decode_route(uint32_t* out4) {
+int lz4hip_last_decode_route(int device, uint32_t* out6) {
   int rc = ensure_init();
   if (rc) return fail(rc, "no HIP device: liblz4hip has no CPU fallback");
-  if (!out4) return fail(LZ4HIP_E_ARG, "null pointer argument");
+  if (!out6) return fail(LZ4HIP_E_ARG, "null pointer argument");
   int ord;
-  if (ordinal(0, &ord)) return fail(LZ4HIP_E_NO_DEVICE, "no device");
+  if (ordinal(device, &ord)) return fail(LZ4HIP_E_ARG, "bad device index");
   DeviceGuard g(ord);
-  const int e = lz4hip::last_decode_route(out4);
+  const int e = lz4hip::last_decode_route(out6);
   if (e) return fail(LZ4HIP_E_HIP, "hipMemcpyFromSymbol", (hipError_t)e);
   return LZ4HIP_OK;
 }

@@ -59,7 +59,7 @@ int launch_container_read(int kind, int block_checksum, const uint8_t* body, uin
 // on the device (decode_route_kernel): by the blocks' compressed sizes between the deep loop and the ring loop (12288 .. 40959 blocks), by
 // the streams' sequence density between the lane-group loops and the wave kernel (set_route_dense: sequences per 256 bytes of stream, 0 = never)
 void set_route_dense(int sequences_per_256_bytes);
-int last_decode_route(uint32_t* out4);   // diagnostic: {route, sampled hops, sampled stream bytes, average compressed size} of the current device's last routed launch (synchronises)
+int last_decode_route(uint32_t* out6);   // diagnostic: {route, sampled hops, sampled stream bytes, average compressed size, offsets within 6 KB, offsets looked at} of the current device's last routed launch (synchronises)
 int launch_decompress(const BatchArgs& a, bool safe, int lanes_per_block, int pipe, int stage, int ring, void* stream, uint32_t* route_word = nullptr);
 int launch_xxh32(const uint8_t* buf, const uint64_t* off, const int32_t* len, uint32_t seed, uint32_t* out, uint32_t n, void* stream);
 int launch_xxh64(const uint8_t* buf, const uint64_t* off, const int32_t* len, uint64_t seed, uint64_t* out, uint32_t n, void* stream);

@@ -1218,7 +1218,7 @@ static int launch_decode_wave(const BatchArgs& a, bool safe, bool par, int ring,
 //      blocks with (typically) a short match window (BASELINE configs[2]: 847 vs 808-835 GB/s and a fabric traffic of 2.x instead of
 //      3.75x the algorithmic bytes); only asked for batches of 12288 .. 40959 blocks (`big` = 0: never);
 //   2  the wave kernel (lz4_decode_wave.h, a wavefront per block, W = 16): the streams are DENSE -- `dense` or more sequences per 256
-//      bytes of stream.  The lane-group loops decode ~21 G sequences/s whatever the data (a match source is a memory request: text at
+//      bytes of stream -- AND NEAR: at least half of the sampled match offsets lie within 6 KB (what the kernel's 8 KB ring still holds).  The lane-group loops decode ~21 G sequences/s whatever the data (a match source is a memory request: text at
 //      6 output bytes per sequence is 128 GB/s where App. F data at 34 are 708), the wave kernel 10 .. 23 G/s growing with the
 //      sequences a 256-byte window holds, its output window on chip: on text it wins at EVERY batch size (65536 blocks: 142 vs 128
 //      GB/s, 8192: 140 vs 60), on everything else it loses up to 2x (profiles/r05_wave_notes.txt section 5);
@@ -1232,13 +1232,13 @@ static int launch_decode_wave(const BatchArgs& a, bool safe, bool par, int ring,
 // byte of the rest: Calgary book1 58 .. 69 sequences per 256 bytes (true: 61), App. F 9 .. 21 (15), 4 MiB App. F blocks 9 .. 16 (14),
 // geo 4 .. 30 (7), pic 1 .. 44 (32) per SAMPLE; the route takes the sum over the 32.  One workgroup of 16 wavefronts, two blocks
 // each, both 1 KB loads in flight together: ~10 us in front of launches of >= 0.9 ms.
-__device__ uint32_t g_last_route[4];
+__device__ uint32_t g_last_route[6];
 __global__ __launch_bounds__(1024) void decode_route_kernel(const uint8_t* src, const uint64_t* src_off, const int32_t* src_len, uint32_t n, uint32_t big, uint32_t dense,
                                                             uint32_t* route) {
   typedef BlockWaveDev<8192, 1024> G;   // (its hand-written walk: a static function of registers)
   constexpr uint32_t SPAN = 1024u, NS = 2u;
   __shared__ __attribute__((aligned(16))) uint8_t win[16][NS][SPAN + 32];
-  __shared__ uint32_t acc[16][2];
+  __shared__ uint32_t acc[16][4];
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
   // ---- the blocks' sizes: 64 of them, wavefront 0 (the ring loop's criterion, unchanged) ----
   uint32_t avg = 0u;
@@ -1270,7 +1270,7 @@ __global__ __launch_bounds__(1024) void decode_route_kernel(const uint8_t* src, 
       if (lane < 8u) *(uint32_t*)&win[wave][k][SPAN + 4u * lane] = tail;
     }
   }
-  uint32_t seqs = 0u, bytes = 0u;
+  uint32_t seqs = 0u, bytes = 0u, near_n = 0u, off_n = 0u;
 #pragma unroll
   for (uint32_t k = 0; k < NS; k++) {
     if (!have[k]) continue;
@@ -1291,23 +1291,40 @@ __global__ __launch_bounds__(1024) void decode_route_kernel(const uint8_t* src, 
       G::vwalk(nxpack, posv, T);
       const uint32_t last = T > 1u ? (uint32_t)__builtin_amdgcn_readlane((int)posv, (int)(T - 1u)) : 256u;   // the last start is where the next window begins
       const uint32_t hops = T > 1u ? T - 1u : 1u;
-      if (wdw != 0u) { seqs += hops; bytes += last; }
+      if (wdw != 0u) {
+        seqs += hops; bytes += last;
+        // the offsets of the sequences that start at the first T - 1 positions: how many sources a wave kernel's ring would still hold
+        if (T > 1u) {
+          const uint8_t* wb = &win[wave][k][0];
+          const uint32_t p = ip + posv;                 // (lanes >= T: position ip + 0, harmless; they are masked out below)
+          const uint32_t tk = wb[p], tl = tk >> 4;
+          const uint32_t q = p + 1u + tl + (tl == 15u ? 1u + wb[p + 1u] : 0u);
+          const bool mine = lane < T - 1u && q + 2u <= SPAN + 32u;
+          const uint32_t off = mine ? (uint32_t)wb[q] | ((uint32_t)wb[q + 1u] << 8) : 0xFFFFu;
+          near_n += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(mine && off <= 6144u));
+          off_n += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(mine));
+        }
+      }
       ip += last;
     }
   }
-  if (lane == 0u) { acc[wave][0] = seqs; acc[wave][1] = bytes; }
+  if (lane == 0u) { acc[wave][0] = seqs; acc[wave][1] = bytes; acc[wave][2] = near_n; acc[wave][3] = off_n; }
   __syncthreads();
   if (threadIdx.x == 0u) {
-    uint32_t ts = 0u, tb = 0u;
-    for (uint32_t w = 0; w < 16u; w++) { ts += acc[w][0]; tb += acc[w][1]; }
+    uint32_t ts = 0u, tb = 0u, tn = 0u, to = 0u;
+    for (uint32_t w = 0; w < 16u; w++) { ts += acc[w][0]; tb += acc[w][1]; tn += acc[w][2]; to += acc[w][3]; }
     const bool is_big = big != 0u && avg >= big;
-    const bool is_dense = dense != 0u && tb >= 2048u && (uint64_t)ts * 256u >= (uint64_t)dense * tb;   // (at least a few windows were sampled)
+    // dense AND near: short sequences whose sources an 8 KB ring still holds (at least half of them within 6 KB).  Density alone is not
+    // it: synthetic streams of one or two literals per 34-byte match with offsets anywhere in 64 KB are as dense as text and decode
+    // 2.5x SLOWER in the wave kernel (every source is a load from memory inside the trip): tools/route_sweep.py, profiles/r06_route_sweep.txt
+    const bool is_dense = dense != 0u && tb >= 2048u && (uint64_t)ts * 256u >= (uint64_t)dense * tb && 2u * tn >= to;   // (tb: at least a few windows were sampled)
     *route = is_big ? 1u : is_dense ? 2u : 0u;
     g_last_route[0] = is_big ? 1u : is_dense ? 2u : 0u; g_last_route[1] = ts; g_last_route[2] = tb; g_last_route[3] = avg;   // (diagnostic: last_decode_route)
+    g_last_route[4] = tn; g_last_route[5] = to;
   }
 }
-int last_decode_route(uint32_t* out4) {   // what the last routed decode launch of this device decided: {route, sampled hops, sampled stream bytes, average compressed size}
-  return (int)hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_last_route), 4 * sizeof(uint32_t));
+int last_decode_route(uint32_t* out6) {   // what the last routed decode launch of this device decided: {route, sampled hops, sampled stream bytes, average compressed size, near offsets, offsets looked at}
+  return (int)hipMemcpyFromSymbol(out6, HIP_SYMBOL(g_last_route), 6 * sizeof(uint32_t));
 }
 
 template <int GL>

@@ -167,8 +167,9 @@ def test_routed_batch_of_big_blocks_vs_reference(amd, ref):
 def test_batches_routed_by_sequence_density_vs_reference(amd, ref, corpus):
     """More than 16 blocks per CU and every knob at its default: decode_route_kernel samples the MIDDLE of 32 streams (the wave loop's
     speculative walk from an arbitrary byte: it falls in with the true token chain within a few sequences) and sends batches of dense
-    streams -- text: ~60 sequences per 256 bytes -- to the wave kernel, everything else (App. F ~15, a bitmap ~30, geophysical data ~7)
-    to the lane-group loop of the batch size.  For text, App. F, bitmap and geophysical batches below and above 40960 blocks: the route
+    streams with near sources -- text: ~60 sequences per 256 bytes, most offsets within 6 KB -- to the wave kernel, everything else
+    (App. F ~15, a bitmap ~30, geophysical data ~7; synthetic streams as dense as text whose offsets lie anywhere in 64 KB) to the
+    lane-group loop of the batch size.  For text, App. F, bitmap and geophysical batches below and above 40960 blocks: the route
     taken, sizes and bytes against the source, a sample of damaged / reference-compressed streams against LZ4_decompress_safe
     (LZ4JNI.c:216); and the same bytes with the density route forced on (decode_route_dense 1) and off (0)."""
     import numpy as np
@@ -183,6 +184,8 @@ def test_batches_routed_by_sequence_density_vs_reference(amd, ref, corpus):
         src = torch.empty(n * blk, dtype=torch.uint8, device=dev)
         if kind == "appf":
             amd.DeviceBatch.gen_blocks(src, blk, blk, n, first_idx=9 << 24)
+        elif kind == "lit2":      # as dense as text (one or two literals per match) with match offsets anywhere in 64 KB: NOT for the wave kernel's 8 KB ring
+            amd.DeviceBatch.gen_blocks(src, blk, blk, n, first_idx=9 << 24, litmax=2)
         elif kind == "book":
             bdev = torch.from_numpy(book.copy()).to(dev)
             offs = torch.arange(n, dtype=torch.int64, device=dev) * 7919 % (len(book) - blk)
@@ -196,7 +199,7 @@ def test_batches_routed_by_sequence_density_vs_reference(amd, ref, corpus):
         return src
 
     try:
-        for kind, n, want_route in (("book", 6144, 2), ("appf", 6144, 0), ("pic", 5000, 0), ("geo", 5000, 0), ("book", 45056, 2), ("appf", 45056, 0), ("book", 20000, 2)):
+        for kind, n, want_route in (("book", 6144, 2), ("appf", 6144, 0), ("lit2", 6144, 0), ("pic", 5000, 0), ("geo", 5000, 0), ("book", 45056, 2), ("appf", 45056, 0), ("book", 20000, 2)):
             src = make(kind, n)
             comp = torch.empty(n * cap, dtype=torch.uint8, device=dev)
             B = _batch(torch, dev, n, blk, cap)
@@ -232,7 +235,7 @@ def test_batches_routed_by_sequence_density_vs_reference(amd, ref, corpus):
                 amd.DeviceBatch.decompress_safe(comp, B["co"], cl, back, B["so"], dc, B["dlen"])
                 torch.cuda.synchronize()
                 route = amd.last_decode_route()
-                assert route[0] == (want_route if dense < 0 else 2 if dense == 1 else 0), (kind, n, dense, route)
+                assert route[0] == (want_route if dense < 0 else (0 if kind == "lit2" else 2) if dense == 1 else 0), (kind, n, dense, route)   # (dense 1: "everything is dense" -- the offsets still have their say)
                 dlen = B["dlen"].cpu().numpy()
                 for i in bad:
                     er, ed = want[i]

@@ -5,9 +5,9 @@ export GRAFT_REPO_ROOT=$PWD
 out=gpurun_out/${1:-r06c}; mkdir -p $out
 timeout 900 python -m pytest tests/test_gpu_scale.py tests/test_gpu_parity.py -m gpu -q -x --durations=5 > $out/pytest.log 2>&1; echo "pytest rc=$?" >> $out/pytest.log
 tail -6 $out/pytest.log
-timeout 900 python tools/route_sweep.py 6144,16384,32768,65536 book,lit2,lit4,lit8,lit16,appf,pic,geo > $out/sweep.log 2>&1
+timeout 900 python tools/route_sweep.py 6144,16384,65536 book,lit2,lit8,lit8w4k,lit16w4k,appfw4k,appf,pic,geo > $out/sweep.log 2>&1
 cat $out/sweep.log
-timeout 600 python tools/route_sweep.py 8192 cfg2_8192,cfg2_16384 >> $out/sweep.log 2>&1
+timeout 600 python tools/route_sweep.py 8192 cfg2_8192 >> $out/sweep.log 2>&1
 tail -3 $out/sweep.log
-timeout 300 python tools/ring_matrix.py cfg2_512,appf512,appf1024,book512,book1024 d,64:5:0:0,64:7:0:0 > $out/matrix.log 2>&1
+echo
 tail -24 $out/matrix.log

@@ -28,8 +28,10 @@ def make(kind, n, blk):
         b = np.frombuffer(open(os.path.join(ROOT, "tests/golden/%s_65536.bin" % kind), "rb").read(), dtype=np.uint8)
         src = torch.from_numpy(b.copy()).to(dev).repeat(n)
     else:
-        lm = 38 if kind in ("appf", "cfg2") else int(kind[3:])
-        amd.DeviceBatch.gen_blocks(src, blk, blk, n, first_idx=3 << 24, litmax=lm, win=4096 if kind == "cfg2" else 65535)
+        near = kind.endswith("w4k")             # appfw4k, lit8w4k: the same generator with a 4 KB match window
+        base = kind[:-3] if near else kind
+        lm = 38 if base in ("appf", "cfg2") else int(base[3:])
+        amd.DeviceBatch.gen_blocks(src, blk, blk, n, first_idx=3 << 24, litmax=lm, win=4096 if (kind == "cfg2" or near) else 65535)
     return src
 
 
@@ -63,9 +65,20 @@ for kind in wls:
             ok = bool(torch.equal(back, src))
             res[dense] = (best, ok, amd.last_decode_route())
         r = res[44][2]
-        print("%-10s n %6d ratio %.2f  sampled %5.1f seq/256B  lane-group %8.3f ms %7.1f GB/s | wave %8.3f ms %7.1f GB/s | default route %d: %8.3f ms  ok=%s" % (
-            kind, n, n * blk / int(clen.sum().item()), 256.0 * r[1] / max(r[2], 1), res[0][0], n * blk / res[0][0] / 1e6, res[1][0], n * blk / res[1][0] / 1e6,
-            r[0], res[44][0], res[0][1] and res[1][1] and res[44][1]), flush=True)
+        deep = ""
+        if n >= 40960:                           # what the deep loop would do where the staged loop is the lane-group default
+            amd.set_option("decode_route_dense", 0); amd.set_option("decode_lanes", 8); amd.set_option("decode_pipe", 2)
+            bd = 1e30
+            for _ in range(3):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(); amd.DeviceBatch.decompress_safe(comp, co, clen, back, so, sl, dlen); b.record()
+                torch.cuda.synchronize()
+                bd = min(bd, a.elapsed_time(b))
+            amd.set_option("decode_lanes", 0); amd.set_option("decode_pipe", -1)
+            deep = " | deep loop %8.3f ms %7.1f GB/s" % (bd, n * blk / bd / 1e6)
+        print("%-10s n %6d ratio %.2f  sampled %5.1f seq/256B near %3.0f %%  lane-group %8.3f ms %7.1f GB/s | wave %8.3f ms %7.1f GB/s | default route %d: %8.3f ms  ok=%s" % (
+            kind, n, n * blk / int(clen.sum().item()), 256.0 * r[1] / max(r[2], 1), 100.0 * r[4] / max(r[5], 1), res[0][0], n * blk / res[0][0] / 1e6, res[1][0], n * blk / res[1][0] / 1e6,
+            r[0], res[44][0], res[0][1] and res[1][1] and res[44][1]) + deep, flush=True)
         del src, comp, back
         torch.cuda.empty_cache()
         if kind.startswith("cfg2_"):
