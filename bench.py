@@ -181,9 +181,11 @@ def routed_decoder(amd, dev_index, n_blocks, safe=True):
     s = "true" if safe else "false"
     if n_blocks <= 16 * 256:
         return decode_kernel_name(n_blocks, safe), None
-    route, hops, nbytes, _avg, near, offs = amd.last_decode_route(dev_index)
-    name = "decode_wave_kernel<16, 8192, 1024, %s, 5>" % s if route == 2 else "decode_ring_kernel<4, 2048, %s>" % s if route == 1 else decode_kernel_name(n_blocks, safe)
+    route, hops, nbytes, _avg, near, offs, outb, _ = amd.last_decode_route(dev_index)
+    name = "decode_wave_kernel<16, 8192, 1024, %s, 5>" % s if route == 2 else "decode_ring_kernel<4, 2048, %s>" % s if route == 1 else \
+        "decode_deep_kernel<8, %s>" % s if route == 3 else decode_kernel_name(n_blocks, safe)
     return name, {"route": route, "sampled_sequences_per_256B": round(256.0 * hops / nbytes, 1) if nbytes else None,
+                  "sampled_output_bytes_per_sequence": round(outb / offs, 2) if offs else None,
                   "sampled_offsets_within_6KB": round(near / offs, 3) if offs else None}
 
 

@@ -61,9 +61,10 @@ int lz4hip_version(void);
  * Which decoder a launch of n blocks gets with every knob at its default (CU = compute units of the device, 256 on an MI355X):
  *   n <= 4 CU    the pair loop (lz4_decode_pair.h): TWO wavefronts per block, a parser and a copier
  *   n <= 16 CU   the parallel wave loop (lz4_decode_wave.h): a wavefront per block, several sequences of it per trip
- *   more         chosen ON THE DEVICE from a sample of the batch (decode_route_kernel): streams of "decode_route_dense" or more sequences
- *                per 256 bytes (text) -> the wave loop; 12288 .. 40959 blocks averaging >= 512 KiB compressed -> the ring loop
- *                (lz4_decode_ring.h); otherwise the deep loop (lz4_decode_deep.h) below 40960 blocks, the 4-lane staged loop from there on
+ *   more         chosen ON THE DEVICE from a sample of the batch (decode_route_kernel): 12288 .. 40959 blocks averaging >= 512 KiB compressed ->
+ *                the ring loop (lz4_decode_ring.h); sequences of "decode_route_short" or fewer output bytes on average with near match
+ *                sources (text) -> the wave loop; otherwise the deep loop (lz4_decode_deep.h) below 40960 blocks and, from there on, for
+ *                near match sources, else the 4-lane staged loop
  * "decode_pipe" = -1 (the table above) or one loop for every launch: 7 = pair loop, 5 = parallel wave loop, 4 = wave loop with one
  *   sequence per trip, 3 = ring loop, 2 = deep loop, 1 = two-trip pipelined loop, 0 = plain loop;
  * "decode_ring" = bytes of the output ring in LDS: 0 (by batch size) / 8192 / 16384 / 32768 / 65536 with decode_pipe 4 / 5,
@@ -72,7 +73,8 @@ int lz4hip_version(void);
  *   loop: a lane per block); a combination no kernel exists for makes the next decode call fail with LZ4HIP_E_ARG and a message that names it;
  * "decode_stage" = 1 / 0 / -1 (by batch size): the plain loop writes through an LDS staging buffer so that output reaches memory as
  *   whole 128-byte lines (faster when the batch is bandwidth-bound);
- * "decode_route_dense" = 0 .. 255 (default 44): the density from which the device-side route sends a batch to the wave loop; 0 = never;
+ * "decode_route_short" = 0 .. 255 (default 8): average output bytes per sequence up to which the device-side route sends a batch (of near match
+ *   sources) to the wave loop; 0 = never;
  * "compress_core" = 5 (default: adaptive two-pass -- blocks of long sequences are finished by the lean core (lz4_fast_v2_core.h), whose
  *   parked hits a partner wavefront writes out, blocks of short sequences by the window-parallel core), 3 (lean core only) or 1
  *   (window-parallel core only); "compress_switch" = routing threshold of the adaptive scheme in bytes per sequence (default 16);
@@ -80,8 +82,9 @@ int lz4hip_version(void);
  *   per CU instead of five (0: every block on the five-chain kernel).                                                           */
 int lz4hip_set_option(const char* name, int value);
 /* diagnostic: what the device-side route of a device's last routed decode launch decided (device = index as in the _dev calls) -- out6
- * = { route (0 lane-group default, 1 ring loop, 2 wave loop), hops counted by the sampler, stream bytes it walked, average compressed
- * size of 64 blocks, sampled match offsets within 6 KB, sampled match offsets }; synchronises the device                        */
+ * (8 words) = { route (0 lane-group default of the batch size, 1 ring loop, 2 wave loop, 3 deep loop instead of the staged one), hops
+ * counted by the sampler, stream bytes it walked, average compressed size of 64 blocks, sampled match offsets within 6 KB, sampled
+ * sequences, their output bytes, 0 }; synchronises the device                                                                  */
 int lz4hip_last_decode_route(int device, uint32_t* out6);
 
 /* == LZ4_compressBound (LZ4JNI.c:237): n + n/255 + 16, 0 if n < 0 or n > 0x7E000000            */

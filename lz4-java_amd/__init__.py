@@ -733,9 +733,9 @@ def set_option(name, value):
 
 
 def last_decode_route(device=0):
-    """diagnostic: (route, sampled hops, sampled stream bytes, average compressed size, sampled offsets within 6 KB, sampled offsets) of
-    the last decode launch that was routed on the device (more than 16 blocks per compute unit, every knob at its default); route 0 =
-    lane-group default, 1 = ring loop, 2 = wave loop"""
-    out = (C.c_uint32 * 6)()
+    """diagnostic: (route, sampled hops, sampled stream bytes, average compressed size, sampled offsets within 6 KB, sampled sequences,
+    their output bytes, 0) of the last decode launch that was routed on the device (more than 16 blocks per compute unit, every knob at
+    its default); route 0 = lane-group default of the batch size, 1 = ring loop, 2 = wave loop, 3 = deep loop instead of the staged one"""
+    out = (C.c_uint32 * 8)()
     _chk(lib().lz4hip_last_decode_route(device, out))
     return tuple(int(x) for x in out)

@@ -1156,9 +1156,9 @@ int lz4hip_set_option(const char* name, int value) {
     g_decode_pipe = value;
     return LZ4HIP_OK;
   }
-  if (name && strcmp(name, "decode_route_dense") == 0) {   // sequences per 256 bytes of compressed stream from which a batch of more than 16 blocks per CU goes to the wave kernel; 0: never
-    if (value < 0 || value > 255) return fail(LZ4HIP_E_ARG, "decode_route_dense must be 0 .. 255");
-    lz4hip::set_route_dense(value);
+  if (name && strcmp(name, "decode_route_short") == 0) {   // average output bytes per sampled sequence up to which a batch of more than 16 blocks per CU goes to the wave kernel; 0: never
+    if (value < 0 || value > 255) return fail(LZ4HIP_E_ARG, "decode_route_short must be 0 .. 255");
+    lz4hip::set_route_short(value);
     return LZ4HIP_OK;
   }
   if (name && strcmp(name, "decode_ring") == 0) {

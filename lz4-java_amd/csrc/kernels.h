@@ -57,9 +57,9 @@ int launch_container_read(int kind, int block_checksum, const uint8_t* body, uin
 // pipe 3: the ring loop (lz4_decode_ring.h); ring = bytes of its output ring (512 / 1024 / 2048 / 4096; 0 = default for the lanes)
 // route_word: one device uint32_t of scratch (or nullptr): with every knob at its default, batches of more than 16 blocks per CU are routed
 // on the device (decode_route_kernel): by the blocks' compressed sizes between the deep loop and the ring loop (12288 .. 40959 blocks), by
-// the streams' sequence density between the lane-group loops and the wave kernel (set_route_dense: sequences per 256 bytes of stream, 0 = never)
-void set_route_dense(int sequences_per_256_bytes);
-int last_decode_route(uint32_t* out6);   // diagnostic: {route, sampled hops, sampled stream bytes, average compressed size, offsets within 6 KB, offsets looked at} of the current device's last routed launch (synchronises)
+// the streams' sequence density between the lane-group loops and the wave kernel (set_route_short: average output bytes per sequence up to which a batch is text-like, 0 = never) and between the staged and the deep loop (40960 blocks and more: near sources)
+void set_route_short(int bytes_per_sequence);
+int last_decode_route(uint32_t* out6);   // diagnostic (8 words): {route, sampled hops, sampled stream bytes, average compressed size, offsets within 6 KB, sequences looked at, their output bytes, 0} of the current device's last routed launch (synchronises)
 int launch_decompress(const BatchArgs& a, bool safe, int lanes_per_block, int pipe, int stage, int ring, void* stream, uint32_t* route_word = nullptr);
 int launch_xxh32(const uint8_t* buf, const uint64_t* off, const int32_t* len, uint32_t seed, uint32_t* out, uint32_t n, void* stream);
 int launch_xxh64(const uint8_t* buf, const uint64_t* off, const int32_t* len, uint64_t seed, uint64_t* out, uint32_t n, void* stream);

@@ -1144,11 +1144,11 @@ __global__ __launch_bounds__(128 * W) void decode_pair_kernel(BatchArgs a, const
   G g;
   pair_parser_quit(g, lds);
 }
-#ifndef LZ4HIP_ROUTE_DENSE
-#define LZ4HIP_ROUTE_DENSE 44   /* sequences per 256 bytes of stream from which a batch of more than 16 blocks per CU goes to the wave kernel (decode_route_kernel below) */
+#ifndef LZ4HIP_ROUTE_SHORT
+#define LZ4HIP_ROUTE_SHORT 8   /* average output bytes per sampled sequence up to which a batch of more than 16 blocks per CU goes to the wave kernel (decode_route_kernel below) */
 #endif
-static std::atomic<int> g_route_dense{LZ4HIP_ROUTE_DENSE};   // "decode_route_dense": 0 = no density route
-void set_route_dense(int v) { g_route_dense.store(v, std::memory_order_relaxed); }
+static std::atomic<int> g_route_short{LZ4HIP_ROUTE_SHORT};   // "decode_route_short": 0 = never the wave kernel
+void set_route_short(int v) { g_route_short.store(v, std::memory_order_relaxed); }
 static uint32_t device_cus() {   // compute units of the current device (cached per device)
   static std::atomic<uint32_t> cus[64];
   int d = 0;
@@ -1217,14 +1217,19 @@ static int launch_decode_wave(const BatchArgs& a, bool safe, bool par, int ring,
 //   1  the ring loop (lz4_decode_ring.h, 4 lanes, 2 KiB ring): a sample of the blocks averages at least `big` compressed bytes -- big
 //      blocks with (typically) a short match window (BASELINE configs[2]: 847 vs 808-835 GB/s and a fabric traffic of 2.x instead of
 //      3.75x the algorithmic bytes); only asked for batches of 12288 .. 40959 blocks (`big` = 0: never);
-//   2  the wave kernel (lz4_decode_wave.h, a wavefront per block, W = 16): the streams are DENSE -- `dense` or more sequences per 256
-//      bytes of stream -- AND NEAR: at least half of the sampled match offsets lie within 6 KB (what the kernel's 8 KB ring still holds).  The lane-group loops decode ~21 G sequences/s whatever the data (a match source is a memory request: text at
-//      6 output bytes per sequence is 128 GB/s where App. F data at 34 are 708), the wave kernel 10 .. 23 G/s growing with the
-//      sequences a 256-byte window holds, its output window on chip: on text it wins at EVERY batch size (65536 blocks: 142 vs 128
-//      GB/s, 8192: 140 vs 60), on everything else it loses up to 2x (profiles/r05_wave_notes.txt section 5);
+//   2  the wave kernel (lz4_decode_wave.h, a wavefront per block, W = 16): the sampled sequences are SHORT -- `seq_bytes` (8) or fewer
+//      output bytes per sequence on average: text -- and NEAR: at least half of their offsets lie within 6 KB (the kernel's 8 KB ring).
+//      The lane-group loops decode ~20 G sequences/s whatever the data (a match source is a memory request: text at 6 output bytes per
+//      sequence is 128 GB/s where App. F data at 34 are 700); the wave kernel, its output window on chip, does text at 147 GB/s (65536
+//      blocks; 8192: 140 against 60) and loses on everything longer, up to 2.5x (profiles/r06_route_sweep.txt);
+//   3  the deep loop (lz4_decode_deep.h) for a batch of 40960 blocks or more whose sources are NEAR: the 4-lane staged loop -- the
+//      default there since round 1, for App. F's offsets anywhere in 64 KB: 700 against 625 GB/s -- reads match sources from flushed
+//      memory only and flushes everything when one reaches into staged bytes: a bitmap (run-length matches) decodes at 258 GB/s in
+//      it and at 806 in the deep loop, near-offset synthetic streams gain 1 .. 15 %, text 10 %;
 //   0  the lane-group default of the batch size (deep loop below 40960 blocks, 4-lane staged loop from there on).
 // Round 5 sampled the HEAD of 16 streams with one lane each and took the route out again: a block's head is not its body (a text
-// stream runs 16 compressed bytes per sequence in its first 512 bytes -- no history yet -- and 4.2 overall).  This sampler reads the
+// stream runs 16 compressed bytes per sequence in its first 512 bytes -- no history yet -- and 4.2 overall), and it looked at density
+// alone.  This sampler reads the
 // MIDDLE of the streams and needs no parse from the start for it: the walk of the wave loop (speculative next-token positions for
 // every byte of a window, then the chain from the window's first byte) started at an ARBITRARY byte falls in with the true token
 // chain within a few sequences -- chains that meet stay together -- and until it does it hops through literal bytes at about the
@@ -1232,13 +1237,13 @@ static int launch_decode_wave(const BatchArgs& a, bool safe, bool par, int ring,
 // byte of the rest: Calgary book1 58 .. 69 sequences per 256 bytes (true: 61), App. F 9 .. 21 (15), 4 MiB App. F blocks 9 .. 16 (14),
 // geo 4 .. 30 (7), pic 1 .. 44 (32) per SAMPLE; the route takes the sum over the 32.  One workgroup of 16 wavefronts, two blocks
 // each, both 1 KB loads in flight together: ~10 us in front of launches of >= 0.9 ms.
-__device__ uint32_t g_last_route[6];
-__global__ __launch_bounds__(1024) void decode_route_kernel(const uint8_t* src, const uint64_t* src_off, const int32_t* src_len, uint32_t n, uint32_t big, uint32_t dense,
-                                                            uint32_t* route) {
+__device__ uint32_t g_last_route[8];
+__global__ __launch_bounds__(1024) void decode_route_kernel(const uint8_t* src, const uint64_t* src_off, const int32_t* src_len, uint32_t n, uint32_t big, uint32_t seq_bytes,
+                                                            uint32_t deep_if_near, uint32_t* route) {
   typedef BlockWaveDev<8192, 1024> G;   // (its hand-written walk: a static function of registers)
   constexpr uint32_t SPAN = 1024u, NS = 2u;
   __shared__ __attribute__((aligned(16))) uint8_t win[16][NS][SPAN + 32];
-  __shared__ uint32_t acc[16][4];
+  __shared__ uint32_t acc[16][5];
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
   // ---- the blocks' sizes: 64 of them, wavefront 0 (the ring loop's criterion, unchanged) ----
   uint32_t avg = 0u;
@@ -1270,7 +1275,7 @@ __global__ __launch_bounds__(1024) void decode_route_kernel(const uint8_t* src, 
       if (lane < 8u) *(uint32_t*)&win[wave][k][SPAN + 4u * lane] = tail;
     }
   }
-  uint32_t seqs = 0u, bytes = 0u, near_n = 0u, off_n = 0u;
+  uint32_t seqs = 0u, bytes = 0u, near_n = 0u, off_n = 0u, out_n = 0u;
 #pragma unroll
   for (uint32_t k = 0; k < NS; k++) {
     if (!have[k]) continue;
@@ -1293,14 +1298,20 @@ __global__ __launch_bounds__(1024) void decode_route_kernel(const uint8_t* src, 
       const uint32_t hops = T > 1u ? T - 1u : 1u;
       if (wdw != 0u) {
         seqs += hops; bytes += last;
-        // the offsets of the sequences that start at the first T - 1 positions: how many sources a wave kernel's ring would still hold
+        // the sequences that start at the first T - 1 positions: how long they are (literals + match), and how many of their sources
+        // lie within 6 KB (what a wave kernel's 8 KB ring still holds; the deep loop's near reads hit in L2)
         if (T > 1u) {
           const uint8_t* wb = &win[wave][k][0];
-          const uint32_t p = ip + posv;                 // (lanes >= T: position ip + 0, harmless; they are masked out below)
-          const uint32_t tk = wb[p], tl = tk >> 4;
-          const uint32_t q = p + 1u + tl + (tl == 15u ? 1u + wb[p + 1u] : 0u);
-          const bool mine = lane < T - 1u && q + 2u <= SPAN + 32u;
+          const uint32_t p = ip + posv;                 // (lanes >= T - 1 are masked out below)
+          const uint32_t tk = wb[p], tl = tk >> 4, tm = tk & 15u;
+          const uint32_t lit = tl + (tl == 15u ? wb[p + 1u] : 0u);
+          const uint32_t q = p + 1u + (tl == 15u ? 1u : 0u) + lit;
+          const bool mine = lane < T - 1u && q + 3u <= SPAN + 32u;
           const uint32_t off = mine ? (uint32_t)wb[q] | ((uint32_t)wb[q + 1u] << 8) : 0xFFFFu;
+          const uint32_t len = mine ? lit + tm + 4u + (tm == 15u ? wb[q + 2u] : 0u) : 0u;
+          uint32_t ls = len;
+          for (int d = 32; d >= 1; d >>= 1) ls += (uint32_t)__shfl_xor((int)ls, d, 64);
+          out_n += (uint32_t)__builtin_amdgcn_readfirstlane((int)ls);
           near_n += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(mine && off <= 6144u));
           off_n += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(mine));
         }
@@ -1308,27 +1319,31 @@ __global__ __launch_bounds__(1024) void decode_route_kernel(const uint8_t* src, 
       ip += last;
     }
   }
-  if (lane == 0u) { acc[wave][0] = seqs; acc[wave][1] = bytes; acc[wave][2] = near_n; acc[wave][3] = off_n; }
+  if (lane == 0u) { acc[wave][0] = seqs; acc[wave][1] = bytes; acc[wave][2] = near_n; acc[wave][3] = off_n; acc[wave][4] = out_n; }
   __syncthreads();
   if (threadIdx.x == 0u) {
-    uint32_t ts = 0u, tb = 0u, tn = 0u, to = 0u;
-    for (uint32_t w = 0; w < 16u; w++) { ts += acc[w][0]; tb += acc[w][1]; tn += acc[w][2]; to += acc[w][3]; }
+    uint32_t ts = 0u, tb = 0u, tn = 0u, to = 0u, tl = 0u;
+    for (uint32_t w = 0; w < 16u; w++) { ts += acc[w][0]; tb += acc[w][1]; tn += acc[w][2]; to += acc[w][3]; tl += acc[w][4]; }
     const bool is_big = big != 0u && avg >= big;
-    // dense AND near: short sequences whose sources an 8 KB ring still holds (at least half of them within 6 KB).  Density alone is not
-    // it: synthetic streams of one or two literals per 34-byte match with offsets anywhere in 64 KB are as dense as text and decode
-    // 2.5x SLOWER in the wave kernel (every source is a load from memory inside the trip): tools/route_sweep.py, profiles/r06_route_sweep.txt
-    const bool is_dense = dense != 0u && tb >= 2048u && (uint64_t)ts * 256u >= (uint64_t)dense * tb && 2u * tn >= to;   // (tb: at least a few windows were sampled)
-    *route = is_big ? 1u : is_dense ? 2u : 0u;
-    g_last_route[0] = is_big ? 1u : is_dense ? 2u : 0u; g_last_route[1] = ts; g_last_route[2] = tb; g_last_route[3] = avg;   // (diagnostic: last_decode_route)
+    const bool sampled = tb >= 2048u && to >= 64u;          // (a few windows, a few dozen sequences)
+    const bool is_near = sampled && 2u * tn >= to;
+    // the wave kernel: SHORT sequences with near sources.  The lane-group loops decode ~20 G sequences/s whatever the data, i.e. GB/s in
+    // proportion to the bytes a sequence produces; the wave kernel's rate grows far more slowly with them (text, 6 bytes per sequence:
+    // 147 GB/s against 128; synthetic streams of 13: 88 against 237; 21: 304 against 483 -- tools/route_sweep.py, profiles/r06_route_sweep.txt)
+    const bool is_short = seq_bytes != 0u && is_near && tl <= seq_bytes * to;
+    const uint32_t r = is_big ? 1u : is_short ? 2u : (deep_if_near != 0u && is_near) ? 3u : 0u;
+    *route = r;
+    g_last_route[0] = r; g_last_route[1] = ts; g_last_route[2] = tb; g_last_route[3] = avg;   // (diagnostic: last_decode_route)
+    g_last_route[6] = tl;
     g_last_route[4] = tn; g_last_route[5] = to;
   }
 }
-int last_decode_route(uint32_t* out6) {   // what the last routed decode launch of this device decided: {route, sampled hops, sampled stream bytes, average compressed size, near offsets, offsets looked at}
-  return (int)hipMemcpyFromSymbol(out6, HIP_SYMBOL(g_last_route), 6 * sizeof(uint32_t));
+int last_decode_route(uint32_t* out6) {   // what the last routed decode launch of this device decided: {route, sampled hops, sampled stream bytes, average compressed size, near offsets, sequences looked at, their output bytes, 0}
+  return (int)hipMemcpyFromSymbol(out6, HIP_SYMBOL(g_last_route), 8 * sizeof(uint32_t));
 }
 
 template <int GL>
-static int launch_decode_gl(const BatchArgs& a, bool safe, int pipe, bool stage, hipStream_t st, const uint32_t* route = nullptr) {
+static int launch_decode_gl(const BatchArgs& a, bool safe, int pipe, bool stage, hipStream_t st, const uint32_t* route = nullptr, uint32_t want = 0u) {
   const uint32_t per_wg = 256u / GL;
   const uint32_t grid = (a.n + per_wg - 1u) / per_wg;
   if (stage) {   // (staging belongs to the plain loop)
@@ -1336,8 +1351,8 @@ static int launch_decode_gl(const BatchArgs& a, bool safe, int pipe, bool stage,
     else hipLaunchKernelGGL((decode_kernel<GL, false, 0, true>), dim3(grid), dim3(256), 0, st, a, route, 0u);
   } else if (pipe == 2 && GL <= 16) {   // (the deep loop works in 64-byte steps: groups of up to 16 lanes)
     if constexpr (GL <= 16) {
-      if (safe) hipLaunchKernelGGL((decode_deep_kernel<GL, true>), dim3(grid), dim3(256), 0, st, a, route, 0u);
-      else hipLaunchKernelGGL((decode_deep_kernel<GL, false>), dim3(grid), dim3(256), 0, st, a, route, 0u);
+      if (safe) hipLaunchKernelGGL((decode_deep_kernel<GL, true>), dim3(grid), dim3(256), 0, st, a, route, want);
+      else hipLaunchKernelGGL((decode_deep_kernel<GL, false>), dim3(grid), dim3(256), 0, st, a, route, want);
     }
   } else if (safe) {
     if (pipe) hipLaunchKernelGGL((decode_kernel<GL, true, 1, false>), dim3(grid), dim3(256), 0, st, a, route, 0u);
@@ -1411,10 +1426,11 @@ int launch_decompress(const BatchArgs& a, bool safe, int lanes_per_block, int pi
     // blocks' sizes between the deep loop and the ring loop (batches that fill the GPU with the ring loop's 16 blocks per wavefront,
     // 12288 .. 40959 blocks: 8192 x 4 MiB 422 vs 544 GB/s for the deep loop; 16384: 847 vs 815), and by the streams' sequence density
     // between either of them and the wave kernel
-    const bool ring_size = a.n >= 12288u && a.n < 40960u;
+    const bool ring_size = a.n >= 12288u && a.n < 40960u, staged = a.n >= 40960u;
     hipLaunchKernelGGL(decode_route_kernel, dim3(1), dim3(1024), 0, st, a.src, a.src_off, a.src_len, a.n, ring_size ? 512u << 10 : 0u,
-                       (uint32_t)g_route_dense.load(std::memory_order_relaxed), route_word);
-    int e = a.n >= 40960u ? launch_decode_gl<4>(a, safe, 0, true, st, route_word) : launch_decode_gl<8>(a, safe, 2, false, st, route_word);
+                       (uint32_t)g_route_short.load(std::memory_order_relaxed), staged ? 1u : 0u, route_word);
+    int e = staged ? launch_decode_gl<4>(a, safe, 0, true, st, route_word) : launch_decode_gl<8>(a, safe, 2, false, st, route_word);
+    if (e == 0 && staged) e = launch_decode_gl<8>(a, safe, 2, false, st, route_word, 3u);
     if (e == 0 && ring_size) e = launch_decode_ring<4, 2048>(a, safe, st, route_word, 1u);
     if (e == 0) e = launch_decode_wave(a, safe, true, 8192, st, route_word, 2u);
     return e;

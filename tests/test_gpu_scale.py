@@ -166,12 +166,12 @@ def test_routed_batch_of_big_blocks_vs_reference(amd, ref):
 
 def test_batches_routed_by_sequence_density_vs_reference(amd, ref, corpus):
     """More than 16 blocks per CU and every knob at its default: decode_route_kernel samples the MIDDLE of 32 streams (the wave loop's
-    speculative walk from an arbitrary byte: it falls in with the true token chain within a few sequences) and sends batches of dense
-    streams with near sources -- text: ~60 sequences per 256 bytes, most offsets within 6 KB -- to the wave kernel, everything else
-    (App. F ~15, a bitmap ~30, geophysical data ~7; synthetic streams as dense as text whose offsets lie anywhere in 64 KB) to the
-    lane-group loop of the batch size.  For text, App. F, bitmap and geophysical batches below and above 40960 blocks: the route
+    speculative walk from an arbitrary byte: it falls in with the true token chain within a few sequences) and sends batches of SHORT
+    sequences with near sources -- text: ~6 output bytes per sequence, most offsets within 6 KB -- to the wave kernel, everything else
+    (App. F 34 bytes per sequence, a bitmap 100+, geophysical data 40; synthetic streams as dense as text of 13 bytes per sequence) to a
+    lane-group loop: the deep loop below 40960 blocks and, from there on, for near sources (the bitmap), else the 4-lane staged loop.  For text, App. F, bitmap and geophysical batches below and above 40960 blocks: the route
     taken, sizes and bytes against the source, a sample of damaged / reference-compressed streams against LZ4_decompress_safe
-    (LZ4JNI.c:216); and the same bytes with the density route forced on (decode_route_dense 1) and off (0)."""
+    (LZ4JNI.c:216); and the same bytes with the wave route opened wide (decode_route_short 255) and closed (0)."""
     import numpy as np
     import torch
     dev = torch.device("cuda:0")
@@ -199,7 +199,7 @@ def test_batches_routed_by_sequence_density_vs_reference(amd, ref, corpus):
         return src
 
     try:
-        for kind, n, want_route in (("book", 6144, 2), ("appf", 6144, 0), ("lit2", 6144, 0), ("pic", 5000, 0), ("geo", 5000, 0), ("book", 45056, 2), ("appf", 45056, 0), ("book", 20000, 2)):
+        for kind, n, want_route in (("book", 6144, 2), ("appf", 6144, 0), ("lit2", 6144, 0), ("pic", 5000, 0), ("geo", 5000, 0), ("book", 45056, 2), ("appf", 45056, 0), ("pic", 45056, 3), ("book", 20000, 2)):
             src = make(kind, n)
             comp = torch.empty(n * cap, dtype=torch.uint8, device=dev)
             B = _batch(torch, dev, n, blk, cap)
@@ -228,14 +228,17 @@ def test_batches_routed_by_sequence_density_vs_reference(amd, ref, corpus):
             want = {i: ref.decompress_safe_raw(streams[i], int(caps[i])) for i in bad}
             ok = np.ones(n, dtype=bool); ok[bad] = False
             okt = torch.from_numpy(ok).to(dev)
-            for dense in (-1, 1, 0):                          # the default, "everything is dense", "nothing is"
-                if dense >= 0:
-                    amd.set_option("decode_route_dense", dense)
+            for short in (-1, 255, 0):                        # the default (8 bytes per sequence), "every sequence is short", "none is"
+                if short >= 0:
+                    amd.set_option("decode_route_short", short)
                 back = torch.zeros(n * blk, dtype=torch.uint8, device=dev)
                 amd.DeviceBatch.decompress_safe(comp, B["co"], cl, back, B["so"], dc, B["dlen"])
                 torch.cuda.synchronize()
                 route = amd.last_decode_route()
-                assert route[0] == (want_route if dense < 0 else (0 if kind == "lit2" else 2) if dense == 1 else 0), (kind, n, dense, route)   # (dense 1: "everything is dense" -- the offsets still have their say)
+                near = 2 * route[4] >= route[5]
+                expect = want_route if short < 0 else (2 if near else 0) if short == 255 else (3 if near and n >= 40960 else 0)
+                assert route[0] == expect, (kind, n, short, route)
+                dense = short
                 dlen = B["dlen"].cpu().numpy()
                 for i in bad:
                     er, ed = want[i]
@@ -245,11 +248,11 @@ def test_batches_routed_by_sequence_density_vs_reference(amd, ref, corpus):
                 assert (dlen[ok] == blk).all()
                 assert torch.equal(back.view(n, blk)[okt], src.view(n, blk)[okt]), (kind, n, dense)
                 del back
-            amd.set_option("decode_route_dense", 44)
+            amd.set_option("decode_route_short", 8)
             del src, comp
             torch.cuda.empty_cache()
     finally:
-        amd.set_option("decode_route_dense", 44)
+        amd.set_option("decode_route_short", 8)
 
 
 def test_cfg4_256_blocks_hc9_every_block_vs_reference(amd, ref):

@@ -1,4 +1,4 @@
-"""world_size-2 (and 3, uneven) gloo test of the multi-GPU path: contiguous block ranges per rank and the
+"""world_size-2 (3, uneven; 8: a whole node) gloo test of the multi-GPU path: contiguous block ranges per rank and the
 int32 size all-gather (lz4-java_amd/shard.py).  The per-rank codec is played by the oracle here (test
 infrastructure standing in for the device launch); on GPUs bench.py drives the same functions over RCCL."""
 import importlib
@@ -35,7 +35,7 @@ def _worker(rank, world, port, n_blocks, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_blocks", [(2, 64), (3, 50), (2, 1)])
+@pytest.mark.parametrize("world,n_blocks", [(2, 64), (3, 50), (2, 1), (8, 16384), (8, 5)])   # (8, 16384): BASELINE configs[2] over the 8 GPUs of a node; (8, 5): ranks without a block
 def test_contiguous_shards_and_size_gather(world, n_blocks):
     from oracle import oracle as O
     chk = O.port()
@@ -46,7 +46,7 @@ def test_contiguous_shards_and_size_gather(world, n_blocks):
     procs = [ctx.Process(target=_worker, args=(r, world, port, n_blocks, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in range(world)]
+    res = [q.get(timeout=300) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0

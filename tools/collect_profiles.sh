@@ -33,3 +33,13 @@ rm -rf gpurun_out/prof_$tag gpurun_out/traffic_$tag gpurun_out/traffic_text_$tag
 # the bench line last: it quotes profiles/traffic.json, which the passes above have just rewritten
 python bench.py 2>&1 | tail -1 > gpurun_out/${tag}_bench_line.json
 cat gpurun_out/${tag}_bench_line.json
+# what one GPU delivers on the shard of each rank count (configs2_shards_per_gpu_GBps of the line): the prediction `bench.py --gpus N` prints beside its measurement
+python - <<PYEOF
+import json
+l = json.load(open("gpurun_out/${tag}_bench_line.json"))
+sh = (l.get("configs") or {}).get("configs2_shards_per_gpu_GBps")
+if sh:
+    json.dump({"configs2_decode_per_gpu_GBps": sh, "source": "profiles/${tag}_bench_line.json (1x MI355X: each rank count's shard of BASELINE configs[2] decoded on one GPU)"},
+              open("profiles/shard_prediction.json", "w"), indent=1, sort_keys=True)
+    json.dump(json.load(open("profiles/shard_prediction.json")), open("gpurun_out/shard_prediction_${tag}.json", "w"), indent=1, sort_keys=True)
+PYEOF

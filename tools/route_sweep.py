@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The density route's crossover: for batches of more than 16 blocks per CU, the lane-group default of the batch size against the wave
-kernel (decode_route_dense 0 / 1 = never / always) on workloads of different sequence density, with the density decode_route_kernel
+kernel (decode_route_short 0 / 1 = never / always) on workloads of different sequence density, with the density decode_route_kernel
 measures (sampled hops per 256 bytes of stream).  route_sweep.py [sizes] [workloads]
 workloads: book, pic, geo, appf (litmax 38), lit16, lit8, lit4, lit2 (App. F generator with shorter literal runs, win 65535), cfg2_N (N x 4 MiB)"""
 import importlib, os, sys
@@ -53,34 +53,27 @@ for kind in wls:
         amd.DeviceBatch.compress_fast(src, so, sl, comp, co, cc, clen)
         torch.cuda.synchronize()
         back = torch.zeros(n * blk, dtype=torch.uint8, device=dev)
-        res = {}
-        for dense in (0, 1, 44):
-            amd.set_option("decode_route_dense", dense)
+        def run(lanes, pipe, stage, ring):
+            amd.set_option("decode_lanes", lanes); amd.set_option("decode_pipe", pipe); amd.set_option("decode_stage", stage); amd.set_option("decode_ring", ring)
+            back.zero_()
             best = 1e30
             for _ in range(3):
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record(); amd.DeviceBatch.decompress_safe(comp, co, clen, back, so, sl, dlen); b.record()
                 torch.cuda.synchronize()
                 best = min(best, a.elapsed_time(b))
-            ok = bool(torch.equal(back, src))
-            res[dense] = (best, ok, amd.last_decode_route())
-        r = res[44][2]
-        deep = ""
-        if n >= 40960:                           # what the deep loop would do where the staged loop is the lane-group default
-            amd.set_option("decode_route_dense", 0); amd.set_option("decode_lanes", 8); amd.set_option("decode_pipe", 2)
-            bd = 1e30
-            for _ in range(3):
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record(); amd.DeviceBatch.decompress_safe(comp, co, clen, back, so, sl, dlen); b.record()
-                torch.cuda.synchronize()
-                bd = min(bd, a.elapsed_time(b))
-            amd.set_option("decode_lanes", 0); amd.set_option("decode_pipe", -1)
-            deep = " | deep loop %8.3f ms %7.1f GB/s" % (bd, n * blk / bd / 1e6)
-        print("%-10s n %6d ratio %.2f  sampled %5.1f seq/256B near %3.0f %%  lane-group %8.3f ms %7.1f GB/s | wave %8.3f ms %7.1f GB/s | default route %d: %8.3f ms  ok=%s" % (
-            kind, n, n * blk / int(clen.sum().item()), 256.0 * r[1] / max(r[2], 1), 100.0 * r[4] / max(r[5], 1), res[0][0], n * blk / res[0][0] / 1e6, res[1][0], n * blk / res[1][0] / 1e6,
-            r[0], res[44][0], res[0][1] and res[1][1] and res[44][1]) + deep, flush=True)
+            return best, bool(torch.equal(back, src))
+        staged = run(4, 0, 1, 0) if n >= 40960 else None
+        deep = run(8, 2, 0, 0)
+        wave = run(64, 5, 0, 8192)
+        dflt = run(0, -1, -1, 0)
+        r = amd.last_decode_route()
+        gb = lambda t: n * blk / t / 1e6
+        print("%-9s n %6d ratio %5.2f  sampled %5.1f seq/256B %6.1f B/seq near %3.0f %%  %s deep %8.3f ms %6.1f GB/s | wave %8.3f ms %6.1f GB/s | default -> route %d %8.3f ms %6.1f GB/s  ok=%s" % (
+            kind, n, n * blk / int(clen.sum().item()), 256.0 * r[1] / max(r[2], 1), r[6] / max(r[5], 1), 100.0 * r[4] / max(r[5], 1),
+            ("staged %8.3f ms %6.1f GB/s |" % (staged[0], gb(staged[0]))) if staged else "", deep[0], gb(deep[0]), wave[0], gb(wave[0]), r[0], dflt[0], gb(dflt[0]),
+            deep[1] and wave[1] and dflt[1] and (staged is None or staged[1])), flush=True)
         del src, comp, back
         torch.cuda.empty_cache()
         if kind.startswith("cfg2_"):
             break
-amd.set_option("decode_route_dense", 44)

@@ -27,7 +27,7 @@ for db in glob.glob(os.path.join(d, "*", "pmc_results.db")):
     # batch has no such block: its real launch is the biggest one (compress_4MiB).
     # decode_wave_kernel<8, 16384, ..> (a wavefront per block): the configs2_shard8 launch (2048 x 4 MiB) and small launches of 64 KiB
     # blocks: its biggest dispatch is the shard
-    BIGGEST = ("decode_deep_kernel<8, true>", "decode_ring_kernel<4, 2048, true>", "compress_fast_v2wp_cu_kernel", "decode_wave_kernel<8, 16384")
+    BIGGEST = ("decode_deep_kernel<8, true>", "decode_ring_kernel<4, 2048, true>", "compress_fast_v2wp_cu_kernel", "decode_wave_kernel<8, 16384", "decode_wave_kernel<16, 8192", "decode_pair_kernel")
     for (k, c), vs in rows.items():
         if any(h in k for h in HEADLINE_FIRST):
             vs = vs[:3]
@@ -36,6 +36,12 @@ for db in glob.glob(os.path.join(d, "*", "pmc_results.db")):
         if any(h in k for h in BIGGEST):
             v = vs[-1]
         full.setdefault(norm(k), {})[c] = v
+        if "compress_fast_v2wp_cu_kernel" in k:
+            # ... and its configs2_shard8_compress launches (2048 of the 16384 blocks): the dispatches at about an eighth of the biggest
+            # (real_book1_4MiB -- 2560 blocks of text -- moves two thirds of it; the launches without such a block next to nothing)
+            sh = [x for x in vs if 0.08 * vs[-1] <= x <= 0.2 * vs[-1]]
+            if sh:
+                full.setdefault(norm(k) + "@shard8", {})[c] = sh[len(sh) // 2]
         if "decode_kernel" in k and "decode_kernel<4, true, 0, true>" not in k:
             continue   # the legacy "decode_kernel" key below is the headline launch (65536 x 64 KiB: 4 lanes, safe, staged) only
         key = None
@@ -80,7 +86,7 @@ if text_dir:
     def pick(*subs):
         vs = [v for k, v in tb.items() if any(s_ in k for s_ in subs)]
         return int(sum(vs)) if vs else None
-    out["text"] = {"real_book1": {"compress": pick("compress_fast_v2w_cu_kernel", "compress_fast_ms_cu_kernel"), "decode": pick("decode_kernel<4, true, 0, true>")},
+    out["text"] = {"real_book1": {"compress": pick("compress_fast_v2w_cu_kernel", "compress_fast_ms_cu_kernel"), "decode": pick("decode_kernel<4, true, 0, true>", "decode_wave_kernel<16, 8192, 1024, true, 5>", "decode_route_kernel")},   # (routed by density since round 6: the wave kernel does the work, the staged loop's launch returns at once)
                    "real_book1_4MiB": {"compress": pick("compress_fast_v2wp_cu_kernel")},
                    "kernels": tb, "source": "tools/gpu_text_legs.py under tools/traffic_passes.sh <dir> 2 text"}
 json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json"), "w"), indent=1, sort_keys=True)
