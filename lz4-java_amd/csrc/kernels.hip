@@ -1043,13 +1043,16 @@ int launch_container_read(int kind, int block_checksum, const uint8_t* body, uin
 // ------------------------------------------------------------------------------------------------
 // decode
 // ------------------------------------------------------------------------------------------------
+#ifndef LZ4HIP_LDS_PAD
+#define LZ4HIP_LDS_PAD 0   /* developer A/B builds: bytes of LDS a workgroup of the lane-group decoders claims beyond what it uses -- fewer wavefronts per CU (tools/r06d.sh: the traffic-mix benchmark runs the headline's bytes faster with 4 wavefronts per CU than with 16) */
+#endif
 template <int GL, bool SAFE, int PIPE, bool STAGE>
 __global__ __launch_bounds__(256) void decode_kernel(BatchArgs a, const uint32_t* route, uint32_t want) {
   if (route && *route != want) return;   // (the launch was routed to another decoder: launch_decompress)
   // STAGE: one staging buffer per block of the workgroup (group_dev.h st_*): 256/GL x 576 bytes; PIPE 2: the block's window of
   // the compressed stream (group_dev.h sr_*): 256/GL x (kStream + 16) bytes
   constexpr uint32_t kPer = PIPE == 2 ? GroupDev<GL>::kStreamLds : GroupDev<GL>::kStage;
-  __shared__ __attribute__((aligned(16))) uint8_t stage_mem[(STAGE || PIPE == 2) ? (256 / GL) * kPer : 16];
+  __shared__ __attribute__((aligned(16))) uint8_t stage_mem[((STAGE || PIPE == 2) ? (256 / GL) * kPer : 16) + LZ4HIP_LDS_PAD];
   const uint32_t gid = (blockIdx.x * 256u + threadIdx.x) / GL;
   if (gid >= a.n) return;  // a whole group leaves together
   GroupDev<GL> g;
@@ -1065,7 +1068,7 @@ __global__ __launch_bounds__(256) void decode_kernel(BatchArgs a, const uint32_t
 template <int GL, bool SAFE>
 __global__ __launch_bounds__(256, LZ4HIP_DEEP_WGS) void decode_deep_kernel(BatchArgs a, const uint32_t* route, uint32_t want) {
   if (route && *route != want) return;   // (the launch was routed to another decoder: launch_decompress)
-  __shared__ __attribute__((aligned(16))) uint8_t stage_mem[(256 / GL) * GroupDev<GL>::kStreamLds];
+  __shared__ __attribute__((aligned(16))) uint8_t stage_mem[(256 / GL) * GroupDev<GL>::kStreamLds + LZ4HIP_LDS_PAD];
   const uint32_t gid = (blockIdx.x * 256u + threadIdx.x) / GL;
   if (gid >= a.n) return;
   GroupDev<GL> g;
@@ -1081,7 +1084,7 @@ template <int GL, int KW, bool SAFE>
 __global__ __launch_bounds__(64) void decode_ring_kernel(BatchArgs a, const uint32_t* route, uint32_t want) {
   if (route && *route != want) return;   // (the launch was routed to another decoder: launch_decompress)
   typedef GroupDev<GL, KW> G;
-  __shared__ __attribute__((aligned(16))) uint8_t ring_mem[(64 / GL) * G::kRingLds];
+  __shared__ __attribute__((aligned(16))) uint8_t ring_mem[(64 / GL) * G::kRingLds + LZ4HIP_LDS_PAD];
   const uint32_t gid = (blockIdx.x * 64u + threadIdx.x) / GL;
   if (gid >= a.n) return;
   G g;
