@@ -1241,8 +1241,8 @@ static int launch_decode_wave(const BatchArgs& a, bool safe, bool par, int ring,
 // geo 4 .. 30 (7), pic 1 .. 44 (32) per SAMPLE; the route takes the sum over the 32.  One workgroup of 16 wavefronts, two blocks
 // each, both 1 KB loads in flight together: ~10 us in front of launches of >= 0.9 ms.
 __device__ uint32_t g_last_route[8];
-__global__ __launch_bounds__(1024) void decode_route_kernel(const uint8_t* src, const uint64_t* src_off, const int32_t* src_len, uint32_t n, uint32_t big, uint32_t seq_bytes,
-                                                            uint32_t deep_if_near, uint32_t* route) {
+__global__ __launch_bounds__(1024) void decode_route_kernel(const uint8_t* src, const uint64_t* src_off, const int32_t* src_len, const int32_t* dst_cap, uint32_t n, uint32_t safe,
+                                                            uint32_t big, uint32_t seq_bytes, uint32_t deep_if_near, uint32_t* route) {
   typedef BlockWaveDev<8192, 1024> G;   // (its hand-written walk: a static function of registers)
   constexpr uint32_t SPAN = 1024u, NS = 2u;
   __shared__ __attribute__((aligned(16))) uint8_t win[16][NS][SPAN + 32];
@@ -1263,8 +1263,14 @@ __global__ __launch_bounds__(1024) void decode_route_kernel(const uint8_t* src, 
     const uint64_t bi = ((uint64_t)(NS * wave + k) * n) / (16u * NS) + n / (32u * NS);
     const uint32_t b = bi < n ? (uint32_t)bi : n - 1u;
     const int32_t len = uniform_i32(src_len[b]);
-    have[k] = len >= 4096 ? 1u : 0u;              // (shorter streams are not sampled: their decode time is not in their interior loops)
-    start[k] = have[k] ? (((uint32_t)len >> 1) & ~3u) : 0u;
+    // where to look: the middle of the stream.  The safe decoder is given the stream's length; the FAST decoder only a readable capacity
+    // (LZ4_decompress_fast trusts the stream to end by itself) -- the middle of THAT is, for a slot of compressBound size, about where a
+    // stream of ratio 2 ends (the first version of the route sampled the zeros behind the headline's streams and sent decompress_fast to
+    // the wave kernel: 710 -> 442 GB/s).  There: a sixteenth of the output size into the stream, at least 2 KB, inside any stream of ratio <= 16
+    uint32_t at = (uint32_t)(len > 0 ? len : 0) >> 1;
+    if (!safe) { const uint32_t o16 = (uint32_t)max(uniform_i32(dst_cap[b]), 0) >> 4; at = at < o16 ? at : o16; }
+    have[k] = (len >= 4096 && at >= 2048u && at + SPAN + 32u <= (uint32_t)len) ? 1u : 0u;   // (shorter streams are not sampled: their decode time is not in their interior loops)
+    start[k] = have[k] ? (at & ~3u) : 0u;
     if (have[k]) {
       const uint8_t* p = uniform_ptr(src + src_off[b]) + start[k];
       // (byte loads assembled into dwords would be 16 instructions; the streams lie at any address, so: unaligned dword loads)
@@ -1430,7 +1436,7 @@ int launch_decompress(const BatchArgs& a, bool safe, int lanes_per_block, int pi
     // 12288 .. 40959 blocks: 8192 x 4 MiB 422 vs 544 GB/s for the deep loop; 16384: 847 vs 815), and by the streams' sequence density
     // between either of them and the wave kernel
     const bool ring_size = a.n >= 12288u && a.n < 40960u, staged = a.n >= 40960u;
-    hipLaunchKernelGGL(decode_route_kernel, dim3(1), dim3(1024), 0, st, a.src, a.src_off, a.src_len, a.n, ring_size ? 512u << 10 : 0u,
+    hipLaunchKernelGGL(decode_route_kernel, dim3(1), dim3(1024), 0, st, a.src, a.src_off, a.src_len, a.dst_cap, a.n, safe ? 1u : 0u, ring_size ? 512u << 10 : 0u,
                        (uint32_t)g_route_short.load(std::memory_order_relaxed), staged ? 1u : 0u, route_word);
     int e = staged ? launch_decode_gl<4>(a, safe, 0, true, st, route_word) : launch_decode_gl<8>(a, safe, 2, false, st, route_word);
     if (e == 0 && staged) e = launch_decode_gl<8>(a, safe, 2, false, st, route_word, 3u);

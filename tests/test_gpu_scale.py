@@ -206,6 +206,14 @@ def test_batches_routed_by_sequence_density_vs_reference(amd, ref, corpus):
             amd.DeviceBatch.compress_fast(src, B["so"], B["sl"], comp, B["co"], B["cc"], B["clen"])
             torch.cuda.synchronize()
             clen = B["clen"].cpu().numpy().copy()
+            # the FAST decoder is given the slots' capacity, not the streams' lengths (LZ4_decompress_fast, LZ4JNI.c:169): the sampler must not
+            # take the middle of THAT for the middle of the stream (it did: the headline's decompress_fast went to the wave kernel, 710 -> 442 GB/s)
+            back = torch.zeros(n * blk, dtype=torch.uint8, device=dev)
+            amd.DeviceBatch.decompress_fast(comp, B["co"], B["cc"], back, B["so"], B["sl"], B["dlen"])
+            torch.cuda.synchronize()
+            assert amd.last_decode_route()[0] == want_route, (kind, n, "fast", amd.last_decode_route())
+            assert torch.equal(back, src) and torch.equal(B["dlen"], B["clen"]), (kind, n, "fast")
+            del back
             sample = rng.sample(range(n), 24)
             good, bad = sample[:8], sample[8:]
             streams = {i: comp[i * cap:i * cap + int(clen[i])].cpu().numpy().tobytes() for i in sample}
