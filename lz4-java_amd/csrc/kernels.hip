@@ -1246,7 +1246,7 @@ __global__ __launch_bounds__(1024) void decode_route_kernel(const uint8_t* src, 
   typedef BlockWaveDev<8192, 1024> G;   // (its hand-written walk: a static function of registers)
   constexpr uint32_t SPAN = 1024u, NS = 2u;
   __shared__ __attribute__((aligned(16))) uint8_t win[16][NS][SPAN + 32];
-  __shared__ uint32_t acc[16][5];
+  __shared__ uint32_t acc[16][6];
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
   // ---- the blocks' sizes: 64 of them, wavefront 0 (the ring loop's criterion, unchanged) ----
   uint32_t avg = 0u;
@@ -1266,9 +1266,11 @@ __global__ __launch_bounds__(1024) void decode_route_kernel(const uint8_t* src, 
     // where to look: the middle of the stream.  The safe decoder is given the stream's length; the FAST decoder only a readable capacity
     // (LZ4_decompress_fast trusts the stream to end by itself) -- the middle of THAT is, for a slot of compressBound size, about where a
     // stream of ratio 2 ends (the first version of the route sampled the zeros behind the headline's streams and sent decompress_fast to
-    // the wave kernel: 710 -> 442 GB/s).  There: a sixteenth of the output size into the stream, at least 2 KB, inside any stream of ratio <= 16
+    // the wave kernel: 710 -> 442 GB/s).  There: a fifth of the OUTPUT size into the stream -- 40 % into a stream of ratio 2, 30 % into
+    // text; not nearer the head: early in a block every offset is near.  Behind the end of a stream of ratio > 5 it finds what follows
+    // it in the slot: zeros decode as sequences of offset 0, which no stream has -- such a sample routes nothing (below)
     uint32_t at = (uint32_t)(len > 0 ? len : 0) >> 1;
-    if (!safe) { const uint32_t o16 = (uint32_t)max(uniform_i32(dst_cap[b]), 0) >> 4; at = at < o16 ? at : o16; }
+    if (!safe) { const uint32_t o5 = (uint32_t)max(uniform_i32(dst_cap[b]), 0) / 5u; at = at < o5 ? at : o5; }
     have[k] = (len >= 4096 && at >= 2048u && at + SPAN + 32u <= (uint32_t)len) ? 1u : 0u;   // (shorter streams are not sampled: their decode time is not in their interior loops)
     start[k] = have[k] ? (at & ~3u) : 0u;
     if (have[k]) {
@@ -1284,7 +1286,7 @@ __global__ __launch_bounds__(1024) void decode_route_kernel(const uint8_t* src, 
       if (lane < 8u) *(uint32_t*)&win[wave][k][SPAN + 4u * lane] = tail;
     }
   }
-  uint32_t seqs = 0u, bytes = 0u, near_n = 0u, off_n = 0u, out_n = 0u;
+  uint32_t seqs = 0u, bytes = 0u, near_n = 0u, off_n = 0u, out_n = 0u, zero_n = 0u;
 #pragma unroll
   for (uint32_t k = 0; k < NS; k++) {
     if (!have[k]) continue;
@@ -1323,18 +1325,19 @@ __global__ __launch_bounds__(1024) void decode_route_kernel(const uint8_t* src, 
           out_n += (uint32_t)__builtin_amdgcn_readfirstlane((int)ls);
           near_n += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(mine && off <= 6144u));
           off_n += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(mine));
+          zero_n += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(mine && off == 0u));
         }
       }
       ip += last;
     }
   }
-  if (lane == 0u) { acc[wave][0] = seqs; acc[wave][1] = bytes; acc[wave][2] = near_n; acc[wave][3] = off_n; acc[wave][4] = out_n; }
+  if (lane == 0u) { acc[wave][0] = seqs; acc[wave][1] = bytes; acc[wave][2] = near_n; acc[wave][3] = off_n; acc[wave][4] = out_n; acc[wave][5] = zero_n; }
   __syncthreads();
   if (threadIdx.x == 0u) {
-    uint32_t ts = 0u, tb = 0u, tn = 0u, to = 0u, tl = 0u;
-    for (uint32_t w = 0; w < 16u; w++) { ts += acc[w][0]; tb += acc[w][1]; tn += acc[w][2]; to += acc[w][3]; tl += acc[w][4]; }
+    uint32_t ts = 0u, tb = 0u, tn = 0u, to = 0u, tl = 0u, tz = 0u;
+    for (uint32_t w = 0; w < 16u; w++) { ts += acc[w][0]; tb += acc[w][1]; tn += acc[w][2]; to += acc[w][3]; tl += acc[w][4]; tz += acc[w][5]; }
     const bool is_big = big != 0u && avg >= big;
-    const bool sampled = tb >= 2048u && to >= 64u;          // (a few windows, a few dozen sequences)
+    const bool sampled = tb >= 2048u && to >= 64u && 16u * tz <= to;   // (a few windows, a few dozen sequences -- and streams: offset 0 does not occur in one, zeros behind a stream's end are full of it)
     const bool is_near = sampled && 2u * tn >= to;
     // the wave kernel: SHORT sequences with near sources.  The lane-group loops decode ~20 G sequences/s whatever the data, i.e. GB/s in
     // proportion to the bytes a sequence produces; the wave kernel's rate grows far more slowly with them (text, 6 bytes per sequence:
@@ -1343,7 +1346,7 @@ __global__ __launch_bounds__(1024) void decode_route_kernel(const uint8_t* src, 
     const uint32_t r = is_big ? 1u : is_short ? 2u : (deep_if_near != 0u && is_near) ? 3u : 0u;
     *route = r;
     g_last_route[0] = r; g_last_route[1] = ts; g_last_route[2] = tb; g_last_route[3] = avg;   // (diagnostic: last_decode_route)
-    g_last_route[6] = tl;
+    g_last_route[6] = tl; g_last_route[7] = tz;
     g_last_route[4] = tn; g_last_route[5] = to;
   }
 }
