@@ -801,6 +801,25 @@ struct BlockWaveDev : GroupDev<64, 0> {
     const u2v8 t = *(lds64p)(pmb + slot * kMailSlotBytes + 2u * l4);
     w0 = t.x; w1 = t.y;
   }
+  // the trio loop's second queue (lz4_decode_trio.h: scanner -> planner), behind the mailbox: kScanSlots entries of 64 positions (a dword
+  // per lane) + {count, window position, next window, flags}
+  static constexpr uint32_t kScanSlots = 3u, kScanBytes = 288u;
+  static constexpr uint32_t kTrioLds = kPairLds + kScanSlots * kScanBytes;
+  typedef __attribute__((address_space(3))) uint32_t* lds32p;
+  typedef uint32_t u4v16 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) u4v16* lds128p;
+  __device__ __forceinline__ void sq_put(uint32_t slot, uint32_t posv, uint32_t T, uint32_t wip, uint32_t nextw, uint32_t flags) {
+    lds8p e = pmb + kMailBytes + slot * kScanBytes;
+    *(lds32p)(e + l4) = posv;
+    const uint32_t hv = this->l == 0u ? T : this->l == 1u ? wip : this->l == 2u ? nextw : flags;
+    if (this->l < 4u) *(lds32p)(e + 256u + l4) = hv;
+  }
+  __device__ __forceinline__ void sq_get(uint32_t slot, uint32_t& posv, uint32_t& T, uint32_t& wip, uint32_t& nextw, uint32_t& flags) const {
+    lds8p e = pmb + kMailBytes + slot * kScanBytes;
+    posv = *(lds32p)(e + l4);
+    const u4v16 h = *(lds128p)(e + 256u);
+    T = uni(h.x); wip = uni(h.y); nextw = uni(h.z); flags = uni(h.w);
+  }
   __device__ __forceinline__ static void pm_nap() { __builtin_amdgcn_s_sleep(1); }    // a message is a few hundred cycles away
   __device__ __forceinline__ static void pm_idle() { __builtin_amdgcn_s_sleep(8); }   // between entries: the copier is in decode_block's exact code, or between blocks
   __device__ __forceinline__ static const uint8_t* pm_ptr(uint32_t lo, uint32_t hi) {   // (through address space 1: a pointer rebuilt from integers is otherwise a FLAT pointer)

@@ -1152,6 +1152,33 @@ __global__ __launch_bounds__(128 * W) void decode_pair_kernel(BatchArgs a, const
 #endif
 static std::atomic<int> g_route_short{LZ4HIP_ROUTE_SHORT};   // "decode_route_short": 0 = never the wave kernel
 void set_route_short(int v) { g_route_short.store(v, std::memory_order_relaxed); }
+// the trio loop's kernel (lz4_decode_trio.h): THREE WAVEFRONTS PER BLOCK -- wavefront 3p of the workgroup is the COPIER of trio p (it runs
+// decode_block), 3p + 1 its PLANNER, 3p + 2 its SCANNER: consecutive wavefronts of a workgroup sit on different SIMDs.  For launches of up
+// to two blocks per CU (W = 1, 2: the single-call path, the smallest batches), where SIMDs idle.
+template <int W, int KW, int KS, bool SAFE>
+__global__ __launch_bounds__(192 * W) void decode_trio_kernel(BatchArgs a, const uint32_t* route, uint32_t want) {
+  if (route && *route != want) return;
+  typedef BlockWaveDev<KW, KS> G;
+  static_assert(G::kMailSlots == PAIR_SLOTS && G::kMailSlotBytes == PAIR_SLOT_BYTES && G::kScanSlots == TRIO_SCAN_SLOTS && G::kScanBytes == TRIO_SCAN_BYTES, "queue layout");
+  __shared__ __attribute__((aligned(16))) uint8_t trio_mem[W * G::kTrioLds];
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t trio = wave / 3u, role = wave - 3u * trio;
+  uint8_t* lds = trio_mem + trio * G::kTrioLds;
+  if (role == 0u && (threadIdx.x & 63u) < PAIR_CTL_WORDS) ((uint32_t*)(lds + G::kWaveLds + PAIR_SLOTS * PAIR_SLOT_BYTES))[threadIdx.x & 63u] = 0u;
+  __syncthreads();
+  if (role != 0u) {
+    G g;
+    trio_service(g, lds, role == 2u);
+    return;
+  }
+  for (uint32_t b = blockIdx.x * W + trio; b < a.n; b += gridDim.x * W) {
+    G g;
+    const int r = decode_block<G, SAFE, 8, false>(g, a.src + a.src_off[b], a.src_len[b], a.dst + a.dst_off[b], a.dst_cap[b], lds);
+    if (g.l == 0) a.out[b] = r;
+  }
+  G g;
+  trio_quit(g, lds);
+}
 static uint32_t device_cus() {   // compute units of the current device (cached per device)
   static std::atomic<uint32_t> cus[64];
   int d = 0;
@@ -1196,6 +1223,23 @@ static int launch_decode_pair(const BatchArgs& a, bool safe, int ring, hipStream
     case 65536: return a.n <= device_cus() ? launch_decode_pair_w<1, 65536, 2048>(a, safe, st, route, want) : launch_decode_pair_w<2, 65536, 2048>(a, safe, st, route, want);
     case 32768: return launch_decode_pair_w<4, 32768, 2048>(a, safe, st, route, want);
     case 16384: return launch_decode_pair_w<8, 16384, 2048>(a, safe, st, route, want);
+    default: return (int)hipErrorInvalidValue;
+  }
+}
+template <int W, int KW, int KS>
+static int launch_decode_trio_w(const BatchArgs& a, bool safe, hipStream_t st, const uint32_t* route, uint32_t want) {
+  const uint32_t wgs = (a.n + W - 1u) / W, cus = device_cus();
+  const uint32_t grid = wgs < cus ? wgs : cus;
+  if (safe) hipLaunchKernelGGL((decode_trio_kernel<W, KW, KS, true>), dim3(grid), dim3(192 * W), 0, st, a, route, want);
+  else hipLaunchKernelGGL((decode_trio_kernel<W, KW, KS, false>), dim3(grid), dim3(192 * W), 0, st, a, route, want);
+  return (int)hipGetLastError();
+}
+// the trio loop: ring = bytes of the output ring (32768 / 65536; 0 = by batch size)
+static int launch_decode_trio(const BatchArgs& a, bool safe, int ring, hipStream_t st, const uint32_t* route = nullptr, uint32_t want = 0) {
+  if (ring == 0) ring = a.n <= 2u * device_cus() ? 65536 : 32768;
+  switch (ring) {
+    case 65536: return a.n <= device_cus() ? launch_decode_trio_w<1, 65536, 2048>(a, safe, st, route, want) : launch_decode_trio_w<2, 65536, 2048>(a, safe, st, route, want);
+    case 32768: return launch_decode_trio_w<4, 32768, 2048>(a, safe, st, route, want);
     default: return (int)hipErrorInvalidValue;
   }
 }
@@ -1388,6 +1432,7 @@ int launch_decompress(const BatchArgs& a, bool safe, int lanes_per_block, int pi
   if (a.n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   if (pipe == 7) return launch_decode_pair(a, safe, ring, st);   // the pair loop: two wavefronts per block (lz4_decode_pair.h)
+  if (pipe == 8) return launch_decode_trio(a, safe, ring, st);   // the trio loop: three (lz4_decode_trio.h)
   if (pipe == 4 || pipe == 5) return launch_decode_wave(a, safe, pipe == 5, ring, st);   // the wave loops: a wavefront per block (lanes_per_block is 64 by construction); 5: several sequences per trip
   if (pipe == 3) {   // the ring loop: lanes 4 / 8 / 16, output ring 512 .. 4096 bytes (0 = 512 with 4 lanes, 4096 otherwise)
     const int gl = lanes_per_block == 0 ? 4 : lanes_per_block;

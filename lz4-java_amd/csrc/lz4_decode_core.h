@@ -40,6 +40,7 @@
 #include "lz4_decode_ring.h"
 #include "lz4_decode_wave.h"
 #include "lz4_decode_pair.h"
+#include "lz4_decode_trio.h"
 namespace lz4hip {
 
 // SAFE: LZ4_decompress_safe(src, dst, src_size, out_size) -> decoded size or negative.
@@ -57,6 +58,7 @@ namespace lz4hip {
 //       5 = the parallel wave loop (same file, same rings): every sequence that starts in a 256-byte window of the stream per trip.
 //       7 = the pair loop of lz4_decode_pair.h (TWO WAVEFRONTS PER BLOCK: the caller is the copier, `stage` = the pair's LDS: the rings of 4 / 5 and a mailbox; a second wavefront
 //       runs pair_parser_service on the same LDS).
+//       8 = the trio loop of lz4_decode_trio.h (THREE WAVEFRONTS PER BLOCK: the caller is the copier; a planner and a scanner wavefront run trio_service on the same LDS).
 // STAGE: the interior loop writes through an LDS staging buffer (`stage`, Grp::kStage bytes for this block) and output leaves
 //        it as whole 128-byte lines (group_dev.h st_*).
 template <class Grp, bool SAFE, int PIPE = 0, bool STAGE = false>
@@ -136,7 +138,10 @@ LZ4HIP_DEV int decode_block(Grp& g, const uint8_t* src, int src_size, uint8_t* d
     if constexpr (PIPE == 7) {   // the pair loop (lz4_decode_pair.h): this wavefront copies, its partner wavefront parses the stream a trip or two ahead
       if (ip + 1536 <= iend && ip <= iend - 306 && op <= oend - 606) decode_pair_loop<Grp>(g, src, iend, dst, oend, ip, op, stage);
     }
-    if ((PIPE == 1 || (PIPE == 2 && ip + 2048 > iend) || (PIPE == 3 && ip + 320 > iend) || (PIPE == 4 && ip + 1024 > iend) || ((PIPE == 5 || PIPE == 6 || PIPE == 7) && ip + 1536 > iend)) && ip <= iend - 306 && op <= oend - 606) {   // (2 .. 7: only the tail of the stream)
+    if constexpr (PIPE == 8) {   // the trio loop (lz4_decode_trio.h): this wavefront copies, a planner and a scanner wavefront run ahead in the stream
+      if (ip + 1536 <= iend && ip <= iend - 306 && op <= oend - 606) decode_trio_loop<Grp>(g, src, iend, dst, oend, ip, op, stage);
+    }
+    if ((PIPE == 1 || (PIPE == 2 && ip + 2048 > iend) || (PIPE == 3 && ip + 320 > iend) || (PIPE == 4 && ip + 1024 > iend) || ((PIPE == 5 || PIPE == 6 || PIPE == 7 || PIPE == 8) && ip + 1536 > iend)) && ip <= iend - 306 && op <= oend - 606) {   // (2 .. 8: only the tail of the stream)
       // ---- the same loop, software-pipelined.  A wavefront's memory operations retire in order, so a wait for a load also
       // waits for every OLDER store.  Here (a) the next sequence's offset word is requested as soon as this sequence's header
       // is parsed, (b) a "simple" sequence (literals and match take one step each, match source entirely before the

@@ -334,6 +334,23 @@ struct GroupHost {
     if (slot >= kMailSlots) { oob = true; return; }
     for (int l = 0; l < 64; l++) { memcpy(&w0.v[l], pmb + slot * kMailSlotBytes + 8u * l, 4); memcpy(&w1.v[l], pmb + slot * kMailSlotBytes + 8u * l + 4u, 4); }
   }
+  // the trio loop's scan queue (lz4_decode_trio.h: scanner -> planner), behind the mailbox
+  static constexpr uint32_t kScanSlots = 3u, kScanBytes = 288u;
+  uint32_t trio_lds_bytes() const { return pair_lds_bytes() + kScanSlots * kScanBytes; }
+  void sq_put(uint32_t slot, const V<uint32_t>& posv, uint32_t T, uint32_t wip, uint32_t nextw, uint32_t flags) {
+    if (slot >= kScanSlots) { oob = true; return; }
+    uint8_t* e = pmb + kMailBytes + slot * kScanBytes;
+    for (int l = 0; l < 64; l++) memcpy(e + 4 * l, &posv.v[l], 4);
+    const uint32_t h[4] = {T, wip, nextw, flags};
+    memcpy(e + 256, h, 16);
+  }
+  void sq_get(uint32_t slot, V<uint32_t>& posv, uint32_t& T, uint32_t& wip, uint32_t& nextw, uint32_t& flags) {
+    if (slot >= kScanSlots) { oob = true; return; }
+    const uint8_t* e = pmb + kMailBytes + slot * kScanBytes;
+    for (int l = 0; l < 64; l++) memcpy(&posv.v[l], e + 4 * l, 4);
+    uint32_t h[4]; memcpy(h, e + 256, 16);
+    T = h[0]; wip = h[1]; nextw = h[2]; flags = h[3];
+  }
   void pm_nap() { pair_naps++; std::this_thread::yield(); }
   void pm_idle() { std::this_thread::yield(); }
   static const uint8_t* pm_ptr(uint32_t lo, uint32_t hi) { return (const uint8_t*)(uintptr_t)(((uint64_t)hi << 32) | lo); }

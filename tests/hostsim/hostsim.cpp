@@ -210,6 +210,23 @@ int sim_decompress(const uint8_t* src, int src_size, uint8_t* dst, int out_size,
   if (wave_ks1k) g.kWs = 1024u;
   int r;
   const bool wave_par = (gl0 & 0x800000) != 0;   // bit 23: the parallel wave loop (several sequences of the block per trip)
+  if (wave && (gl0 & 0x2000000) != 0) {          // bit 25: the TRIO loop (lz4_decode_trio.h): copier, planner and scanner wavefronts = three host threads over one block of "LDS"
+    hostsim::GroupHost gp(gl, src, src_size, dst, out_size), gs(gl, src, src_size, dst, out_size);
+    gp.kWv = gs.kWv = g.kWv; gp.kWs = gs.kWs = g.kWs;
+    std::vector<uint64_t> lds((g.trio_lds_bytes() + 7u) / 8u, 0xEEEEEEEEEEEEEEEEull);
+    g.pair_lds = gp.pair_lds = gs.pair_lds = (uint8_t*)lds.data();
+    memset(g.pair_lds + g.pair_lds_bytes() - 64u, 0, 64);   // the control words
+    static std::atomic<uint64_t> seed3{0xC2B2AE3D27D4EB4Full};
+    g.nap_rng = seed3.fetch_add(0xD1B54A32D192ED03ull) | 1u; gp.nap_rng = g.nap_rng * 0x2545F4914F6CDD1Dull | 1u; gs.nap_rng = gp.nap_rng * 0x9E3779B97F4A7C15ull | 1u;
+    std::thread planner([&] { lz4hip::trio_service(gp, gp.pair_lds, false); });
+    std::thread scanner([&] { lz4hip::trio_service(gs, gs.pair_lds, true); });
+    r = safe ? lz4hip::decode_block<hostsim::GroupHost, true, 8>(g, src, src_size, dst, out_size, g.pair_lds)
+             : lz4hip::decode_block<hostsim::GroupHost, false, 8>(g, src, src_size, dst, out_size, g.pair_lds);
+    lz4hip::trio_quit(g, g.pair_lds);
+    planner.join(); scanner.join();
+    if (g.oob || gp.oob || gs.oob) return -1000000;
+    return r;
+  }
   if (wave && (gl0 & 0x1000000) != 0) {          // bit 24: the PAIR loop (lz4_decode_pair.h): a copier and a parser wavefront = two host threads over one block of "LDS"
     hostsim::GroupHost gp(gl, src, src_size, dst, out_size);
     gp.kWv = g.kWv; gp.kWs = g.kWs;

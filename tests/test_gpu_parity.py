@@ -145,7 +145,8 @@ def test_decode_fuzz_bit_exact(amd, ref, O, corpus):
                                      (1, 3, 0, 256), (1, 3, 0, 512), (4, 3, 0, 512), (4, 3, 0, 1024), (4, 3, 0, 2048), (8, 3, 0, 512), (8, 3, 0, 4096), (16, 3, 0, 4096),   # pipe 3: the ring loop (lz4_decode_ring.h); (4, 3, 2048) is the routed default of 12288..40959 big blocks
                                      (64, 4, 0, 0), (64, 4, 0, 8192), (64, 4, 0, 16384), (64, 4, 0, 32768), (64, 4, 0, 65536),   # pipe 4: the wave loop (lz4_decode_wave.h), a wavefront per block
                                      (64, 5, 0, 0), (64, 5, 0, 8192), (64, 5, 0, 16384), (64, 5, 0, 32768), (64, 5, 0, 65536),   # pipe 5: its parallel form, several sequences of the block per trip
-                                     (64, 7, 0, 0), (64, 7, 0, 16384), (64, 7, 0, 32768), (64, 7, 0, 65536)):   # pipe 7: the pair loop (lz4_decode_pair.h), a parser and a copier wavefront per block
+                                     (64, 7, 0, 0), (64, 7, 0, 16384), (64, 7, 0, 32768), (64, 7, 0, 65536),   # pipe 7: the pair loop (lz4_decode_pair.h), a parser and a copier wavefront per block
+                                     (64, 8, 0, 0), (64, 8, 0, 32768), (64, 8, 0, 65536)):                      # pipe 8: the trio loop (lz4_decode_trio.h): scanner, planner, copier
         amd.set_option("decode_lanes", lanes)
         amd.set_option("decode_pipe", pipe)
         amd.set_option("decode_stage", stage)
@@ -300,7 +301,8 @@ def test_decode_variants_at_odd_offsets(amd, ref, corpus):
                                      (1, 3, 0, 0), (4, 3, 0, 0), (4, 3, 0, 2048), (8, 3, 0, 0), (16, 3, 0, 0),   # (3: the ring loop flushes address-aligned steps)
                                      (64, 4, 0, 0), (64, 4, 0, 8192), (64, 4, 0, 16384), (64, 4, 0, 65536),   # (4: the wave loop flushes 256-byte steps, its first and last byte-exactly)
                                      (64, 5, 0, 0), (64, 5, 0, 8192), (64, 5, 0, 16384), (64, 5, 0, 65536),
-                                     (64, 7, 0, 0), (64, 7, 0, 16384), (64, 7, 0, 65536)):                      # (7: the pair loop, the same flusher in its copier wavefront)
+                                     (64, 7, 0, 0), (64, 7, 0, 16384), (64, 7, 0, 65536),                       # (7: the pair loop, the same flusher in its copier wavefront)
+                                     (64, 8, 0, 0), (64, 8, 0, 32768)):                                         # (8: the trio loop, the same copier)
         amd.set_option("decode_lanes", lanes); amd.set_option("decode_pipe", pipe); amd.set_option("decode_stage", stage); amd.set_option("decode_ring", ring)
         dst = bytearray(b"\xC3" * total)
         out = amd.LZ4HIPBatch.decompressSafe(bytes(src), so, [len(c) for c in comp], dst, dst_off, [len(b) for b in blocks])
@@ -327,7 +329,8 @@ def test_deep_decoder_loop_long_streams(amd, ref, O, corpus):
         for lanes, pipe, ring in ((4, 2, 0), (8, 2, 0), (16, 2, 0), (1, 3, 256), (1, 3, 512), (4, 3, 512), (4, 3, 1024), (4, 3, 2048), (8, 3, 512), (8, 3, 2048), (8, 3, 4096), (16, 3, 2048), (16, 3, 4096),
                                   (64, 4, 0), (64, 4, 8192), (64, 4, 16384), (64, 4, 32768), (64, 4, 65536),
                                   (64, 5, 0), (64, 5, 8192), (64, 5, 16384), (64, 5, 32768), (64, 5, 65536),
-                                  (64, 7, 0), (64, 7, 16384), (64, 7, 32768), (64, 7, 65536)):
+                                  (64, 7, 0), (64, 7, 16384), (64, 7, 32768), (64, 7, 65536),
+                                  (64, 8, 0), (64, 8, 32768), (64, 8, 65536)):
             amd.set_option("decode_lanes", lanes); amd.set_option("decode_pipe", pipe); amd.set_option("decode_stage", 0); amd.set_option("decode_ring", ring)
             res = gpu_decode_safe_many(amd, streams, caps)
             for k, ((r, d), (er, ed)) in enumerate(zip(res, want)):
@@ -351,7 +354,7 @@ def test_wave_par_trip_behind_a_one_sequence_step(amd, ref):
     want = [ref.decompress_safe_raw(c, n) for c, n in cases]
     assert all(r == n for (r, _), n in zip(want, caps))
     try:
-        for pipe, ring in ((5, 0), (5, 8192), (5, 16384), (5, 32768), (5, 65536), (4, 8192), (4, 65536), (7, 0), (7, 16384), (7, 32768), (7, 65536)):
+        for pipe, ring in ((5, 0), (5, 8192), (5, 16384), (5, 32768), (5, 65536), (4, 8192), (4, 65536), (7, 0), (7, 16384), (7, 32768), (7, 65536), (8, 0), (8, 32768), (8, 65536)):
             amd.set_option("decode_lanes", 64); amd.set_option("decode_pipe", pipe); amd.set_option("decode_stage", 0); amd.set_option("decode_ring", ring)
             res = gpu_decode_safe_many(amd, streams, caps)
             for k, ((r, d), (er, ed)) in enumerate(zip(res, want)):
@@ -372,7 +375,7 @@ def test_wave_loops_ring_edge_streams(amd, ref):
     want = [ref.decompress_safe_raw(c, n) for c, n in cases]
     assert all(r == n for (r, _), n in zip(want, caps))
     try:
-        for pipe, ring in ((5, 0), (5, 8192), (5, 16384), (5, 32768), (5, 65536), (4, 0), (4, 8192), (4, 32768), (7, 0), (7, 16384), (7, 32768), (7, 65536)):
+        for pipe, ring in ((5, 0), (5, 8192), (5, 16384), (5, 32768), (5, 65536), (4, 0), (4, 8192), (4, 32768), (7, 0), (7, 16384), (7, 32768), (7, 65536), (8, 0), (8, 32768), (8, 65536)):
             amd.set_option("decode_lanes", 64); amd.set_option("decode_pipe", pipe); amd.set_option("decode_stage", 0); amd.set_option("decode_ring", ring)
             res = gpu_decode_safe_many(amd, streams, caps)
             for k, ((r, d), (er, ed)) in enumerate(zip(res, want)):

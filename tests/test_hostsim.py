@@ -18,7 +18,7 @@ def load_sim():
     d = os.path.join(ROOT, "tests", "hostsim")
     so = os.path.join(d, "libhostsim.so")
     srcs = [os.path.join(d, f) for f in ("hostsim.cpp", "wave_host.h", "group_host.h")] + \
-           [os.path.join(ROOT, "lz4-java_amd", "csrc", f) for f in ("lz4_fast_core.h", "lz4_fast_ms_core.h", "lz4_fast_v2_core.h", "lz4_decode_core.h", "lz4_decode_deep.h", "lz4_decode_ring.h", "lz4_decode_wave.h", "lz4_decode_pair.h", "lz4_hc_core.h")]
+           [os.path.join(ROOT, "lz4-java_amd", "csrc", f) for f in ("lz4_fast_core.h", "lz4_fast_ms_core.h", "lz4_fast_v2_core.h", "lz4_decode_core.h", "lz4_decode_deep.h", "lz4_decode_ring.h", "lz4_decode_wave.h", "lz4_decode_pair.h", "lz4_decode_trio.h", "lz4_hc_core.h")]
     srcs.append(os.path.join(ROOT, "lz4-java_amd", "csrc", "mail_ring.h"))
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", so, os.path.join(d, "hostsim.cpp")])
@@ -397,11 +397,12 @@ def test_ring_decoder_loop(sim, ref, O, corpus):
 def wave_flag(log, ks1k=False, par=False):
     """sim_decompress flag of the wave loop: 64 lanes, bit 16, bits 17..21 = log2 of the output ring, bit 22 = 1 KB stream ring,
     bit 23 = the parallel loop (several sequences of the block per trip); par == "pair": bit 24 as well = the PAIR loop
-    (csrc/lz4_decode_pair.h: a parser and a copier wavefront per block -- two host threads over one block of "LDS")"""
-    return 64 | 0x10000 | (log << 17) | (0x400000 if ks1k else 0) | (0x800000 if par else 0) | (0x1000000 if par == "pair" else 0)
+    (csrc/lz4_decode_pair.h: a parser and a copier wavefront per block -- two host threads over one block of "LDS"); par == "trio":
+    bit 25 = the TRIO loop (csrc/lz4_decode_trio.h: scanner, planner, copier -- three host threads)"""
+    return 64 | 0x10000 | (log << 17) | (0x400000 if ks1k else 0) | (0x800000 if par else 0) | (0x1000000 if par == "pair" else 0) | (0x2000000 if par == "trio" else 0)
 
 
-@pytest.mark.parametrize("par", [False, True, "pair"])
+@pytest.mark.parametrize("par", [False, True, "pair", "trio"])
 def test_wave_decoder_loop(sim, ref, O, corpus, par):
     """The wave loop (csrc/lz4_decode_wave.h: one wavefront per block, stream ring + an output ring of 4 .. 64 KB in LDS, wave-uniform
     parse, pieces of up to 252 bytes stored as aligned dwords, far sources from flushed memory, byte-exact entry / exit flushes) in
@@ -451,7 +452,7 @@ def test_wave_decoder_loop(sim, ref, O, corpus, par):
         assert trips > 100000 and seqs > 1.2 * trips, (trips, seqs)   # trips did the work (this corpus is mostly irregular streams: App. F data runs 9-12 sequences per trip, text 18)
 
 
-@pytest.mark.parametrize("par", [False, True, "pair"])
+@pytest.mark.parametrize("par", [False, True, "pair", "trio"])
 def test_wave_decoder_small_and_fuzz(sim, ref, O, corpus, par):
     """the wave loop's instantiation of decode_block on everything the other decoders' fuzz test sees (short, empty, damaged and
     random streams: mostly the exact tiers with 64 lanes, the wave loop where a stream is long enough)"""
@@ -494,7 +495,7 @@ def test_wave_par_trip_behind_a_one_sequence_step(sim, ref, O):
             assert want_r == n
             for lg in sorted({log, 13, 16}):
                 for ks1k in (False, True):
-                    for par in (True, "pair"):
+                    for par in (True, "pair", "trio"):
                         r, d = sim_decode(sim, c, n, 1, wave_flag(lg, ks1k, par), shift=rng.choice([0, 3, 64, 131]))
                         assert r == n and d[:n] == want, (log, rep, lg, ks1k, par, r, n, next((i for i in range(min(r, n)) if d[i] != want[i]), None))
 
@@ -509,7 +510,7 @@ def test_wave_loops_ring_edge_streams(sim, ref):
         want_r, want = ref.decompress_safe_raw(c, n)
         assert want_r == n
         for log in (12, 13, 14, 15, 16):
-            for par in (True, "pair", False) if log in (13, 16) else (True, "pair"):
+            for par in (True, "pair", "trio", False) if log in (13, 16) else (True, "pair", "trio"):
                 r, d = sim_decode(sim, c, n, 1, wave_flag(log, rng.random() < 0.5, par), shift=rng.choice([0, 3, 64, 131, 255]))
                 assert r == n and d[:n] == want, (rep, log, par, r, n, next((i for i in range(min(max(r, 0), n)) if d[i] != want[i]), None))
 

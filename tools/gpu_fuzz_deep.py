@@ -44,9 +44,9 @@ src, so, sl, dst, do = pack(streams, caps)
 pipe = int(os.environ.get("FUZZ_PIPE", "2")); ring = int(os.environ.get("FUZZ_RING", "0"))
 # FUZZ_PIPE=4 [FUZZ_RING=8192|16384|32768|65536]: the wave loop (lz4_decode_wave.h), a wavefront per block
 # FUZZ_PIPE=7 [FUZZ_RING=16384|32768|65536]: the pair loop (lz4_decode_pair.h), a parser and a copier wavefront per block
-for lanes in ((4, 8, 16) if pipe == 2 else (64,) if pipe in (4, 5, 7) else (1, 4, 8, 16)):
+for lanes in ((4, 8, 16) if pipe == 2 else (64,) if pipe in (4, 5, 7, 8) else (1, 4, 8, 16)):
     amd.set_option("decode_lanes", lanes); amd.set_option("decode_pipe", pipe); amd.set_option("decode_stage", 0)
-    amd.set_option("decode_ring", ring if pipe in (4, 5, 7) or lanes != 1 or ring in (0, 256, 512) else 256)
+    amd.set_option("decode_ring", ring if pipe in (4, 5, 7, 8) or lanes != 1 or ring in (0, 256, 512) else 256)
     out = amd.LZ4HIPBatch.decompressSafe(src, so, sl, dst, do, caps)
     bad = 0
     for k, (r, (er, ed)) in enumerate(zip(out, want)):
