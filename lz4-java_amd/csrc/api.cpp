@@ -156,7 +156,7 @@ const char* decode_knobs_error(int lanes, int pipe, int ring) {
   const bool wave_ring = ring == 0 || ring == 8192 || ring == 16384 || ring == 32768 || ring == 65536;
   if (pipe == 4 || pipe == 5) return wave_ring ? nullptr : "decode_pipe 4 / 5 (the wave loops) take decode_ring 0, 8192, 16384, 32768 or 65536";
   if (pipe == 7) return (wave_ring && ring != 8192) ? nullptr : "decode_pipe 7 (the pair loop) takes decode_ring 0, 16384, 32768 or 65536";
-  if (pipe == 8) return (ring == 0 || ring == 32768 || ring == 65536) ? nullptr : "decode_pipe 8 (the trio loop) takes decode_ring 0, 32768 or 65536";
+  if (pipe == 8) return wave_ring ? nullptr : "decode_pipe 8 (the trio loop) takes decode_ring 0, 8192, 16384, 32768 or 65536";
   if (pipe == 3) {
     const int gl = lanes == 0 ? 4 : lanes;
     const int kw = ring ? ring : (gl == 1 ? 256 : gl == 4 ? 512 : 4096);

@@ -1155,8 +1155,10 @@ void set_route_short(int v) { g_route_short.store(v, std::memory_order_relaxed);
 // the trio loop's kernel (lz4_decode_trio.h): THREE WAVEFRONTS PER BLOCK -- wavefront 3p of the workgroup is the COPIER of trio p (it runs
 // decode_block), 3p + 1 its PLANNER, 3p + 2 its SCANNER: consecutive wavefronts of a workgroup sit on different SIMDs.  For launches of up
 // to two blocks per CU (W = 1, 2: the single-call path, the smallest batches), where SIMDs idle.
-template <int W, int KW, int KS, bool SAFE>
-__global__ __launch_bounds__(192 * W) void decode_trio_kernel(BatchArgs a, const uint32_t* route, uint32_t want) {
+// WPE: wavefronts per SIMD the kernel is compiled for (0: whatever its registers allow).  Two workgroups of four trios share a CU in the
+// 8 KB-ring form (24 wavefronts = 6 per SIMD: at most 80 VGPRs each).
+template <int W, int KW, int KS, bool SAFE, int WPE = 1>
+__global__ __launch_bounds__(192 * W, WPE) void decode_trio_kernel(BatchArgs a, const uint32_t* route, uint32_t want) {
   if (route && *route != want) return;
   typedef BlockWaveDev<KW, KS> G;
   static_assert(G::kMailSlots == PAIR_SLOTS && G::kMailSlotBytes == PAIR_SLOT_BYTES && G::kScanSlots == TRIO_SCAN_SLOTS && G::kScanBytes == TRIO_SCAN_BYTES, "queue layout");
@@ -1234,12 +1236,20 @@ static int launch_decode_trio_w(const BatchArgs& a, bool safe, hipStream_t st, c
   else hipLaunchKernelGGL((decode_trio_kernel<W, KW, KS, false>), dim3(grid), dim3(192 * W), 0, st, a, route, want);
   return (int)hipGetLastError();
 }
-// the trio loop: ring = bytes of the output ring (32768 / 65536; 0 = by batch size)
+// the trio loop: ring = bytes of the output ring (8192 / 16384 / 32768 / 65536; 0 = the largest that lets the batch spread over all CUs)
 static int launch_decode_trio(const BatchArgs& a, bool safe, int ring, hipStream_t st, const uint32_t* route = nullptr, uint32_t want = 0) {
-  if (ring == 0) ring = a.n <= 2u * device_cus() ? 65536 : 32768;
+  const uint32_t cus = device_cus();
+  if (ring == 0) ring = a.n <= 2u * cus ? 65536 : a.n <= 4u * cus ? 32768 : a.n <= 5u * cus ? 16384 : 8192;
   switch (ring) {
-    case 65536: return a.n <= device_cus() ? launch_decode_trio_w<1, 65536, 2048>(a, safe, st, route, want) : launch_decode_trio_w<2, 65536, 2048>(a, safe, st, route, want);
+    case 65536: return a.n <= cus ? launch_decode_trio_w<1, 65536, 2048>(a, safe, st, route, want) : launch_decode_trio_w<2, 65536, 2048>(a, safe, st, route, want);
     case 32768: return launch_decode_trio_w<4, 32768, 2048>(a, safe, st, route, want);
+    case 16384: return launch_decode_trio_w<5, 16384, 2048>(a, safe, st, route, want);   // (five trios = 960 threads: what a workgroup can have)
+    case 8192: {                                                                          // two workgroups of four trios per CU
+      const uint32_t wgs = (a.n + 3u) / 4u, grid = wgs < 2u * cus ? wgs : 2u * cus;
+      if (safe) hipLaunchKernelGGL((decode_trio_kernel<4, 8192, 1024, true, 6>), dim3(grid), dim3(768), 0, st, a, route, want);
+      else hipLaunchKernelGGL((decode_trio_kernel<4, 8192, 1024, false, 6>), dim3(grid), dim3(768), 0, st, a, route, want);
+      return (int)hipGetLastError();
+    }
     default: return (int)hipErrorInvalidValue;
   }
 }

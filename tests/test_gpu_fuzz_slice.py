@@ -28,7 +28,7 @@ def test_gpu_fuzz_slice(seed):
     assert "core 3: 2500 inputs bit-exact" in out and "decode safe/fast" in out
 
 
-@pytest.mark.parametrize("pipe,ring", [(2, 0), (3, 2048), (4, 0), (4, 8192), (5, 0), (5, 8192), (7, 0), (7, 16384), (8, 0), (8, 32768)])
+@pytest.mark.parametrize("pipe,ring", [(2, 0), (3, 2048), (4, 0), (4, 8192), (5, 0), (5, 8192), (7, 0), (7, 16384), (8, 0), (8, 8192), (8, 32768)])
 def test_gpu_fuzz_deep_slice(pipe, ring):
     """long streams, valid and damaged, through the deep loop, the ring loop with the 2 KiB ring the routed default uses, and the wave
     loop (its default ring for the batch and the smallest one)"""

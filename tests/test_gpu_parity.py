@@ -146,7 +146,7 @@ def test_decode_fuzz_bit_exact(amd, ref, O, corpus):
                                      (64, 4, 0, 0), (64, 4, 0, 8192), (64, 4, 0, 16384), (64, 4, 0, 32768), (64, 4, 0, 65536),   # pipe 4: the wave loop (lz4_decode_wave.h), a wavefront per block
                                      (64, 5, 0, 0), (64, 5, 0, 8192), (64, 5, 0, 16384), (64, 5, 0, 32768), (64, 5, 0, 65536),   # pipe 5: its parallel form, several sequences of the block per trip
                                      (64, 7, 0, 0), (64, 7, 0, 16384), (64, 7, 0, 32768), (64, 7, 0, 65536),   # pipe 7: the pair loop (lz4_decode_pair.h), a parser and a copier wavefront per block
-                                     (64, 8, 0, 0), (64, 8, 0, 32768), (64, 8, 0, 65536)):                      # pipe 8: the trio loop (lz4_decode_trio.h): scanner, planner, copier
+                                     (64, 8, 0, 0), (64, 8, 0, 8192), (64, 8, 0, 16384), (64, 8, 0, 32768), (64, 8, 0, 65536)):   # pipe 8: the trio loop (lz4_decode_trio.h): scanner, planner, copier
         amd.set_option("decode_lanes", lanes)
         amd.set_option("decode_pipe", pipe)
         amd.set_option("decode_stage", stage)
@@ -330,7 +330,7 @@ def test_deep_decoder_loop_long_streams(amd, ref, O, corpus):
                                   (64, 4, 0), (64, 4, 8192), (64, 4, 16384), (64, 4, 32768), (64, 4, 65536),
                                   (64, 5, 0), (64, 5, 8192), (64, 5, 16384), (64, 5, 32768), (64, 5, 65536),
                                   (64, 7, 0), (64, 7, 16384), (64, 7, 32768), (64, 7, 65536),
-                                  (64, 8, 0), (64, 8, 32768), (64, 8, 65536)):
+                                  (64, 8, 0), (64, 8, 8192), (64, 8, 16384), (64, 8, 32768), (64, 8, 65536)):
             amd.set_option("decode_lanes", lanes); amd.set_option("decode_pipe", pipe); amd.set_option("decode_stage", 0); amd.set_option("decode_ring", ring)
             res = gpu_decode_safe_many(amd, streams, caps)
             for k, ((r, d), (er, ed)) in enumerate(zip(res, want)):
@@ -354,7 +354,7 @@ def test_wave_par_trip_behind_a_one_sequence_step(amd, ref):
     want = [ref.decompress_safe_raw(c, n) for c, n in cases]
     assert all(r == n for (r, _), n in zip(want, caps))
     try:
-        for pipe, ring in ((5, 0), (5, 8192), (5, 16384), (5, 32768), (5, 65536), (4, 8192), (4, 65536), (7, 0), (7, 16384), (7, 32768), (7, 65536), (8, 0), (8, 32768), (8, 65536)):
+        for pipe, ring in ((5, 0), (5, 8192), (5, 16384), (5, 32768), (5, 65536), (4, 8192), (4, 65536), (7, 0), (7, 16384), (7, 32768), (7, 65536), (8, 0), (8, 8192), (8, 16384), (8, 32768), (8, 65536)):
             amd.set_option("decode_lanes", 64); amd.set_option("decode_pipe", pipe); amd.set_option("decode_stage", 0); amd.set_option("decode_ring", ring)
             res = gpu_decode_safe_many(amd, streams, caps)
             for k, ((r, d), (er, ed)) in enumerate(zip(res, want)):
@@ -375,7 +375,7 @@ def test_wave_loops_ring_edge_streams(amd, ref):
     want = [ref.decompress_safe_raw(c, n) for c, n in cases]
     assert all(r == n for (r, _), n in zip(want, caps))
     try:
-        for pipe, ring in ((5, 0), (5, 8192), (5, 16384), (5, 32768), (5, 65536), (4, 0), (4, 8192), (4, 32768), (7, 0), (7, 16384), (7, 32768), (7, 65536), (8, 0), (8, 32768), (8, 65536)):
+        for pipe, ring in ((5, 0), (5, 8192), (5, 16384), (5, 32768), (5, 65536), (4, 0), (4, 8192), (4, 32768), (7, 0), (7, 16384), (7, 32768), (7, 65536), (8, 0), (8, 8192), (8, 16384), (8, 32768), (8, 65536)):
             amd.set_option("decode_lanes", 64); amd.set_option("decode_pipe", pipe); amd.set_option("decode_stage", 0); amd.set_option("decode_ring", ring)
             res = gpu_decode_safe_many(amd, streams, caps)
             for k, ((r, d), (er, ed)) in enumerate(zip(res, want)):

@@ -97,7 +97,7 @@ def test_cfg3_reference_compressed_4MiB_blocks_every_decoder_variant(amd, ref, O
                                          (64, 4, 0, 0), (64, 4, 0, 8192), (64, 4, 0, 16384), (64, 4, 0, 32768),      # the wave loop: a wavefront per block
                                          (64, 5, 0, 0), (64, 5, 0, 8192), (64, 5, 0, 16384), (64, 5, 0, 32768),      # ... several sequences of the block per trip
                                          (64, 7, 0, 0), (64, 7, 0, 16384), (64, 7, 0, 32768),                        # the pair loop: two wavefronts per block
-                                         (64, 8, 0, 0), (64, 8, 0, 32768)):                                          # the trio loop: three
+                                         (64, 8, 0, 0), (64, 8, 0, 8192), (64, 8, 0, 16384), (64, 8, 0, 32768)):          # the trio loop: three
             amd.set_option("decode_lanes", lanes); amd.set_option("decode_pipe", pipe); amd.set_option("decode_stage", stage); amd.set_option("decode_ring", ring)
             back.zero_()
             amd.DeviceBatch.decompress_safe(dcomp, co, cl, back, B["so"], B["sl"], B["dlen"])
