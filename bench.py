@@ -161,9 +161,9 @@ def decode_kernel_name(n_blocks, safe=True, big_blocks=False):
     """the decoder instantiation launch_decompress (kernels.hip) picks: by batch size, and -- batches of 12288 .. 40959 blocks -- on the
     device by the blocks' compressed sizes (decode_route_kernel: blocks of >= 512 KiB go to the ring loop, csrc/lz4_decode_ring.h)"""
     s = "true" if safe else "false"
-    if n_blocks <= 4 * 256:    # up to 4 blocks per CU: a parser and a copier wavefront per block (csrc/lz4_decode_pair.h)
-        w, kw = (1, 65536) if n_blocks <= 256 else (2, 65536) if n_blocks <= 512 else (4, 32768)
-        return "decode_pair_kernel<%d, %d, 2048, %s>" % (w, kw, s)
+    if n_blocks <= 5 * 256:    # up to 5 blocks per CU: scanner, planner and copier wavefronts per block (csrc/lz4_decode_trio.h)
+        w, kw = (1, 65536) if n_blocks <= 256 else (2, 65536) if n_blocks <= 512 else (4, 32768) if n_blocks <= 1024 else (5, 16384)
+        return "decode_trio_kernel<%d, %d, 2048, %s, 1>" % (w, kw, s)
     if n_blocks <= 16 * 256:   # up to 16 blocks per CU: a wavefront per block, several sequences per trip (csrc/lz4_decode_wave.h)
         w, kw, ks = (8, 16384, 2048) if n_blocks <= 2048 else (16, 8192, 1024)
         return "decode_wave_kernel<%d, %d, %d, %s, 5>" % (w, kw, ks, s)

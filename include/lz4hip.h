@@ -59,16 +59,17 @@ const char* lz4hip_last_error(void);      /* thread-local description of the las
 int lz4hip_version(void);
 /* tuning knobs (not part of the reference API; process-wide atomics read once per launch; every setting produces the same bytes).
  * Which decoder a launch of n blocks gets with every knob at its default (CU = compute units of the device, 256 on an MI355X):
- *   n <= 4 CU    the pair loop (lz4_decode_pair.h): TWO wavefronts per block, a parser and a copier
+ *   n <= 5 CU    the trio loop (lz4_decode_trio.h): THREE wavefronts per block -- scanner, planner, copier
  *   n <= 16 CU   the parallel wave loop (lz4_decode_wave.h): a wavefront per block, several sequences of it per trip
  *   more         chosen ON THE DEVICE from a sample of the batch (decode_route_kernel): 12288 .. 40959 blocks averaging >= 512 KiB compressed ->
  *                the ring loop (lz4_decode_ring.h); sequences of "decode_route_short" or fewer output bytes on average with near match
  *                sources (text) -> the wave loop; otherwise the deep loop (lz4_decode_deep.h) below 40960 blocks and, from there on, for
  *                near match sources, else the 4-lane staged loop
- * "decode_pipe" = -1 (the table above) or one loop for every launch: 7 = pair loop, 5 = parallel wave loop, 4 = wave loop with one
+ * "decode_pipe" = -1 (the table above) or one loop for every launch: 8 = trio loop, 7 = pair loop (two wavefronts per block: a parser and a
+ *   copier), 5 = parallel wave loop, 4 = wave loop with one
  *   sequence per trip, 3 = ring loop, 2 = deep loop, 1 = two-trip pipelined loop, 0 = plain loop;
  * "decode_ring" = bytes of the output ring in LDS: 0 (by batch size) / 8192 / 16384 / 32768 / 65536 with decode_pipe 4 / 5,
- *   0 / 16384 / 32768 / 65536 with 7, 0 / 256 / 512 / 1024 / 2048 / 4096 with 3 (which ones: by "decode_lanes");
+ *   and 8, 0 / 16384 / 32768 / 65536 with 7, 0 / 256 / 512 / 1024 / 2048 / 4096 with 3 (which ones: by "decode_lanes");
  * "decode_lanes" = lanes of a wavefront sharing one block in the lane-group loops (0 = by batch size, 4 / 8 / 16 / 32 / 64; 1 with the ring
  *   loop: a lane per block); a combination no kernel exists for makes the next decode call fail with LZ4HIP_E_ARG and a message that names it;
  * "decode_stage" = 1 / 0 / -1 (by batch size): the plain loop writes through an LDS staging buffer so that output reaches memory as

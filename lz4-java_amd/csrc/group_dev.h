@@ -820,7 +820,15 @@ struct BlockWaveDev : GroupDev<64, 0> {
     const u4v16 h = *(lds128p)(e + 256u);
     T = uni(h.x); wip = uni(h.y); nextw = uni(h.z); flags = uni(h.w);
   }
-  __device__ __forceinline__ static void pm_nap() { __builtin_amdgcn_s_sleep(1); }    // a message is a few hundred cycles away
+  // (why: developer builds with -DLZ4HIP_RING_DBG count the naps by reason -- which stage of the trio loop waits for which: tools/wave_stats.py)
+  __device__ __forceinline__ static void pm_nap(uint32_t why = 7u) {                  // a message is a few hundred cycles away
+#ifdef LZ4HIP_RING_DBG
+    if ((threadIdx.x & 63u) == 0u) atomicAdd(&g_ring_stat[why & 7u], 1ull);
+#else
+    (void)why;
+#endif
+    __builtin_amdgcn_s_sleep(1);
+  }
   __device__ __forceinline__ static void pm_idle() { __builtin_amdgcn_s_sleep(8); }   // between entries: the copier is in decode_block's exact code, or between blocks
   __device__ __forceinline__ static const uint8_t* pm_ptr(uint32_t lo, uint32_t hi) {   // (through address space 1: a pointer rebuilt from integers is otherwise a FLAT pointer)
     typedef __attribute__((address_space(1))) const uint8_t* G;

@@ -1476,11 +1476,12 @@ int launch_decompress(const BatchArgs& a, bool safe, int lanes_per_block, int pi
   // trip (lz4_decode_wave.h, decode_pipe 5).  Against the lane-group loops below (GB/s of output, gpurun_out/r05j): 4 MiB blocks 256:
   // 17 -> 45, 2048: 135 -> 285, 4096: 272 -> 403 (8192: 519 -> 404, so not beyond 16 per CU); 64 KiB App. F 512: 31 -> 50, 2048: 120 -> 146,
   // 4096: 213 -> 232; 64 KiB text 512: 4.2 -> 16.1, 2048: 16.4 -> 49.6, 4096: 30.7 -> 66.4; one 64 KiB block 0.71 -> 0.43 ms.
-  // Round 6: up to FOUR blocks per CU a block gets TWO wavefronts -- a parser and a copier (lz4_decode_pair.h, decode_pipe 7): with at most
-  // one wavefront per SIMD the trip's two halves run side by side (4 MiB blocks 256: 69 -> 93 GB/s, 1024: 258 -> 293; one 64 KiB block
-  // 0.286 -> 0.223 ms).  From eight blocks per CU on the SIMDs are saturated by one wavefront per block (two per SIMD, each issuing 52 % of
-  // its cycles) and the second wavefront's messages are pure overhead (2048 x 4 MiB: 432 -> 393): profiles/r06_pair_notes.txt.
-  if (auto_lanes && pipe < 0 && stage < 0 && a.n <= 4u * device_cus()) return launch_decode_pair(a, safe, 0, st);
+  // Round 6: up to FIVE blocks per CU a block gets THREE wavefronts -- scanner, planner, copier (lz4_decode_trio.h, decode_pipe 8): with
+  // SIMDs to spare the trip's three parts run side by side (4 MiB blocks 256: 69 -> 120 GB/s, 1024: 259 -> 352, 1280: 270 -> 383; one 64 KiB
+  // block 0.284 -> 0.164 ms; two wavefronts -- the pair loop, decode_pipe 7 -- 93 / 295 / 0.221).  From six blocks per CU on one wavefront
+  // per block is the faster form again: two of them per SIMD each issue 52 % of their cycles, the SIMD is full, and more wavefronts per
+  // block only add their queues' instructions (2048 x 4 MiB: wave loop 432, trio with 8 KB rings 350, pair 393): profiles/r06_pair_notes.txt.
+  if (auto_lanes && pipe < 0 && stage < 0 && a.n <= 5u * device_cus()) return launch_decode_trio(a, safe, 0, st);
   if (auto_lanes && pipe < 0 && stage < 0 && a.n <= 16u * device_cus()) return launch_decode_wave(a, safe, true, 0, st);
   if (auto_lanes) lanes_per_block = a.n >= 40960u ? 4 : 8;
   const int p = pipe < 0 ? ((a.n < 40960u && lanes_per_block >= 8) ? (lanes_per_block <= 16 ? 2 : 1) : 0) : pipe;

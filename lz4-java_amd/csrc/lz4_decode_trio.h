@@ -57,7 +57,7 @@ LZ4HIP_DEV void trio_scan_loop(Grp& g, const uint8_t* src, const uint32_t iend, 
     while (shead - stail_seen >= TRIO_SCAN_SLOTS) {        // the planner is behind
       if (g.pm_peek(PC_STOP) == epoch) return false;
       stail_seen = g.pm_peek(PC_STAIL);
-      if (shead - stail_seen >= TRIO_SCAN_SLOTS) g.pm_nap();
+      if (shead - stail_seen >= TRIO_SCAN_SLOTS) g.pm_nap(0u);
     }
     g.sq_put(shead % TRIO_SCAN_SLOTS, posv, T, wip, nextw, flags);
     shead++;
@@ -79,7 +79,7 @@ LZ4HIP_DEV void trio_scan_loop(Grp& g, const uint8_t* src, const uint32_t iend, 
         }
         if (!((ip + AHEAD > avail) & (avail + STEP <= iend))) break;     // enough, or the end of the stream
         if (g.pm_peek(PC_STOP) == epoch) { stopped = true; break; }
-        g.pm_nap();                                                       // the copier still reads where the next step would go
+        g.pm_nap(1u);                                                     // the copier still reads where the next step would go
         keep = g.pm_peek(PC_IPDONE) & ~(STEP - 1u);
       }
       if (stopped | (ip + AHEAD > avail)) break;
@@ -136,7 +136,7 @@ LZ4HIP_DEV void trio_plan_loop(Grp& g, const uint32_t iend, const uint32_t oend,
   auto post = [&](const VU& w0, const VU& w1) {
     while (head - tail_seen >= PAIR_SLOTS) {
       tail_seen = g.pm_peek(PC_TAIL);
-      if (head - tail_seen >= PAIR_SLOTS) g.pm_nap();
+      if (head - tail_seen >= PAIR_SLOTS) g.pm_nap(3u);
     }
     g.pm_put(head % PAIR_SLOTS, w0, w1);
     head++;
@@ -148,7 +148,7 @@ LZ4HIP_DEV void trio_plan_loop(Grp& g, const uint32_t iend, const uint32_t oend,
   uint32_t wild = op;
   uint32_t exit_ip = 0u;
   for (;;) {
-    while (g.pm_peek(PC_SHEAD) == stail) g.pm_nap();
+    while (g.pm_peek(PC_SHEAD) == stail) g.pm_nap(2u);
     VU posv;
     uint32_t T, wip, nextw, flags;
     g.sq_get(stail % TRIO_SCAN_SLOTS, posv, T, wip, nextw, flags);
@@ -290,7 +290,7 @@ LZ4HIP_DEV void decode_trio_loop(Grp& g, const uint8_t* src, const int iend, uin
   const VB isM = (g.vlane() & 1u) != 0u;
   uint32_t tail = 0u;
   for (;;) {
-    while (g.pm_peek(PC_HEAD) == tail) g.pm_nap();
+    while (g.pm_peek(PC_HEAD) == tail) g.pm_nap(4u);
     VU w0, w1;
     g.pm_get(tail % PAIR_SLOTS, w0, w1);
     const uint32_t hdr = Grp::vreadlane(w0, 62u), opn = Grp::vreadlane(w1, 62u), mip = Grp::vreadlane(w0, 63u), ipn = Grp::vreadlane(w1, 63u);
@@ -322,7 +322,7 @@ LZ4HIP_DEV void decode_trio_loop(Grp& g, const uint8_t* src, const int iend, uin
     if (kind == PAIR_EXIT) break;
   }
   if (op + db != fl) g.wv_store(dst, fl, g.wv_read_al(fl), op0 + db, op + db);
-  while (g.pm_peek(PC_SACK) != epoch) g.pm_nap();   // the scanner has seen STOP (or its own end): nobody writes the rings or the queues any more
+  while (g.pm_peek(PC_SACK) != epoch) g.pm_nap(5u);   // the scanner has seen STOP (or its own end): nobody writes the rings or the queues any more
   ip_io = (int)ip; op_io = (int)op;
 }
 template <class Grp>

@@ -351,7 +351,7 @@ struct GroupHost {
     uint32_t h[4]; memcpy(h, e + 256, 16);
     T = h[0]; wip = h[1]; nextw = h[2]; flags = h[3];
   }
-  void pm_nap() { pair_naps++; std::this_thread::yield(); }
+  void pm_nap(uint32_t = 7u) { pair_naps++; std::this_thread::yield(); }
   void pm_idle() { std::this_thread::yield(); }
   static const uint8_t* pm_ptr(uint32_t lo, uint32_t hi) { return (const uint8_t*)(uintptr_t)(((uint64_t)hi << 32) | lo); }
   static inline std::atomic<uint64_t> pair_naps{0}, pair_entries{0};

@@ -130,9 +130,10 @@ def test_bench_names_the_decoder_the_library_routes_to():
     its `traffic`)."""
     import json
     import bench
-    want = {1: "decode_pair_kernel<1, 65536, 2048, true>", 256: "decode_pair_kernel<1, 65536, 2048, true>",
-            257: "decode_pair_kernel<2, 65536, 2048, true>", 512: "decode_pair_kernel<2, 65536, 2048, true>",
-            1024: "decode_pair_kernel<4, 32768, 2048, true>", 1025: "decode_wave_kernel<8, 16384, 2048, true, 5>", 2048: "decode_wave_kernel<8, 16384, 2048, true, 5>",
+    want = {1: "decode_trio_kernel<1, 65536, 2048, true, 1>", 256: "decode_trio_kernel<1, 65536, 2048, true, 1>",
+            257: "decode_trio_kernel<2, 65536, 2048, true, 1>", 512: "decode_trio_kernel<2, 65536, 2048, true, 1>",
+            1024: "decode_trio_kernel<4, 32768, 2048, true, 1>", 1280: "decode_trio_kernel<5, 16384, 2048, true, 1>",
+            1281: "decode_wave_kernel<8, 16384, 2048, true, 5>", 2048: "decode_wave_kernel<8, 16384, 2048, true, 5>",
             4096: "decode_wave_kernel<16, 8192, 1024, true, 5>", 4097: "decode_deep_kernel<8, true>", 16384: "decode_deep_kernel<8, true>",
             40959: "decode_deep_kernel<8, true>", 40960: "decode_kernel<4, true, 0, true>", 65536: "decode_kernel<4, true, 0, true>"}
     for n, name in want.items():
@@ -140,9 +141,9 @@ def test_bench_names_the_decoder_the_library_routes_to():
     assert bench.decode_kernel_name(16384, big_blocks=True) == "decode_ring_kernel<4, 2048, true>"
     assert bench.decode_kernel_name(65536, safe=False) == "decode_kernel<4, false, 0, true>"
     src = open(os.path.join(ROOT, "lz4-java_amd", "csrc", "kernels.hip")).read()
-    assert "a.n <= 4u * device_cus()" in src and "a.n <= 16u * device_cus()" in src and "a.n >= 40960u ? 4 : 8" in src and "a.n >= 12288u && a.n < 40960u" in src   # the thresholds the table restates
+    assert "a.n <= 5u * device_cus()" in src and "a.n <= 16u * device_cus()" in src and "a.n >= 40960u ? 4 : 8" in src and "a.n >= 12288u && a.n < 40960u" in src   # the thresholds the table restates
     tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     if tr.get("kernel_source_hash") == bench.kernel_source_hash():
         for name in ("decode_kernel<4, true, 0, true>", "decode_kernel<4, false, 0, true>", "decode_ring_kernel<4, 2048, true>", "decode_wave_kernel<8, 16384, 2048, true, 5>",
-                     "decode_pair_kernel<1, 65536, 2048, true>", "compress_fast_v2w_cu_kernel", "compress_fast_v2wp_cu_kernel"):
+                     "decode_trio_kernel<1, 65536, 2048, true, 1>", "compress_fast_v2w_cu_kernel", "compress_fast_v2wp_cu_kernel"):
             assert name in tr["kernels"], name

@@ -27,7 +27,7 @@ for db in glob.glob(os.path.join(d, "*", "pmc_results.db")):
     # batch has no such block: its real launch is the biggest one (compress_4MiB).
     # decode_wave_kernel<8, 16384, ..> (a wavefront per block): the configs2_shard8 launch (2048 x 4 MiB) and small launches of 64 KiB
     # blocks: its biggest dispatch is the shard
-    BIGGEST = ("decode_deep_kernel<8, true>", "decode_ring_kernel<4, 2048, true>", "compress_fast_v2wp_cu_kernel", "decode_wave_kernel<8, 16384", "decode_wave_kernel<16, 8192", "decode_pair_kernel")
+    BIGGEST = ("decode_deep_kernel<8, true>", "decode_ring_kernel<4, 2048, true>", "compress_fast_v2wp_cu_kernel", "decode_wave_kernel<8, 16384", "decode_wave_kernel<16, 8192", "decode_pair_kernel", "decode_trio_kernel")
     for (k, c), vs in rows.items():
         if any(h in k for h in HEADLINE_FIRST):
             vs = vs[:3]
