@@ -797,6 +797,17 @@ struct BlockWaveDev : GroupDev<64, 0> {
     u2v8 t; t.x = w0; t.y = w1;
     *(lds64p)(pmb + slot * kMailSlotBytes + 2u * l4) = t;
   }
+  // a control word and a message slot in ONE round trip: the slot is read BEHIND the word (the LDS executes the two reads in order), so if
+  // the word says the slot is published the data are the message; if not, they are discarded (the copier of the trio loop: HEAD + its next slot)
+  __device__ __forceinline__ uint32_t pm_peek_get(uint32_t i, uint32_t slot, uint32_t& w0, uint32_t& w1) const {
+    asm volatile("" ::: "memory");
+    const uint32_t v = *(lds32vp)(pmb + kMailSlots * kMailSlotBytes + 4u * i);
+    asm volatile("" ::: "memory");
+    const u2v8 t = *(lds64p)(pmb + slot * kMailSlotBytes + 2u * l4);
+    asm volatile("" ::: "memory");
+    w0 = t.x; w1 = t.y;
+    return uni(v);
+  }
   __device__ __forceinline__ void pm_get(uint32_t slot, uint32_t& w0, uint32_t& w1) const {
     const u2v8 t = *(lds64p)(pmb + slot * kMailSlotBytes + 2u * l4);
     w0 = t.x; w1 = t.y;

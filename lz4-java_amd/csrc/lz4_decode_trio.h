@@ -287,12 +287,25 @@ LZ4HIP_DEV void decode_trio_loop(Grp& g, const uint8_t* src, const int iend, uin
   g.pm_post(PC_IP, ip); g.pm_post(PC_OP, op); g.pm_post(PC_IEND, (uint32_t)iend); g.pm_post(PC_OEND, (uint32_t)oend); g.pm_post(PC_DB, db);
   g.pm_post(PC_SRC_LO, (uint32_t)(uintptr_t)src); g.pm_post(PC_SRC_HI, (uint32_t)((uint64_t)(uintptr_t)src >> 32));
   g.pm_post(PC_CMD, epoch);
+  typedef typename Grp::LChunk LChunk;
   const VB isM = (g.vlane() & 1u) != 0u;
   uint32_t tail = 0u;
   for (;;) {
-    while (g.pm_peek(PC_HEAD) == tail) g.pm_nap(4u);
+    // flusher: the whole aligned steps below op -- the messages before this one put them into the ring -- are REQUESTED here, in front of
+    // the wait for the next message, and stored once that has arrived: their LDS round trips hide behind it (they stood at the end of
+    // every message, one after the other: the copier is the trio's slowest stage on big blocks, tools/trio_stats.py).  Memory holds
+    // everything below (op + db) & ~255 before the message's far loads, as the planner assumed
+    const uint32_t pend = (op + db - fl) >> 8;
+    LChunk fx0 = LChunk(), fx1 = LChunk(), fx2 = LChunk();
+    if (pend >= 1u) fx0 = g.wv_read_al(fl);
+    if (pend >= 2u) fx1 = g.wv_read_al(fl + STEP);
+    if (pend >= 3u) fx2 = g.wv_read_al(fl + 2u * STEP);
     VU w0, w1;
-    g.pm_get(tail % PAIR_SLOTS, w0, w1);
+    while (g.pm_peek_get(PC_HEAD, tail % PAIR_SLOTS, w0, w1) == tail) g.pm_nap(4u);   // (the word and the slot behind it in one round trip)
+    if (pend >= 1u) { g.wv_store(dst, fl, fx0, op0 + db, 0xFFFFFFFFu); fl += STEP; }
+    if (pend >= 2u) { g.wv_store(dst, fl, fx1, op0 + db, 0xFFFFFFFFu); fl += STEP; }
+    if (pend >= 3u) { g.wv_store(dst, fl, fx2, op0 + db, 0xFFFFFFFFu); fl += STEP; }
+    while (LZ4HIP_UNLIKELY(op + db - fl >= STEP)) { g.wv_store(dst, fl, g.wv_read_al(fl), op0 + db, 0xFFFFFFFFu); fl += STEP; }
     const uint32_t hdr = Grp::vreadlane(w0, 62u), opn = Grp::vreadlane(w1, 62u), mip = Grp::vreadlane(w0, 63u), ipn = Grp::vreadlane(w1, 63u);
     const uint32_t kind = hdr & 255u;
     if (kind == PAIR_PASS) {
@@ -318,9 +331,9 @@ LZ4HIP_DEV void decode_trio_loop(Grp& g, const uint8_t* src, const int iend, uin
     tail++;
     g.pm_post(PC_IPDONE, ipn);                  // behind the message's last read of the stream ring: nothing in front of the next message's sequences is needed any more
     g.pm_post(PC_TAIL, tail);
-    while (op + db - fl >= STEP) { g.wv_store(dst, fl, g.wv_read_al(fl), op0 + db, 0xFFFFFFFFu); fl += STEP; }
     if (kind == PAIR_EXIT) break;
   }
+  while (op + db - fl >= STEP) { g.wv_store(dst, fl, g.wv_read_al(fl), op0 + db, 0xFFFFFFFFu); fl += STEP; }
   if (op + db != fl) g.wv_store(dst, fl, g.wv_read_al(fl), op0 + db, op + db);
   while (g.pm_peek(PC_SACK) != epoch) g.pm_nap(5u);   // the scanner has seen STOP (or its own end): nobody writes the rings or the queues any more
   ip_io = (int)ip; op_io = (int)op;

@@ -330,6 +330,11 @@ struct GroupHost {
     if (slot >= kMailSlots) { oob = true; return; }
     for (int l = 0; l < 64; l++) { memcpy(pmb + slot * kMailSlotBytes + 8u * l, &w0.v[l], 4); memcpy(pmb + slot * kMailSlotBytes + 8u * l + 4u, &w1.v[l], 4); }
   }
+  uint32_t pm_peek_get(uint32_t i, uint32_t slot, V<uint32_t>& w0, V<uint32_t>& w1) {   // (the word first, the slot behind it)
+    const uint32_t v = pm_peek(i);
+    pm_get(slot, w0, w1);
+    return v;
+  }
   void pm_get(uint32_t slot, V<uint32_t>& w0, V<uint32_t>& w1) {
     if (slot >= kMailSlots) { oob = true; return; }
     for (int l = 0; l < 64; l++) { memcpy(&w0.v[l], pmb + slot * kMailSlotBytes + 8u * l, 4); memcpy(&w1.v[l], pmb + slot * kMailSlotBytes + 8u * l + 4u, 4); }
