@@ -788,6 +788,12 @@ struct BlockWaveDev : GroupDev<64, 0> {
     asm volatile("" ::: "memory");
     return uni(v);
   }
+  __device__ __forceinline__ void pm_peek2(uint32_t i, uint32_t& a, uint32_t& b) const {   // control words i (even) and i + 1 in one round trip
+    asm volatile("" ::: "memory");
+    const u2v8 t = *(__attribute__((address_space(3))) volatile u2v8*)(pmb + kMailSlots * kMailSlotBytes + 4u * i);
+    asm volatile("" ::: "memory");
+    a = uni(t.x); b = uni(t.y);
+  }
   __device__ __forceinline__ void pm_post(uint32_t i, uint32_t v) {
     asm volatile("" ::: "memory");
     if (this->l == 0u) *(lds32vp)(pmb + kMailSlots * kMailSlotBytes + 4u * i) = v;
@@ -824,6 +830,18 @@ struct BlockWaveDev : GroupDev<64, 0> {
     *(lds32p)(e + l4) = posv;
     const uint32_t hv = this->l == 0u ? T : this->l == 1u ? wip : this->l == 2u ? nextw : flags;
     if (this->l < 4u) *(lds32p)(e + 256u + l4) = hv;
+  }
+  // (a control word and the entry behind it in one round trip: pm_peek_get's rule)
+  __device__ __forceinline__ uint32_t sq_peek_get(uint32_t i, uint32_t slot, uint32_t& posv, uint32_t& T, uint32_t& wip, uint32_t& nextw, uint32_t& flags) const {
+    asm volatile("" ::: "memory");
+    const uint32_t v = *(lds32vp)(pmb + kMailSlots * kMailSlotBytes + 4u * i);
+    asm volatile("" ::: "memory");
+    lds8p e = pmb + kMailBytes + slot * kScanBytes;
+    posv = *(lds32p)(e + l4);
+    const u4v16 h = *(lds128p)(e + 256u);
+    asm volatile("" ::: "memory");
+    T = uni(h.x); wip = uni(h.y); nextw = uni(h.z); flags = uni(h.w);
+    return uni(v);
   }
   __device__ __forceinline__ void sq_get(uint32_t slot, uint32_t& posv, uint32_t& T, uint32_t& wip, uint32_t& nextw, uint32_t& flags) const {
     lds8p e = pmb + kMailBytes + slot * kScanBytes;

@@ -30,7 +30,7 @@ namespace lz4hip {
 
 constexpr uint32_t TRIO_SCAN_SLOTS = 3u;       // windows in flight between scanner and planner
 constexpr uint32_t TRIO_SCAN_BYTES = 288u;     // 64 positions (a dword each) + {count, window position, next window, flags} + pad
-enum : uint32_t { PC_SHEAD = 11u, PC_STAIL = 12u, PC_STOP = 13u, PC_SACK = 14u, PC_IPDONE = 15u };   // (behind the pair loop's control words)
+enum : uint32_t { PC_SHEAD = 11u, PC_STAIL = 12u, PC_SACK = 13u, PC_STOP = 14u, PC_IPDONE = 15u };   // (behind the pair loop's control words; STOP and IPDONE are one aligned pair: the scanner reads both at the top of every window)
 constexpr uint32_t TRIO_END = 1u;              // flags: the scanner's last entry -- the loop ends at its window position
 
 // ---- SCANNER ----
@@ -65,12 +65,14 @@ LZ4HIP_DEV void trio_scan_loop(Grp& g, const uint8_t* src, const uint32_t iend, 
     return true;
   };
   for (;;) {
-    if (g.pm_peek(PC_STOP) == epoch) { stopped = true; break; }
+    uint32_t stop, ipdone;
+    g.pm_peek2(PC_STOP, stop, ipdone);
+    if (stop == epoch) { stopped = true; break; }
     if (ip > ilim) break;
     // the stream ring keeps everything from the copier's oldest unfinished message on (it reads literals there; the planner is ahead of
     // it).  IPDONE = where the sequences of the copier's NEXT message begin: with nothing in flight that is this window, and the
     // condition below is the one-wavefront loop's (a 1 KB stream ring cannot hold the previous window's start AND this window's 512 bytes)
-    uint32_t keep = g.pm_peek(PC_IPDONE) & ~(STEP - 1u);
+    uint32_t keep = ipdone & ~(STEP - 1u);
     if (LZ4HIP_UNLIKELY(ip + AHEAD > avail)) {
       for (;;) {
         while ((ip + AHEAD > avail) & (avail + STEP <= iend) & (avail + STEP <= keep + KS)) {
@@ -148,10 +150,9 @@ LZ4HIP_DEV void trio_plan_loop(Grp& g, const uint32_t iend, const uint32_t oend,
   uint32_t wild = op;
   uint32_t exit_ip = 0u;
   for (;;) {
-    while (g.pm_peek(PC_SHEAD) == stail) g.pm_nap(2u);
     VU posv;
     uint32_t T, wip, nextw, flags;
-    g.sq_get(stail % TRIO_SCAN_SLOTS, posv, T, wip, nextw, flags);
+    while (g.sq_peek_get(PC_SHEAD, stail % TRIO_SCAN_SLOTS, posv, T, wip, nextw, flags) == stail) g.pm_nap(2u);   // (the word and the entry behind it in one round trip)
     if (flags & TRIO_END) { exit_ip = wip; break; }
     uint32_t tk = 0u;
     bool leave = false;

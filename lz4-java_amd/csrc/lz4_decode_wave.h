@@ -31,10 +31,6 @@
 #pragma once
 #include <stdint.h>
 
-#ifndef LZ4HIP_WAVE_FLUSH_TOP
-#define LZ4HIP_WAVE_FLUSH_TOP 0   /* 1: the parallel wave loop's flusher at the TOP of the trip (developer A/B builds: tools/r06j.sh) */
-#endif
-
 namespace lz4hip {
 
 // entry: ip + 1024 <= iend (three 256-byte steps of the stream around ip are readable), ip <= iend - 306, op <= oend - 606 (the
@@ -301,17 +297,6 @@ LZ4HIP_DEV void decode_wave_par_loop(Grp& g, const uint8_t* src, const int iend,
     // relative to ip.  (The window is read as ALIGNED dwords funnelled in registers: five unaligned reads by 64 lanes kept the CU's
     // LDS busy for ~400 cycles per trip -- SQ_LDS_UNALIGNED_STALL was 80 % of SQ_LDS_IDX_ACTIVE and at 16 wavefronts per CU the LDS,
     // not the wavefronts, set the pace: 4096 x 4 MiB 110 ms, gpurun_out/r05g) ----
-#if LZ4HIP_WAVE_FLUSH_TOP
-    // ---- flusher: whole aligned steps below op -- the trip before this one put them into the ring (LDS operations of a wavefront execute in
-    // order) -- are REQUESTED here, next to the window read, and stored behind the discovery: their LDS round trips (two or three steps a trip)
-    // hide behind the discovery's arithmetic instead of standing at the trip's end, one after the other.  Memory holds everything below
-    // (op + db) & ~255 before the trip's passes look at `fl`, as before ----
-    const uint32_t pend = (op + db - fl) >> 8;
-    LChunk fx0 = LChunk(), fx1 = LChunk(), fx2 = LChunk();
-    if (pend >= 1u) fx0 = g.wv_read_al(fl);
-    if (pend >= 2u) fx1 = g.wv_read_al(fl + STEP);
-    if (pend >= 3u) fx2 = g.wv_read_al(fl + 2u * STEP);
-#endif
     VU posv = VU(0u);
     uint32_t T = 0u;
     VU blo, bhi;
@@ -327,12 +312,6 @@ LZ4HIP_DEV void decode_wave_par_loop(Grp& g, const uint8_t* src, const int iend,
         const VU nxt = p0 + (j + 3u) + Grp::vsel(l15, VU(1u), VU(0u)) + tl + Grp::vsel(l15, e1, VU(0u)) + Grp::vsel((w & 15u) == 15u, VU(1u), VU(0u));
         nxpack = nxpack | (Grp::vsel(nxt <= 250u, nxt, VU(255u)) << (8 * (int)j));
       }
-#if LZ4HIP_WAVE_FLUSH_TOP
-      if (pend >= 1u) { g.wv_store(dst, fl, fx0, op0 + db, 0xFFFFFFFFu); fl += STEP; }
-      if (pend >= 2u) { g.wv_store(dst, fl, fx1, op0 + db, 0xFFFFFFFFu); fl += STEP; }
-      if (pend >= 3u) { g.wv_store(dst, fl, fx2, op0 + db, 0xFFFFFFFFu); fl += STEP; }
-      while (LZ4HIP_UNLIKELY(op + db - fl >= STEP)) { g.wv_store(dst, fl, g.wv_read_al(fl), op0 + db, 0xFFFFFFFFu); fl += STEP; }
-#endif
       Grp::vwalk(nxpack, posv, T);              // the starts of the sequences in the window, the k-th to lane k
     }
     // ---- 3. records, output positions: A LANE PER RUN -- lane 2k the literals of a sequence, lane 2k + 1 its match.  (A lane per
@@ -431,10 +410,11 @@ LZ4HIP_DEV void decode_wave_par_loop(Grp& g, const uint8_t* src, const int iend,
       g.rs_put(avail, rf0);
       avail += STEP;
     }
-#if !LZ4HIP_WAVE_FLUSH_TOP
-    // ---- flusher: whole aligned steps below op ----
+    // ---- flusher: whole aligned steps below op.  (Requested at the TOP of the next trip instead, next to the window read, and stored behind
+    // the discovery -- what the trio loop's copier does in front of its wait for a message, +5 % there -- it is 1.5 % SLOWER here: 2048 x 4 MiB
+    // 429.7 -> 422.8 GB/s, 4096: 578.8 -> 572.0, gpurun_out/r06j: at two and four wavefronts per SIMD the round trips are hidden by the other
+    // wavefronts already, and the three conditional stores in the middle of the trip cost more than they save) ----
     while (op + db - fl >= STEP) { g.wv_store(dst, fl, g.wv_read_al(fl), op0 + db, 0xFFFFFFFFu); fl += STEP; }
-#endif
   }
   while (op + db - fl >= STEP) { g.wv_store(dst, fl, g.wv_read_al(fl), op0 + db, 0xFFFFFFFFu); fl += STEP; }
   if (op + db != fl) g.wv_store(dst, fl, g.wv_read_al(fl), op0 + db, op + db);

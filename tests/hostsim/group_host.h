@@ -349,6 +349,12 @@ struct GroupHost {
     const uint32_t h[4] = {T, wip, nextw, flags};
     memcpy(e + 256, h, 16);
   }
+  void pm_peek2(uint32_t i, uint32_t& a, uint32_t& b) { if (i & 1u) oob = true; a = pm_peek(i); b = pm_peek(i + 1u); }   // (the device reads the two words with one aligned 8-byte load: they are published one at a time, so either order of the two loads is one the device can see)
+  uint32_t sq_peek_get(uint32_t i, uint32_t slot, V<uint32_t>& posv, uint32_t& T, uint32_t& wip, uint32_t& nextw, uint32_t& flags) {
+    const uint32_t v = pm_peek(i);
+    sq_get(slot, posv, T, wip, nextw, flags);
+    return v;
+  }
   void sq_get(uint32_t slot, V<uint32_t>& posv, uint32_t& T, uint32_t& wip, uint32_t& nextw, uint32_t& flags) {
     if (slot >= kScanSlots) { oob = true; return; }
     const uint8_t* e = pmb + kMailBytes + slot * kScanBytes;
