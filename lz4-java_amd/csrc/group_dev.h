@@ -454,6 +454,20 @@ struct BlockWaveDev : GroupDev<64, 0> {
     __builtin_memcpy(&r, src + pos + l4, 4);
     return r;
   }
+  // the stream's LAST, partial step (pos: a multiple of 256 with pos < iend < pos + 256): the bytes below iend, zeros behind them -- nothing at
+  // or behind src + iend is read (the trio loop's scanner: with it the whole stream is in the ring and the loop runs up to the block's last
+  // 306 bytes instead of leaving the last 512 .. 767 to the slower loops behind it)
+  __device__ __forceinline__ LChunk rs_fetch_upto(const uint8_t* src, uint32_t pos, uint32_t iend) const {
+    LChunk r;
+    r.w[0] = 0u;
+    const uint32_t a = pos + l4;
+    if (a + 4u <= iend) __builtin_memcpy(&r, src + a, 4);
+    else {
+#pragma unroll
+      for (uint32_t k = 0; k < 3u; k++) if (a + k < iend) r.w[0] |= (uint32_t)src[a + k] << (8u * k);
+    }
+    return r;
+  }
   __device__ __forceinline__ void rs_put(uint32_t pos, const LChunk& r) {
     const uint32_t q = (pos & ((uint32_t)KS - 1u)) + l4;
     *Base::dwp(wsb + q) = r.w[0];

@@ -79,12 +79,18 @@ LZ4HIP_DEV void trio_scan_loop(Grp& g, const uint8_t* src, const uint32_t iend, 
           g.rs_put(avail, g.rs_fetch(src, avail));
           avail += STEP;
         }
-        if (!((ip + AHEAD > avail) & (avail + STEP <= iend))) break;     // enough, or the end of the stream
+        // the stream's last, partial step: its bytes below iend (zeros behind them).  With it the WHOLE stream is in the ring and the windows
+        // go on up to ilim -- a sequence that starts there ends inside the stream; what a window reads behind iend is nothing the planner uses
+        if ((ip + AHEAD > avail) & (avail < iend) & (avail + STEP > iend) & (avail + STEP <= keep + KS)) {
+          g.rs_put(avail, g.rs_fetch_upto(src, avail, iend));
+          avail += STEP;
+        }
+        if (!((ip + AHEAD > avail) & (avail < iend))) break;             // enough, or the whole stream
         if (g.pm_peek(PC_STOP) == epoch) { stopped = true; break; }
         g.pm_nap(1u);                                                     // the copier still reads where the next step would go
         keep = g.pm_peek(PC_IPDONE) & ~(STEP - 1u);
       }
-      if (stopped | (ip + AHEAD > avail)) break;
+      if (stopped | ((ip + AHEAD > avail) & (avail < iend))) break;
     }
     uint32_t nf = 0u;
     if ((avail + STEP <= iend) & (avail + STEP <= keep + KS)) {

@@ -229,6 +229,14 @@ struct GroupHost {
     for (int l = 0; l < GL; l++) if (rd_ok(s + pos + l * LB, LB)) memcpy(r.b[l], s + pos + l * LB, LB);
     return r;
   }
+  LChunk rs_fetch_upto(const uint8_t* s, uint32_t pos, uint32_t iend) {   // (wave backend: a dword per lane; nothing at or behind s + iend is read)
+    LChunk r; memset(&r, 0, sizeof r);
+    for (int l = 0; l < GL; l++) {
+      const uint32_t a = pos + 4u * (uint32_t)l;
+      for (uint32_t k = 0; k < 4u; k++) if (a + k < iend && rd_ok(s + a + k, 1)) r.b[l][k] = s[a + k];
+    }
+    return r;
+  }
   void rs_put(uint32_t pos, const LChunk& r) {
     const uint32_t LB = lb();
     for (int l = 0; l < GL; l++) {
