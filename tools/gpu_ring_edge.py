@@ -26,7 +26,10 @@ for c, m in cases:
     so.append(p); do.append(q); p += len(c); q += m + 64
 total = 0
 try:
-    for pipe, ring in ((5, 0), (5, 8192), (5, 16384), (5, 32768), (5, 65536), (4, 0), (4, 8192), (4, 16384), (4, 65536)):
+    variants = ((5, 0), (5, 8192), (5, 16384), (5, 32768), (5, 65536), (4, 0), (4, 8192), (4, 16384), (4, 65536))
+    if os.environ.get("RING_EDGE_PIPES") == "78":   # the pair and trio loops (round 6)
+        variants = ((7, 0), (7, 16384), (7, 32768), (7, 65536), (8, 0), (8, 8192), (8, 16384), (8, 32768), (8, 65536))
+    for pipe, ring in variants:
         amd.set_option("decode_lanes", 64); amd.set_option("decode_pipe", pipe); amd.set_option("decode_stage", 0); amd.set_option("decode_ring", ring)
         dst = bytearray(q)
         out = amd.LZ4HIPBatch.decompressSafe(src, so, [len(c) for c in streams], dst, do, caps)
