@@ -587,6 +587,30 @@ struct BlockWaveDev : GroupDev<64, 0> {
         : "m0", "scc", "vcc");
 #undef LZ4HIP_WALK_HOP
   }
+  // The same walk by POINTER DOUBLING, for windows full of sequences (text: ~58 starts in 256 bytes, i.e. ~460 scalar instructions of the
+  // walk above = a third of a text trip): J_0 = nx (the successor of every window position, a byte each, four per lane); J_k = J_(k-1) o
+  // J_(k-1) is the 2^k-th successor -- four lane gathers per level, five levels; the start of rank r is J_5^(b5) .. J_0^(b0) (0) with b the
+  // bits of r -- one gather per level for all 64 ranks at once, lane r its own.  Position 255 is its own successor, so ranks past the last
+  // start read 255 and T is the first such lane, as above.  ~190 vector instructions whatever T: the caller takes it when the window before
+  // this one held 24 starts or more.  Same posv, same T as vwalk -- the CPU suite's backend computes both and compares.
+  __device__ __forceinline__ static uint32_t vgather8(VU tab, VU q) {   // byte q (0 .. 255) of a 256-byte table held four bytes per lane
+    const uint32_t t = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(q & ~3u), (int)tab);
+    return (t >> ((q & 3u) * 8u)) & 255u;
+  }
+  __device__ __forceinline__ static void vwalk_par(VU nx, VU lane, VU& posv, uint32_t& T) {
+    VU J = nx;
+    VU pos = (lane & 1u) ? vgather8(J, VU(0u)) : VU(0u);
+#pragma unroll
+    for (uint32_t k = 1; k < 6u; k++) {
+      const VU n0 = vgather8(J, J & 255u), n1 = vgather8(J, (J >> 8) & 255u), n2 = vgather8(J, (J >> 16) & 255u), n3 = vgather8(J, J >> 24);
+      J = n0 | (n1 << 8) | (n2 << 16) | (n3 << 24);
+      const VU nxt = vgather8(J, pos);
+      pos = ((lane >> k) & 1u) ? nxt : pos;
+    }
+    posv = pos;
+    const uint64_t endm = __builtin_amdgcn_ballot_w64(pos == 255u);
+    T = endm ? (uint32_t)__builtin_ctzll(endm) : 64u;
+  }
   __device__ __forceinline__ static VU vshfl(VU v, VU srcl) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(srcl << 2), (int)v); }
   __device__ __forceinline__ static VU vexcl_scan(VU a) {   // exclusive prefix sum across the wavefront: row_shr DPP adds + row_bcast15/31
     int x = (int)a;

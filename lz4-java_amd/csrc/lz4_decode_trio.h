@@ -53,6 +53,7 @@ LZ4HIP_DEV void trio_scan_loop(Grp& g, const uint8_t* src, const uint32_t iend, 
   const VU lane = g.vlane();
   const VU p0 = lane * 4u;
   bool stopped = false;
+  uint32_t Tprev = 0u;
   auto post = [&](const VU& posv, uint32_t T, uint32_t wip, uint32_t nextw, uint32_t flags) -> bool {
     while (shead - stail_seen >= TRIO_SCAN_SLOTS) {        // the planner is behind
       if (g.pm_peek(PC_STOP) == epoch) return false;
@@ -113,7 +114,8 @@ LZ4HIP_DEV void trio_scan_loop(Grp& g, const uint8_t* src, const uint32_t iend, 
         nxfull[j] = nxt;
         nxpack = nxpack | (Grp::vsel(nxt <= 250u, nxt, VU(255u)) << (8 * (int)j));
       }
-      Grp::vwalk(nxpack, posv, T);
+      if (Tprev >= 24u) Grp::vwalk_par(nxpack, lane, posv, T); else Grp::vwalk(nxpack, posv, T);   // (lz4_decode_wave.h: pointer doubling for windows full of sequences)
+      Tprev = T;
     }
     // where the next window begins: behind the last sequence that starts in this one (the same formula, not clamped to the window)
     const uint32_t lp = Grp::vreadlane(posv, T - 1u);

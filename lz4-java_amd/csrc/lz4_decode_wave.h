@@ -265,6 +265,7 @@ LZ4HIP_DEV void decode_wave_par_loop(Grp& g, const uint8_t* src, const int iend,
   const VU lane = g.vlane();
   const VU p0 = lane * 4u;
   uint32_t wild = op;                          // end of what one-sequence steps have written into the ring (see `bound`)
+  uint32_t Tprev = 0u;                         // starts the window before this one held (which walk this one gets)
 #ifdef LZ4HIP_RING_DBG   /* developer build: what the loop did (tools/wave_stats.py) */
   uint32_t dbg_trips = 0, dbg_seqs = 0, dbg_rounds = 0, dbg_single = 0, dbg_hungry = 0, dbg_T = 0;
 #endif
@@ -312,7 +313,11 @@ LZ4HIP_DEV void decode_wave_par_loop(Grp& g, const uint8_t* src, const int iend,
         const VU nxt = p0 + (j + 3u) + Grp::vsel(l15, VU(1u), VU(0u)) + tl + Grp::vsel(l15, e1, VU(0u)) + Grp::vsel((w & 15u) == 15u, VU(1u), VU(0u));
         nxpack = nxpack | (Grp::vsel(nxt <= 250u, nxt, VU(255u)) << (8 * (int)j));
       }
-      Grp::vwalk(nxpack, posv, T);              // the starts of the sequences in the window, the k-th to lane k
+      // the starts of the sequences in the window, the k-th to lane k: hop by hop (8 scalar instructions a start), or -- a window of text holds
+      // ~58 starts: a third of its trip was this walk -- by pointer doubling (group_dev.h vwalk_par: ~190 vector instructions whatever the
+      // count) when the window before this one was that full.  Either way the same posv and T
+      if (Tprev >= 24u) Grp::vwalk_par(nxpack, lane, posv, T); else Grp::vwalk(nxpack, posv, T);
+      Tprev = T;
     }
     // ---- 3. records, output positions: A LANE PER RUN -- lane 2k the literals of a sequence, lane 2k + 1 its match.  (A lane per
     // sequence copied two runs, 16 reads and 16 predicated stores a round: ~220 instructions of a trip of ~900 that is bound by

@@ -437,6 +437,33 @@ struct GroupHost {
     if (!done) while ((s != 255u) & (T < 64u)) hop();
     for (uint32_t k = 0; k < 64u; k++) if (posv.v[k] == 255u) { if (k < T) T = k; break; }
   }
+  // group_dev.h vwalk_par: the same starts by pointer doubling -- the device's levels and gathers, and the result compared with the plain
+  // definition of the walk (a mismatch counts as a failure of the simulated wavefront: walk_mismatch, folded into every decode's verdict)
+  static inline std::atomic<uint64_t> walk_mismatch{0}, walk_par_calls{0};
+  static uint32_t vgather8(const VU& tab, uint32_t q) { return (tab.v[(q >> 2) & 63u] >> ((q & 3u) * 8u)) & 255u; }
+  static void vwalk_par(const VU& nx, const VU& lane, VU& posv, uint32_t& T) {
+    walk_par_calls++;
+    VU J = nx, pos;
+    for (int l = 0; l < 64; l++) pos.v[l] = (lane.v[l] & 1u) ? vgather8(J, 0u) : 0u;
+    for (uint32_t k = 1; k < 6u; k++) {
+      VU Jn;
+      for (int l = 0; l < 64; l++) {
+        uint32_t w = 0;
+        for (uint32_t j = 0; j < 4u; j++) w |= vgather8(J, (J.v[l] >> (8u * j)) & 255u) << (8u * j);
+        Jn.v[l] = w;
+      }
+      J = Jn;
+      for (int l = 0; l < 64; l++) if ((lane.v[l] >> k) & 1u) pos.v[l] = vgather8(J, pos.v[l]);
+    }
+    uint32_t Tn = 64u;
+    for (uint32_t l = 0; l < 64u; l++) if (pos.v[l] == 255u) { Tn = l; break; }
+    VU pref = posv; uint32_t Tref = T;
+    vwalk(nx, pref, Tref);                       // the definition
+    bool same = Tn == Tref;
+    for (uint32_t l = 0; same && l < Tref; l++) same = pos.v[l] == pref.v[l];
+    if (!same) walk_mismatch++;
+    posv = pos; T = Tn;
+  }
   static VU vexcl_scan(const VU& a) { par_trips++; VU r; uint32_t acc = 0; for (int l = 0; l < 64; l++) { r.v[l] = acc; acc += a.v[l]; } return r; }
   static inline uint64_t why[8] = {0};
   void vnote(const VB& act, const VB& a, const VB& b, const VB& c, const VB& d, const VB& e, const VB& f, const VB& ok) {

@@ -224,7 +224,7 @@ int sim_decompress(const uint8_t* src, int src_size, uint8_t* dst, int out_size,
              : lz4hip::decode_block<hostsim::GroupHost, false, 8>(g, src, src_size, dst, out_size, g.pair_lds);
     lz4hip::trio_quit(g, g.pair_lds);
     planner.join(); scanner.join();
-    if (g.oob || gp.oob || gs.oob) return -1000000;
+    if (g.oob || gp.oob || gs.oob || hostsim::GroupHost::walk_mismatch.load() != 0) return -1000000;
     return r;
   }
   if (wave && (gl0 & 0x1000000) != 0) {          // bit 24: the PAIR loop (lz4_decode_pair.h): a copier and a parser wavefront = two host threads over one block of "LDS"
@@ -259,9 +259,10 @@ int sim_decompress(const uint8_t* src, int src_size, uint8_t* dst, int out_size,
                      : lz4hip::decode_block<hostsim::GroupHost, false, 1>(g, src, src_size, dst, out_size);
   else r = safe ? lz4hip::decode_block<hostsim::GroupHost, true>(g, src, src_size, dst, out_size)
                 : lz4hip::decode_block<hostsim::GroupHost, false>(g, src, src_size, dst, out_size);
-  if (g.oob) return -1000000;
+  if (g.oob || hostsim::GroupHost::walk_mismatch.load() != 0) return -1000000;
   return r;
 }
+unsigned long long sim_walk_par_calls() { return hostsim::GroupHost::walk_par_calls.load(); }
 
 // LZ4 HC (levels 1..12): phase 1 (delta[] build) + phase 2 (lazy parse, or the optimal parser for 10..12) in the lock-step
 // simulator.  returns the compressed size, 0 (does not fit) or -1000 (out-of-slot access)
