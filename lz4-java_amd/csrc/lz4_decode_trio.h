@@ -114,7 +114,7 @@ LZ4HIP_DEV void trio_scan_loop(Grp& g, const uint8_t* src, const uint32_t iend, 
         nxfull[j] = nxt;
         nxpack = nxpack | (Grp::vsel(nxt <= 250u, nxt, VU(255u)) << (8 * (int)j));
       }
-      if (Tprev >= 24u) Grp::vwalk_par(nxpack, lane, posv, T); else Grp::vwalk(nxpack, posv, T);   // (lz4_decode_wave.h: pointer doubling for windows full of sequences)
+      if (Tprev >= LZ4HIP_WALK_PAR_MIN) Grp::vwalk_par(nxpack, lane, posv, T); else Grp::vwalk(nxpack, posv, T);   // (lz4_decode_wave.h: pointer doubling for windows full of sequences)
       Tprev = T;
     }
     // where the next window begins: behind the last sequence that starts in this one (the same formula, not clamped to the window)

@@ -31,6 +31,10 @@
 #pragma once
 #include <stdint.h>
 
+#ifndef LZ4HIP_WALK_PAR_MIN
+#define LZ4HIP_WALK_PAR_MIN 24u   /* starts in the window before from which a window's walk is done by pointer doubling (65: never; developer A/B builds) */
+#endif
+
 namespace lz4hip {
 
 // entry: ip + 1024 <= iend (three 256-byte steps of the stream around ip are readable), ip <= iend - 306, op <= oend - 606 (the
@@ -316,7 +320,7 @@ LZ4HIP_DEV void decode_wave_par_loop(Grp& g, const uint8_t* src, const int iend,
       // the starts of the sequences in the window, the k-th to lane k: hop by hop (8 scalar instructions a start), or -- a window of text holds
       // ~58 starts: a third of its trip was this walk -- by pointer doubling (group_dev.h vwalk_par: ~190 vector instructions whatever the
       // count) when the window before this one was that full.  Either way the same posv and T
-      if (Tprev >= 24u) Grp::vwalk_par(nxpack, lane, posv, T); else Grp::vwalk(nxpack, posv, T);
+      if (Tprev >= LZ4HIP_WALK_PAR_MIN) Grp::vwalk_par(nxpack, lane, posv, T); else Grp::vwalk(nxpack, posv, T);
       Tprev = T;
     }
     // ---- 3. records, output positions: A LANE PER RUN -- lane 2k the literals of a sequence, lane 2k + 1 its match.  (A lane per
