@@ -168,14 +168,38 @@ const char* decode_knobs_error(int lanes, int pipe, int ring) {
   return nullptr;
 }
 
+// The device-side route's word: one of kRouteWords words of a per-device buffer, handed out round robin.  (It was a stream-ordered
+// allocation per launch: hipMallocAsync + hipFreeAsync in front of and behind EVERY routed launch -- tens of microseconds on the headline's
+// 6 ms decode, measured with the route's kernels in profiles/r06l_bench_kernel_trace.txt.)  A word is only meaningful between a launch's
+// route kernel and its candidate kernels, which follow it in stream order: a slot would have to come round again -- 256 routed launches
+// later -- while they are still in flight to be disturbed.
+constexpr uint32_t kRouteWords = 256u;
+uint32_t* g_route_ring[64];
+std::atomic<uint32_t> g_route_next[64];
+std::mutex g_route_mu;
+uint32_t* route_word() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return nullptr;
+  uint32_t* ring = __atomic_load_n(&g_route_ring[d], __ATOMIC_ACQUIRE);
+  if (!ring) {
+    std::lock_guard<std::mutex> lk(g_route_mu);
+    ring = g_route_ring[d];
+    if (!ring) {
+      if (hipMalloc((void**)&ring, kRouteWords * sizeof(uint32_t)) != hipSuccess) return nullptr;
+      __atomic_store_n(&g_route_ring[d], ring, __ATOMIC_RELEASE);
+    }
+  }
+  return ring + (g_route_next[d].fetch_add(1u, std::memory_order_relaxed) % kRouteWords);
+}
+void route_release(int d) {   // lz4hip_shutdown (the device is current)
+  std::lock_guard<std::mutex> lk(g_route_mu);
+  if (d >= 0 && d < 64 && g_route_ring[d]) { (void)hipFree(g_route_ring[d]); g_route_ring[d] = nullptr; }
+}
+
 int launch_decode(const lz4hip::BatchArgs& a, bool safe, hipStream_t st) {
   if (const char* why = decode_knobs_error(g_decode_lanes.load(), g_decode_pipe.load(), g_decode_ring.load())) return fail(LZ4HIP_E_ARG, why);
-  // (a word of scratch for the device-side choice between the deep and the ring loop: only batches of 12288 .. 40959 blocks use it)
-  uint32_t* route = nullptr;
-  if (a.n > 16u * cu_count() && hipMallocAsync((void**)&route, sizeof(uint32_t), st) != hipSuccess) route = nullptr;
-  const int e = lz4hip::launch_decompress(a, safe, g_decode_lanes.load(), g_decode_pipe.load(), g_decode_stage.load(), g_decode_ring.load(), st, route);
-  if (route) (void)hipFreeAsync(route, st);
-  return e;
+  uint32_t* route = a.n > 16u * cu_count() ? route_word() : nullptr;   // (nullptr: no device-side route, the lane-group default of the batch size)
+  return lz4hip::launch_decompress(a, safe, g_decode_lanes.load(), g_decode_pipe.load(), g_decode_stage.load(), g_decode_ring.load(), st, route);
 }
 
 int launch_op(Op op, const lz4hip::BatchArgs& a, hipStream_t st) {
@@ -1117,7 +1141,7 @@ void lz4hip_shutdown(void) {
   (void)hipGetDevice(&prev);
   for (int ord : g_devs) {
     if (ord < 0 || ord >= 64) continue;
-    if (hipSetDevice(ord) == hipSuccess) g_ctx[ord].release();
+    if (hipSetDevice(ord) == hipSuccess) { g_ctx[ord].release(); route_release(ord); }
   }
   if (prev >= 0) (void)hipSetDevice(prev);
   g_devs.clear();
