@@ -825,11 +825,11 @@ def main():
     per_rank = None
     if world > 1:
         c2 = (extra.get("configs2_decode_4MiB") or {})
-        mine = torch.tensor([t_c * 1e3, t_g * 1e3, t_d * 1e3, float(c2.get("value") or 0.0) / world, float((c2.get("route") or {}).get("route") or 0)], dtype=torch.float64, device=dev)
+        mine = torch.tensor([t_c * 1e3, t_g * 1e3, t_d * 1e3, float((c2.get("roofline") or {}).get("avg_launch_ms") or 0.0), float((c2.get("route") or {}).get("route") or 0)], dtype=torch.float64, device=dev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         per_rank = [{"rank": r_, "compress_ms": round(float(v_[0]), 3), "gather_ms": round(float(v_[1]), 4), "decompress_ms": round(float(v_[2]), 3),
-                     "configs2_decode_GBps_this_rank_clock": round(float(v_[3]), 3), "configs2_route": int(v_[4])} for r_, v_ in enumerate(allr)]
+                     "configs2_decode_ms": round(float(v_[3]), 3), "configs2_route": int(v_[4])} for r_, v_ in enumerate(allr)]
     if rank == 0:
         ratio = nbytes / csum
         value = world * nbytes * args.steps / dt / 1e9
