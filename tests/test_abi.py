@@ -121,6 +121,15 @@ def test_fails_loudly_without_gpu(amd):
         amd.LZ4HIPCompressor().compress(b"hello hello hello hello")
     with pytest.raises(amd.LZ4HIPError):
         amd.LZ4Factory.hipInstance()
+    with pytest.raises(amd.LZ4HIPError):
+        amd.last_decode_route()                       # (the route diagnostic reads device memory: no device, no answer)
+    amd.set_option("decode_route_short", 8)           # knobs are host state: settable without a device, ranges checked
+    with pytest.raises(amd.LZ4HIPError):
+        amd.set_option("decode_route_short", 256)
+    with pytest.raises(amd.LZ4HIPError):
+        amd.set_option("decode_pipe", 6)
+    for v in (7, 8, -1):
+        amd.set_option("decode_pipe", v)
     assert amd.lib().lz4hip_device_count() == 0
 
 
