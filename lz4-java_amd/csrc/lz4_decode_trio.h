@@ -41,7 +41,6 @@ LZ4HIP_DEV void trio_scan_loop(Grp& g, const uint8_t* src, const uint32_t iend, 
   typedef typename Grp::VB VB;
   constexpr uint32_t STEP = 256u, AHEAD = 512u;
   const uint32_t KS = g.wv_stream();
-  const uint32_t ilim = iend - 306u;
   uint32_t shead = 0u, stail_seen = 0u;
   uint32_t avail = ip & ~(STEP - 1u);
   {
@@ -69,7 +68,7 @@ LZ4HIP_DEV void trio_scan_loop(Grp& g, const uint8_t* src, const uint32_t iend, 
     uint32_t stop, ipdone;
     g.pm_peek2(PC_STOP, stop, ipdone);
     if (stop == epoch) { stopped = true; break; }
-    if (ip > ilim) break;
+    if (ip + 32u > iend) break;                 // (the planner's end rules stop in front of the stream's last 32 bytes: below)
     // the stream ring keeps everything from the copier's oldest unfinished message on (it reads literals there; the planner is ahead of
     // it).  IPDONE = where the sequences of the copier's NEXT message begin: with nothing in flight that is this window, and the
     // condition below is the one-wavefront loop's (a 1 KB stream ring cannot hold the previous window's start AND this window's 512 bytes)
@@ -167,7 +166,6 @@ LZ4HIP_DEV void trio_plan_loop(Grp& g, const uint32_t iend, const uint32_t oend,
     // segments: each is what the one-wavefront loop calls a trip -- from start tk of this window on, until a pass is cut or the window is done
     while (tk < T) {
       const uint32_t ip = wip + Grp::vreadlane(posv, tk);     // the stream position of the segment's first sequence
-      if (!((ip <= ilim) & (op <= olim))) { exit_ip = ip; leave = true; break; }
       uint32_t tk0 = tk, opc = op;
       for (;;) {
         const uint32_t np = T - tk < 31u ? T - tk : 31u;
@@ -199,7 +197,17 @@ LZ4HIP_DEV void trio_plan_loop(Grp& g, const uint32_t iend, const uint32_t oend,
         constexpr uint64_t litm = 0x5555555555555555ull;
         const uint64_t heldm = Grp::vballot(mp >= VU(op0)) & Grp::vballot((mp + KW) >= VU(bound));
         const uint64_t srcm = Grp::vballot(mp < VU(0x80000000u)) & (heldm | Grp::vballot(send <= VU(memlim)));
-        const uint64_t okbm = actm & simplem & (litm | srcm) & Grp::vballot((pv + wip) <= VU(ilim)) & Grp::vballot(o <= VU(olim)) & Grp::vballot((oe - op) <= VU(TRIPMAX));
+        // THE BLOCK'S END, sequence by sequence.  The other interior loops stop 306 stream / 606 output bytes in front of the block's ends,
+        // where every check of liblz4's fast loop provably passes for ANY simple sequence, and leave the rest -- ~17 sequences of an
+        // App. F block, a memory round trip or two each in decode_block's exact code: ~20 us of a 150-us single-block call -- to it.
+        // Here the lengths are known per lane, so the rule is liblz4's own, per sequence (lz4.c LZ4_decompress_generic, fast loop; the
+        // exact code restates it in decode_block's tier 1): literals that end 32 bytes in front of the stream's end (covers `ip + length >
+        // iend - 32` and, for short runs, `ip > iend - 17`), a match that ends more than 64 bytes in front of the output's end (`op +
+        // length >= oend - FASTLOOP_SAFE_DISTANCE`; it implies `cpy > oend - 32` for the literals).  A sequence that passes is one
+        // liblz4 decodes in its fast loop without leaving it, with these bytes; the first that does not is where the loop ends (a lane
+        // pair: the rounds take whole sequences) and the exact code takes over with liblz4's own branch.  Both decoders: the fast
+        // decoder's conditions (`cpy > oend - 8`, the bounded reads) are weaker.
+        const uint64_t okbm = actm & simplem & (litm | srcm) & Grp::vballot((lp + lit + 32u) <= VU(iend)) & Grp::vballot((oe + 64u) < VU(oend)) & Grp::vballot((oe - op) <= VU(TRIPMAX));
         const uint64_t farm = ~litm & ~heldm;
         const VU spv = Grp::vsel(isM, mp + db, lp);
         const uint64_t oddm = g.vodd_mask(o + db, len);
