@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Soak of the trio loop's end-of-block rules in the lane simulator (tests/hostsim: three host threads per block): trio_end_soak.py <seed> <cases> --
+"""Soak of the trio loop's end-of-block rules in the lane simulator (tests/hostsim: three host threads per block): trio_end_soak.py <seed> <cases> [trio|pair|par|wave] --
 streams of 2.5 .. 30 KB of five kinds, intact / with capacities off by -607 .. +700 / damaged in their last 400 bytes / truncated there / extended / damaged anywhere, safe decoder
 against the reference library, bounded fast decoder against the C restatement, every ring, both stream rings, five slot alignments."""
 import sys, random, time
@@ -10,6 +10,7 @@ sim = T.load_sim(); ref = O.ref()
 rng = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 book = open("tests/golden/book1_200000.bin", "rb").read()
 n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 1500
+loop = {"trio": "trio", "pair": "pair", "par": True, "wave": False}[sys.argv[3] if len(sys.argv) > 3 else "trio"]   # which loop of the wave family
 t0 = time.time(); bad = 0; stats = {}
 for it in range(n_cases):
     kind = rng.randrange(5)
@@ -29,7 +30,7 @@ for it in range(n_cases):
     elif mode == 5:                       # damage anywhere
         for _ in range(rng.randrange(1, 3)): c[rng.randrange(len(c))] = rng.randrange(256)
     c = bytes(c)
-    flag = T.wave_flag(rng.choice([13, 14, 16]), rng.random() < 0.5, "trio")
+    flag = T.wave_flag(rng.choice([13, 14, 16]), rng.random() < 0.5, loop)
     shift = rng.choice([0, 1, 5, 64, 131])
     r2, d2 = ref.decompress_safe_raw(c, cap)
     r1, d1 = T.sim_decode(sim, c, cap, 1, flag, shift=shift)
