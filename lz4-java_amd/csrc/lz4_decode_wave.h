@@ -31,6 +31,12 @@
 #pragma once
 #include <stdint.h>
 
+#ifndef LZ4HIP_WAVE_CONT
+#define LZ4HIP_WAVE_CONT 1
+#endif
+#ifndef LZ4HIP_WAVE_SKIP
+#define LZ4HIP_WAVE_SKIP 1
+#endif
 #ifndef LZ4HIP_WALK_PAR_MIN
 #define LZ4HIP_WALK_PAR_MIN 24u   /* starts in the window before from which a window's walk is done by pointer doubling (65: never; developer A/B builds) */
 #endif
@@ -264,7 +270,7 @@ LZ4HIP_DEV void decode_wave_par_loop(Grp& g, const uint8_t* src, const int iend,
     g.rs_put(avail, a0); g.rs_put(avail + STEP, a1); g.rs_put(avail + 2u * STEP, a2); g.rs_put(avail + 3u * STEP, a3);
     avail += 4u * STEP;
   }
-  LChunk rf0 = LChunk();                   // the step requested at the top of a trip; it goes into the ring at its end
+  LChunk rf0 = LChunk(), rf1 = LChunk();   // the steps requested at the top of a trip; they go into the ring at its end
   uint32_t fl = (op + db) & ~(STEP - 1u);
   const VU lane = g.vlane();
   const VU p0 = lane * 4u;
@@ -275,7 +281,7 @@ LZ4HIP_DEV void decode_wave_par_loop(Grp& g, const uint8_t* src, const int iend,
 #endif
 
   for (;;) {
-    if (!((ip <= ilim) & (op <= olim))) break;
+    if (ip + 32u > (uint32_t)iend) break;       // (the end rules of step 3 stop in front of the stream's last 32 bytes)
     // ---- the stream ring holds what this trip may read ----
     if (LZ4HIP_UNLIKELY(ip + AHEAD > avail)) {
 #ifdef LZ4HIP_RING_DBG
@@ -285,15 +291,27 @@ LZ4HIP_DEV void decode_wave_par_loop(Grp& g, const uint8_t* src, const int iend,
         g.rs_put(avail, g.rs_fetch(src, avail));
         avail += STEP;
       }
-      if (ip + AHEAD > avail) break;            // (the end of the stream is near: the loops behind this one do the rest)
+      // the stream's last, partial step: its bytes below iend (zeros behind them).  With it the WHOLE stream is in the ring and the windows go on
+      // to the block's end -- a sequence the end rules take ends inside the stream; what a window reads behind iend is nothing a pass uses
+      if ((ip + AHEAD > avail) & (avail < (uint32_t)iend) & (avail + STEP > (uint32_t)iend) & (avail + STEP <= (ip & ~(STEP - 1u)) + KS)) {
+        g.rs_put(avail, g.rs_fetch_upto(src, avail, (uint32_t)iend));
+        avail += STEP;
+      }
+      if ((ip + AHEAD > avail) & (avail < (uint32_t)iend)) break;
     }
     // ---- stream refill: REQUESTED here, at the top of the trip, PUT into the ring at its end -- the loads are a whole trip old when
     // they are waited for, and nothing is carried from trip to trip.  The ring keeps everything from ip & ~255 on: this trip's
     // reads.  One step per trip: what a window consumes (a trip that consumes more finds the ring short and takes the refill above) ----
+    // A window whose starts are all taken consumes MORE than a step (its last sequence ends behind it): a second step is requested when the ring
+    // holds less than a step beyond what this trip may read -- without it every ~30th trip found the ring short and waited for memory
     uint32_t nf = 0u;
     if ((avail + STEP <= (uint32_t)iend) & (avail + STEP <= (ip & ~(STEP - 1u)) + KS)) {
       rf0 = g.rs_fetch(src, avail);
       nf = 1u;
+      if ((avail < ip + AHEAD + STEP) & (avail + 2u * STEP <= (uint32_t)iend) & (avail + 2u * STEP <= (ip & ~(STEP - 1u)) + KS)) {
+        rf1 = g.rs_fetch(src, avail + STEP);
+        nf = 2u;
+      }
     }
     // ---- 1 + 2. discovery and walk.  The speculative part decodes only what the WALK needs: where a sequence that starts at window
     // position p would be followed by the next one -- token, literal-length byte: all inside the window registers, no LDS access;
@@ -330,7 +348,18 @@ LZ4HIP_DEV void decode_wave_par_loop(Grp& g, const uint8_t* src, const int iend,
     // The wavefront holds 31 sequences that way: a window with more of them (text: up to 64) is taken in PASSES of 31, each pass from
     // the sequence the pass before it ended with -- discovery and walk are paid once per window ----
     const VB isM = (lane & 1u) != 0u;
-    uint32_t tk = 0u, opc = op, lend = 0u;      // sequences taken by this trip, the output position behind them, where the last one ends in the stream
+    uint32_t tk = 0u, lend = 0u;                // sequences of the window taken so far, where the last one ends in the stream
+    bool stuck = false, skip = false;
+    // A window is taken in SEGMENTS: passes from the current output position on, until a pass is cut (a source the flusher has not written
+    // yet, TRIPMAX, a sequence that is not for a pass) -- then the flusher runs, a sequence no pass takes gets its one-sequence step, and
+    // the NEXT SEGMENT goes on with the same window's starts (LZ4HIP_WAVE_CONT; 0: a cut ends the trip and the rest of the window is
+    // discovered and walked again)
+    for (;;) {
+    const uint32_t tk0 = tk;
+    uint32_t opc = op;                          // the output position behind the sequences taken
+    const bool skipnow = skip;                  // (the pass before this segment has seen that its first sequence is for no pass)
+    skip = false;
+    if (!(LZ4HIP_WAVE_SKIP && skipnow))
     for (;;) {
       const uint32_t np = T - tk < 31u ? T - tk : 31u;   // (31: the rounds' ballot keeps lane 63 out)
       const VU sq = (lane >> 1) + tk;           // this lane's sequence
@@ -370,7 +399,12 @@ LZ4HIP_DEV void decode_wave_par_loop(Grp& g, const uint8_t* src, const int iend,
       constexpr uint64_t litm = 0x5555555555555555ull;                        // the even lanes: literal runs
       const uint64_t heldm = Grp::vballot(mp >= VU(op0)) & Grp::vballot((mp + KW) >= VU(bound));
       const uint64_t srcm = Grp::vballot(mp < VU(0x80000000u)) & (heldm | Grp::vballot(send <= VU(memlim)));   // match lanes: the source is valid and can be had
-      const uint64_t okbm = actm & simplem & (litm | srcm) & Grp::vballot((pv + ip) <= VU(ilim)) & Grp::vballot(o <= VU(olim)) & Grp::vballot((oe - op) <= VU(TRIPMAX));
+      // THE BLOCK'S END, sequence by sequence (lz4_decode_trio.h has the derivation): the lengths are known per lane, so the rule is liblz4's own
+      // fast-loop rule -- literals that end 32 bytes in front of the stream's end, a match that ends more than 64 bytes in front of the
+      // output's end -- instead of a blanket 306 / 606 bytes that left ~40 (text: ~110) sequences of every block to decode_block's exact code,
+      // a memory round trip or two each: 6-9 % of a 64 KiB block's time.  The first sequence that does not pass ends the loop (its
+      // one-sequence step keeps the blanket margins and refuses)
+      const uint64_t okbm = actm & simplem & (litm | srcm) & Grp::vballot((lp + lit + 32u) <= VU((uint32_t)iend)) & Grp::vballot((oe + 64u) < VU((uint32_t)oend)) & Grp::vballot((oe - op) <= VU(TRIPMAX));
       const uint64_t farm = ~litm & ~heldm;
       // (mp "negative" -- an offset that reaches in front of the block -- is a huge unsigned number: tested by itself, the sums may wrap)
       // ---- 4. copies in DEPENDENCY ROUNDS, a lane per run, exact.  A round takes the runs from lane `a` on; a literal run has no
@@ -402,22 +436,42 @@ LZ4HIP_DEV void decode_wave_par_loop(Grp& g, const uint8_t* src, const int iend,
       tk += a >> 1;
       opc = Grp::vreadlane(oe, a - 1u);
       lend = Grp::vreadlane(endp, a - 1u);
+      // a pass that was cut at a sequence NO pass takes -- a length of 255 or more, a match that overlaps its own output (offset < length: its
+      // source never lies below a round's output) -- is followed by that sequence's one-sequence step at once: the next segment's pass
+      // would set itself up (~130 instructions), copy the literals and take nothing
+      if (LZ4HIP_WAVE_SKIP && a < 2u * np) skip = (((~simplem | Grp::vballot(off < ml)) >> a) & 1ull) != 0ull;
       if ((a < 2u * np) | (tk >= T)) break;     // the pass ended early, or the window is done
     }
 #ifdef LZ4HIP_RING_DBG
-    dbg_trips++; dbg_seqs += tk; dbg_T += T; dbg_single += tk == 0u ? 1u : 0u;
+    dbg_trips++; dbg_seqs += tk - tk0; dbg_T += T - tk0; dbg_single += tk == tk0 ? 1u : 0u;
 #endif
-    if (LZ4HIP_UNLIKELY(tk == 0u)) {
-      if (!wave_single_step(g, dst, ip, op, op0, fl, db, ilim, olim)) break;
+    if (LZ4HIP_UNLIKELY(tk == tk0)) {
+      // no pass takes sequence tk: its one-sequence step.  It reads up to AHEAD bytes from the sequence's own start: in the middle of a
+      // window the requested refill step goes into the ring first, and a ring that is still short ends the trip in front of the sequence
+      uint32_t ip1 = ip + Grp::vreadlane(posv, tk);
+      if (tk != 0u) {
+        if (nf != 0u) { g.rs_put(avail, rf0); avail += STEP; if (nf == 2u) { g.rs_put(avail, rf1); avail += STEP; } nf = 0u; }
+        if (ip1 + AHEAD > avail) break;
+      }
+      const uint32_t ipq = ip1;
+      if (!wave_single_step(g, dst, ip1, op, op0, fl, db, ilim, olim)) { ip = ipq; stuck = true; break; }
       wild = op + STEP;                         // its wave-wide pieces end up to a step behind the sequence: the ring has lost what lies KW below that
+      tk++;
+      lend = ip1 - ip;
     } else {
-      ip += tk < T ? Grp::vreadlane(posv, tk) : lend;   // (every start was taken: the next token lies behind the last sequence)
       op = opc;
     }
+    if (!LZ4HIP_WAVE_CONT || tk >= T) break;
+    // the next segment of this window: the flusher first (a far source wants everything below op in memory)
+    while (op + db - fl >= STEP) { g.wv_store(dst, fl, g.wv_read_al(fl), op0 + db, 0xFFFFFFFFu); fl += STEP; }
+    }
+    if (stuck) break;
+    ip += tk < T ? Grp::vreadlane(posv, tk) : lend;   // (every start was taken: the next token lies behind the last sequence)
     // ---- the requested steps into the ring (in front of the flusher's stores: stores count in vmcnt on this part) ----
     if (nf != 0u) {
       g.rs_put(avail, rf0);
       avail += STEP;
+      if (nf == 2u) { g.rs_put(avail, rf1); avail += STEP; }
     }
     // ---- flusher: whole aligned steps below op.  (Requested at the TOP of the next trip instead, next to the window read, and stored behind
     // the discovery -- what the trio loop's copier does in front of its wait for a message, +5 % there -- it is 1.5 % SLOWER here: 2048 x 4 MiB

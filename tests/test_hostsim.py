@@ -518,15 +518,16 @@ def test_wave_loops_ring_edge_streams(sim, ref):
                 assert r == n and d[:n] == want, (rep, log, par, r, n, next((i for i in range(min(max(r, 0), n)) if d[i] != want[i]), None))
 
 
-def test_trio_end_of_block_rules(sim):
-    """The trio loop's planner ends the loop by liblz4's OWN fast-loop conditions, sequence by sequence (literals that end 32 bytes in front
+@pytest.mark.parametrize("loop", ["trio", "par"])
+def test_trio_end_of_block_rules(sim, loop):
+    """The trio loop's planner -- and, with the same rule, the one-wavefront parallel loop (csrc/lz4_decode_wave.h) -- ends the loop by liblz4's OWN fast-loop conditions, sequence by sequence (literals that end 32 bytes in front
     of the stream's end, a match that ends more than 64 bytes in front of the output's end: csrc/lz4_decode_trio.h) instead of the other
     interior loops' blanket 306 / 606-byte margin -- so which tier of liblz4 meets a defect near a block's end must come out the same.
     A slice of tools/trio_end_soak.py (70000 cases without a mismatch when the rule went in): streams of five kinds, capacities off by
     -607 .. +700, damage / truncation in the last 400 stream bytes, extension, damage anywhere; safe decoder against the reference
     library's codes and bytes, bounded fast decoder against the C restatement."""
     import subprocess, sys
-    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "trio_end_soak.py"), "20260930", "1200"], timeout=600).decode()
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "trio_end_soak.py"), "20260930", "1200", loop], timeout=600).decode()
     assert "bad 0" in out and "cases 1200" in out, out[-400:]
 
 
