@@ -158,7 +158,7 @@ def cpu_bench(args, env=None):
 
 
 def decode_kernel_name(n_blocks, safe=True, big_blocks=False):
-    """the decoder instantiation launch_decompress (kernels.hip) picks: by batch size, and -- batches of 12288 .. 40959 blocks -- on the
+    """the decoder instantiation launch_decompress (kernels.hip) picks: by batch size, and -- batches of 16384 .. 40959 blocks -- on the
     device by the blocks' compressed sizes (decode_route_kernel: blocks of >= 512 KiB go to the ring loop, csrc/lz4_decode_ring.h)"""
     s = "true" if safe else "false"
     if n_blocks <= 5 * 256:    # up to 5 blocks per CU: scanner, planner and copier wavefronts per block (csrc/lz4_decode_trio.h)
@@ -169,7 +169,7 @@ def decode_kernel_name(n_blocks, safe=True, big_blocks=False):
         return "decode_wave_kernel<%d, %d, %d, %s, 5>" % (w, kw, ks, s)
     if n_blocks >= 40960:
         return "decode_kernel<4, %s, 0, true>" % s
-    if 12288 <= n_blocks < 40960 and big_blocks:
+    if 16384 <= n_blocks < 40960 and big_blocks:
         return "decode_ring_kernel<4, 2048, %s>" % s
     return "decode_deep_kernel<8, %s>" % s   # the deep interior loop, csrc/lz4_decode_deep.h
 

@@ -61,10 +61,10 @@ int lz4hip_version(void);
  * Which decoder a launch of n blocks gets with every knob at its default (CU = compute units of the device, 256 on an MI355X):
  *   n <= 5 CU    the trio loop (lz4_decode_trio.h): THREE wavefronts per block -- scanner, planner, copier
  *   n <= 16 CU   the parallel wave loop (lz4_decode_wave.h): a wavefront per block, several sequences of it per trip
- *   more         chosen ON THE DEVICE from a sample of the batch (decode_route_kernel): 12288 .. 40959 blocks averaging >= 512 KiB compressed ->
+ *   more         chosen ON THE DEVICE from a sample of the batch (decode_route_kernel): 16384 .. 40959 blocks averaging >= 512 KiB compressed ->
  *                the ring loop (lz4_decode_ring.h); sequences of "decode_route_short" or fewer output bytes on average with near match
- *                sources (text) -> the wave loop; otherwise the deep loop (lz4_decode_deep.h) below 40960 blocks and, from there on, for
- *                near match sources, else the 4-lane staged loop
+ *                sources (text) -> the wave loop; n <= 32 CU and streams that are not mostly literals -> the wave loop; otherwise the deep
+ *                loop (lz4_decode_deep.h) below 40960 blocks and, from there on, for near match sources, else the 4-lane staged loop
  * "decode_pipe" = -1 (the table above) or one loop for every launch: 8 = trio loop, 7 = pair loop (two wavefronts per block: a parser and a
  *   copier), 5 = parallel wave loop, 4 = wave loop with one
  *   sequence per trip, 3 = ring loop, 2 = deep loop, 1 = two-trip pipelined loop, 0 = plain loop;

@@ -102,6 +102,12 @@ struct GroupDev {
   // block is evicted from L2 between the small stores that fill it and reaches HBM several times (WRITE_SIZE 11.8 GB for
   // 4.3 GB of output, profiles/r01n).  Staging holds the output bytes [fl, fl + kStage); everything below fl is in memory.
   // Match sources are read from memory only, so the caller flushes everything first when a source reaches past fl. ----
+#ifndef LZ4HIP_RUN_TIERS
+#define LZ4HIP_RUN_TIERS 1    /* the wave loops' copy rounds in three forms by their longest run (< 16 / < 32 / <= 64 bytes); 0: always the 64-byte form (developer A/B builds) */
+#endif
+#ifndef LZ4HIP_TIER_GUARD
+#define LZ4HIP_TIER_GUARD 0   /* 1: the short forms take their operands through an empty asm -- their address math stays in their branch instead of in front of the round loop (developer A/B builds) */
+#endif
 #ifndef LZ4HIP_KSTAGE
 #define LZ4HIP_KSTAGE 576   /* bytes of staging per block (developer A/B builds: smaller = more blocks resident per CU, more flushes) */
 #endif
@@ -704,13 +710,16 @@ struct BlockWaveDev : GroupDev<64, 0> {
   // then the predicated stores; the step-by-step form above waits for the LDS once per step (14 round trips per trip, 43 % of the
   // wavefront's cycles when it was the only form: profiles/r05_wave_notes.txt)
   struct Run16 { u4a a0, a1, a2, a3; u2a b; uint32_t c; uint32_t d; uint32_t e; };
+  // NA: the 16-byte pieces a round reads and stores -- 4: runs of up to 64 bytes; 1: every run of the round is shorter than 32 bytes; 0: shorter than
+  // 16 (text: most rounds).  An unaligned LDS access costs a cycle per active lane whether its bytes are wanted or not
+  template <int NA>
   __device__ __forceinline__ static Run16 vrun_load(const uint8_t* sb, uint32_t sm, VU sp, VU len) {
     Run16 r;
-    r.a0 = *(const u4a*)(sb + (sp & sm));
-    r.a1 = *(const u4a*)(sb + ((sp + 16u) & sm));
-    r.a2 = *(const u4a*)(sb + ((sp + 32u) & sm));
-    r.a3 = *(const u4a*)(sb + ((sp + 48u) & sm));
-    uint32_t c = len & ~15u;
+    if (NA >= 1) r.a0 = *(const u4a*)(sb + (sp & sm));
+    if (NA >= 2) r.a1 = *(const u4a*)(sb + ((sp + 16u) & sm));
+    if (NA >= 3) r.a2 = *(const u4a*)(sb + ((sp + 32u) & sm));
+    if (NA >= 4) r.a3 = *(const u4a*)(sb + ((sp + 48u) & sm));
+    uint32_t c = NA >= 1 ? len & ~15u : 0u;
     r.b = *(const u2a*)(sb + ((sp + c) & sm));
     c += len & 8u;
     r.c = *(const u1a*)(sb + ((sp + c) & sm));
@@ -753,13 +762,14 @@ struct BlockWaveDev : GroupDev<64, 0> {
     r.c = c; r.d = d; r.e = e;
     return r;
   }
+  template <int NA>
   __device__ __forceinline__ void vrun_store(VU dw, VU len, const Run16& r) {   // (no destination at the ring's ends: no mirror stores)
     uint8_t* a = wrb + (dw & ((uint32_t)KW - 1u));   // (contiguous: the caller checked that [dw, dw + len) does not reach the end)
-    if (len >= 16u) *(u4a*)a = r.a0;
-    if (len >= 32u) *(u4a*)(a + 16) = r.a1;
-    if (len >= 48u) *(u4a*)(a + 32) = r.a2;
-    if (len >= 64u) *(u4a*)(a + 48) = r.a3;
-    uint32_t c = len & ~15u;
+    if (NA >= 1) if (len >= 16u) *(u4a*)a = r.a0;
+    if (NA >= 2) if (len >= 32u) *(u4a*)(a + 16) = r.a1;
+    if (NA >= 3) if (len >= 48u) *(u4a*)(a + 32) = r.a2;
+    if (NA >= 4) if (len >= 64u) *(u4a*)(a + 48) = r.a3;
+    uint32_t c = NA >= 1 ? len & ~15u : 0u;
     if (len & 8u) *(u2a*)(a + c) = r.b;
     c += len & 8u;
     if (len & 4u) *(u1a*)(a + c) = r.c;
@@ -779,20 +789,40 @@ struct BlockWaveDev : GroupDev<64, 0> {
     const uint32_t x = dw & ((uint32_t)KW - 1u);
     return __builtin_amdgcn_ballot_w64(len > 64u) | __builtin_amdgcn_ballot_w64(x < 16u) | __builtin_amdgcn_ballot_w64(x + len + 16u > (uint32_t)KW);   // (a ballot per comparison: see lz4_decode_wave.h)
   }
-  __device__ __forceinline__ void vcopy_run(VU dw, bool from_stream, VU sp, VU len, uint64_t gom, const uint8_t* mem, VU mpos, uint64_t farm, uint64_t oddm) {
+  template <int NA>
+  __device__ __forceinline__ void vround(VU dw, bool from_stream, VU sp, VU len, uint64_t gom, const uint8_t* mem, VU mpos, uint64_t gfm) {
+    if (vlanes(gom)) {
+      Run16 r = vrun_load<NA>(from_stream ? wsb : wrb, from_stream ? (uint32_t)KS - 1u : (uint32_t)KW - 1u, sp, len);
+      if (__builtin_expect(gfm != 0ull, 0)) {
+        // (the rare branches take their operands through an empty asm: what is computed from them -- 64-bit addresses here, ring
+        // masks and mirror tests below -- is computed IN the branch; the compiler otherwise hoists ~55 instructions of it in front
+        // of the round loop, where every pass pays for them)
+        VU mp2 = mpos, ln2 = len;
+        asm volatile("" : "+v"(mp2), "+v"(ln2));
+        if (vlanes(gfm)) r = vrun_load_mem(mem + mp2, ln2);
+      }
+      vrun_store<NA>(dw, len, r);
+    }
+  }
+  __device__ __forceinline__ static uint32_t vrun_tier(VU len, uint64_t actm) {   // the short form the runs of the lanes actm allow: 0 / 1, or 4 = none
+    if ((__builtin_amdgcn_ballot_w64(len >= 32u) & actm) != 0ull) return 4u;
+    return (__builtin_amdgcn_ballot_w64(len >= 16u) & actm) != 0ull ? 1u : 0u;
+  }
+  __device__ __forceinline__ void vcopy_run(VU dw, bool from_stream, VU sp, VU len, uint64_t gom, const uint8_t* mem, VU mpos, uint64_t farm, uint64_t oddm,
+                                            uint32_t tier = 4u) {
     const uint64_t gfm = gom & farm;
     if (__builtin_expect((oddm & gom) == 0ull, 1)) {
-      if (vlanes(gom)) {
-        Run16 r = vrun_load(from_stream ? wsb : wrb, from_stream ? (uint32_t)KS - 1u : (uint32_t)KW - 1u, sp, len);
-        if (__builtin_expect(gfm != 0ull, 0)) {
-          // (the rare branches take their operands through an empty asm: what is computed from them -- 64-bit addresses here, ring
-          // masks and mirror tests below -- is computed IN the branch; the compiler otherwise hoists ~55 instructions of it in front
-          // of the round loop, where every pass pays for them)
-          VU mp2 = mpos, ln2 = len;
-          asm volatile("" : "+v"(mp2), "+v"(ln2));
-          if (vlanes(gfm)) r = vrun_load_mem(mem + mp2, ln2);
-        }
-        vrun_store(dw, len, r);
+      // the form of the round: 4 = pieces for runs of up to 64 bytes; 1 / 0 = every run of the PASS is shorter than 32 / 16 bytes (vrun_tier, once per
+      // pass; only the wave loop's SHORT instance passes anything but 4: lz4_decode_wave.h)
+      if (LZ4HIP_RUN_TIERS && tier != 4u) {
+        VU dw2 = dw, sp2 = sp, ln2 = len;
+#if LZ4HIP_TIER_GUARD
+        asm volatile("" : "+v"(dw2), "+v"(sp2), "+v"(ln2));
+#endif
+        if (tier == 0u) vround<0>(dw2, from_stream, sp2, ln2, gom, mem, mpos, gfm);
+        else vround<1>(dw2, from_stream, sp2, ln2, gom, mem, mpos, gfm);
+      } else {
+        vround<4>(dw, from_stream, sp, len, gom, mem, mpos, gfm);
       }
     } else {
       VU dw2 = dw, sp2 = sp, ln2 = len, mp2 = mpos;

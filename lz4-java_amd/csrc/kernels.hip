@@ -1273,7 +1273,7 @@ static int launch_decode_wave(const BatchArgs& a, bool safe, bool par, int ring,
 // meant return at once.  *route =
 //   1  the ring loop (lz4_decode_ring.h, 4 lanes, 2 KiB ring): a sample of the blocks averages at least `big` compressed bytes -- big
 //      blocks with (typically) a short match window (BASELINE configs[2]: 847 vs 808-835 GB/s and a fabric traffic of 2.x instead of
-//      3.75x the algorithmic bytes); only asked for batches of 12288 .. 40959 blocks (`big` = 0: never);
+//      3.75x the algorithmic bytes); only asked for batches of 16384 .. 40959 blocks (`big` = 0: never);
 //   2  the wave kernel (lz4_decode_wave.h, a wavefront per block, W = 16): the sampled sequences are SHORT -- `seq_bytes` (8) or fewer
 //      output bytes per sequence on average: text -- and NEAR: at least half of their offsets lie within 6 KB (the kernel's 8 KB ring).
 //      The lane-group loops decode ~20 G sequences/s whatever the data (a match source is a memory request: text at 6 output bytes per
@@ -1296,7 +1296,7 @@ static int launch_decode_wave(const BatchArgs& a, bool safe, bool par, int ring,
 // each, both 1 KB loads in flight together: ~10 us in front of launches of >= 0.9 ms.
 __device__ uint32_t g_last_route[8];
 __global__ __launch_bounds__(1024) void decode_route_kernel(const uint8_t* src, const uint64_t* src_off, const int32_t* src_len, const int32_t* dst_cap, uint32_t n, uint32_t safe,
-                                                            uint32_t big, uint32_t seq_bytes, uint32_t deep_if_near, uint32_t* route) {
+                                                            uint32_t big, uint32_t seq_bytes, uint32_t deep_if_near, uint32_t wave_small, uint32_t* route) {
   typedef BlockWaveDev<8192, 1024> G;   // (its hand-written walk: a static function of registers)
   constexpr uint32_t SPAN = 1024u, NS = 2u;
   __shared__ __attribute__((aligned(16))) uint8_t win[16][NS][SPAN + 32];
@@ -1397,7 +1397,15 @@ __global__ __launch_bounds__(1024) void decode_route_kernel(const uint8_t* src, 
     // proportion to the bytes a sequence produces; the wave kernel's rate grows far more slowly with them (text, 6 bytes per sequence:
     // 147 GB/s against 128; synthetic streams of 13: 88 against 237; 21: 304 against 483 -- tools/route_sweep.py, profiles/r06_route_sweep.txt)
     const bool is_short = seq_bytes != 0u && is_near && tl <= seq_bytes * to;
-    const uint32_t r = is_big ? 1u : is_short ? 2u : (deep_if_near != 0u && is_near) ? 3u : 0u;
+    // ... and, since the wave loop takes a window in segments and ends a block by liblz4's own rule (round 6, sessions w .. af), EVERY kind of data
+    // in batches of up to 32 blocks per CU -- two rounds of its 16 wavefronts per CU -- but streams that are mostly literals (less than 1.25 output
+    // bytes per stream byte as the sampled sequences have it: runs of 255 and more are one-sequence steps there).  6144 / 8192 blocks, wave against
+    // deep loop (profiles/r06_route_sweep.txt, second sweep): text 156 / 206 against 46 / 60 GB/s, App. F 318 / 422 : 304 / 394, its 4 KB-window form
+    // 383 / 512 : 348 / 453, a bitmap 428 / 565 : 383 / 488, 4 MiB blocks 432 / 576 : 401 / 533; geo (ratio 1.07) 196 / 260 : 328 / 421.  From
+    // 12288 blocks on the lane-group loops win everything but text
+    const bool lit_heavy = 4ull * tl * ts < 5ull * to * tb;
+    const bool small_wave = wave_small != 0u && seq_bytes != 0u && sampled && !lit_heavy;
+    const uint32_t r = is_big ? 1u : (is_short || small_wave) ? 2u : (deep_if_near != 0u && is_near) ? 3u : 0u;
     *route = r;
     g_last_route[0] = r; g_last_route[1] = ts; g_last_route[2] = tb; g_last_route[3] = avg;   // (diagnostic: last_decode_route)
     g_last_route[6] = tl; g_last_route[7] = tz;
@@ -1492,11 +1500,11 @@ int launch_decompress(const BatchArgs& a, bool safe, int lanes_per_block, int pi
   if (auto_lanes && pipe < 0 && stage < 0 && route_word) {
     // every default in place and more than 16 blocks per CU: the decoder is chosen on the device (decode_route_kernel above) -- by the
     // blocks' sizes between the deep loop and the ring loop (batches that fill the GPU with the ring loop's 16 blocks per wavefront,
-    // 12288 .. 40959 blocks: 8192 x 4 MiB 422 vs 544 GB/s for the deep loop; 16384: 847 vs 815), and by the streams' sequence density
-    // between either of them and the wave kernel
-    const bool ring_size = a.n >= 12288u && a.n < 40960u, staged = a.n >= 40960u;
+    // 16384 .. 40959 blocks: 8192 x 4 MiB 409 vs 533 GB/s for the deep loop; 12288: 604 vs 670; 14336: 701 vs 757; 16384: 847 vs 815), and by what the streams
+    // hold between either of them and the wave kernel
+    const bool ring_size = a.n >= 16384u && a.n < 40960u, staged = a.n >= 40960u, wave_small = a.n <= 32u * device_cus();
     hipLaunchKernelGGL(decode_route_kernel, dim3(1), dim3(1024), 0, st, a.src, a.src_off, a.src_len, a.dst_cap, a.n, safe ? 1u : 0u, ring_size ? 512u << 10 : 0u,
-                       (uint32_t)g_route_short.load(std::memory_order_relaxed), staged ? 1u : 0u, route_word);
+                       (uint32_t)g_route_short.load(std::memory_order_relaxed), staged ? 1u : 0u, wave_small ? 1u : 0u, route_word);
     int e = staged ? launch_decode_gl<4>(a, safe, 0, true, st, route_word) : launch_decode_gl<8>(a, safe, 2, false, st, route_word);
     if (e == 0 && staged) e = launch_decode_gl<8>(a, safe, 2, false, st, route_word, 3u);
     if (e == 0 && ring_size) e = launch_decode_ring<4, 2048>(a, safe, st, route_word, 1u);

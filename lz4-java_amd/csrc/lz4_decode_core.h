@@ -133,7 +133,9 @@ LZ4HIP_DEV int decode_block(Grp& g, const uint8_t* src, int src_size, uint8_t* d
       if (ip + 1024 <= iend && ip <= iend - 306 && op <= oend - 606) decode_wave_loop(g, src, iend, dst, oend, ip, op, stage);
     }
     if constexpr (PIPE == 5 || PIPE == 6) {   // the parallel wave loop: several sequences of the block per trip (6: one window of the stream per trip whatever the backend's ring -- the simulator's way to the form a 1 KB stream ring runs)
-      if (ip + 1536 <= iend && ip <= iend - 306 && op <= oend - 606) decode_wave_par_loop<Grp>(g, src, iend, dst, oend, ip, op, stage);
+      if (ip + 1536 <= iend && ip <= iend - 306 && op <= oend - 606)
+        if (decode_wave_par_loop<Grp, false>(g, src, iend, dst, oend, ip, op, stage))             // (true: the stream is full of sequences -- the loop's SHORT instance)
+          if (ip + 1536 <= iend && ip <= iend - 306 && op <= oend - 606) (void)decode_wave_par_loop<Grp, true>(g, src, iend, dst, oend, ip, op, stage);
     }
     if constexpr (PIPE == 7) {   // the pair loop (lz4_decode_pair.h): this wavefront copies, its partner wavefront parses the stream a trip or two ahead
       if (ip + 1536 <= iend && ip <= iend - 306 && op <= oend - 606) decode_pair_loop<Grp>(g, src, iend, dst, oend, ip, op, stage);

@@ -34,6 +34,15 @@
 #ifndef LZ4HIP_WAVE_CONT
 #define LZ4HIP_WAVE_CONT 1
 #endif
+#ifndef LZ4HIP_RUN_TIERS
+#define LZ4HIP_RUN_TIERS 1       /* (group_dev.h) 0: no SHORT instance of the parallel loop -- the copy rounds always in their 64-byte form (developer A/B builds) */
+#endif
+#ifndef LZ4HIP_SHORT_MIN_T
+#define LZ4HIP_SHORT_MIN_T 48u   /* starts in a window from which it counts as full of sequences ... */
+#endif
+#ifndef LZ4HIP_SHORT_AFTER
+#define LZ4HIP_SHORT_AFTER 4u    /* ... and so many of them in a row send the block to the loop's SHORT instance (decode_wave_par_loop) */
+#endif
 #ifndef LZ4HIP_WAVE_SKIP
 #define LZ4HIP_WAVE_SKIP 1
 #endif
@@ -250,8 +259,17 @@ LZ4HIP_DEV bool wave_single_step(Grp& g, const uint8_t* dst, uint32_t& ip, uint3
 
 // entry: ip + 1536 <= iend, ip <= iend - 306, op <= oend - 606.  Leaves with ip / op at the first sequence it did not decode;
 // everything below op is in memory then.
-template <class Grp>
-LZ4HIP_DEV void decode_wave_par_loop(Grp& g, const uint8_t* src, const int iend, uint8_t* dst, const int oend, int& ip_io, int& op_io, uint8_t* lds) {
+// SHORT: the loop for streams FULL of sequences (text: ~58 starts per window, runs of 2 .. 6 bytes) -- every pass picks the form of its copy rounds by
+// its longest run (group_dev.h vcopy_run: pieces for runs shorter than 16 / 32 / up to 64 bytes; an unaligned LDS access costs a cycle per active lane,
+// wanted or not: text 161 -> 210-220 GB/s).  A SECOND INSTANCE of the loop, not a test inside one: with the short forms present the compiler's code for the
+// 64-byte form is 1.3 .. 6 % slower on every other kind of data, however the choice is made (per round, per window, per pass, behind an empty asm:
+// profiles/r06_wave_segments.txt -- a test of what the window produced at the end of the trip was enough for 2 %; a third instance to come back to, 1.6 %).
+// The plain instance returns true when LZ4HIP_SHORT_AFTER windows in a row held LZ4HIP_SHORT_MIN_T starts or more, and decode_block goes on in the SHORT
+// instance (it starts with empty rings: sources below its entry come from memory, once per block).  48 starts: text has 58-65 per window; a bitmap's
+// windows hold 36, of sequences of 26 bytes on average with runs of hundreds among them -- every pass takes the 64-byte form, which the SHORT instance
+// does 4.5 % slower -- and App. F data 15.
+template <class Grp, bool SHORT>
+LZ4HIP_DEV bool decode_wave_par_loop(Grp& g, const uint8_t* src, const int iend, uint8_t* dst, const int oend, int& ip_io, int& op_io, uint8_t* lds) {
   typedef typename Grp::LChunk LChunk;
   typedef typename Grp::VU VU;
   typedef typename Grp::VB VB;
@@ -276,6 +294,8 @@ LZ4HIP_DEV void decode_wave_par_loop(Grp& g, const uint8_t* src, const int iend,
   const VU p0 = lane * 4u;
   uint32_t wild = op;                          // end of what one-sequence steps have written into the ring (see `bound`)
   uint32_t Tprev = 0u;                         // starts the window before this one held (which walk this one gets)
+  uint32_t full = 0u;                          // windows in a row that were full of sequences
+  bool other = false;                          // leave for the loop's SHORT instance
 #ifdef LZ4HIP_RING_DBG   /* developer build: what the loop did (tools/wave_stats.py) */
   uint32_t dbg_trips = 0, dbg_seqs = 0, dbg_rounds = 0, dbg_single = 0, dbg_hungry = 0, dbg_T = 0;
 #endif
@@ -340,6 +360,10 @@ LZ4HIP_DEV void decode_wave_par_loop(Grp& g, const uint8_t* src, const int iend,
       // count) when the window before this one was that full.  Either way the same posv and T
       if (Tprev >= LZ4HIP_WALK_PAR_MIN) Grp::vwalk_par(nxpack, lane, posv, T); else Grp::vwalk(nxpack, posv, T);
       Tprev = T;
+    }
+    if (!SHORT && LZ4HIP_RUN_TIERS) {           // (windows full of sequences: the loop's SHORT instance goes on from here)
+      full = T >= LZ4HIP_SHORT_MIN_T ? full + 1u : 0u;
+      if (full >= LZ4HIP_SHORT_AFTER) { other = true; break; }
     }
     // ---- 3. records, output positions: A LANE PER RUN -- lane 2k the literals of a sequence, lane 2k + 1 its match.  (A lane per
     // sequence copied two runs, 16 reads and 16 predicated stores a round: ~220 instructions of a trip of ~900 that is bound by
@@ -414,6 +438,7 @@ LZ4HIP_DEV void decode_wave_par_loop(Grp& g, const uint8_t* src, const int iend,
       const VU spv = Grp::vsel(isM, mp + db, lp);   // the run's source: ring coordinates of the match source / stream position of the literals
       // (the round's lane sets are wave-uniform MASKS, combined with scalar instructions: one vector compare per round)
       const uint64_t oddm = g.vodd_mask(o + db, len);
+      const uint32_t tier = SHORT ? Grp::vrun_tier(len, actm) : 4u;
       uint32_t a = 0u;
       for (;;) {
         const uint32_t oa = Grp::vreadlane(o, a);
@@ -424,7 +449,7 @@ LZ4HIP_DEV void decode_wave_par_loop(Grp& g, const uint8_t* src, const int iend,
         g.vnote(act, Grp::vlanes(simplem), !isM | (mp < VU(0x80000000u)), !isM | (send <= VU(oa)) | (lane < a), Grp::vlanes(litm | heldm) | (send <= VU(memlim)), Grp::vlanes(litm | heldm), (oe - op) <= VU(TRIPMAX), Grp::vlanes(okm));
 #endif
         if (Te == a) break;
-        g.vcopy_run(o + db, !isM, spv, len, ((1ull << Te) - 1ull) & ~below, dst, mp, farm, oddm);
+        g.vcopy_run(o + db, !isM, spv, len, ((1ull << Te) - 1ull) & ~below, dst, mp, farm, oddm, tier);
 #ifdef LZ4HIP_RING_DBG
         dbg_rounds++;
 #endif
@@ -485,6 +510,7 @@ LZ4HIP_DEV void decode_wave_par_loop(Grp& g, const uint8_t* src, const int iend,
   g.wv_stats(dbg_trips, dbg_seqs, dbg_rounds, dbg_single, dbg_hungry, dbg_T, 0u);
 #endif
   ip_io = (int)ip; op_io = (int)op;
+  return other;
 }
 
 }  // namespace lz4hip

@@ -439,7 +439,7 @@ struct GroupHost {
   }
   // group_dev.h vwalk_par: the same starts by pointer doubling -- the device's levels and gathers, and the result compared with the plain
   // definition of the walk (a mismatch counts as a failure of the simulated wavefront: walk_mismatch, folded into every decode's verdict)
-  static inline std::atomic<uint64_t> walk_mismatch{0}, walk_par_calls{0};
+  static inline std::atomic<uint64_t> walk_mismatch{0}, walk_par_calls{0}, short_rounds{0};
   static uint32_t vgather8(const VU& tab, uint32_t q) { return (tab.v[(q >> 2) & 63u] >> ((q & 3u) * 8u)) & 255u; }
   static void vwalk_par(const VU& nx, const VU& lane, VU& posv, uint32_t& T) {
     walk_par_calls++;
@@ -528,7 +528,17 @@ struct GroupHost {
     for (int l = 0; l < 64; l++) { const uint32_t x = dw.v[l] & (kWv - 1u); if (len.v[l] > 64u || x < 16u || x + len.v[l] + 16u > kWv) m |= 1ull << l; }
     return m;
   }
-  void vcopy_run(const VU& dw, const VB& from_stream, const VU& sp, const VU& len, uint64_t gom, const uint8_t* mem, const VU& mpos, uint64_t farm, uint64_t oddm) {
+  static uint32_t vrun_tier(const VU& len, uint64_t actm) {
+    uint32_t t = 0u;
+    for (int l = 0; l < 64; l++) if ((actm >> l) & 1ull) { if (len.v[l] >= 32u) return 4u; if (len.v[l] >= 16u) t = 1u; }
+    return t;
+  }
+  void vcopy_run(const VU& dw, const VB& from_stream, const VU& sp, const VU& len, uint64_t gom, const uint8_t* mem, const VU& mpos, uint64_t farm, uint64_t oddm,
+                 uint32_t tier = 4u) {
+    // (the device picks a round's form -- pieces of 16 bytes read and stored: none / one / four -- by the tier: a lane of the round whose run is
+    // longer than its tier says would lose bytes there)
+    for (int l = 0; l < 64; l++) if ((gom >> l) & 1ull) { if (len.v[l] >= 16u && tier == 0u) oob = true; if (len.v[l] >= 32u && tier != 4u) oob = true; }
+    if (tier != 4u) short_rounds++;
     const VB go = vlanes(gom), far = vlanes(farm);
     if ((oddm ^ vodd_mask(dw, len)) & gom) oob = true;   // (the caller's mask must be the rule below, for the lanes of the round: the pair loop's copier gets the mask from the parser, and lanes 62 / 63 of its message are header words)
     par_rounds++;

@@ -263,6 +263,7 @@ int sim_decompress(const uint8_t* src, int src_size, uint8_t* dst, int out_size,
   return r;
 }
 unsigned long long sim_walk_par_calls() { return hostsim::GroupHost::walk_par_calls.load(); }
+unsigned long long sim_short_rounds() { return hostsim::GroupHost::short_rounds.load(); }   // copy rounds in a short form (the wave loop's SHORT instance)
 
 // LZ4 HC (levels 1..12): phase 1 (delta[] build) + phase 2 (lazy parse, or the optimal parser for 10..12) in the lock-step
 // simulator.  returns the compressed size, 0 (does not fit) or -1000 (out-of-slot access)

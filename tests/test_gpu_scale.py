@@ -110,15 +110,15 @@ def test_cfg3_reference_compressed_4MiB_blocks_every_decoder_variant(amd, ref, O
 
 
 def test_routed_batch_of_big_blocks_vs_reference(amd, ref):
-    """Every decode knob at its default and a batch of 12288..40959 blocks whose compressed size averages >= 512 KiB: the launch is
+    """Every decode knob at its default and a batch of 16384..40959 blocks whose compressed size averages >= 512 KiB: the launch is
     routed ON THE DEVICE (decode_route_kernel) to the ring loop with 4 lanes and a 2 KiB ring -- the instantiation behind the
-    configs[2] number of the bench line.  12288 blocks of 1.25 MiB; a sample of the streams is the reference library's own bytes
+    configs[2] number of the bench line.  16384 blocks of 1.25 MiB; a sample of the streams is the reference library's own bytes
     (asserted), a second sample is damaged (flipped bytes, truncated, capacity too small): sizes, bytes and error codes against
     LZ4_decompress_safe (LZ4JNI.c:216), and the untouched blocks against their source."""
     import numpy as np
     import torch
     dev = torch.device("cuda:0")
-    n, blk = 12288, 1310720
+    n, blk = 16384, 1310720
     cap = amd.maxCompressedLength(blk)
     src = torch.empty(n * blk, dtype=torch.uint8, device=dev)
     amd.DeviceBatch.gen_blocks(src, blk, blk, n, first_idx=5 << 24, win=4096)
@@ -170,7 +170,9 @@ def test_batches_routed_by_sequence_density_vs_reference(amd, ref, corpus):
     speculative walk from an arbitrary byte: it falls in with the true token chain within a few sequences) and sends batches of SHORT
     sequences with near sources -- text: ~6 output bytes per sequence, most offsets within 6 KB -- to the wave kernel, everything else
     (App. F 34 bytes per sequence, a bitmap 100+, geophysical data 40; synthetic streams as dense as text of 13 bytes per sequence) to a
-    lane-group loop: the deep loop below 40960 blocks and, from there on, for near sources (the bitmap), else the 4-lane staged loop.  For text, App. F, bitmap and geophysical batches below and above 40960 blocks: the route
+    lane-group loop: the deep loop below 40960 blocks and, from there on, for near sources (the bitmap), else the 4-lane staged loop.  Batches of
+    up to 32 blocks per CU (two rounds of the wave kernel's 16 wavefronts per CU) go to the wave kernel whatever they hold, unless their streams are
+    mostly literals (the geophysical data).  For text, App. F, bitmap and geophysical batches below and above 40960 blocks: the route
     taken, sizes and bytes against the source, a sample of damaged / reference-compressed streams against LZ4_decompress_safe
     (LZ4JNI.c:216); and the same bytes with the wave route opened wide (decode_route_short 255) and closed (0)."""
     import numpy as np
@@ -200,7 +202,8 @@ def test_batches_routed_by_sequence_density_vs_reference(amd, ref, corpus):
         return src
 
     try:
-        for kind, n, want_route in (("book", 6144, 2), ("appf", 6144, 0), ("lit2", 6144, 0), ("pic", 5000, 0), ("geo", 5000, 0), ("book", 45056, 2), ("appf", 45056, 0), ("pic", 45056, 3), ("book", 20000, 2)):
+        # (up to 32 blocks per CU -- 8192 -- the wave kernel takes every kind of data but streams that are mostly literals: geo, ratio 1.07)
+        for kind, n, want_route in (("book", 6144, 2), ("appf", 6144, 2), ("lit2", 6144, 2), ("pic", 5000, 2), ("geo", 5000, 0), ("appf", 10240, 0), ("book", 45056, 2), ("appf", 45056, 0), ("pic", 45056, 3), ("book", 20000, 2)):
             src = make(kind, n)
             comp = torch.zeros(n * cap, dtype=torch.uint8, device=dev)   # (zeros behind every stream: what the fast decoder's sampler may look at is defined)
             B = _batch(torch, dev, n, blk, cap)
@@ -213,7 +216,8 @@ def test_batches_routed_by_sequence_density_vs_reference(amd, ref, corpus):
             amd.DeviceBatch.decompress_fast(comp, B["co"], B["cc"], back, B["so"], B["sl"], B["dlen"])
             torch.cuda.synchronize()
             # (a fifth of the output size into the slot; the bitmap's streams -- ratio 14 -- end before that: zeros, offset 0, nothing is routed)
-            assert amd.last_decode_route()[0] == (0 if kind == "pic" else want_route), (kind, n, "fast", amd.last_decode_route())
+            # (geo: a fifth of the output size into ITS streams lies in the file's header region, which is not mostly literals -- either route)
+            assert amd.last_decode_route()[0] in ((0,) if kind == "pic" else (0, 2) if kind == "geo" else (want_route,)), (kind, n, "fast", amd.last_decode_route())
             assert torch.equal(back, src) and torch.equal(B["dlen"], B["clen"]), (kind, n, "fast")
             del back
             sample = rng.sample(range(n), 24)
@@ -246,7 +250,7 @@ def test_batches_routed_by_sequence_density_vs_reference(amd, ref, corpus):
                 torch.cuda.synchronize()
                 route = amd.last_decode_route()
                 near = 2 * route[4] >= route[5]
-                expect = want_route if short < 0 else (2 if near else 0) if short == 255 else (3 if near and n >= 40960 else 0)
+                expect = want_route if short < 0 else (2 if (near or (n <= 8192 and kind != "geo")) else 0) if short == 255 else (3 if near and n >= 40960 else 0)
                 assert route[0] == expect, (kind, n, short, route)
                 dense = short
                 dlen = B["dlen"].cpu().numpy()

@@ -16,12 +16,15 @@ _u8p = C.POINTER(C.c_uint8)
 
 def load_sim():
     d = os.path.join(ROOT, "tests", "hostsim")
-    so = os.path.join(d, "libhostsim.so")
+    # (LZ4HIP_SIM_FLAGS: a developer / soak build of the simulator with other macros -- e.g. the wave loop's instances switching every few windows --
+    # into a library of its own: <name>:<flags>)
+    extra = os.environ.get("LZ4HIP_SIM_FLAGS", "")
+    so = os.path.join(d, "libhostsim%s.so" % (("_" + extra.split(":", 1)[0]) if extra else ""))
     srcs = [os.path.join(d, f) for f in ("hostsim.cpp", "wave_host.h", "group_host.h")] + \
            [os.path.join(ROOT, "lz4-java_amd", "csrc", f) for f in ("lz4_fast_core.h", "lz4_fast_ms_core.h", "lz4_fast_v2_core.h", "lz4_decode_core.h", "lz4_decode_deep.h", "lz4_decode_ring.h", "lz4_decode_wave.h", "lz4_decode_pair.h", "lz4_decode_trio.h", "lz4_hc_core.h")]
     srcs.append(os.path.join(ROOT, "lz4-java_amd", "csrc", "mail_ring.h"))
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", so, os.path.join(d, "hostsim.cpp")])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread"] + (extra.split(":", 1)[1].split() if extra else []) + ["-o", so, os.path.join(d, "hostsim.cpp")])
     l = C.CDLL(so)
     l.sim_compress_fast.restype = C.c_int
     l.sim_compress_fast.argtypes = [C.c_char_p, C.c_int, _u8p, C.c_int, C.POINTER(C.c_uint64), C.c_uint64]
@@ -453,6 +456,9 @@ def test_wave_decoder_loop(sim, ref, O, corpus, par):
         if par is True or par == "trio":   # windows full of sequences take the walk by pointer doubling (group_dev.h vwalk_par): the backend runs it NEXT TO the plain walk and any difference fails the decode
             sim.sim_walk_par_calls.restype = C.c_ulonglong
             assert sim.sim_walk_par_calls() > 2000, sim.sim_walk_par_calls()   # trips did the work (this corpus is mostly irregular streams: App. F data runs 9-12 sequences per trip, text 18)
+        if par is True:   # ... and go on in the loop's SHORT instance, whose passes pick the form of their copy rounds by their longest run (the backend checks every round's lanes against the form)
+            sim.sim_short_rounds.restype = C.c_ulonglong
+            assert sim.sim_short_rounds() > 2000, sim.sim_short_rounds()
 
 
 @pytest.mark.parametrize("par", [False, True, "pair", "trio"])
@@ -529,6 +535,17 @@ def test_trio_end_of_block_rules(sim, loop):
     import subprocess, sys
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "trio_end_soak.py"), "20260930", "1200", loop], timeout=600).decode()
     assert "bad 0" in out and "cases 1200" in out, out[-400:]
+
+
+def test_wave_loop_switches_instances_on_any_data():
+    """The parallel wave loop exists in two instances (csrc/lz4_decode_wave.h: plain, and SHORT -- copy rounds in the form their longest run allows);
+    decode_block moves a block from the first to the second where the loop leaves it, the second starting with empty rings.  A build of the simulator
+    in which that happens on every kind of data and at once (full from 4 starts per window on, after 1 window), a slice of the end-of-block soak on
+    it: the reference library's codes and bytes."""
+    import subprocess, sys
+    env = dict(os.environ, LZ4HIP_SIM_FLAGS="switchy:-DLZ4HIP_SHORT_AFTER=1u -DLZ4HIP_SHORT_MIN_T=4u")
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "trio_end_soak.py"), "20260931", "800", "par"], timeout=900, env=env).decode()
+    assert "bad 0" in out and "cases 800" in out, out[-400:]
 
 
 def test_decode_core_malformed_vectors(sim, golden):

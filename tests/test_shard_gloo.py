@@ -141,7 +141,7 @@ def test_bench_names_the_decoder_the_library_routes_to():
     assert bench.decode_kernel_name(16384, big_blocks=True) == "decode_ring_kernel<4, 2048, true>"
     assert bench.decode_kernel_name(65536, safe=False) == "decode_kernel<4, false, 0, true>"
     src = open(os.path.join(ROOT, "lz4-java_amd", "csrc", "kernels.hip")).read()
-    assert "a.n <= 5u * device_cus()" in src and "a.n <= 16u * device_cus()" in src and "a.n >= 40960u ? 4 : 8" in src and "a.n >= 12288u && a.n < 40960u" in src   # the thresholds the table restates
+    assert "a.n <= 5u * device_cus()" in src and "a.n <= 16u * device_cus()" in src and "a.n >= 40960u ? 4 : 8" in src and "a.n >= 16384u && a.n < 40960u" in src and "a.n <= 32u * device_cus()" in src   # the thresholds the table restates
     tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     if tr.get("kernel_source_hash") == bench.kernel_source_hash():
         for name in ("decode_kernel<4, true, 0, true>", "decode_kernel<4, false, 0, true>", "decode_ring_kernel<4, 2048, true>", "decode_wave_kernel<8, 16384, 2048, true, 5>",

@@ -66,13 +66,14 @@ for kind in wls:
         staged = run(4, 0, 1, 0) if n >= 40960 else None
         deep = run(8, 2, 0, 0)
         wave = run(64, 5, 0, 8192)
+        ringl = run(4, 3, 0, 2048) if kind.startswith("cfg2_") else None   # (big blocks: the ring loop too)
         dflt = run(0, -1, -1, 0)
         r = amd.last_decode_route()
         gb = lambda t: n * blk / t / 1e6
         print("%-9s n %6d ratio %5.2f  sampled %5.1f seq/256B %6.1f B/seq near %3.0f %%  %s deep %8.3f ms %6.1f GB/s | wave %8.3f ms %6.1f GB/s | default -> route %d %8.3f ms %6.1f GB/s  ok=%s" % (
             kind, n, n * blk / int(clen.sum().item()), 256.0 * r[1] / max(r[2], 1), r[6] / max(r[5], 1), 100.0 * r[4] / max(r[5], 1),
             ("staged %8.3f ms %6.1f GB/s |" % (staged[0], gb(staged[0]))) if staged else "", deep[0], gb(deep[0]), wave[0], gb(wave[0]), r[0], dflt[0], gb(dflt[0]),
-            deep[1] and wave[1] and dflt[1] and (staged is None or staged[1])), flush=True)
+            deep[1] and wave[1] and dflt[1] and (staged is None or staged[1])) + ((" | ring %8.3f ms %6.1f GB/s" % (ringl[0], gb(ringl[0]))) if ringl else ""), flush=True)
         del src, comp, back
         torch.cuda.empty_cache()
         if kind.startswith("cfg2_"):
