@@ -428,3 +428,57 @@ def test_host_batch_many_chunks_ragged_concurrent_callers(amd, ref, O):
     assert list(got) == [lens[i] for i in ok]
     for i in ok:
         assert bytes(back[int(so[i]):int(so[i]) + lens[i]]) == srcs[i], i
+
+
+def test_batches_that_are_not_a_multiple_of_a_workgroup_per_cu_vs_reference(amd, ref):
+    """The trio and wave kernels give a workgroup W blocks; a batch that is not a multiple of W x CUs is SPREAD -- wavefront k of workgroup i takes
+    block i + k * grid, every CU gets ceil(n / CUs) blocks (kernels.hip wave_spread) -- where that puts fewer blocks on a CU than packing W neighbours
+    does.  Batch sizes on both sides of every W (trio 1 / 2 / 4 / 5, wave 8 / 16) with every knob at its default, safe and fast decoders: sizes and
+    bytes against the source, a sample of streams against the reference's own bytes, a damaged sample against LZ4_decompress_safe (LZ4JNI.c:216)."""
+    import numpy as np
+    import torch
+    dev = torch.device("cuda:0")
+    blk = 65536
+    cap = amd.maxCompressedLength(blk)
+    rng = random.Random(4711)
+    for n in (255, 257, 300, 511, 700, 1023, 1100, 1279, 1300, 1800, 2047, 2300, 3000, 4095):
+        src = torch.empty(n * blk, dtype=torch.uint8, device=dev)
+        amd.DeviceBatch.gen_blocks(src, blk, blk, n, first_idx=(11 << 24) + n)
+        comp = torch.zeros(n * cap, dtype=torch.uint8, device=dev)
+        B = _batch(torch, dev, n, blk, cap)
+        amd.DeviceBatch.compress_fast(src, B["so"], B["sl"], comp, B["co"], B["cc"], B["clen"])
+        torch.cuda.synchronize()
+        clen = B["clen"].cpu().numpy().copy()
+        back = torch.zeros(n * blk, dtype=torch.uint8, device=dev)
+        amd.DeviceBatch.decompress_fast(comp, B["co"], B["cc"], back, B["so"], B["sl"], B["dlen"])
+        torch.cuda.synchronize()
+        assert torch.equal(back, src) and torch.equal(B["dlen"], B["clen"]), (n, "fast")
+        sample = rng.sample(range(n), 12)
+        good, bad = sample[:4], sample[4:]
+        streams = {i: comp[i * cap:i * cap + int(clen[i])].cpu().numpy().tobytes() for i in sample}
+        for i in good:
+            assert streams[i] == ref.compress_fast(src[i * blk:(i + 1) * blk].cpu().numpy().tobytes()), (n, i)
+        caps = np.full(n, blk, dtype=np.int32)
+        for k, i in enumerate(bad):
+            c = bytearray(streams[i])
+            if k % 2 == 0:
+                c[rng.randrange(len(c))] ^= 1 + rng.randrange(255)
+                comp[i * cap:i * cap + len(c)] = torch.from_numpy(np.frombuffer(bytes(c), dtype=np.uint8).copy()).to(dev)
+            else:
+                caps[i] = blk - rng.randrange(1, 3000)
+            streams[i] = bytes(c)
+        want = {i: ref.decompress_safe_raw(streams[i], int(caps[i])) for i in bad}
+        ok = np.ones(n, dtype=bool); ok[bad] = False
+        okt = torch.from_numpy(ok).to(dev)
+        back = torch.zeros(n * blk, dtype=torch.uint8, device=dev)
+        amd.DeviceBatch.decompress_safe(comp, B["co"], torch.from_numpy(clen).to(dev), back, B["so"], torch.from_numpy(caps).to(dev), B["dlen"])
+        torch.cuda.synchronize()
+        dlen = B["dlen"].cpu().numpy()
+        for i in bad:
+            er, ed = want[i]
+            assert int(dlen[i]) == er, (n, i, int(dlen[i]), er)
+            if er >= 0:
+                assert back[i * blk:i * blk + er].cpu().numpy().tobytes() == ed[:er], (n, i)
+        assert (dlen[ok] == blk).all(), n
+        assert torch.equal(back.view(n, blk)[okt], src.view(n, blk)[okt]), n
+        del src, comp, back
