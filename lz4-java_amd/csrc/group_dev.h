@@ -712,13 +712,23 @@ struct BlockWaveDev : GroupDev<64, 0> {
   struct Run16 { u4a a0, a1, a2, a3; u2a b; uint32_t c; uint32_t d; uint32_t e; };
   // NA: the 16-byte pieces a round reads and stores -- 4: runs of up to 64 bytes; 1: every run of the round is shorter than 32 bytes; 0: shorter than
   // 16 (text: most rounds).  An unaligned LDS access costs a cycle per active lane whether its bytes are wanted or not
-  template <int NA>
+  template <int NA, bool PRED = false>
   __device__ __forceinline__ static Run16 vrun_load(const uint8_t* sb, uint32_t sm, VU sp, VU len) {
     Run16 r;
-    if (NA >= 1) r.a0 = *(const u4a*)(sb + (sp & sm));
-    if (NA >= 2) r.a1 = *(const u4a*)(sb + ((sp + 16u) & sm));
-    if (NA >= 3) r.a2 = *(const u4a*)(sb + ((sp + 32u) & sm));
-    if (NA >= 4) r.a3 = *(const u4a*)(sb + ((sp + 48u) & sm));
+    if (PRED) {   // the 16-byte pieces read only by the lanes whose run has them (as the stores are): an unaligned LDS access costs a cycle per ACTIVE lane.
+      // Three more mask set-ups per round: it pays where the LDS is busy -- the one-wavefront kernels at 8-16 wavefronts per CU (4096 x 4 MiB +2.4 %,
+      // text +2 %) -- and costs where a lone wavefront waits for its own instructions (the trio's copier: one block 0.153 -> 0.156 ms); gpurun_out/r06ap
+      r.a0 = u4a(); r.a1 = u4a(); r.a2 = u4a(); r.a3 = u4a();
+      if (NA >= 1) if (len >= 16u) r.a0 = *(const u4a*)(sb + (sp & sm));
+      if (NA >= 2) if (len >= 32u) r.a1 = *(const u4a*)(sb + ((sp + 16u) & sm));
+      if (NA >= 3) if (len >= 48u) r.a2 = *(const u4a*)(sb + ((sp + 32u) & sm));
+      if (NA >= 4) if (len >= 64u) r.a3 = *(const u4a*)(sb + ((sp + 48u) & sm));
+    } else {
+      if (NA >= 1) r.a0 = *(const u4a*)(sb + (sp & sm));
+      if (NA >= 2) r.a1 = *(const u4a*)(sb + ((sp + 16u) & sm));
+      if (NA >= 3) r.a2 = *(const u4a*)(sb + ((sp + 32u) & sm));
+      if (NA >= 4) r.a3 = *(const u4a*)(sb + ((sp + 48u) & sm));
+    }
     uint32_t c = NA >= 1 ? len & ~15u : 0u;
     r.b = *(const u2a*)(sb + ((sp + c) & sm));
     c += len & 8u;
@@ -789,10 +799,10 @@ struct BlockWaveDev : GroupDev<64, 0> {
     const uint32_t x = dw & ((uint32_t)KW - 1u);
     return __builtin_amdgcn_ballot_w64(len > 64u) | __builtin_amdgcn_ballot_w64(x < 16u) | __builtin_amdgcn_ballot_w64(x + len + 16u > (uint32_t)KW);   // (a ballot per comparison: see lz4_decode_wave.h)
   }
-  template <int NA>
+  template <int NA, bool PRED>
   __device__ __forceinline__ void vround(VU dw, bool from_stream, VU sp, VU len, uint64_t gom, const uint8_t* mem, VU mpos, uint64_t gfm) {
     if (vlanes(gom)) {
-      Run16 r = vrun_load<NA>(from_stream ? wsb : wrb, from_stream ? (uint32_t)KS - 1u : (uint32_t)KW - 1u, sp, len);
+      Run16 r = vrun_load<NA, PRED>(from_stream ? wsb : wrb, from_stream ? (uint32_t)KS - 1u : (uint32_t)KW - 1u, sp, len);
       if (__builtin_expect(gfm != 0ull, 0)) {
         // (the rare branches take their operands through an empty asm: what is computed from them -- 64-bit addresses here, ring
         // masks and mirror tests below -- is computed IN the branch; the compiler otherwise hoists ~55 instructions of it in front
@@ -808,6 +818,7 @@ struct BlockWaveDev : GroupDev<64, 0> {
     if ((__builtin_amdgcn_ballot_w64(len >= 32u) & actm) != 0ull) return 4u;
     return (__builtin_amdgcn_ballot_w64(len >= 16u) & actm) != 0ull ? 1u : 0u;
   }
+  template <bool PRED = false>
   __device__ __forceinline__ void vcopy_run(VU dw, bool from_stream, VU sp, VU len, uint64_t gom, const uint8_t* mem, VU mpos, uint64_t farm, uint64_t oddm,
                                             uint32_t tier = 4u) {
     const uint64_t gfm = gom & farm;
@@ -819,10 +830,10 @@ struct BlockWaveDev : GroupDev<64, 0> {
 #if LZ4HIP_TIER_GUARD
         asm volatile("" : "+v"(dw2), "+v"(sp2), "+v"(ln2));
 #endif
-        if (tier == 0u) vround<0>(dw2, from_stream, sp2, ln2, gom, mem, mpos, gfm);
-        else vround<1>(dw2, from_stream, sp2, ln2, gom, mem, mpos, gfm);
+        if (tier == 0u) vround<0, PRED>(dw2, from_stream, sp2, ln2, gom, mem, mpos, gfm);
+        else vround<1, PRED>(dw2, from_stream, sp2, ln2, gom, mem, mpos, gfm);
       } else {
-        vround<4>(dw, from_stream, sp, len, gom, mem, mpos, gfm);
+        vround<4, PRED>(dw, from_stream, sp, len, gom, mem, mpos, gfm);
       }
     } else {
       VU dw2 = dw, sp2 = sp, ln2 = len, mp2 = mpos;

@@ -34,6 +34,9 @@
 #ifndef LZ4HIP_WAVE_CONT
 #define LZ4HIP_WAVE_CONT 1
 #endif
+#ifndef LZ4HIP_PRED_LOADS
+#define LZ4HIP_PRED_LOADS 1      /* (group_dev.h vrun_load) the parallel loop's copy rounds read their 16-byte pieces only in the lanes whose run has them; 0: every active lane reads all (developer A/B builds) */
+#endif
 #ifndef LZ4HIP_RUN_TIERS
 #define LZ4HIP_RUN_TIERS 1       /* (group_dev.h) 0: no SHORT instance of the parallel loop -- the copy rounds always in their 64-byte form (developer A/B builds) */
 #endif
@@ -449,7 +452,7 @@ LZ4HIP_DEV bool decode_wave_par_loop(Grp& g, const uint8_t* src, const int iend,
         g.vnote(act, Grp::vlanes(simplem), !isM | (mp < VU(0x80000000u)), !isM | (send <= VU(oa)) | (lane < a), Grp::vlanes(litm | heldm) | (send <= VU(memlim)), Grp::vlanes(litm | heldm), (oe - op) <= VU(TRIPMAX), Grp::vlanes(okm));
 #endif
         if (Te == a) break;
-        g.vcopy_run(o + db, !isM, spv, len, ((1ull << Te) - 1ull) & ~below, dst, mp, farm, oddm, tier);
+        g.template vcopy_run<LZ4HIP_PRED_LOADS != 0>(o + db, !isM, spv, len, ((1ull << Te) - 1ull) & ~below, dst, mp, farm, oddm, tier);
 #ifdef LZ4HIP_RING_DBG
         dbg_rounds++;
 #endif

@@ -533,6 +533,7 @@ struct GroupHost {
     for (int l = 0; l < 64; l++) if ((actm >> l) & 1ull) { if (len.v[l] >= 32u) return 4u; if (len.v[l] >= 16u) t = 1u; }
     return t;
   }
+  template <bool PRED = false>   // (the device's choice between reading a round's pieces in every active lane and only where the run has them: the same bytes)
   void vcopy_run(const VU& dw, const VB& from_stream, const VU& sp, const VU& len, uint64_t gom, const uint8_t* mem, const VU& mpos, uint64_t farm, uint64_t oddm,
                  uint32_t tier = 4u) {
     // (the device picks a round's form -- pieces of 16 bytes read and stored: none / one / four -- by the tier: a lane of the round whose run is
