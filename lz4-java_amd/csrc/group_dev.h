@@ -105,6 +105,9 @@ struct GroupDev {
 #ifndef LZ4HIP_RUN_TIERS
 #define LZ4HIP_RUN_TIERS 1    /* the wave loops' copy rounds in three forms by their longest run (< 16 / < 32 / <= 64 bytes); 0: always the 64-byte form (developer A/B builds) */
 #endif
+#ifndef LZ4HIP_PRED_CASCADE
+#define LZ4HIP_PRED_CASCADE 1   /* 0: only the 16-byte pieces of a round are predicated (developer A/B builds) */
+#endif
 #ifndef LZ4HIP_TIER_GUARD
 #define LZ4HIP_TIER_GUARD 0   /* 1: the short forms take their operands through an empty asm -- their address math stays in their branch instead of in front of the round loop (developer A/B builds) */
 #endif
@@ -730,6 +733,19 @@ struct BlockWaveDev : GroupDev<64, 0> {
       if (NA >= 4) r.a3 = *(const u4a*)(sb + ((sp + 48u) & sm));
     }
     uint32_t c = NA >= 1 ? len & ~15u : 0u;
+#if LZ4HIP_PRED_CASCADE   /* the 8- and 4-byte pieces too: nothing on long runs, text 214 -> 224 GB/s (its runs are 2 .. 6 bytes: the 8-byte piece is rarely wanted); gpurun_out/r06ar */
+    if (PRED) {
+      r.b = u2a(); r.c = 0u;
+      if (len & 8u) r.b = *(const u2a*)(sb + ((sp + c) & sm));
+      c += len & 8u;
+      if (len & 4u) r.c = *(const u1a*)(sb + ((sp + c) & sm));
+      c += len & 4u;
+      r.d = *(const h1a*)(sb + ((sp + c) & sm));
+      c += len & 2u;
+      r.e = *(sb + ((sp + c) & sm));
+      return r;
+    }
+#endif
     r.b = *(const u2a*)(sb + ((sp + c) & sm));
     c += len & 8u;
     r.c = *(const u1a*)(sb + ((sp + c) & sm));
