@@ -46,6 +46,9 @@
 #ifndef LZ4HIP_SHORT_AFTER
 #define LZ4HIP_SHORT_AFTER 4u    /* ... and so many of them in a row send the block to the loop's SHORT instance (decode_wave_par_loop) */
 #endif
+#ifndef LZ4HIP_WAVE_OVL
+#define LZ4HIP_WAVE_OVL 1        /* a match that overlaps its own output is copied inside the pass (0: it cuts the pass and gets a one-sequence step; developer A/B builds) */
+#endif
 #ifndef LZ4HIP_WAVE_SKIP
 #define LZ4HIP_WAVE_SKIP 1
 #endif
@@ -215,6 +218,24 @@ LZ4HIP_DEV void decode_wave_loop(Grp& g, const uint8_t* src, const int iend, uin
 // its pipelining; what that cannot take either leaves the loop for the exact code of decode_block.
 // ================================================================================================================================
 
+// a match whose source lies in the output ring, wave-wide pieces: pos = where it goes (ring coordinates).  One piece for the usual match; one that overlaps its
+// own output (offset < length) replicates by doubling.  Writes up to a piece beyond the match's end ("wild" bytes: whoever produces them later overwrites them)
+template <class Grp>
+LZ4HIP_DEV void wave_match_ring(Grp& g, const uint32_t pos, const uint32_t off, const uint32_t ml) {
+  constexpr uint32_t PIECE = 252u;
+  g.wv_put(pos, g.wv_get_ring(pos - off, pos));
+  if ((int32_t)((off - ml) | (PIECE - ml)) < 0) {
+    uint32_t o = off, n = o < PIECE ? o : PIECE, p = pos, rem = ml;
+    do {
+      rem -= n; p += n;
+      o = n == o ? 2u * o : o;
+      n = rem < o ? rem : o;
+      n = n < PIECE ? n : PIECE;
+      g.wv_put(p, g.wv_get_ring(p - o, p));
+    } while (rem > n);
+  }
+}
+
 // one sequence at ip through the rings, wave-wide pieces (the body of decode_wave_loop, not pipelined).  false: not for this loop.
 template <class Grp>
 LZ4HIP_DEV bool wave_single_step(Grp& g, const uint8_t* dst, uint32_t& ip, uint32_t& op, const uint32_t op0, const uint32_t fl, const uint32_t db,
@@ -240,17 +261,7 @@ LZ4HIP_DEV bool wave_single_step(Grp& g, const uint8_t* dst, uint32_t& ip, uint3
   if (lit > PIECE) g.wv_put(op + db + PIECE, g.wv_get_stream(ip + hdr + PIECE, op + db + PIECE));
   const uint32_t pos = op + lit + db;
   if ((int32_t)farw >= 0) {
-    g.wv_put(pos, g.wv_get_ring(pos - off, pos));
-    if ((int32_t)((off - ml) | (PIECE - ml)) < 0) {
-      uint32_t o = off, n = o < PIECE ? o : PIECE, p = pos, rem = ml;
-      do {
-        rem -= n; p += n;
-        o = n == o ? 2u * o : o;
-        n = rem < o ? rem : o;
-        n = n < PIECE ? n : PIECE;
-        g.wv_put(p, g.wv_get_ring(p - o, p));
-      } while (rem > n);
-    }
+    wave_match_ring(g, pos, off, ml);
   } else {
     g.wv_put(pos, g.wv_get_mem(dst + mpos, pos));
     if (ml > PIECE) g.wv_put(pos + PIECE, g.wv_get_mem(dst + mpos + PIECE, pos + PIECE));
@@ -420,7 +431,12 @@ LZ4HIP_DEV bool decode_wave_par_loop(Grp& g, const uint8_t* src, const int iend,
       // lies below bound - KW); a source the ring does not hold is FAR and comes from the block's flushed output in memory -- which
       // has everything below the flusher's position (and below the loop's entry position)
       const uint32_t oe_all = Grp::vreadlane(oe, 2u * np - 1u);
-      const uint32_t tb = (oe_all - op < TRIPMAX ? oe_all : op + TRIPMAX) + 16u;
+      // A match that OVERLAPS its own output (offset < length: 0.5 % of the sequences of 4 MiB blocks, 0.8 % of App. F's) is no lane's run -- its source never
+      // lies below a round's output.  It used to cut the pass (flusher, one-sequence step, a new pass for the rest of the window); now the round loop copies it
+      // where it stands, wave-wide, by doubling (wave_match_ring), and goes on with the next lane.  Its pieces write up to a step beyond its end: a pass that
+      // holds such a match counts that step into what it touches
+      const uint64_t ovlm = Grp::vballot(off < ml);
+      const uint32_t tb = (oe_all - op < TRIPMAX ? oe_all : op + TRIPMAX) + 16u + ((LZ4HIP_WAVE_OVL && (ovlm & actm) != 0ull) ? STEP : 0u);
       const uint32_t bound = (int32_t)(wild - tb) > 0 ? wild : tb;   // (... or what a one-sequence step before this trip has touched: its pieces are a whole step wide)
       const uint32_t memlim = fl > op0 + db ? fl - db : op0;
       constexpr uint64_t litm = 0x5555555555555555ull;                        // the even lanes: literal runs
@@ -451,7 +467,21 @@ LZ4HIP_DEV bool decode_wave_par_loop(Grp& g, const uint8_t* src, const int iend,
 #ifdef LZ4HIP_WAVE_DBG   /* developer build of the simulator: why rounds end (tests/hostsim) */
         g.vnote(act, Grp::vlanes(simplem), !isM | (mp < VU(0x80000000u)), !isM | (send <= VU(oa)) | (lane < a), Grp::vlanes(litm | heldm) | (send <= VU(memlim)), Grp::vlanes(litm | heldm), (oe - op) <= VU(TRIPMAX), Grp::vlanes(okm));
 #endif
-        if (Te == a) break;
+        if (Te == a) {
+          // an empty round.  At the match lane of a sequence every other rule passes -- simple, source valid and held, the block's ends, TRIPMAX -- it is
+          // the overlap: the literals are done (the round before ended here), the match goes wave-wide
+          if (LZ4HIP_WAVE_OVL && (a & 1u) != 0u && (((okbm & heldm & ovlm) >> a) & 1ull) != 0ull) {
+            const uint32_t ml_a = Grp::vreadlane(ml, a);
+            if ((int32_t)(bound - (oa + ml_a + STEP)) >= 0) {
+              wave_match_ring(g, oa + db, Grp::vreadlane(off, a), ml_a);
+              if ((int32_t)(oa + ml_a + STEP - wild) > 0) wild = oa + ml_a + STEP;
+              a += 1u;
+              if (a >= 2u * np) break;
+              continue;
+            }
+          }
+          break;
+        }
         g.template vcopy_run<LZ4HIP_PRED_LOADS != 0>(o + db, !isM, spv, len, ((1ull << Te) - 1ull) & ~below, dst, mp, farm, oddm, tier);
 #ifdef LZ4HIP_RING_DBG
         dbg_rounds++;
@@ -467,7 +497,7 @@ LZ4HIP_DEV bool decode_wave_par_loop(Grp& g, const uint8_t* src, const int iend,
       // a pass that was cut at a sequence NO pass takes -- a length of 255 or more, a match that overlaps its own output (offset < length: its
       // source never lies below a round's output) -- is followed by that sequence's one-sequence step at once: the next segment's pass
       // would set itself up (~130 instructions), copy the literals and take nothing
-      if (LZ4HIP_WAVE_SKIP && a < 2u * np) skip = (((~simplem | Grp::vballot(off < ml)) >> a) & 1ull) != 0ull;
+      if (LZ4HIP_WAVE_SKIP && a < 2u * np) skip = (((~simplem | ovlm) >> a) & 1ull) != 0ull;
       if ((a < 2u * np) | (tk >= T)) break;     // the pass ended early, or the window is done
     }
 #ifdef LZ4HIP_RING_DBG
