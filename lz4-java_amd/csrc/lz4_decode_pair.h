@@ -42,7 +42,7 @@ constexpr uint32_t PAIR_MAIL_BYTES = PAIR_SLOTS * PAIR_SLOT_BYTES + PAIR_CTL_WOR
 enum : uint32_t { PAIR_PASS = 1u, PAIR_SINGLE = 2u, PAIR_EXIT = 3u };
 enum : uint32_t { PC_HEAD = 0u, PC_TAIL = 1u, PC_CMD = 2u, PC_QUIT = 3u, PC_IP = 4u, PC_OP = 5u, PC_IEND = 6u, PC_OEND = 7u, PC_SRC_LO = 8u, PC_SRC_HI = 9u, PC_DB = 10u };
 // w0 of a run: ring index of its output (16 bits: rings of up to 64 KB) | length << 16 (9 bits) | flags
-constexpr uint32_t PAIR_F_FAR = 1u << 25, PAIR_F_ODD = 1u << 26, PAIR_F_ROUND = 1u << 27;
+constexpr uint32_t PAIR_F_FAR = 1u << 25, PAIR_F_ODD = 1u << 26, PAIR_F_ROUND = 1u << 27, PAIR_F_OVL = 1u << 28;   // (OVL: the trio planner only -- a round that is one match overlapping its own output)
 
 // the checks of wave_single_step (lz4_decode_wave.h) without its copies: is the sequence at ip one for the one-sequence step, and
 // where does it end.  Same reads of the stream ring, same rules: the copier's wave_single_step on the same {ip, op, fl} agrees.

@@ -191,7 +191,10 @@ LZ4HIP_DEV void trio_plan_loop(Grp& g, const uint32_t iend, const uint32_t oend,
         const VU oe = o + tot;
         const VU send = mp + ml;
         const uint32_t oe_all = Grp::vreadlane(oe, 2u * np - 1u);
-        const uint32_t tb = (oe_all - op < TRIPMAX ? oe_all : op + TRIPMAX) + 16u;
+        // (lz4_decode_wave.h LZ4HIP_WAVE_OVL: a match that overlaps its own output does not cut the pass -- the copier does it wave-wide where it stands; its
+        // pieces write up to a step beyond its end, which a pass that holds one counts into what it touches)
+        const uint64_t ovlm = Grp::vballot(off < ml);
+        const uint32_t tb = (oe_all - op < TRIPMAX ? oe_all : op + TRIPMAX) + 16u + ((LZ4HIP_WAVE_OVL && (ovlm & actm) != 0ull) ? STEP : 0u);
         const uint32_t bound = (int32_t)(wild - tb) > 0 ? wild : tb;
         const uint32_t memlim = fl > op0 + db ? fl - db : op0;
         constexpr uint64_t litm = 0x5555555555555555ull;
@@ -212,13 +215,25 @@ LZ4HIP_DEV void trio_plan_loop(Grp& g, const uint32_t iend, const uint32_t oend,
         const VU spv = Grp::vsel(isM, mp + db, lp);
         const uint64_t oddm = g.vodd_mask(o + db, len);
         uint32_t a = 0u;
-        uint64_t rsm = 0ull;
+        uint64_t rsm = 0ull, ovm = 0ull;                       // lanes that start a round; rounds that are one overlapping match
         for (;;) {
           const uint32_t oa = Grp::vreadlane(o, a);
           const uint64_t below = (1ull << a) - 1ull;
           const uint64_t okm = (okbm & (litm | Grp::vballot(send <= VU(oa)))) | below;
           const uint32_t Te = (uint32_t)__builtin_ctzll(~okm | (1ull << 63));
-          if (Te == a) break;
+          if (Te == a) {
+            if (LZ4HIP_WAVE_OVL && (a & 1u) != 0u && (((okbm & heldm & ovlm) >> a) & 1ull) != 0ull) {
+              const uint32_t ml_a = Grp::vreadlane(ml, a);
+              if ((int32_t)(bound - (oa + ml_a + STEP)) >= 0) {
+                rsm |= 1ull << a; ovm |= 1ull << a;
+                if ((int32_t)(oa + ml_a + STEP - wild) > 0) wild = oa + ml_a + STEP;
+                a += 1u;
+                if (a >= 2u * np) break;
+                continue;
+              }
+            }
+            break;
+          }
           rsm |= 1ull << a;
           a = Te;
           if (a >= 2u * np) break;
@@ -229,7 +244,7 @@ LZ4HIP_DEV void trio_plan_loop(Grp& g, const uint32_t iend, const uint32_t oend,
         opc = Grp::vreadlane(oe, a - 1u);
         {
           VU w0 = ((o + db) & 0xFFFFu) | (len << 16) | Grp::vsel(Grp::vlanes(farm), VU(PAIR_F_FAR), VU(0u)) | Grp::vsel(Grp::vlanes(oddm), VU(PAIR_F_ODD), VU(0u)) |
-                  Grp::vsel(Grp::vlanes(rsm), VU(PAIR_F_ROUND), VU(0u));
+                  Grp::vsel(Grp::vlanes(rsm), VU(PAIR_F_ROUND), VU(0u)) | Grp::vsel(Grp::vlanes(ovm), VU(PAIR_F_OVL), VU(0u));
           VU w1 = spv;
           w0 = Grp::vwritelane(w0, PAIR_PASS | (a << 8), 62u);
           w1 = Grp::vwritelane(w1, opc, 62u);
@@ -330,11 +345,16 @@ LZ4HIP_DEV void decode_trio_loop(Grp& g, const uint8_t* src, const int iend, uin
       const VU dw = w0 & 0xFFFFu, len = (w0 >> 16) & 0x1FFu;
       const uint64_t farm = Grp::vballot((w0 & PAIR_F_FAR) != 0u), oddm = Grp::vballot((w0 & PAIR_F_ODD) != 0u), rsm = Grp::vballot((w0 & PAIR_F_ROUND) != 0u);
       const VU mp = w1 - db;
+      const uint64_t ovm = Grp::vballot((w0 & PAIR_F_OVL) != 0u);
       uint32_t a = 0u;
       do {
         const uint64_t later = rsm & ~((2ull << a) - 1ull);
         uint32_t Te = later != 0ull ? (uint32_t)__builtin_ctzll(later) : a_end;
         Te = Te < a_end ? Te : a_end;
+        if (LZ4HIP_UNLIKELY(((ovm >> a) & 1ull) != 0ull)) {   // a round that is one match overlapping its own output: wave-wide, by doubling (ring coordinates mod 2^16: the rings divide that)
+          const uint32_t dwa = Grp::vreadlane(dw, a);
+          wave_match_ring(g, dwa, (dwa - Grp::vreadlane(w1, a)) & 0xFFFFu, Grp::vreadlane(len, a));
+        } else
         g.vcopy_run(dw, !isM, w1, len, ((1ull << Te) - 1ull) & ~((1ull << a) - 1ull), dst, mp, farm, oddm);
         a = Te;
       } while (a < a_end);

@@ -452,7 +452,7 @@ def test_wave_decoder_loop(sim, ref, O, corpus, par):
         ps = (C.c_ulonglong * 3)()
         sim.sim_wave_par_stats(ps)
         trips, seqs = ps[0] - ps0[0], ps[1] - ps0[1]
-        assert trips > (50000 if par is True else 100000) and seqs > 1.2 * trips, (trips, seqs)   # (the one-wavefront loop copies self-overlapping matches inside its passes: a third fewer passes on this corpus)
+        assert trips > (50000 if par in (True, "trio") else 100000) and seqs > 1.2 * trips, (trips, seqs)   # (the one-wavefront loop and the trio copy self-overlapping matches inside their passes: up to a third fewer passes on this corpus)
         if par is True or par == "trio":   # windows full of sequences take the walk by pointer doubling (group_dev.h vwalk_par): the backend runs it NEXT TO the plain walk and any difference fails the decode
             sim.sim_walk_par_calls.restype = C.c_ulonglong
             assert sim.sim_walk_par_calls() > 2000, sim.sim_walk_par_calls()   # trips did the work (this corpus is mostly irregular streams: App. F data runs 9-12 sequences per trip, text 18)

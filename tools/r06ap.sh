@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 6, GPU session aa: the copy rounds in three forms by their longest run (LZ4HIP_RUN_TIERS: < 16 / < 32 / <= 64 bytes; group_dev.h vcopy_run: wave loop, pair and trio copiers);
-# this session: a match that overlaps its own output is copied inside the pass (product) against noovl (-DLZ4HIP_WAVE_OVL=0: it cuts the pass and gets a one-sequence step)
+# this session: overlapping matches inside the passes of the TRIO too (planner marks the round, copier copies wave-wide) against notrioovl (-DLZ4HIP_WAVE_OVL=0: neither loop)
 cd "$(dirname "$0")/.."
 export GRAFT_REPO_ROOT=$PWD
 out=gpurun_out/${1:-r06af}; mkdir -p $out
@@ -12,7 +12,7 @@ for rep in 1 2; do
 echo "== product $rep" >> $out/matrix.log
 timeout 600 python tools/ring_matrix.py $shapes 64:5:0:0 >> $out/matrix.log 2>&1
 timeout 600 python tools/ring_matrix.py $small 64:8:0:0 >> $out/matrix.log 2>&1
-for v in noovl; do
+for v in notrioovl; do
 echo "== $v $rep" >> $out/matrix.log
 LZ4HIP_LIBRARY=$PWD/lz4-java_amd/variants/$v.so timeout 600 python tools/ring_matrix.py $shapes 64:5:0:0 >> $out/matrix.log 2>&1
 LZ4HIP_LIBRARY=$PWD/lz4-java_amd/variants/$v.so timeout 600 python tools/ring_matrix.py $small 64:8:0:0 >> $out/matrix.log 2>&1
