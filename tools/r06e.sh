@@ -2,7 +2,7 @@
 # round 6, GPU session e: checkpoint at the current sources -- whole GPU suite, smoke, the evidence collection (bench line, kernel traces, PMC traffic passes)
 cd "$(dirname "$0")/.."
 export GRAFT_REPO_ROOT=$PWD
-tag=${1:-r06fin4}
+tag=${1:-r06fin5}
 out=gpurun_out/$tag; mkdir -p $out
 timeout 1500 python -m pytest tests -m gpu -q -x --durations=8 > $out/pytest.log 2>&1; echo "pytest rc=$?" >> $out/pytest.log
 tail -14 $out/pytest.log
